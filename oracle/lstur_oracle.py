@@ -1,0 +1,469 @@
+"""CPU oracle for the LSTUR training path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module.  The product path (``mnexp_amd``) never
+does; it fails loudly when the HIP extension is missing.
+
+What this is: a NumPy restatement (explicit forward + hand-derived backward +
+Keras-style Adam) of the Keras graph the reference builds in
+
+  * news encoder ``cnnatt``      /root/reference/task/paper.py:132-160
+  * additive attention pool      /root/reference/models.py:444-492
+  * history mask                 /root/reference/models.py:20-30, task/paper.py:644-645
+  * user encoder (igru/gru/hgru) /root/reference/task/paper.py:584-633
+  * dot scorer + softmax         /root/reference/task/paper.py:443-464
+  * loss / optimizer / test head /root/reference/task/paper.py:635-665
+
+PARITY UNPINNED at the Keras boundary: the arithmetic lives in third-party
+``keras`` (unpinned in requirements.txt:1; Keras 2.2.4 semantics are assumed)
+on TensorFlow 1.x, neither of which is present in /root/reference or
+installable here, and the reference ships no golden outputs for this path.
+The restatement is therefore cross-checked two independent ways in tests/:
+(1) against a torch-CPU autograd re-derivation of the same forward (fp64),
+(2) by finite differences.  The integer data path is pinned separately by the
+fixtures under tests/golden/.
+
+Layout conventions (shared with the HIP library, see include/lstur.h):
+  titles  int32 [N_t, T]   N_t = B*W history titles (b-major) then B*(K+1) candidates
+  conv_w  [k, D, F] (Keras Conv1D kernel layout), conv_b [F]
+  att_w   [F], att_b [1]
+  dense_w [F, U], dense_b [U]
+  user_emb [N_u, Ue]
+  gru_w [U, 3H], gru_u [H, 3H], gru_b [3H]   gate column order z | r | h
+  con_w [H+Ue, U], con_b [U]                  (arch 'gru' only)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+EPS = 1e-7  # keras.backend.epsilon()
+
+ARCHS = ("igru", "gru", "hgru")
+
+
+# --------------------------------------------------------------------------
+# counter-based dropout mask (restated identically in csrc/lstur_device.h)
+# --------------------------------------------------------------------------
+def _fmix32(h):
+    h = h.astype(np.uint32, copy=True)
+    h ^= h >> np.uint32(16)
+    h *= np.uint32(0x85EBCA6B)
+    h ^= h >> np.uint32(13)
+    h *= np.uint32(0xC2B2AE35)
+    h ^= h >> np.uint32(16)
+    return h
+
+
+def dropout_key(seed: int, step: int, stream: int) -> int:
+    """32-bit key for one (seed, step, stream) triple."""
+    with np.errstate(over="ignore"):
+        k = np.array([seed & 0xFFFFFFFF], dtype=np.uint32)
+        k = _fmix32(k + np.uint32(0x9E3779B9) * np.uint32(stream + 1))
+        k = _fmix32(k ^ (np.uint32(step & 0xFFFFFFFF) * np.uint32(0x7FEB352D) + np.uint32(0x165667B1)))
+    return int(k[0])
+
+
+def dropout_keep(key: int, n: int, p: float, start: int = 0):
+    """keep[i] for element indices start..start+n-1:  (hash >> 8) >= floor(p * 2^24)."""
+    if p <= 0.0:
+        return np.ones(n, dtype=bool)
+    with np.errstate(over="ignore"):
+        idx = np.arange(start, start + n, dtype=np.uint64).astype(np.uint32)
+        h = _fmix32(idx * np.uint32(0x9E3779B1) + np.uint32(key))
+    thresh = np.uint32(int(p * 16777216.0))
+    return (h >> np.uint32(8)) >= thresh
+
+
+# --------------------------------------------------------------------------
+# initialisers (Keras 2.2.4 defaults for the layers the graph instantiates)
+# --------------------------------------------------------------------------
+def glorot_uniform(rng, shape, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape)
+
+
+def orthogonal(rng, rows, cols):
+    a = rng.normal(0.0, 1.0, size=(rows, cols))
+    u, _, vt = np.linalg.svd(a, full_matrices=False)
+    q = u if u.shape == (rows, cols) else vt
+    return q[:rows, :cols]
+
+
+def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.float32):
+    """Random-init parameters with the reference's initialisers
+    (conv/dense/att: glorot_uniform, biases zero -- paper.py:146,159, models.py:448-449;
+    user table uniform +-0.05 -- paper.py:589; GRU kernel glorot, recurrent orthogonal)."""
+    assert arch in ARCHS
+    H = U // 2 if arch == "hgru" else U
+    Ue = U // 2 if arch == "hgru" else U
+    p = {}
+    if word_emb is None:
+        word_emb = rng.normal(0.0, 0.1, size=(V, D))
+        word_emb[0] = 0.0
+    p["word_emb"] = word_emb
+    p["conv_w"] = glorot_uniform(rng, (k, D, F), k * D, k * F)
+    p["conv_b"] = np.zeros(F)
+    p["att_w"] = glorot_uniform(rng, (F,), F, 1)
+    p["att_b"] = np.zeros(1)
+    p["dense_w"] = glorot_uniform(rng, (F, U), F, U)
+    p["dense_b"] = np.zeros(U)
+    p["user_emb"] = rng.uniform(-0.05, 0.05, size=(N_u, Ue))
+    p["gru_w"] = glorot_uniform(rng, (U, 3 * H), U, 3 * H)
+    p["gru_u"] = orthogonal(rng, H, 3 * H)
+    p["gru_b"] = np.zeros(3 * H)
+    if arch == "gru":
+        p["con_w"] = glorot_uniform(rng, (H + Ue, U), H + Ue, U)
+        p["con_b"] = np.zeros(U)
+    return {n: np.ascontiguousarray(a, dtype=dtype) for n, a in p.items()}
+
+
+def dense_param_names(arch, word_trainable=False):
+    """Order of the flat dense-parameter bucket (same order in the HIP library)."""
+    names = ["conv_w", "conv_b", "att_w", "att_b", "dense_w", "dense_b", "gru_w", "gru_u", "gru_b"]
+    if arch == "gru":
+        names += ["con_w", "con_b"]
+    return names
+
+
+def hard_sigmoid(x):
+    return np.clip(0.2 * x + 0.5, 0.0, 1.0)
+
+
+# --------------------------------------------------------------------------
+# news encoder
+# --------------------------------------------------------------------------
+def _im2col(Epad, T, k):
+    n, Tp, D = Epad.shape
+    s0, s1, s2 = Epad.strides
+    win = np.lib.stride_tricks.as_strided(Epad, shape=(n, T, k, D), strides=(s0, s1, s1, s2), writeable=False)
+    return win.reshape(n * T, k * D)
+
+
+def news_encoder_fwd(p, titles, drop_p=0.0, keys=(0, 0), training=True, chunk=4096):
+    """titles int [N_t,T] -> doc vectors [N_t,U]; returns (v, cache)."""
+    dt = p["conv_w"].dtype
+    ids = np.asarray(titles).astype(np.int64)
+    N, T = ids.shape
+    k, D, F = p["conv_w"].shape
+    pl = (k - 1) // 2
+    pr = k - 1 - pl
+    Wm = p["conv_w"].reshape(k * D, F)
+    use_drop = training and drop_p > 0.0
+    scale = dt.type(1.0 / (1.0 - drop_p)) if use_drop else dt.type(1.0)
+
+    c = np.empty((N, T, F), dtype=dt)
+    for s in range(0, N, chunk):
+        e = min(N, s + chunk)
+        E = p["word_emb"][ids[s:e]].astype(dt)  # gather, pad id 0 is gathered too
+        if use_drop:
+            keep = dropout_keep(keys[0], (e - s) * T * D, drop_p, start=s * T * D).reshape(e - s, T, D)
+            E = E * keep * scale
+        Epad = np.zeros((e - s, T + k - 1, D), dtype=dt)
+        Epad[:, pl:pl + T] = E
+        cc = _im2col(Epad, T, k) @ Wm + p["conv_b"]
+        c[s:e] = np.maximum(cc, 0).reshape(e - s, T, F)
+    c *= (ids != 0)[..., None]                      # paper.py:150-155
+    tmask = np.any(c != 0, axis=-1)                 # keras Masking(0.) paper.py:157
+    if use_drop:
+        keep2 = dropout_keep(keys[1], N * T * F, drop_p).reshape(N, T, F)
+        x = c * keep2 * scale
+    else:
+        keep2 = None
+        x = c
+    a = np.tanh(x @ p["att_w"] + p["att_b"][0])     # models.py:474-477
+    e_ = np.exp(a) * tmask                          # models.py:480
+    S = e_.sum(axis=1, keepdims=True) + dt.type(EPS)
+    w = e_ / S                                      # models.py:485
+    pooled = np.einsum("ntf,nt->nf", x, w)
+    v = pooled @ p["dense_w"] + p["dense_b"]        # paper.py:159
+    cache = dict(ids=ids, c=c, tmask=tmask, keep2=keep2, x=x, a=a, w=w, pooled=pooled,
+                 scale=scale, drop_p=drop_p if use_drop else 0.0, keys=keys)
+    return v, cache
+
+
+def news_encoder_bwd(p, cache, dv, word_trainable=False, chunk=4096):
+    """dv [N_t,U] -> grads dict for conv/att/dense (+ word_emb when trainable)."""
+    dt = p["conv_w"].dtype
+    ids, c, x, a, w = cache["ids"], cache["c"], cache["x"], cache["a"], cache["w"]
+    N, T = ids.shape
+    k, D, F = p["conv_w"].shape
+    pl = (k - 1) // 2
+    g = {}
+    g["dense_w"] = cache["pooled"].T @ dv
+    g["dense_b"] = dv.sum(axis=0)
+    dpooled = dv @ p["dense_w"].T                   # [N,F]
+    dw = np.einsum("nf,ntf->nt", dpooled, x)
+    # w = e/(S+eps): de_t = (dw_t - sum_t' dw_t' w_t')/(S+eps); da_t = de_t*e_t = (..)*w_t
+    da = (dw - (dw * w).sum(axis=1, keepdims=True)) * w
+    ds = da * (1.0 - a * a)
+    dx = dpooled[:, None, :] * w[..., None] + ds[..., None] * p["att_w"][None, None, :]
+    g["att_w"] = np.einsum("nt,ntf->f", ds, x)
+    g["att_b"] = np.array([ds.sum()], dtype=dt)
+    if cache["keep2"] is not None:
+        dx = dx * cache["keep2"] * cache["scale"]
+    dc = dx * (c > 0)                               # ReLU' ; pad-masked / masked rows have c == 0
+    g["conv_b"] = dc.sum(axis=(0, 1))
+    gW = np.zeros((k * D, F), dtype=dt)
+    use_drop = cache["drop_p"] > 0.0
+    if word_trainable:
+        g_word = np.zeros_like(p["word_emb"])
+        Wm = p["conv_w"].reshape(k * D, F)
+    for s in range(0, N, chunk):
+        e = min(N, s + chunk)
+        E = p["word_emb"][ids[s:e]].astype(dt)
+        if use_drop:
+            keep = dropout_keep(cache["keys"][0], (e - s) * T * D, cache["drop_p"], start=s * T * D).reshape(e - s, T, D)
+            E = E * keep * cache["scale"]
+        Epad = np.zeros((e - s, T + k - 1, D), dtype=dt)
+        Epad[:, pl:pl + T] = E
+        dcf = dc[s:e].reshape((e - s) * T, F)
+        gW += _im2col(Epad, T, k).T @ dcf
+        if word_trainable:
+            dcol = (dcf @ Wm.T).reshape(e - s, T, k, D)
+            dEpad = np.zeros((e - s, T + k - 1, D), dtype=dt)
+            for j in range(k):
+                dEpad[:, j:j + T] += dcol[:, :, j]
+            dE = dEpad[:, pl:pl + T]
+            if use_drop:
+                dE = dE * keep * cache["scale"]
+            np.add.at(g_word, ids[s:e].reshape(-1), dE.reshape(-1, D))
+    g["conv_w"] = gW.reshape(k, D, F)
+    if word_trainable:
+        g["word_emb"] = g_word
+    return g
+
+
+# --------------------------------------------------------------------------
+# masked GRU (Keras 2.2.4: gates z|r|h, hard_sigmoid / tanh, reset_after=False)
+# --------------------------------------------------------------------------
+def gru_fwd(p, x, gmask, h0):
+    """x [B,W,U], gmask bool [B,W], h0 [B,H] -> last output [B,H]."""
+    dt = x.dtype
+    B, W, _ = x.shape
+    H = p["gru_u"].shape[0]
+    xw = x.reshape(B * W, -1) @ p["gru_w"] + p["gru_b"]
+    xw = xw.reshape(B, W, 3 * H)
+    Uz, Ur, Uh = p["gru_u"][:, :H], p["gru_u"][:, H:2 * H], p["gru_u"][:, 2 * H:]
+    hs = np.empty((B, W + 1, H), dtype=dt)
+    hs[:, 0] = h0
+    zs = np.empty((B, W, H), dtype=dt)
+    rs = np.empty((B, W, H), dtype=dt)
+    hhs = np.empty((B, W, H), dtype=dt)
+    h = h0
+    for t in range(W):
+        z = hard_sigmoid(xw[:, t, :H] + h @ Uz)
+        r = hard_sigmoid(xw[:, t, H:2 * H] + h @ Ur)
+        hh = np.tanh(xw[:, t, 2 * H:] + (r * h) @ Uh)
+        hn = z * h + (1 - z) * hh
+        m = gmask[:, t][:, None]
+        h = np.where(m, hn, h)                      # K.rnn: masked step carries state and output
+        zs[:, t], rs[:, t], hhs[:, t], hs[:, t + 1] = z, r, hh, h
+    return h, dict(x=x, gmask=gmask, hs=hs, zs=zs, rs=rs, hhs=hhs, xw=xw)
+
+
+def _hsig_grad(pre):
+    # tf.clip_by_value passes the gradient where 0 <= 0.2x+0.5 <= 1 (inclusive)
+    y = 0.2 * pre + 0.5
+    return np.where((y >= 0.0) & (y <= 1.0), 0.2, 0.0)
+
+
+def gru_bwd(p, cache, dh_last):
+    dt = dh_last.dtype
+    x, gmask, hs, zs, rs, hhs, xw = (cache[n] for n in ("x", "gmask", "hs", "zs", "rs", "hhs", "xw"))
+    B, W, _ = x.shape
+    H = p["gru_u"].shape[0]
+    Uz, Ur, Uh = p["gru_u"][:, :H], p["gru_u"][:, H:2 * H], p["gru_u"][:, 2 * H:]
+    dgates = np.zeros((B, W, 3 * H), dtype=dt)
+    dU = np.zeros_like(p["gru_u"])
+    dh = dh_last.copy()
+    for t in range(W - 1, -1, -1):
+        m = gmask[:, t][:, None]
+        hp = hs[:, t]
+        z, r, hh = zs[:, t], rs[:, t], hhs[:, t]
+        dhn = np.where(m, dh, 0.0)
+        dh_carry = np.where(m, 0.0, dh)
+        dz = dhn * (hp - hh)
+        dhh = dhn * (1 - z)
+        dpre_h = dhh * (1 - hh * hh)
+        drh = dpre_h @ Uh.T
+        dr = drh * hp
+        pre_z = xw[:, t, :H] + hp @ Uz
+        pre_r = xw[:, t, H:2 * H] + hp @ Ur
+        dpre_z = dz * _hsig_grad(pre_z)
+        dpre_r = dr * _hsig_grad(pre_r)
+        dgates[:, t, :H] = dpre_z
+        dgates[:, t, H:2 * H] = dpre_r
+        dgates[:, t, 2 * H:] = dpre_h
+        dU[:, :H] += hp.T @ dpre_z
+        dU[:, H:2 * H] += hp.T @ dpre_r
+        dU[:, 2 * H:] += (r * hp).T @ dpre_h
+        dh = dh_carry + dhn * z + drh * r + dpre_z @ Uz.T + dpre_r @ Ur.T
+    dg = dgates.reshape(B * W, 3 * H)
+    g = dict(gru_w=x.reshape(B * W, -1).T @ dg, gru_b=dg.sum(axis=0), gru_u=dU)
+    dx = (dg @ p["gru_w"].T).reshape(x.shape)
+    return g, dx, dh
+
+
+# --------------------------------------------------------------------------
+# whole model
+# --------------------------------------------------------------------------
+def split_titles(v, B, W, K1):
+    hv = v[:B * W].reshape(B, W, -1)
+    dv = v[B * W:].reshape(B, K1, -1)
+    return hv, dv
+
+
+def user_encoder_fwd(p, arch, user, hv, hist_ids):
+    """paper.py:584-633 for arch in igru|gru|hgru; hv [B,W,U] raw doc vectors of the history."""
+    hmask = np.any(hist_ids != 0, axis=-1)           # models.ComputeMasking, paper.py:644
+    hvm = hv * hmask[..., None]                      # paper.py:645
+    gmask = np.any(hvm != 0, axis=-1)                # Masking() paper.py:592
+    uvec = p["user_emb"][user]
+    H = p["gru_u"].shape[0]
+    if arch == "igru":
+        h, gc = gru_fwd(p, hvm, gmask, uvec)
+        u = h
+        extra = None
+    else:
+        h, gc = gru_fwd(p, hvm, gmask, np.zeros((len(user), H), dtype=hv.dtype))
+        cat = np.concatenate([h, uvec], axis=1)
+        if arch == "gru":
+            u = cat @ p["con_w"] + p["con_b"]
+        else:  # hgru
+            u = cat
+        extra = cat
+    return u, dict(gc=gc, hmask=hmask, user=user, cat=extra, arch=arch)
+
+
+def user_encoder_bwd(p, cache, du):
+    arch, gc = cache["arch"], cache["gc"]
+    H = p["gru_u"].shape[0]
+    g = {}
+    if arch == "igru":
+        gg, dx, dh0 = gru_bwd(p, gc, du)
+        duser = dh0
+    else:
+        if arch == "gru":
+            g["con_w"] = cache["cat"].T @ du
+            g["con_b"] = du.sum(axis=0)
+            dcat = du @ p["con_w"].T
+        else:
+            dcat = du
+        gg, dx, _ = gru_bwd(p, gc, np.ascontiguousarray(dcat[:, :H]))
+        duser = dcat[:, H:]
+    g.update(gg)
+    dhv = dx * cache["hmask"][..., None]
+    return g, dhv, duser
+
+
+def softmax_ce(z):
+    """softmax -> Keras categorical_crossentropy on probabilities with label [1,0,..,0]
+    (paper.py:463, 655-659); returns per-sample loss, probabilities and dL/dz (per sample)."""
+    dt = z.dtype
+    zs = z - z.max(axis=1, keepdims=True)
+    ez = np.exp(zs)
+    pr = ez / ez.sum(axis=1, keepdims=True)
+    S = pr.sum(axis=1, keepdims=True)
+    q = pr / S
+    cq = np.clip(q, dt.type(EPS), dt.type(1.0 - EPS))
+    loss = -np.log(cq[:, 0])
+    inside = (q[:, 0] >= dt.type(EPS)) & (q[:, 0] <= dt.type(1.0 - EPS))
+    gq = np.zeros_like(pr)
+    gq[:, 0] = np.where(inside, -1.0 / cq[:, 0], 0.0)
+    dp = gq / S - (gq * pr).sum(axis=1, keepdims=True) / (S * S)
+    dz = pr * (dp - (dp * pr).sum(axis=1, keepdims=True))
+    return loss, pr, dz
+
+
+def forward_backward(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0, word_trainable=False,
+                     want_grads=True):
+    """One training step's loss + gradients.
+    user int [B]; hist int [B,W,T]; cands int [B,K+1,T] (candidate 0 is the positive).
+    Returns dict(loss, acc, probs, logits, grads{name: array}, user_rows, user_row_grads)."""
+    user = np.asarray(user).astype(np.int64).reshape(-1)
+    hist = np.asarray(hist).astype(np.int64)
+    cands = np.asarray(cands).astype(np.int64)
+    B, W, T = hist.shape
+    K1 = cands.shape[1]
+    titles = np.concatenate([hist.reshape(B * W, T), cands.reshape(B * K1, T)], axis=0)
+    keys = (dropout_key(seed, step, 0), dropout_key(seed, step, 1))
+    v, nc = news_encoder_fwd(p, titles, drop_p, keys, training=True)
+    hv, dv = split_titles(v, B, W, K1)
+    u, uc = user_encoder_fwd(p, arch, user, hv, hist)
+    z = np.einsum("bu,bju->bj", u, dv)
+    loss_i, pr, dz = softmax_ce(z)
+    out = dict(loss=float(loss_i.mean()), acc=float((pr.argmax(axis=1) == 0).mean()),
+               probs=pr, logits=z, user_vec=u, doc_vec=v)
+    if not want_grads:
+        return out
+    dz = dz / v.dtype.type(B)
+    du = np.einsum("bj,bju->bu", dz, dv)
+    ddv = dz[..., None] * u[:, None, :]
+    g, dhv, duser = user_encoder_bwd(p, uc, du)
+    dvv = np.concatenate([dhv.reshape(B * W, -1), ddv.reshape(B * K1, -1)], axis=0)
+    g.update(news_encoder_bwd(p, nc, dvv, word_trainable))
+    out["grads"] = g
+    out["user_rows"] = user
+    out["user_row_grads"] = duser
+    return out
+
+
+def predict(p, arch, user, hist, cand):
+    """test_model (paper.py:661-665): sigmoid(u . d) for one candidate per row.
+    user [n], hist [n,W,T], cand [n,T] -> [n]"""
+    user = np.asarray(user).astype(np.int64).reshape(-1)
+    hist = np.asarray(hist).astype(np.int64)
+    cand = np.asarray(cand).astype(np.int64)
+    n, W, T = hist.shape
+    titles = np.concatenate([hist.reshape(n * W, T), cand.reshape(n, T)], axis=0)
+    v, _ = news_encoder_fwd(p, titles, training=False)
+    hv, dv = split_titles(v, n, W, 1)
+    u, _ = user_encoder_fwd(p, arch, user, hv, hist)
+    z = np.einsum("bu,bu->b", u, dv[:, 0])
+    return 1.0 / (1.0 + np.exp(-z))
+
+
+# --------------------------------------------------------------------------
+# Keras-2.2.4 Adam (eps outside sqrt(v), bias correction folded into lr_t,
+# DENSE update of the embedding table: TF-1 densifies the IndexedSlices grad)
+# --------------------------------------------------------------------------
+class Adam:
+    def __init__(self, params, names, lr=1e-3, beta1=0.9, beta2=0.999, eps=EPS):
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.t = 0
+        self.names = list(names)
+        self.m = {n: np.zeros_like(params[n]) for n in self.names}
+        self.v = {n: np.zeros_like(params[n]) for n in self.names}
+
+    def lr_t(self, dt=np.float32):
+        """Evaluated in the parameter dtype like the TF graph (fp32 for Keras)."""
+        t = dt(self.t)
+        return dt(self.lr) * (np.sqrt(dt(1.0) - np.power(dt(self.b2), t)) / (dt(1.0) - np.power(dt(self.b1), t)))
+
+    def step(self, params, grads):
+        self.t += 1
+        for n in self.names:
+            dt = params[n].dtype.type
+            g = grads[n].astype(params[n].dtype)
+            lr_t = self.lr_t(dt)
+            self.m[n] = dt(self.b1) * self.m[n] + dt(1.0 - self.b1) * g
+            self.v[n] = dt(self.b2) * self.v[n] + dt(1.0 - self.b2) * (g * g)
+            params[n] = params[n] - lr_t * self.m[n] / (np.sqrt(self.v[n]) + dt(self.eps))
+
+
+def densify_user_grad(N_u, Ue, rows, row_grads, dtype):
+    """Sum duplicate rows in ascending sample order (the order the HIP library uses)."""
+    g = np.zeros((N_u, Ue), dtype=dtype)
+    for r, gr in zip(rows, row_grads):
+        g[r] += gr
+    return g
+
+
+def train_step(p, arch, opt, user, hist, cands, drop_p=0.0, seed=0, step=0):
+    """forward/backward + Adam over dense params and the (densified) user table."""
+    out = forward_backward(p, arch, user, hist, cands, drop_p, seed, step)
+    g = out["grads"]
+    g["user_emb"] = densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"],
+                                      p["user_emb"].dtype)
+    opt.step(p, g)
+    return out

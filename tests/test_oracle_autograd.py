@@ -1,0 +1,91 @@
+"""Pins the oracle's hand-written backward against torch autograd (fp64) and
+the dropout-hash / Adam restatements against direct formulas."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_batch
+from oracle import lstur_oracle as O
+import torch_ref as TR
+
+DIMS = dict(V=60, D=12, F=16, k=3, U=8, N_u=11)
+
+
+@pytest.mark.parametrize("arch", ["igru", "gru", "hgru"])
+@pytest.mark.parametrize("drop", [0.0, 0.25])
+def test_grads_match_autograd(arch, drop):
+    rng = np.random.default_rng(3)
+    p = O.init_params(rng, arch=arch, dtype=np.float64, **DIMS)
+    for n in ("conv_b", "att_b", "dense_b", "gru_b"):
+        p[n] = rng.normal(0, 0.1, size=p[n].shape)
+    B, W, T, K1 = 5, 4, 7, 3
+    user, hist, cands = make_batch(rng, B, W, T, K1, DIMS["V"], DIMS["N_u"])
+    user[1] = user[0]  # duplicate user rows must sum
+    out = O.forward_backward(p, arch, user, hist, cands, drop_p=drop, seed=7, step=2, word_trainable=True)
+
+    names = [n for n in p]
+    tp = TR.to_t(p, grad_names=names)
+    keep1 = keep2 = None
+    scale = 1.0
+    if drop > 0:
+        N_t = B * (W + K1)
+        keep1 = O.dropout_keep(O.dropout_key(7, 2, 0), N_t * T * DIMS["D"], drop).reshape(N_t, T, DIMS["D"])
+        keep2 = O.dropout_keep(O.dropout_key(7, 2, 1), N_t * T * DIMS["F"], drop).reshape(N_t, T, DIMS["F"])
+        scale = 1.0 / (1.0 - drop)
+        assert 0.6 < keep1.mean() < 0.9
+    loss, z, pr = TR.model_loss(tp, arch, user, hist, cands, keep1, keep2, scale)
+    loss.backward()
+    assert abs(loss.item() - out["loss"]) < 1e-12
+    np.testing.assert_allclose(out["logits"], z.detach().numpy(), rtol=1e-10, atol=1e-12)
+    g = dict(out["grads"])
+    g["user_emb"] = O.densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"], np.float64)
+    for n in names:
+        ref = tp[n].grad.numpy()
+        np.testing.assert_allclose(g[n], ref, rtol=1e-8, atol=1e-12, err_msg=n)
+
+
+def test_all_masked_history_returns_initial_state():
+    rng = np.random.default_rng(0)
+    p = O.init_params(rng, arch="igru", dtype=np.float64, **DIMS)
+    user, hist, cands = make_batch(rng, 3, 4, 7, 2, DIMS["V"], DIMS["N_u"])
+    hist[:] = 0
+    out = O.forward_backward(p, "igru", user, hist, cands, want_grads=False)
+    np.testing.assert_array_equal(out["user_vec"], p["user_emb"][user])
+
+
+def test_dropout_hash_scalar_restatement():
+    def fmix(h):
+        h &= 0xFFFFFFFF
+        h ^= h >> 16
+        h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+        h ^= h >> 13
+        h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+        h ^= h >> 16
+        return h
+
+    seed, step, stream = 1234, 17, 1
+    k = fmix((seed + 0x9E3779B9 * (stream + 1)) & 0xFFFFFFFF)
+    k = fmix(k ^ ((step * 0x7FEB352D + 0x165667B1) & 0xFFFFFFFF))
+    assert k == O.dropout_key(seed, step, stream)
+    keep = O.dropout_keep(k, 1000, 0.2, start=5)
+    thr = int(0.2 * 16777216.0)
+    for i in range(1000):
+        h = fmix(((i + 5) * 0x9E3779B1 + k) & 0xFFFFFFFF)
+        assert keep[i] == ((h >> 8) >= thr)
+
+
+def test_adam_matches_keras_formula():
+    rng = np.random.default_rng(1)
+    p = {"w": rng.normal(size=(4, 3)).astype(np.float32)}
+    opt = O.Adam(p, ["w"], lr=1e-3)
+    w = p["w"].astype(np.float64).copy()
+    m = np.zeros_like(w)
+    v = np.zeros_like(w)
+    for t in range(1, 6):
+        g = rng.normal(size=(4, 3)).astype(np.float32)
+        opt.step(p, {"w": g})
+        lr_t = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        m = 0.9 * m + 0.1 * g
+        v = 0.999 * v + 0.001 * g.astype(np.float64) ** 2
+        w = w - lr_t * m / (np.sqrt(v) + 1e-7)
+        np.testing.assert_allclose(p["w"], w, rtol=2e-6, atol=1e-7)

@@ -1,0 +1,90 @@
+"""Independent torch-CPU (autograd) re-derivation of the LSTUR forward pass.
+
+Test infrastructure only: used to cross-check the hand-written backward of
+oracle/lstur_oracle.py ("cross-checked two independent ways").
+Written against the Keras-2.2.4 semantics listed there, using torch ops
+(F.conv1d, autograd) rather than the oracle's im2col / explicit gradients.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-7
+
+
+def to_t(p, dtype=torch.float64, grad_names=()):
+    out = {}
+    for n, a in p.items():
+        t = torch.tensor(np.asarray(a), dtype=dtype)
+        if n in grad_names:
+            t.requires_grad_(True)
+        out[n] = t
+    return out
+
+
+def news_encoder(p, titles, keep1=None, keep2=None, scale=1.0):
+    ids = torch.as_tensor(np.asarray(titles), dtype=torch.long)
+    N, T = ids.shape
+    k, D, Fo = p["conv_w"].shape
+    E = p["word_emb"][ids]                                  # [N,T,D]
+    if keep1 is not None:
+        E = E * torch.as_tensor(keep1, dtype=E.dtype) * scale
+    pl = (k - 1) // 2
+    x = F.pad(E.transpose(1, 2), (pl, k - 1 - pl))           # [N,D,T+k-1]
+    w = p["conv_w"].permute(2, 1, 0)                        # [F,D,k]
+    c = F.relu(F.conv1d(x, w, p["conv_b"])).transpose(1, 2)  # [N,T,F]
+    c = c * (ids != 0).unsqueeze(-1).to(c.dtype)
+    tmask = (c.detach() != 0).any(dim=-1)
+    c = c * tmask.unsqueeze(-1).to(c.dtype)
+    xx = c
+    if keep2 is not None:
+        xx = c * torch.as_tensor(keep2, dtype=c.dtype) * scale
+    a = torch.tanh(xx @ p["att_w"] + p["att_b"])
+    e = torch.exp(a) * tmask.to(a.dtype)
+    wgt = e / (e.sum(dim=1, keepdim=True) + EPS)
+    pooled = (xx * wgt.unsqueeze(-1)).sum(dim=1)
+    return pooled @ p["dense_w"] + p["dense_b"]
+
+
+def gru(p, x, mask, h0):
+    B, W, _ = x.shape
+    H = p["gru_u"].shape[0]
+    h = h0
+    for t in range(W):
+        xt = x[:, t] @ p["gru_w"] + p["gru_b"]
+        rec = h @ p["gru_u"][:, :2 * H]
+        z = torch.clamp(0.2 * (xt[:, :H] + rec[:, :H]) + 0.5, 0, 1)
+        r = torch.clamp(0.2 * (xt[:, H:2 * H] + rec[:, H:]) + 0.5, 0, 1)
+        hh = torch.tanh(xt[:, 2 * H:] + (r * h) @ p["gru_u"][:, 2 * H:])
+        hn = z * h + (1 - z) * hh
+        h = torch.where(mask[:, t].unsqueeze(-1), hn, h)
+    return h
+
+
+def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0):
+    user = torch.as_tensor(np.asarray(user), dtype=torch.long).reshape(-1)
+    hist_np = np.asarray(hist)
+    B, W, T = hist_np.shape
+    K1 = np.asarray(cands).shape[1]
+    titles = np.concatenate([hist_np.reshape(B * W, T), np.asarray(cands).reshape(B * K1, T)], 0)
+    v = news_encoder(p, titles, keep1, keep2, scale)
+    hv = v[:B * W].reshape(B, W, -1)
+    dv = v[B * W:].reshape(B, K1, -1)
+    hmask = torch.as_tensor((hist_np != 0).any(-1))
+    hv = hv * hmask.unsqueeze(-1).to(hv.dtype)
+    gmask = (hv.detach() != 0).any(-1)
+    uvec = p["user_emb"][user]
+    H = p["gru_u"].shape[0]
+    if arch == "igru":
+        u = gru(p, hv, gmask, uvec)
+    else:
+        h = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
+        u = torch.cat([h, uvec], dim=1)
+        if arch == "gru":
+            u = u @ p["con_w"] + p["con_b"]
+    z = (u.unsqueeze(1) * dv).sum(-1)
+    pr = torch.softmax(z, dim=-1)
+    q = pr / pr.sum(-1, keepdim=True)
+    q = torch.clamp(q, EPS, 1 - EPS)
+    loss = -(torch.log(q[:, 0])).mean()
+    return loss, z, pr
