@@ -1,0 +1,177 @@
+"""LSTUR task family (softmax ranking with user-id embedding) on the native MI355X model.
+
+Host-side mirror of /root/reference/task/paper.py:
+  ``Seq2VecPaper``          :6-255   in-memory ClickData (``_load_data`` :24-35, ``Impression`` :7-18)
+  ``Seq2VecPaperSoftmax``   :384-524 1+K softmax samples, lr decay + per-impression metrics ``callback`` :497-524
+  ``Seq2VecPaperSoftmaxId`` :527-665 user index = ClickData row number; LSTUR-ini (``igru``) / LSTUR-con (``gru``, ``hgru``)
+Everything under ``_build_model`` is replaced by ``mnexp_amd.native_model.NativeModel`` (HIP/gfx950).
+"""
+import logging
+from datetime import datetime
+
+import numpy as np
+from sklearn.metrics import roc_auc_score
+
+from .. import utils
+from .seq2vec import Seq2Vec
+
+
+class Seq2VecPaper(Seq2Vec):
+    class Impression:
+        __slots__ = ['pos', 'neg', 'time']
+
+        def __init__(self, d):
+            fields = d.split('#TAB#')
+            self.pos = [int(k) for k in fields[0].split(' ')]
+            self.neg = [int(k) for k in fields[1].split(' ')]
+            if len(fields) >= 3:
+                self.time = datetime.strptime(fields[2], '%m/%d/%Y %I:%M:%S %p')
+
+        def negative_samples(self, n):
+            return np.random.choice(self.neg, n)
+
+    def _extract_impressions(self, x):
+        # impressions without positives (segment starts with '#TAB#') are dropped (paper.py:21)
+        return [self.Impression(d) for d in x.split('#N#') if not d.startswith('#TAB#')]
+
+    def _load_data(self):
+        """ClickData.tsv col[2] = training-period history, col[3] = validation-period history."""
+        logging.info('[+] loading data')
+        self.data = []
+        with open(self.config.training_data_input) as file:
+            for line in file:
+                cols = line.strip('\n').split('\t')
+                self.data.append((
+                    self._extract_impressions(cols[2]) if cols[2] else [],
+                    self._extract_impressions(cols[3]) if cols[3] else [],
+                ))
+        for tr, va in self.data:                      # fail at load time on unknown doc ids
+            for imp in tr + va:
+                self.docs.check(imp.pos)
+                self.docs.check(imp.neg)
+        super(Seq2VecPaper, self)._load_data()
+        logging.info('[-] loaded data')
+
+    def save_model(self):
+        pass                                          # paper.py:254-255
+
+
+class Seq2VecPaperSoftmax(Seq2VecPaper):
+    """Samples: (hist_ids[W], [pos, neg_1..neg_K], label=[1,0..0])."""
+    has_user = False
+
+    def _label(self):
+        return [1] + [0] * self.config.negative_samples
+
+    def _users(self):
+        return ((None, d) for d in self.data)
+
+    def _sample(self, user, ch, pos, impression, label):
+        cands = [pos] + [int(n) for n in impression.negative_samples(self.config.negative_samples)]
+        head = (user,) if self.has_user else ()
+        return head + (ch.get_ids(), cands, label)
+
+    def train_gen_ids(self):
+        """paper.py:385-399 / :528-542: history excludes the current click and grows inside an impression."""
+        label = self._label()
+        while True:
+            for user, (ih, _) in self._users():
+                if not ih:
+                    continue
+                ch = self.Window(self.docs, self.config.window_size)
+                for impression in ih:
+                    for pos in impression.pos:
+                        if ch.count:
+                            yield self._sample(user, ch, pos, impression, label)
+                        ch.push(pos)
+
+    def valid_gen_ids(self):
+        """paper.py:401-418 / :544-562: history = all training clicks; pushed after each valid impression."""
+        label = self._label()
+        while True:
+            for user, (ih1, ih2) in self._users():
+                if not (ih1 and ih2):
+                    continue
+                ch = self._history_after_training(ih1)
+                for impression in ih2:
+                    for pos in impression.pos:
+                        yield self._sample(user, ch, pos, impression, label)
+                    for pos in impression.pos:
+                        ch.push(pos)
+
+    def test_gen_ids(self):
+        """paper.py:420-441 / :563-582: per valid impression all pos then all neg, history frozen before it."""
+        for user, (ih1, ih2) in self._users():
+            if not (ih1 and ih2):
+                continue
+            ch = self._history_after_training(ih1)
+            for impression in ih2:
+                hist = ch.get_ids()
+                head = (user,) if self.has_user else ()
+                yield ([head + (hist, [p], 1) for p in impression.pos] +
+                       [head + (hist, [n], 0) for n in impression.neg])
+                for pos in impression.pos:
+                    ch.push(pos)
+
+    def _history_after_training(self, ih1):
+        ch = self.Window(self.docs, self.config.window_size)
+        for impression in ih1:
+            for pos in impression.pos:
+                ch.push(pos)
+        return ch
+
+    # ---- batching ------------------------------------------------------------
+    def _stack_ids(self, samples):
+        cols = list(zip(*samples))
+        labels = np.stack(cols[-1])
+        hist = np.stack(cols[-3]).astype(np.int32)
+        cands = np.array(cols[-2], dtype=np.int32)
+        if self.has_user:
+            return (np.array(cols[0], dtype=np.int64), hist, cands), labels
+        return (hist, cands), labels
+
+    def _expand(self, samples):
+        ids, labels = self._stack_ids(samples)
+        hist, cands = ids[-2], ids[-1]
+        tf64 = self.docs.titles_f64
+        X = [tf64[hist]] + [tf64[cands[:, j]] for j in range(cands.shape[1])]
+        if self.has_user:
+            X = [ids[0]] + X
+        return X, labels
+
+    # ---- model -----------------------------------------------------------------
+    def _build_model(self):
+        from ..native_model import NativeModel
+        self.model = NativeModel.from_task(self, user_count=len(self.data) if self.has_user else 0)
+        self.test_model = self.model.test_view()
+
+    def callback(self, epoch):
+        """paper.py:497-524: lr *= decay every epoch; mean per-impression AUC / nDCG@10 / nDCG@5 / MRR."""
+        self.model.optimizer.lr = self.model.optimizer.lr * self.config.learning_rate_decay
+        self.model, self.test_model = self.test_model, self.model
+
+        def rows(limit):
+            for i, (y_pred, y_true) in zip(range(limit), self.test):
+                yield (roc_auc_score(y_true, y_pred), utils.ndcg_score(y_true, y_pred, 10),
+                       utils.ndcg_score(y_true, y_pred, 5), utils.mrr_score(y_true, y_pred),
+                       np.sum(y_true), len(y_true), i)
+
+        def report(limit):
+            v = [np.mean(x) for x in zip(*rows(limit))]
+            utils.logging_evaluation(dict(auc=v[0], ndcgx=v[1], ndcgv=v[2], mrr=v[3]))
+            utils.logging_evaluation(dict(pos=v[4], size=v[5], num=v[6] * 2 + 1))
+            return dict(auc=v[0], ndcgx=v[1], ndcgv=v[2], mrr=v[3])
+
+        self.last_metrics = report(self.config.validation_impression)
+        if epoch == self.config.epochs - 1:
+            self.is_training = False
+            self.last_metrics = report(self.config.testing_impression)
+        self.model, self.test_model = self.test_model, self.model
+
+
+class Seq2VecPaperSoftmaxId(Seq2VecPaperSoftmax):
+    """User id = row number of ClickData.tsv (paper.py:531)."""
+    has_user = True
+
+    def _users(self):
+        return enumerate(self.data)
