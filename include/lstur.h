@@ -1,0 +1,225 @@
+/*
+ * lstur.h -- C-ABI of liblstur_hip.so: the MI355X (gfx950) LSTUR training path.
+ *
+ * The reference (nvagus/mnexp) has no FFI: its seam is the Python task-handler protocol
+ * (task/__init__.py:15-16, main.py:66-94) and everything under `build_model()` is a Keras
+ * graph (task/paper.py:635-665).  This library replaces that graph.  Each entry point cites
+ * the reference construct it stands in for.  Conventions:
+ *   - extern "C", plain pointers and sizes, no torch types; every function returns
+ *     0 on success or a negative lstur_status; lstur_last_error() gives the message
+ *     (thread-local).  No exception crosses the boundary.
+ *   - the CALLER owns every device buffer (parameters, optimizer state, workspace) and the
+ *     HIP stream; the library only launches kernels on the stream it is given and never
+ *     allocates, frees or synchronises.  A context is re-entrant across contexts, not
+ *     thread-safe within one.
+ *   - all tensors are dense row-major fp32 / int32 device memory unless stated.
+ *
+ * Title batch layout: N_t = n*(W) history titles (sample-major) followed by n*K1 candidate
+ * titles (sample-major); candidate 0 of a training sample is the clicked (positive) one.
+ */
+#ifndef LSTUR_H
+#define LSTUR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lstur_ctx lstur_ctx;
+typedef void* lstur_stream;               /* hipStream_t */
+
+enum lstur_status {
+  LSTUR_OK = 0,
+  LSTUR_ERR_ARG = -1,        /* bad argument / unsupported shape */
+  LSTUR_ERR_HIP = -2,        /* a HIP call or kernel launch failed */
+  LSTUR_ERR_STATE = -3,      /* call order violated (e.g. buffers not bound) */
+  LSTUR_ERR_NOGPU = -4       /* no gfx950 device visible */
+};
+
+enum lstur_arch {            /* user encoders of Seq2VecPaperSoftmaxId.get_user_encoder, paper.py:584-633 */
+  LSTUR_ARCH_IGRU = 0,       /* LSTUR-ini: GRU(U)(x, initial_state=user_vec)            paper.py:612-613 */
+  LSTUR_ARCH_GRU = 1,        /* LSTUR-con: Dense(U)(concat[GRU(U)(x), user_vec])        paper.py:596-599 */
+  LSTUR_ARCH_HGRU = 2        /* LSTUR-con: concat[GRU(U/2)(x), Embedding(N_u, U/2)]     paper.py:603-607 */
+};
+
+typedef struct lstur_cfg {
+  int32_t max_batch;         /* largest n passed to train_step (-b)                                    */
+  int32_t window;            /* W  history length (-w / window_size)                                   */
+  int32_t title_len;         /* T  (--title-shape)                                                     */
+  int32_t cands;             /* K1 = negative_samples + 1 (-n)                                         */
+  int32_t vocab;             /* V  rows of the word table (utils.load_textual_embedding)               */
+  int32_t word_dim;          /* D  (--textual-embedding-dim); must be a multiple of 4                  */
+  int32_t filters;           /* F  (--title-filter-shape F k)                                          */
+  int32_t kernel;            /* k                                                                      */
+  int32_t user_dim;          /* U  (--user-embedding-dim) = doc-vector dim                             */
+  int32_t n_users;           /* rows of the user table = len(ClickData.tsv), paper.py:589              */
+  int32_t arch;              /* lstur_arch                                                             */
+  float dropout;             /* -d, applied after the embedding and before the attention, paper.py:147,158 */
+  uint32_t seed;             /* dropout stream seed                                                    */
+  float beta1, beta2, eps;   /* Keras Adam defaults .9 / .999 / 1e-7 (paper.py:657)                    */
+} lstur_cfg;
+
+/* Sizes (in floats unless named _bytes) the caller must allocate for a configuration. */
+typedef struct lstur_sizes {
+  size_t word_emb;           /* V*D                                                     */
+  size_t dense;              /* flat bucket of all dense parameters (see lstur_param)   */
+  size_t user_emb;           /* n_users * Ue  (Ue = U, or U/2 for hgru)                 */
+  size_t workspace_bytes;    /* scratch for one train_step / predict at max_batch       */
+  int32_t user_emb_dim;      /* Ue                                                      */
+  int32_t gru_dim;           /* H                                                       */
+  int32_t max_predict_rows;  /* largest n for lstur_predict with this workspace         */
+} lstur_sizes;
+
+typedef struct lstur_buffers {
+  float* word_emb;           /* [V, D]   frozen word table (Embedding weights, paper.py:132-138) */
+  float* dense_param;        /* [dense]  flat parameter bucket                          */
+  float* dense_grad;         /* [dense]  flat gradient bucket (all-reduced by the host under DP) */
+  float* dense_m;            /* [dense]  Adam first moment                              */
+  float* dense_v;            /* [dense]  Adam second moment                             */
+  float* user_emb;           /* [n_users, Ue] trainable user table (paper.py:589)       */
+  float* user_m;             /* [n_users, Ue]                                           */
+  float* user_v;             /* [n_users, Ue]                                           */
+  void* workspace;           /* workspace_bytes, 256-byte aligned                       */
+  size_t workspace_bytes;
+} lstur_buffers;
+
+const char* lstur_last_error(void);
+const char* lstur_version(void);
+
+/* Sizes for a configuration (no GPU needed). */
+int lstur_query_sizes(const lstur_cfg* cfg, lstur_sizes* out);
+
+/* Named slices of the dense bucket, in Keras-weight terms:
+ *   conv_w [k,D,F], conv_b [F]            Conv1D            paper.py:146
+ *   att_w [F], att_b [1]                  SimpleAttentionMaskSupport  models.py:456-468
+ *   dense_w [F,U], dense_b [U]            Dense(U)          paper.py:159
+ *   gru_w [U,3H], gru_u [H,3H], gru_b [3H] GRU (z|r|h)      paper.py:597-613
+ *   con_w [H+Ue,U], con_b [U]             Dense after concat (arch gru only) paper.py:599
+ * Returns offset/count in floats; LSTUR_ERR_ARG for an unknown name. */
+int lstur_param(const lstur_cfg* cfg, const char* name, size_t* offset, size_t* count);
+/* i-th parameter name in bucket order, NULL past the end. */
+const char* lstur_param_name(const lstur_cfg* cfg, int i);
+
+/* Replaces Seq2VecPaperSoftmaxId._build_model (paper.py:635-665): binds caller-owned buffers. */
+int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out);
+int lstur_destroy(lstur_ctx* ctx);
+
+/* Optional resident title table int32 [n_docs, T] (the reference keeps titles on the host,
+ * task/seq2vec.py:85-110); enables the *_ids entry points. */
+int lstur_set_title_table(lstur_ctx* ctx, const int32_t* titles, int32_t n_docs);
+
+/* One forward + backward of model.train_on_batch (inside fit_generator, main.py:73-78) WITHOUT
+ * the optimizer update: fills dense_grad (mean over the n samples, scaled by grad_scale) and the
+ * per-sample user-row gradients.
+ *   user  int32 [n]; hist int32 [n,W,T]; cands int32 [n,K1,T]   (token ids; 0 = pad)
+ *   step  = global step counter (selects the dropout stream)
+ *   stats = 2 device floats: mean categorical_crossentropy, categorical_accuracy (paper.py:655-659)
+ * grad_scale lets data-parallel callers pre-divide by the world size (1.0 otherwise). */
+int lstur_forward_backward(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands,
+                           int32_t n, uint32_t step, float grad_scale, float* stats, lstur_stream stream);
+/* Same with doc ids: hist_ids int32 [n,W], cand_ids int32 [n,K1] into the resident title table. */
+int lstur_forward_backward_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_ids,
+                               const int32_t* cand_ids, int32_t n, uint32_t step, float grad_scale,
+                               float* stats, lstur_stream stream);
+
+/* Per-sample sparse user-table gradient of the last forward_backward: rows int32 [n], grads [n,Ue]
+ * (device pointers into the workspace; what a DP host all-gathers). */
+int lstur_user_grad(lstur_ctx* ctx, const int32_t** rows, const float** grads, int32_t* n);
+
+/* keras.optimizers.Adam update (paper.py:657) of the dense bucket from dense_grad, and the DENSE
+ * update of the whole user table (TF-1 densifies the IndexedSlices gradient) from n_rows sparse
+ * rows (duplicates are summed in ascending order).  t = 1-based Adam iteration. */
+int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, const float* row_grads,
+                    int32_t n_rows, lstur_stream stream);
+
+/* test_model.predict (paper.py:661-665; task/seq2vec.py:206): sigmoid(u . d), one candidate per row.
+ *   user int32 [n]; hist int32 [n,W,T]; cand int32 [n,T]; scores float [n]; n <= max_predict_rows */
+int lstur_predict(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cand,
+                  int32_t n, float* scores, lstur_stream stream);
+int lstur_predict_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_ids, const int32_t* cand_ids,
+                      int32_t n, float* scores, lstur_stream stream);
+
+/* model.evaluate_generator step (main.py:83-87): forward only, no dropout; stats as above. */
+int lstur_evaluate(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands,
+                   int32_t n, float* stats, lstur_stream stream);
+
+/* Debug/inspection: device pointers to intermediates of the last call (valid until the next call).
+ * names: "doc_vec" [N_t,U], "user_vec" [n,U], "logits" [n,K1], "probs" [n,K1], "conv_out" [N_t,T,F],
+ *        "att_w" [N_t,T], "emb" [N_t,T+k-1,D] */
+int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* count);
+
+/* ---- per-kernel entry points (unit parity tests, micro-benchmarks) --------------------------- */
+
+/* keras.layers.Embedding gather (+ inverted Dropout, paper.py:132-147): out[i,:] = table[ids[i],:].
+ * With pad_rows = k-1 the output is the zero-padded per-title layout [N_t, T+k-1, D] the conv reads.
+ * key = 0 and drop = 0 disables dropout. */
+int lstur_gather_f32(const float* table, const int32_t* ids, float* out, int32_t n_titles, int32_t title_len,
+                     int32_t dim, int32_t pad_left, int32_t pad_right, float drop, uint32_t key,
+                     lstur_stream stream);
+/* Conv1D('same', relu) * (id != 0)  (paper.py:146-155) on the padded embedding layout.
+ * w_packed from lstur_pack_b(conv_w as [k*D, F]). */
+int lstur_conv1d_relu_mask_fwd(const float* emb_padded, const float* w_packed, const float* bias,
+                               const int32_t* ids, float* out, int32_t n_titles, int32_t title_len,
+                               int32_t dim, int32_t ksize, int32_t filters, lstur_stream stream);
+/* Conv1D kernel gradient: dW[k*D,F] = im2col(emb)^T . dOut ; scratch >= lstur_conv1d_wgrad_scratch() bytes. */
+size_t lstur_conv1d_wgrad_scratch(int32_t dim, int32_t ksize, int32_t filters);
+int lstur_conv1d_wgrad(const float* emb_padded, const float* dout, float* dw, void* scratch,
+                       int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters,
+                       lstur_stream stream);
+/* Pack a row-major B[K,N] (leading dim ldb) into the MFMA operand image [ceil(K/16)][ceil16(N)][16]. */
+size_t lstur_pack_b_floats(int32_t K, int32_t N);
+int lstur_pack_b(const float* B, int32_t ldb, int32_t K, int32_t N, float* packed, lstur_stream stream);
+/* Same image for B = Bt^T, Bt stored row-major [N, K] with leading dim ldb. */
+int lstur_pack_bt(const float* Bt, int32_t ldb, int32_t K, int32_t N, float* packed, lstur_stream stream);
+/* Masking + Dropout + SimpleAttentionMaskSupport (paper.py:157-158, models.py:474-489).
+ * conv_out [N_t,T,F] -> pooled [N_t,F]; saves att_tanh [N_t,T], att_weight [N_t,T]. */
+int lstur_attpool_fwd(const float* conv_out, const float* att_w, const float* att_b, float* pooled,
+                      float* att_tanh, float* att_weight, int32_t n_titles, int32_t title_len,
+                      int32_t filters, float drop, uint32_t key, lstur_stream stream);
+/* Backward of the above + ReLU'; dconv [N_t,T,F]; partial sums [n_part, 2F+1] reduced by the caller
+ * through lstur_colsum: layout per row = datt_w[F] | dconv_b[F] | datt_b. */
+int32_t lstur_attpool_bwd_parts(int32_t n_titles);
+int lstur_attpool_bwd(const float* conv_out, const float* att_w, const float* att_tanh,
+                      const float* att_weight, const float* dpooled, float* dconv, float* parts,
+                      int32_t n_titles, int32_t title_len, int32_t filters, float drop, uint32_t key,
+                      lstur_stream stream);
+/* out[j] (+)= sum_i x[i, j]   (bias gradients, partial-sum reduction) */
+int lstur_colsum(const float* x, int32_t rows, int32_t cols, int32_t ld, float* out, float scale,
+                 lstur_stream stream);
+/* C[M,N] = alpha * op(A) . op(B) + bias (row broadcast) ; op = transpose when ta/tb != 0.
+ * scratch (split-K partials) may be NULL for small K; size from lstur_gemm_scratch. */
+size_t lstur_gemm_scratch(int32_t M, int32_t N, int32_t K);
+int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int32_t ldb, int32_t tb,
+                   float* C, int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K,
+                   float alpha, void* scratch, lstur_stream stream);
+/* Masked Keras-2.2.4 GRU over W steps (paper.py:592,597-613; K.rnn mask semantics).
+ *   xw [n,W,3H] input projection incl. bias; gmask uint8 [n,W]; h0 [n,H] or NULL (zeros)
+ *   u_zr_packed = lstur_pack_b(gru_u[:, :2H]); u_h_packed = lstur_pack_b(gru_u[:, 2H:])  (ldb = 3H)
+ *   outputs hs [n,W+1,H], z/r/hh [n,W,H];  H <= 512 */
+int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
+                  const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int32_t n, int32_t W,
+                  int32_t H, lstur_stream stream);
+/* BPTT: dh_last [n,H] -> dgates [n,W,3H], rh [n,W,H] (= r * h_prev, operand of dU_h),
+ *   hprev [n,W,H] (= h_{t-1}, operand of dU_zr), dh0 [n,H].
+ *   ut_zr_packed = lstur_pack_bt(gru_u, 3H, 2H, H)      (U[:, :2H]^T as [2H, H])
+ *   ut_h_packed  = lstur_pack_bt(gru_u + 2H, 3H, H, H)  (U[:, 2H:]^T as [H, H]) */
+int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, const float* hs, const float* zs,
+                  const float* rs, const float* hhs, const float* ut_zr_packed, const float* ut_h_packed,
+                  float* dgates, float* rh, float* hprev, float* dh0, int32_t n, int32_t W, int32_t H,
+                  lstur_stream stream);
+/* dot scorer + softmax + categorical_crossentropy (paper.py:446-447,463,658) and its gradient.
+ *   u [n,U]; d [n,K1,U]; outputs logits/probs [n,K1], loss_i [n], correct_i [n], du [n,U], dd [n,K1,U]
+ *   (du/dd may be NULL: forward only).  inv_n scales the gradient (1/batch * grad_scale). */
+int lstur_score_softmax_ce(const float* u, const float* d, float* logits, float* probs, float* loss_i,
+                           float* correct_i, float* du, float* dd, int32_t n, int32_t K1, int32_t U,
+                           float inv_n, lstur_stream stream);
+/* Keras Adam on a flat fp32 array. */
+int lstur_adam_flat(float* p, const float* g, float* m, float* v, size_t count, float lr_t, float beta1,
+                    float beta2, float eps, lstur_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSTUR_H */

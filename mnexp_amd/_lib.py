@@ -1,0 +1,126 @@
+"""ctypes binding of liblstur_hip.so (C-ABI declared in include/lstur.h).
+
+There is NO CPU fallback: if the shared library is missing the import of this module
+raises, and ``lstur_create`` fails with LSTUR_ERR_NOGPU when no gfx950 device is visible.
+Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C mnexp_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblstur_hip.so')
+
+ARCH = {'igru': 0, 'gru': 1, 'hgru': 2}
+
+
+class LsturError(RuntimeError):
+    pass
+
+
+class Cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('max_batch', 'window', 'title_len', 'cands', 'vocab', 'word_dim',
+                                         'filters', 'kernel', 'user_dim', 'n_users', 'arch')] + [
+        ('dropout', C.c_float), ('seed', C.c_uint32), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float)]
+
+
+class Sizes(C.Structure):
+    _fields_ = [('word_emb', C.c_size_t), ('dense', C.c_size_t), ('user_emb', C.c_size_t),
+                ('workspace_bytes', C.c_size_t), ('user_emb_dim', C.c_int32), ('gru_dim', C.c_int32),
+                ('max_predict_rows', C.c_int32)]
+
+
+class Buffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('word_emb', 'dense_param', 'dense_grad', 'dense_m', 'dense_v',
+                                          'user_emb', 'user_m', 'user_v', 'workspace')] + [
+        ('workspace_bytes', C.c_size_t)]
+
+
+_P, _I, _U, _F, _Z = C.c_void_p, C.c_int32, C.c_uint32, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/lstur.h declares
+SIGNATURES = {
+    'lstur_last_error': (C.c_char_p, []),
+    'lstur_version': (C.c_char_p, []),
+    'lstur_query_sizes': (_I, [C.POINTER(Cfg), C.POINTER(Sizes)]),
+    'lstur_param': (_I, [C.POINTER(Cfg), C.c_char_p, C.POINTER(_Z), C.POINTER(_Z)]),
+    'lstur_param_name': (C.c_char_p, [C.POINTER(Cfg), _I]),
+    'lstur_create': (_I, [C.POINTER(Cfg), C.POINTER(Buffers), C.POINTER(_P)]),
+    'lstur_destroy': (_I, [_P]),
+    'lstur_set_title_table': (_I, [_P, _P, _I]),
+    'lstur_forward_backward': (_I, [_P, _P, _P, _P, _I, _U, _F, _P, _P]),
+    'lstur_forward_backward_ids': (_I, [_P, _P, _P, _P, _I, _U, _F, _P, _P]),
+    'lstur_user_grad': (_I, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I)]),
+    'lstur_adam_step': (_I, [_P, _F, _I, _P, _P, _I, _P]),
+    'lstur_predict': (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    'lstur_predict_ids': (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    'lstur_evaluate': (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    'lstur_peek': (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_Z)]),
+    'lstur_gather_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _P]),
+    'lstur_conv1d_relu_mask_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'lstur_conv1d_wgrad_scratch': (_Z, [_I, _I, _I]),
+    'lstur_conv1d_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'lstur_pack_b_floats': (_Z, [_I, _I]),
+    'lstur_pack_b': (_I, [_P, _I, _I, _I, _P, _P]),
+    'lstur_pack_bt': (_I, [_P, _I, _I, _I, _P, _P]),
+    'lstur_attpool_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _P]),
+    'lstur_attpool_bwd_parts': (_I, [_I]),
+    'lstur_attpool_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _P]),
+    'lstur_colsum': (_I, [_P, _I, _I, _I, _P, _F, _P]),
+    'lstur_gemm_scratch': (_Z, [_I, _I, _I]),
+    'lstur_gemm_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),
+    'lstur_gru_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'lstur_gru_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'lstur_score_softmax_ce': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    'lstur_adam_flat': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise LsturError(
+            'liblstur_hip.so is not built ({}): the LSTUR path is HIP-only and has no CPU fallback. '
+            'Run `make -C mnexp_amd/csrc` (hipcc, gfx950).'.format(LIB_PATH))
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise LsturError('{} failed ({}): {}'.format(what or 'lstur call', rc, lib.lstur_last_error().decode()))
+
+
+def make_cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
+             arch='igru', dropout=0.0, seed=0, beta1=0.9, beta2=0.999, eps=1e-7):
+    if arch not in ARCH:
+        raise LsturError('arch {!r} is not supported by the native path (have {})'.format(arch, sorted(ARCH)))
+    return Cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
+               ARCH[arch], dropout, seed, beta1, beta2, eps)
+
+
+def query_sizes(cfg):
+    s = Sizes()
+    check(lib.lstur_query_sizes(C.byref(cfg), C.byref(s)), 'lstur_query_sizes')
+    return s
+
+
+def param_layout(cfg):
+    """[(name, offset, count)] in bucket order."""
+    out = []
+    i = 0
+    while True:
+        nm = lib.lstur_param_name(C.byref(cfg), i)
+        if nm is None:
+            break
+        off, cnt = _Z(), _Z()
+        check(lib.lstur_param(C.byref(cfg), nm, C.byref(off), C.byref(cnt)), 'lstur_param')
+        out.append((nm.decode(), off.value, cnt.value))
+        i += 1
+    return out

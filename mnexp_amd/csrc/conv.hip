@@ -1,0 +1,328 @@
+// Conv1D over title tokens as an implicit-im2col fp32 MFMA contraction (gfx950).
+//
+// Reference op: keras.layers.Conv1D(F, k, padding='same', activation='relu') followed by the
+// pad-id mask Lambda (task/paper.py:146-155).  The embedding tensor is materialised ONCE per step in a
+// zero-padded per-title layout  E[n][pad_l + T + pad_r][D]  (misc.hip: gather_kernel), so the im2col
+// row of output token (n,t) is the CONTIGUOUS window  E_flat[(n*Tp + t)*D .. +k*D)  -- im2col is never
+// built, and both the forward (M = tokens, K = k*D, N = F) and the kernel gradient (M = k*D, N = F,
+// K = tokens) read plain row-major tiles.
+//
+// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD).  Operand lane map: A lane l holds
+// A[row l&15][k l>>4], B lane l holds B[k l>>4][col l&15]; C/D lane l, reg j: row (l>>4)*4+j, col l&15.
+#include "lstur_device.h"
+#include "lstur_internal.h"
+
+namespace lstur {
+
+// ---------------------------------------------------------------------------------------------
+// Forward.  Workgroup = WAVES waves; wave w owns 16 token rows x NTW column tiles (all of F when
+// NTW*16 >= F).  Per 16-deep K chunk: one float4 of A per lane straight from global (each A element is
+// reused by the wave's NTW tiles from registers), the packed-W chunk [NTW*16][16] through LDS
+// (double buffered, shared by all waves), NTW*4 MFMAs.  The k index inside a chunk is permuted
+// identically on both operands (lane kq supplies k = 4kq+s to MFMA s), which is legal for a sum.
+// ---------------------------------------------------------------------------------------------
+template <int NTW, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void conv_fwd_kernel(const float* __restrict__ E,
+                                                              const float* __restrict__ Wp,
+                                                              const float* __restrict__ bias,
+                                                              const int32_t* __restrict__ ids,
+                                                              float* __restrict__ C, int M, int T, int Tp, int D,
+                                                              int F, int Fp, int nchunk) {
+  static_assert(NTW >= 1 && WAVES >= 1, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CH = NTW * 256;  // floats per packed chunk of this column group
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int c = lane & 15, kq = lane >> 4;
+  const int tile0 = blockIdx.y * NTW;  // first column tile of this group
+  const int m0 = (blockIdx.x * WAVES + wv) * 16;
+
+  // A row of this lane (clamped so tail rows read valid memory; their results are not stored)
+  int mr = min(m0 + c, M - 1);
+  int n = mr / T, t = mr - n * T;
+  const float* arow = E + ((size_t)n * Tp + t) * D + kq * 4;
+
+  const float* wsrc = Wp + (size_t)tile0 * 256;  // + ch * Fp * 16
+  constexpr int NV4 = CH / 4;                    // float4 per chunk
+  constexpr int PER = (NV4 + WAVES * 64 - 1) / (WAVES * 64);
+  const int valid4 = min(NV4, (Fp / 16 - tile0) * 64);  // last column group may be partial
+  float4 stage[PER];
+
+  auto load_w = [&](int ch) {
+    const float4* src = (const float4*)(wsrc + (size_t)ch * Fp * 16);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int idx = tid + i * WAVES * 64;
+      stage[i] = (idx < valid4) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_w = [&](int buf) {
+    float4* dst = (float4*)(smem + buf * CH);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int idx = tid + i * WAVES * 64;
+      if (idx < NV4) dst[idx] = stage[i];
+    }
+  };
+
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_w(0);
+  store_w(0);
+  float4 a_cur = *(const float4*)(arow);
+  __syncthreads();
+
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    float4 a_nxt = a_cur;
+    if (ch + 1 < nchunk) {
+      load_w(ch + 1);
+      a_nxt = *(const float4*)(arow + (ch + 1) * 16);
+    }
+    const float* bs = smem + buf * CH + c * 16 + kq * 4;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      float4 b = *(const float4*)(bs + nt * 256);
+      acc[nt] = mfma16(a_cur.x, b.x, acc[nt]);
+      acc[nt] = mfma16(a_cur.y, b.y, acc[nt]);
+      acc[nt] = mfma16(a_cur.z, b.z, acc[nt]);
+      acc[nt] = mfma16(a_cur.w, b.w, acc[nt]);
+    }
+    if (ch + 1 < nchunk) store_w(buf ^ 1);
+    a_cur = a_nxt;
+    __syncthreads();
+  }
+
+  // epilogue: + bias, ReLU, * (id != 0)   (paper.py:146, 150-155)
+  const int rq = lane >> 4;
+  float keep[4];
+  int rows[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    rows[j] = m0 + rq * 4 + j;
+    keep[j] = (rows[j] < M && ids[rows[j]] != 0) ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    int col = (tile0 + nt) * 16 + c;
+    if (col < F) {
+      float bv = bias[col];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (rows[j] < M) C[(size_t)rows[j] * F + col] = fmaxf(acc[nt][j] + bv, 0.f) * keep[j];
+    }
+  }
+}
+
+void launch_conv_fwd(const float* emb, const float* w_packed, const float* bias, const int32_t* ids, float* out,
+                     int n_titles, int T, int D, int ksize, int F, hipStream_t s) {
+  int M = n_titles * T;
+  if (M == 0) return;
+  int Tp = T + ksize - 1, KD = ksize * D, Fp = ceil16(F), nchunk = cdiv(KD, 16), ntiles = Fp / 16;
+  if (ntiles == 25) {
+    constexpr int NTW = 25, WAVES = 8;
+    hipLaunchKernelGGL((conv_fwd_kernel<NTW, WAVES>), dim3(cdiv(M, WAVES * 16), 1), dim3(WAVES * 64),
+                       2 * NTW * 256 * sizeof(float), s, emb, w_packed, bias, ids, out, M, T, Tp, D, F, Fp, nchunk);
+  } else {
+    constexpr int NTW = 4, WAVES = 4;
+    hipLaunchKernelGGL((conv_fwd_kernel<NTW, WAVES>), dim3(cdiv(M, WAVES * 16), cdiv(ntiles, NTW)),
+                       dim3(WAVES * 64), 2 * NTW * 256 * sizeof(float), s, emb, w_packed, bias, ids, out, M, T, Tp,
+                       D, F, Fp, nchunk);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel gradient  dW[kk, f] = sum_tokens im2col[tok, kk] * dC[tok, f]   (kk in [0, k*D)).
+// Workgroup = WK x WN waves; wave tile = 64 kk x (CT*16) f.  The contraction index is the token, and
+// both operands are token-major with the OUTPUT index contiguous, so LDS tiles are straight copies:
+//   As[TK][64*WK] <- E_flat window rows,   Bs[TK][16*CT*WN] <- dC rows.
+// A lane (i, kq) reads ONE float4 As[4s+kq][64wk + 4i ..+3]; element e feeds the MFMA whose output
+// rows are kk = 64wk + 4i' + e  (an output-row permutation, undone in the store).  B lanes read b32.
+// grid = (kk blocks, splits); split partial slabs are reduced by colsum-style kernel below.
+// ---------------------------------------------------------------------------------------------
+template <int WK, int WN, int CT, int TK>
+__global__ __launch_bounds__(WK * WN * 64) void conv_wgrad_kernel(const float* __restrict__ E,
+                                                                  const float* __restrict__ dC,
+                                                                  float* __restrict__ part, int M, int T, int Tp,
+                                                                  int D, int KD, int F, int tok_per_split) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NTH = WK * WN * 64;
+  constexpr int AW = 64 * WK;        // A tile width (kk)
+  constexpr int BW = 16 * CT * WN;   // B tile width (f)
+  constexpr int STAGE = TK * (AW + BW);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wk = wv / WN, wn = wv - wk * WN;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int kk0 = blockIdx.x * AW;
+  const int f0 = blockIdx.z * BW;
+  const int tok_begin = blockIdx.y * tok_per_split;
+  const int tok_end = min(M, tok_begin + tok_per_split);
+
+  const bool fvec = (F & 3) == 0;
+  constexpr int A4 = TK * AW / 4, B4 = TK * BW / 4;
+  constexpr int PA = (A4 + NTH - 1) / NTH, PB = (B4 + NTH - 1) / NTH;
+  float4 sa[PA], sb[PB];
+
+  auto load_tiles = [&](int tok0) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      int idx = tid + p * NTH;
+      if (idx < A4) {
+        int r = idx / (AW / 4), x4 = idx - r * (AW / 4);
+        int m = min(tok0 + r, M - 1);  // tail rows: valid address; their dC row is zero
+        int n = m / T, t = m - n * T;
+        sa[p] = *(const float4*)(E + ((size_t)n * Tp + t) * D + kk0 + x4 * 4);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      int idx = tid + p * NTH;
+      if (idx < B4) {
+        int r = idx / (BW / 4), y4 = idx - r * (BW / 4);
+        int m = tok0 + r, f = f0 + y4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < tok_end) {
+          const float* src = dC + (size_t)m * F + f;
+          if (fvec && f + 3 < F) {
+            v = *(const float4*)src;
+          } else {
+            if (f < F) v.x = src[0];
+            if (f + 1 < F) v.y = src[1];
+            if (f + 2 < F) v.z = src[2];
+            if (f + 3 < F) v.w = src[3];
+          }
+        }
+        sb[p] = v;
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float4* da = (float4*)(smem + buf * STAGE);
+    float4* db = (float4*)(smem + buf * STAGE + TK * AW);
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      int idx = tid + p * NTH;
+      if (idx < A4) da[idx] = sa[p];
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      int idx = tid + p * NTH;
+      if (idx < B4) db[idx] = sb[p];
+    }
+  };
+
+  f32x4 acc[4][CT];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[e][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nstage = (tok_end > tok_begin) ? cdiv(tok_end - tok_begin, TK) : 0;
+  if (nstage > 0) {
+    load_tiles(tok_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstage) load_tiles(tok_begin + (st + 1) * TK);
+    const float* as = smem + buf * STAGE + wk * 64 + i16 * 4;
+    const float* bs = smem + buf * STAGE + TK * AW + wn * CT * 16 + i16;
+#pragma unroll
+    for (int s4 = 0; s4 < TK / 4; ++s4) {
+      float4 a = *(const float4*)(as + (s4 * 4 + kq) * AW);
+      float b[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) b[ct] = bs[(s4 * 4 + kq) * BW + ct * 16];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        acc[0][ct] = mfma16(a.x, b[ct], acc[0][ct]);
+        acc[1][ct] = mfma16(a.y, b[ct], acc[1][ct]);
+        acc[2][ct] = mfma16(a.z, b[ct], acc[2][ct]);
+        acc[3][ct] = mfma16(a.w, b[ct], acc[3][ct]);
+      }
+    }
+    if (st + 1 < nstage) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // partial slab [split][KD][F]; MFMA row (rq*4+j) of accumulator e is kk = kk0 + 64wk + 4(rq*4+j) + e
+  float* dst = part + (size_t)blockIdx.y * KD * F;
+  const int rq = lane >> 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      int f = f0 + (wn * CT + ct) * 16 + i16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int kk = kk0 + wk * 64 + 4 * (rq * 4 + j) + e;
+        if (kk < KD && f < F) dst[(size_t)kk * F + f] = acc[e][ct][j];
+      }
+    }
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ part, int nsplit, size_t count,
+                                    float* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float acc = 0.f;
+  for (int s = 0; s < nsplit; ++s) acc += part[(size_t)s * count + i];
+  out[i] = acc;
+}
+
+static int wgrad_splits(int kblocks, int fblocks) { return std::max(1, 256 / (kblocks * fblocks)); }
+
+struct WgradGeom {
+  int aw, bw, kblocks, fblocks, nsplit;
+  bool big;
+};
+static WgradGeom wgrad_geom(int D, int ksize, int F) {
+  WgradGeom g;
+  int KD = ksize * D;
+  g.big = (F == 400);
+  g.aw = g.big ? 192 : 128;
+  g.bw = g.big ? 400 : 64;
+  g.kblocks = cdiv(KD, g.aw);
+  g.fblocks = cdiv(F, g.bw);
+  g.nsplit = wgrad_splits(g.kblocks, g.fblocks);
+  return g;
+}
+
+size_t conv_wgrad_scratch_bytes(int D, int ksize, int F) {
+  WgradGeom g = wgrad_geom(D, ksize, F);
+  return (size_t)g.nsplit * ksize * D * F * sizeof(float);
+}
+
+void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
+                       int ksize, int F, hipStream_t s) {
+  int M = n_titles * T, Tp = T + ksize - 1, KD = ksize * D;
+  WgradGeom g = wgrad_geom(D, ksize, F);
+  constexpr int TK = 16;
+  int nsplit = std::min(g.nsplit, std::max(1, cdiv(M, TK)));
+  int tps = cdiv(cdiv(M, nsplit), TK) * TK;
+  nsplit = cdiv(M, tps);
+  float* part = (float*)scratch;
+  if (g.big) {
+    constexpr int WK = 3, WN = 5, CT = 5;
+    size_t lds = 2 * TK * (64 * WK + 16 * CT * WN) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<WK, WN, CT, TK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_kernel<WK, WN, CT, TK>), dim3(g.kblocks, nsplit, g.fblocks), dim3(WK * WN * 64),
+                       lds, s, emb, dout, part, M, T, Tp, D, KD, F, tps);
+  } else {
+    constexpr int WK = 2, WN = 2, CT = 2;
+    size_t lds = 2 * TK * (64 * WK + 16 * CT * WN) * sizeof(float);
+    hipLaunchKernelGGL((conv_wgrad_kernel<WK, WN, CT, TK>), dim3(g.kblocks, nsplit, g.fblocks), dim3(WK * WN * 64),
+                       lds, s, emb, dout, part, M, T, Tp, D, KD, F, tps);
+  }
+  size_t count = (size_t)KD * F;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdivz(count, 256)), dim3(256), 0, s, part, nsplit, count, dw);
+}
+
+}  // namespace lstur

@@ -1,0 +1,653 @@
+// C-ABI of liblstur_hip.so (include/lstur.h): context, workspace carving and the per-step kernel
+// sequence that replaces the Keras graph of Seq2VecPaperSoftmaxId._build_model
+// (reference task/paper.py:635-665).  No allocation, no synchronisation, no torch types.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lstur.h"
+#include "lstur_device.h"
+#include "lstur_internal.h"
+
+using namespace lstur;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+struct ParamSlot {
+  const char* name;
+  size_t offset, count;
+};
+
+struct Dims {
+  int B, W, T, K1, V, D, F, k, U, Nu, arch, H, Ue, Tp, KD;
+  int nt_max;   // titles per call
+  int n_cap;    // per-sample buffers
+  int rows_cap; // sparse user-grad rows per adam step
+};
+
+constexpr size_t kParamAlign = 64;  // floats
+
+bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
+  if (!c) {
+    *why = "cfg is NULL";
+    return false;
+  }
+  d->B = c->max_batch; d->W = c->window; d->T = c->title_len; d->K1 = c->cands; d->V = c->vocab;
+  d->D = c->word_dim; d->F = c->filters; d->k = c->kernel; d->U = c->user_dim; d->Nu = c->n_users;
+  d->arch = c->arch;
+  if (d->B < 1 || d->W < 1 || d->T < 1 || d->K1 < 1 || d->V < 1 || d->D < 1 || d->F < 1 || d->k < 1 || d->U < 1 ||
+      d->Nu < 1) {
+    *why = "all dimensions must be >= 1";
+    return false;
+  }
+  if (d->D % 4) {
+    *why = "word_dim must be a multiple of 4 (16-byte embedding rows)";
+    return false;
+  }
+  if (d->K1 > 64) {
+    *why = "cands (negative_samples + 1) must be <= 64";
+    return false;
+  }
+  if (d->F > 1024) {
+    *why = "filters must be <= 1024";
+    return false;
+  }
+  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_HGRU) {
+    *why = "unknown arch";
+    return false;
+  }
+  if (d->arch == LSTUR_ARCH_HGRU && (d->U % 2)) {
+    *why = "hgru needs an even user_dim";
+    return false;
+  }
+  if (!(c->dropout >= 0.f && c->dropout < 1.f)) {
+    *why = "dropout must be in [0, 1)";
+    return false;
+  }
+  d->H = d->arch == LSTUR_ARCH_HGRU ? d->U / 2 : d->U;
+  d->Ue = d->arch == LSTUR_ARCH_HGRU ? d->U / 2 : d->U;
+  if (d->H > 512) {
+    *why = "GRU width must be <= 512";
+    return false;
+  }
+  d->Tp = d->T + d->k - 1;
+  d->KD = d->k * d->D;
+  d->nt_max = d->B * (d->W + d->K1);
+  int pred_rows = d->nt_max / (d->W + 1);
+  d->n_cap = std::max(d->B, pred_rows);
+  d->rows_cap = d->B * 8;
+  return true;
+}
+
+std::vector<ParamSlot> param_layout(const Dims& d, size_t* total) {
+  std::vector<ParamSlot> v;
+  size_t off = 0;
+  auto add = [&](const char* n, size_t cnt) {
+    v.push_back({n, off, cnt});
+    off += (cnt + kParamAlign - 1) / kParamAlign * kParamAlign;
+  };
+  add("conv_w", (size_t)d.KD * d.F);
+  add("conv_b", d.F);
+  add("att_w", d.F);
+  add("att_b", 1);
+  add("dense_w", (size_t)d.F * d.U);
+  add("dense_b", d.U);
+  add("gru_w", (size_t)d.U * 3 * d.H);
+  add("gru_u", (size_t)d.H * 3 * d.H);
+  add("gru_b", 3 * d.H);
+  if (d.arch == LSTUR_ARCH_GRU) {
+    add("con_w", (size_t)(d.H + d.Ue) * d.U);
+    add("con_b", d.U);
+  }
+  *total = off;
+  return v;
+}
+
+// Workspace carving: identical in lstur_query_sizes and lstur_create.
+struct Workspace {
+  int32_t* ids; float* emb; float* conv; float* dconv; float* att_a; float* att_wt; float* pooled; float* dpooled;
+  float* docvec; float* ddocvec; uint8_t* hmask; uint8_t* gmask; float* uvec; float* xw; float* hs; float* zs;
+  float* rs; float* hhs; float* dgates; float* rh; float* hprev; float* dh0; float* hlast; float* dhlast;
+  float* cat; float* dcat; float* uservec; float* duser; float* du; float* logits; float* probs; float* loss_i;
+  float* correct_i; float* parts; float* conv_wp; float* u_zr_p; float* u_h_p; float* ut_zr_p; float* ut_h_p;
+  void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; int32_t* first; float* gsum; int32_t* slot;
+  int32_t* user_rows; float* scores; size_t bytes;
+};
+
+size_t max_gemm_scratch(const Dims& d) {
+  int nW = d.n_cap * d.W, nt = d.nt_max;
+  size_t m = 0;
+  auto upd = [&](int M, int N, int K) { m = std::max(m, gemm_scratch_bytes(M, N, K)); };
+  upd(nt, d.U, d.F);            // dense fwd
+  upd(nW, 3 * d.H, d.U);        // gru input projection
+  upd(d.F, d.U, nt);            // ddense_w
+  upd(nt, d.F, d.U);            // dpooled
+  upd(d.U, 3 * d.H, nW);        // dgru_w
+  upd(d.H, 2 * d.H, nW);        // dgru_u zr
+  upd(d.H, d.H, nW);            // dgru_u h
+  upd(nW, d.U, 3 * d.H);        // dx
+  upd(d.n_cap, d.U, d.H + d.Ue);
+  upd(d.H + d.Ue, d.U, d.n_cap);
+  upd(d.n_cap, d.H + d.Ue, d.U);
+  // split-K slab bound for any smaller runtime batch: (256/tiles + 1) * tiles * 64*64 floats < 8 MiB
+  return std::max(m, (size_t)8 << 20);
+}
+
+void carve(const Dims& d, void* base, Workspace* w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) -> void* {
+    void* p = base ? (void*)((char*)base + off) : nullptr;
+    off += (bytes + 255) / 256 * 256;
+    return p;
+  };
+  const size_t nt = d.nt_max, nc = d.n_cap, nW = (size_t)d.n_cap * d.W, f4 = sizeof(float);
+  w->ids = (int32_t*)take(nt * d.T * 4);
+  w->emb = (float*)take((nt * d.Tp * d.D + kEmbSlack) * f4);
+  w->conv = (float*)take(nt * d.T * d.F * f4);
+  w->dconv = (float*)take(nt * d.T * d.F * f4);
+  w->att_a = (float*)take(nt * d.T * f4);
+  w->att_wt = (float*)take(nt * d.T * f4);
+  w->pooled = (float*)take(nt * d.F * f4);
+  w->dpooled = (float*)take(nt * d.F * f4);
+  w->docvec = (float*)take(nt * d.U * f4);
+  w->ddocvec = (float*)take(nt * d.U * f4);
+  w->hmask = (uint8_t*)take(nW);
+  w->gmask = (uint8_t*)take(nW);
+  w->uvec = (float*)take(nc * d.Ue * f4);
+  w->xw = (float*)take(nW * 3 * d.H * f4);
+  w->hs = (float*)take(nc * (d.W + 1) * d.H * f4);
+  w->zs = (float*)take(nW * d.H * f4);
+  w->rs = (float*)take(nW * d.H * f4);
+  w->hhs = (float*)take(nW * d.H * f4);
+  w->dgates = (float*)take(nW * 3 * d.H * f4);
+  w->rh = (float*)take(nW * d.H * f4);
+  w->hprev = (float*)take(nW * d.H * f4);
+  w->dh0 = (float*)take(nc * d.H * f4);
+  w->hlast = (float*)take(nc * d.H * f4);
+  w->dhlast = (float*)take(nc * d.H * f4);
+  w->cat = (float*)take(nc * (d.H + d.Ue) * f4);
+  w->dcat = (float*)take(nc * (d.H + d.Ue) * f4);
+  w->uservec = (float*)take(nc * d.U * f4);
+  w->duser = (float*)take(nc * d.Ue * f4);
+  w->du = (float*)take(nc * d.U * f4);
+  w->logits = (float*)take(nc * d.K1 * f4);
+  w->probs = (float*)take(nc * d.K1 * f4);
+  w->loss_i = (float*)take(nc * f4);
+  w->correct_i = (float*)take(nc * f4);
+  w->parts = (float*)take((size_t)1024 * (2 * d.F + 1) * f4);
+  w->conv_wp = (float*)take(pack_b_floats(d.KD, d.F) * f4);
+  w->u_zr_p = (float*)take(pack_b_floats(d.H, 2 * d.H) * f4);
+  w->u_h_p = (float*)take(pack_b_floats(d.H, d.H) * f4);
+  w->ut_zr_p = (float*)take(pack_b_floats(2 * d.H, d.H) * f4);
+  w->ut_h_p = (float*)take(pack_b_floats(d.H, d.H) * f4);
+  w->wgrad_scratch = take(conv_wgrad_scratch_bytes(d.D, d.k, d.F));
+  w->gemm_scratch_bytes = max_gemm_scratch(d);
+  w->gemm_scratch = take(w->gemm_scratch_bytes);
+  w->first = (int32_t*)take((size_t)d.rows_cap * 4);
+  w->gsum = (float*)take((size_t)d.rows_cap * d.Ue * f4);
+  w->slot = (int32_t*)take((size_t)d.Nu * 4);
+  w->user_rows = (int32_t*)take(nc * 4);
+  w->scores = (float*)take(nc * f4);
+  w->bytes = off;
+}
+
+}  // namespace
+
+struct lstur_ctx {
+  lstur_cfg cfg;
+  Dims d;
+  lstur_buffers buf;
+  Workspace ws;
+  std::vector<ParamSlot> layout;
+  size_t dense_total;
+  const int32_t* title_table = nullptr;
+  int32_t n_docs = 0;
+  bool lazy_init_done = false;
+  int last_n = 0, last_k1 = 0;
+  float* P(const char* name) const {
+    for (auto& s : layout)
+      if (!strcmp(s.name, name)) return buf.dense_param + s.offset;
+    return nullptr;
+  }
+  float* G(const char* name) const {
+    for (auto& s : layout)
+      if (!strcmp(s.name, name)) return buf.dense_grad + s.offset;
+    return nullptr;
+  }
+};
+
+namespace {
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(LSTUR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  return LSTUR_OK;
+}
+
+void lazy_init(lstur_ctx* c, hipStream_t s) {
+  if (c->lazy_init_done) return;
+  const Dims& d = c->d;
+  (void)hipMemsetAsync(c->ws.emb + (size_t)d.nt_max * d.Tp * d.D, 0, kEmbSlack * sizeof(float), s);
+  launch_fill_i32(c->ws.slot, -1, d.Nu, s);
+  c->lazy_init_done = true;
+}
+
+// titles already in ws.ids as [n*W history | n*k1 candidates] ; runs the network up to user_vec / doc_vec
+void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training, uint32_t step, hipStream_t s) {
+  const Dims& d = c->d;
+  Workspace& w = c->ws;
+  const int nW = n * d.W, nt = nW + n * k1;
+  const float drop = training ? c->cfg.dropout : 0.f;
+  const uint32_t key0 = dropout_key(c->cfg.seed, step, 0), key1 = dropout_key(c->cfg.seed, step, 1);
+  lazy_init(c, s);
+  // operand images of the weights used by MFMA kernels this step
+  launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, s);
+  const float* gu = c->P("gru_u");
+  launch_pack_b(gu, 3 * d.H, d.H, 2 * d.H, w.u_zr_p, s);
+  launch_pack_b(gu + 2 * d.H, 3 * d.H, d.H, d.H, w.u_h_p, s);
+  // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
+  const int pl = (d.k - 1) / 2;
+  launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s);
+  launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, s);
+  launch_attpool_fwd(w.conv, c->P("att_w"), c->P("att_b"), w.pooled, w.att_a, w.att_wt, nt, d.T, d.F, drop, key1, s);
+  launch_gemm(w.pooled, d.F, 0, c->P("dense_w"), d.U, 0, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, 1.f,
+              w.gemm_scratch, s);
+  // user encoder (paper.py:584-633)
+  launch_hist_mask(w.ids, w.docvec, w.hmask, w.gmask, nW, d.T, d.U, s);
+  (void)hipMemcpyAsync(w.user_rows, user, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
+  launch_gather_rows(c->buf.user_emb, user, w.uvec, n, d.Ue, s);
+  launch_gemm(w.docvec, d.U, 0, c->P("gru_w"), 3 * d.H, 0, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, 1.f,
+              w.gemm_scratch, s);
+  launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.u_zr_p, w.u_h_p, w.hs, w.zs, w.rs,
+                 w.hhs, n, d.W, d.H, s);
+  (void)hipMemcpy2DAsync(w.hlast, (size_t)d.H * 4, w.hs + (size_t)d.W * d.H, (size_t)(d.W + 1) * d.H * 4,
+                         (size_t)d.H * 4, n, hipMemcpyDeviceToDevice, s);
+  if (d.arch == LSTUR_ARCH_IGRU) {
+    (void)hipMemcpyAsync(w.uservec, w.hlast, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
+  } else {
+    launch_concat2(w.hlast, d.H, w.uvec, d.Ue, w.cat, n, s);
+    if (d.arch == LSTUR_ARCH_GRU)
+      launch_gemm(w.cat, d.H + d.Ue, 0, c->P("con_w"), d.U, 0, w.uservec, d.U, c->P("con_b"), n, d.U, d.H + d.Ue, 1.f,
+                  w.gemm_scratch, s);
+    else
+      (void)hipMemcpyAsync(w.uservec, w.cat, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
+  }
+  c->last_n = n;
+  c->last_k1 = k1;
+}
+
+void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
+  const Dims& d = c->d;
+  Workspace& w = c->ws;
+  const int nW = n * d.W, nt = nW + n * d.K1;
+  const float drop = c->cfg.dropout;
+  const uint32_t key1 = dropout_key(c->cfg.seed, step, 1);
+  // user encoder head
+  const float* dhl = w.du;
+  if (d.arch == LSTUR_ARCH_GRU) {
+    launch_gemm(w.cat, d.H + d.Ue, 1, w.du, d.U, 0, c->G("con_w"), d.U, nullptr, d.H + d.Ue, d.U, n, 1.f,
+                w.gemm_scratch, s);
+    launch_colsum(w.du, n, d.U, d.U, c->G("con_b"), 1.f, s);
+    launch_gemm(w.du, d.U, 0, c->P("con_w"), d.U, 1, w.dcat, d.H + d.Ue, nullptr, n, d.H + d.Ue, d.U, 1.f,
+                w.gemm_scratch, s);
+    launch_split2(w.dcat, d.H, d.Ue, w.dhlast, w.duser, n, s);
+    dhl = w.dhlast;
+  } else if (d.arch == LSTUR_ARCH_HGRU) {
+    launch_split2(w.du, d.H, d.Ue, w.dhlast, w.duser, n, s);
+    dhl = w.dhlast;
+  }
+  const float* gu = c->P("gru_u");
+  launch_pack_b_t(gu, 3 * d.H, 2 * d.H, d.H, w.ut_zr_p, s);          // (U[:, :2H])^T  as [2H x H]
+  launch_pack_b_t(gu + 2 * d.H, 3 * d.H, d.H, d.H, w.ut_h_p, s);     // (U[:, 2H:])^T  as [H x H]
+  launch_gru_bwd(dhl, w.gmask, w.hs, w.zs, w.rs, w.hhs, w.ut_zr_p, w.ut_h_p, w.dgates, w.rh, w.hprev,
+                 d.arch == LSTUR_ARCH_IGRU ? w.duser : w.dh0, n, d.W, d.H, s);
+  // GRU parameter gradients
+  launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
+              w.gemm_scratch, s);
+  launch_colsum(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, s);
+  launch_gemm(w.hprev, d.H, 1, w.dgates, 3 * d.H, 0, c->G("gru_u"), 3 * d.H, nullptr, d.H, 2 * d.H, nW, 1.f,
+              w.gemm_scratch, s);
+  launch_gemm(w.rh, d.H, 1, w.dgates + 2 * d.H, 3 * d.H, 0, c->G("gru_u") + 2 * d.H, 3 * d.H, nullptr, d.H, d.H, nW,
+              1.f, w.gemm_scratch, s);
+  // d(history doc vectors) = dgates . gru_w^T, masked by the history mask (paper.py:644-645)
+  launch_gemm(w.dgates, 3 * d.H, 0, c->P("gru_w"), 3 * d.H, 1, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, 1.f,
+              w.gemm_scratch, s);
+  launch_scale_rows_u8(w.ddocvec, w.hmask, nW, d.U, s);
+  // news encoder backward (candidate rows of ddocvec were written by the scorer)
+  launch_gemm(w.pooled, d.F, 1, w.ddocvec, d.U, 0, c->G("dense_w"), d.U, nullptr, d.F, d.U, nt, 1.f, w.gemm_scratch, s);
+  launch_colsum(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, s);
+  launch_gemm(w.ddocvec, d.U, 0, c->P("dense_w"), d.U, 1, w.dpooled, d.F, nullptr, nt, d.F, d.U, 1.f, w.gemm_scratch, s);
+  launch_attpool_bwd(w.conv, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, nt, d.T, d.F, drop, key1, s);
+  const int np = attpool_bwd_parts(nt), ldp = 2 * d.F + 1;
+  launch_colsum(w.parts, np, d.F, ldp, c->G("att_w"), 1.f, s);
+  launch_colsum(w.parts + d.F, np, d.F, ldp, c->G("conv_b"), 1.f, s);
+  launch_colsum(w.parts + 2 * d.F, np, 1, ldp, c->G("att_b"), 1.f, s);
+  launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, s);
+}
+
+int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n, int k1, bool ids_form, hipStream_t s) {
+  const Dims& d = c->d;
+  Workspace& w = c->ws;
+  const size_t nW = (size_t)n * d.W;
+  if (ids_form) {
+    if (!c->title_table) return fail(LSTUR_ERR_STATE, "no title table bound (lstur_set_title_table)");
+    launch_expand_titles(c->title_table, hist, w.ids, (int)nW, d.T, s);
+    launch_expand_titles(c->title_table, cands, w.ids + nW * d.T, n * k1, d.T, s);
+  } else {
+    (void)hipMemcpyAsync(w.ids, hist, nW * d.T * 4, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(w.ids + nW * d.T, cands, (size_t)n * k1 * d.T * 4, hipMemcpyDeviceToDevice, s);
+  }
+  return LSTUR_OK;
+}
+
+int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int32_t* cands, int n, uint32_t step,
+               float grad_scale, float* stats, hipStream_t s, bool ids_form, bool backward, bool training) {
+  if (!c || !user || !hist || !cands) return fail(LSTUR_ERR_ARG, "NULL argument");
+  const Dims& d = c->d;
+  if (n < 1 || n > d.B) return fail(LSTUR_ERR_ARG, "n must be in [1, max_batch]");
+  int rc = stage_titles(c, hist, cands, n, d.K1, ids_form, s);
+  if (rc) return rc;
+  Workspace& w = c->ws;
+  run_forward(c, user, n, d.K1, training, step, s);
+  const int nW = n * d.W;
+  launch_score(w.uservec, w.docvec + (size_t)nW * d.U, w.logits, w.probs, w.loss_i, w.correct_i,
+               backward ? w.du : nullptr, backward ? w.ddocvec + (size_t)nW * d.U : nullptr, n, d.K1, d.U,
+               grad_scale / (float)n, s);
+  if (stats) launch_mean2(w.loss_i, w.correct_i, n, stats, s);
+  if (backward) run_backward(c, n, step, s);
+  return check_launch(backward ? "forward_backward" : "evaluate");
+}
+
+int predict_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int32_t* cand, int n, float* scores,
+                 hipStream_t s, bool ids_form) {
+  if (!c || !user || !hist || !cand || !scores) return fail(LSTUR_ERR_ARG, "NULL argument");
+  const Dims& d = c->d;
+  int cap = d.nt_max / (d.W + 1);
+  if (n < 1 || n > cap) return fail(LSTUR_ERR_ARG, "n exceeds max_predict_rows");
+  int rc = stage_titles(c, hist, cand, n, 1, ids_form, s);
+  if (rc) return rc;
+  run_forward(c, user, n, 1, false, 0, s);
+  launch_predict_score(c->ws.uservec, c->ws.docvec + (size_t)n * d.W * d.U, scores, n, d.U, s);
+  return check_launch("predict");
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* lstur_last_error(void) { return g_err.c_str(); }
+const char* lstur_version(void) { return "lstur-hip 0.1 (gfx950)"; }
+
+int lstur_query_sizes(const lstur_cfg* cfg, lstur_sizes* out) {
+  Dims d;
+  std::string why;
+  if (!out) return fail(LSTUR_ERR_ARG, "out is NULL");
+  if (!make_dims(cfg, &d, &why)) return fail(LSTUR_ERR_ARG, why);
+  size_t total;
+  param_layout(d, &total);
+  Workspace w;
+  carve(d, nullptr, &w);
+  out->word_emb = (size_t)d.V * d.D;
+  out->dense = total;
+  out->user_emb = (size_t)d.Nu * d.Ue;
+  out->workspace_bytes = w.bytes;
+  out->user_emb_dim = d.Ue;
+  out->gru_dim = d.H;
+  out->max_predict_rows = d.nt_max / (d.W + 1);
+  return LSTUR_OK;
+}
+
+int lstur_param(const lstur_cfg* cfg, const char* name, size_t* offset, size_t* count) {
+  Dims d;
+  std::string why;
+  if (!name) return fail(LSTUR_ERR_ARG, "name is NULL");
+  if (!make_dims(cfg, &d, &why)) return fail(LSTUR_ERR_ARG, why);
+  size_t total;
+  for (auto& s : param_layout(d, &total))
+    if (!strcmp(s.name, name)) {
+      if (offset) *offset = s.offset;
+      if (count) *count = s.count;
+      return LSTUR_OK;
+    }
+  return fail(LSTUR_ERR_ARG, std::string("unknown parameter ") + name);
+}
+
+const char* lstur_param_name(const lstur_cfg* cfg, int i) {
+  Dims d;
+  std::string why;
+  if (!make_dims(cfg, &d, &why)) return nullptr;
+  size_t total;
+  auto v = param_layout(d, &total);
+  return (i >= 0 && i < (int)v.size()) ? v[i].name : nullptr;
+}
+
+int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out) {
+  Dims d;
+  std::string why;
+  if (!buf || !out) return fail(LSTUR_ERR_ARG, "NULL argument");
+  if (!make_dims(cfg, &d, &why)) return fail(LSTUR_ERR_ARG, why);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(LSTUR_ERR_NOGPU, "no HIP device visible: the LSTUR path has no CPU fallback");
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+    return fail(LSTUR_ERR_HIP, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(LSTUR_ERR_NOGPU, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+  if (!buf->word_emb || !buf->dense_param || !buf->dense_grad || !buf->dense_m || !buf->dense_v || !buf->user_emb ||
+      !buf->user_m || !buf->user_v || !buf->workspace)
+    return fail(LSTUR_ERR_ARG, "every buffer must be bound");
+  if (((uintptr_t)buf->workspace & 255) || ((uintptr_t)buf->word_emb & 15) || ((uintptr_t)buf->dense_param & 15) ||
+      ((uintptr_t)buf->dense_grad & 15) || ((uintptr_t)buf->user_emb & 15))
+    return fail(LSTUR_ERR_ARG, "buffers must be 16-byte (workspace 256-byte) aligned");
+  lstur_ctx* c = new lstur_ctx();
+  c->cfg = *cfg;
+  c->d = d;
+  c->buf = *buf;
+  c->layout = param_layout(d, &c->dense_total);
+  carve(d, buf->workspace, &c->ws);
+  if (c->ws.bytes > buf->workspace_bytes) {
+    delete c;
+    return fail(LSTUR_ERR_ARG, "workspace too small (see lstur_query_sizes)");
+  }
+  *out = c;
+  return LSTUR_OK;
+}
+
+int lstur_destroy(lstur_ctx* ctx) {
+  delete ctx;
+  return LSTUR_OK;
+}
+
+int lstur_set_title_table(lstur_ctx* ctx, const int32_t* titles, int32_t n_docs) {
+  if (!ctx || !titles || n_docs < 1) return fail(LSTUR_ERR_ARG, "bad title table");
+  ctx->title_table = titles;
+  ctx->n_docs = n_docs;
+  return LSTUR_OK;
+}
+
+int lstur_forward_backward(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands, int32_t n,
+                           uint32_t step, float grad_scale, float* stats, lstur_stream stream) {
+  return train_impl(ctx, user, hist, cands, n, step, grad_scale, stats, (hipStream_t)stream, false, true, true);
+}
+int lstur_forward_backward_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_ids, const int32_t* cand_ids,
+                               int32_t n, uint32_t step, float grad_scale, float* stats, lstur_stream stream) {
+  return train_impl(ctx, user, hist_ids, cand_ids, n, step, grad_scale, stats, (hipStream_t)stream, true, true, true);
+}
+int lstur_evaluate(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands, int32_t n,
+                   float* stats, lstur_stream stream) {
+  return train_impl(ctx, user, hist, cands, n, 0, 1.f, stats, (hipStream_t)stream, false, false, false);
+}
+
+int lstur_user_grad(lstur_ctx* ctx, const int32_t** rows, const float** grads, int32_t* n) {
+  if (!ctx) return fail(LSTUR_ERR_ARG, "ctx is NULL");
+  if (rows) *rows = ctx->ws.user_rows;
+  if (grads) *grads = ctx->ws.duser;
+  if (n) *n = ctx->last_n;
+  return LSTUR_OK;
+}
+
+int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, const float* row_grads, int32_t n_rows,
+                    lstur_stream stream) {
+  if (!ctx || t < 1) return fail(LSTUR_ERR_ARG, "bad adam step");
+  hipStream_t s = (hipStream_t)stream;
+  const Dims& d = ctx->d;
+  const lstur_cfg& c = ctx->cfg;
+  if (!rows) {
+    rows = ctx->ws.user_rows;
+    row_grads = ctx->ws.duser;
+    n_rows = ctx->last_n;
+  }
+  if (n_rows < 0 || n_rows > d.rows_cap) return fail(LSTUR_ERR_ARG, "too many sparse rows for one adam step");
+  const float lr_t = lr * (sqrtf(1.0f - powf(c.beta2, (float)t)) / (1.0f - powf(c.beta1, (float)t)));
+  lazy_init(ctx, s);
+  launch_adam_flat(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v, ctx->dense_total,
+                   lr_t, c.beta1, c.beta2, c.eps, s);
+  launch_user_grad_combine(rows, row_grads, n_rows, d.Ue, ctx->ws.first, ctx->ws.gsum, ctx->ws.slot, s);
+  launch_adam_table(ctx->buf.user_emb, ctx->buf.user_m, ctx->buf.user_v, ctx->ws.slot, ctx->ws.gsum, d.Nu, d.Ue, lr_t,
+                    c.beta1, c.beta2, c.eps, s);
+  launch_user_slot_clear(rows, n_rows, ctx->ws.slot, s);
+  return check_launch("adam_step");
+}
+
+int lstur_predict(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cand, int32_t n,
+                  float* scores, lstur_stream stream) {
+  return predict_impl(ctx, user, hist, cand, n, scores, (hipStream_t)stream, false);
+}
+int lstur_predict_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_ids, const int32_t* cand_ids, int32_t n,
+                      float* scores, lstur_stream stream) {
+  return predict_impl(ctx, user, hist_ids, cand_ids, n, scores, (hipStream_t)stream, true);
+}
+
+int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* count) {
+  if (!ctx || !name || !ptr) return fail(LSTUR_ERR_ARG, "NULL argument");
+  const Dims& d = ctx->d;
+  const Workspace& w = ctx->ws;
+  const size_t n = ctx->last_n, k1 = ctx->last_k1, nt = n * (d.W + k1);
+  struct { const char* nm; const float* p; size_t cnt; } tab[] = {
+      {"doc_vec", w.docvec, nt * d.U},      {"user_vec", w.uservec, n * d.U},
+      {"logits", w.logits, n * k1},         {"probs", w.probs, n * k1},
+      {"conv_out", w.conv, nt * d.T * d.F}, {"att_w", w.att_wt, nt * d.T},
+      {"emb", w.emb, nt * d.Tp * d.D},      {"pooled", w.pooled, nt * d.F},
+      {"loss_i", w.loss_i, n},              {"user_grad", w.duser, n * d.Ue},
+      {"dconv", w.dconv, nt * d.T * d.F},   {"hs", w.hs, n * (d.W + 1) * d.H},
+      {"dgates", w.dgates, n * d.W * 3 * d.H}, {"ddoc_vec", w.ddocvec, nt * d.U},
+  };
+  for (auto& e : tab)
+    if (!strcmp(e.nm, name)) {
+      *ptr = e.p;
+      if (count) *count = e.cnt;
+      return LSTUR_OK;
+    }
+  return fail(LSTUR_ERR_ARG, std::string("unknown intermediate ") + name);
+}
+
+// ---- per-kernel entry points ---------------------------------------------------------------------
+int lstur_gather_f32(const float* table, const int32_t* ids, float* out, int32_t n_titles, int32_t title_len,
+                     int32_t dim, int32_t pad_left, int32_t pad_right, float drop, uint32_t key, lstur_stream stream) {
+  if (!table || !ids || !out || dim % 4 || n_titles < 0) return fail(LSTUR_ERR_ARG, "gather: bad argument (dim % 4)");
+  launch_gather(table, ids, out, n_titles, title_len, dim, pad_left, pad_right, drop, key, (hipStream_t)stream);
+  return check_launch("gather");
+}
+int lstur_conv1d_relu_mask_fwd(const float* emb_padded, const float* w_packed, const float* bias, const int32_t* ids,
+                               float* out, int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize,
+                               int32_t filters, lstur_stream stream) {
+  if (!emb_padded || !w_packed || !bias || !ids || !out || dim % 4) return fail(LSTUR_ERR_ARG, "conv fwd: bad argument");
+  launch_conv_fwd(emb_padded, w_packed, bias, ids, out, n_titles, title_len, dim, ksize, filters, (hipStream_t)stream);
+  return check_launch("conv_fwd");
+}
+size_t lstur_conv1d_wgrad_scratch(int32_t dim, int32_t ksize, int32_t filters) {
+  return conv_wgrad_scratch_bytes(dim, ksize, filters);
+}
+int lstur_conv1d_wgrad(const float* emb_padded, const float* dout, float* dw, void* scratch, int32_t n_titles,
+                       int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, lstur_stream stream) {
+  if (!emb_padded || !dout || !dw || !scratch || dim % 4) return fail(LSTUR_ERR_ARG, "conv wgrad: bad argument");
+  launch_conv_wgrad(emb_padded, dout, dw, scratch, n_titles, title_len, dim, ksize, filters, (hipStream_t)stream);
+  return check_launch("conv_wgrad");
+}
+size_t lstur_pack_b_floats(int32_t K, int32_t N) { return pack_b_floats(K, N); }
+int lstur_pack_b(const float* B, int32_t ldb, int32_t K, int32_t N, float* packed, lstur_stream stream) {
+  if (!B || !packed) return fail(LSTUR_ERR_ARG, "pack_b: NULL");
+  launch_pack_b(B, ldb, K, N, packed, (hipStream_t)stream);
+  return check_launch("pack_b");
+}
+int lstur_pack_bt(const float* Bt, int32_t ldb, int32_t K, int32_t N, float* packed, lstur_stream stream) {
+  if (!Bt || !packed) return fail(LSTUR_ERR_ARG, "pack_bt: NULL");
+  launch_pack_b_t(Bt, ldb, K, N, packed, (hipStream_t)stream);
+  return check_launch("pack_bt");
+}
+int lstur_attpool_fwd(const float* conv_out, const float* att_w, const float* att_b, float* pooled, float* att_tanh,
+                      float* att_weight, int32_t n_titles, int32_t title_len, int32_t filters, float drop, uint32_t key,
+                      lstur_stream stream) {
+  if (!conv_out || !att_w || !att_b || !pooled || !att_tanh || !att_weight) return fail(LSTUR_ERR_ARG, "attpool: NULL");
+  launch_attpool_fwd(conv_out, att_w, att_b, pooled, att_tanh, att_weight, n_titles, title_len, filters, drop, key,
+                     (hipStream_t)stream);
+  return check_launch("attpool_fwd");
+}
+int32_t lstur_attpool_bwd_parts(int32_t n_titles) { return attpool_bwd_parts(n_titles); }
+int lstur_attpool_bwd(const float* conv_out, const float* att_w, const float* att_tanh, const float* att_weight,
+                      const float* dpooled, float* dconv, float* parts, int32_t n_titles, int32_t title_len,
+                      int32_t filters, float drop, uint32_t key, lstur_stream stream) {
+  if (!conv_out || !att_w || !att_tanh || !att_weight || !dpooled || !dconv || !parts || filters > 1024)
+    return fail(LSTUR_ERR_ARG, "attpool bwd: bad argument");
+  launch_attpool_bwd(conv_out, att_w, att_tanh, att_weight, dpooled, dconv, parts, n_titles, title_len, filters, drop,
+                     key, (hipStream_t)stream);
+  return check_launch("attpool_bwd");
+}
+int lstur_colsum(const float* x, int32_t rows, int32_t cols, int32_t ld, float* out, float scale, lstur_stream stream) {
+  if (!x || !out) return fail(LSTUR_ERR_ARG, "colsum: NULL");
+  launch_colsum(x, rows, cols, ld, out, scale, (hipStream_t)stream);
+  return check_launch("colsum");
+}
+size_t lstur_gemm_scratch(int32_t M, int32_t N, int32_t K) { return gemm_scratch_bytes(M, N, K); }
+int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int32_t ldb, int32_t tb, float* C,
+                   int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, void* scratch,
+                   lstur_stream stream) {
+  if (!A || !B || !C) return fail(LSTUR_ERR_ARG, "gemm: NULL");
+  launch_gemm(A, lda, ta, B, ldb, tb, C, ldc, bias, M, N, K, alpha, scratch, (hipStream_t)stream);
+  return check_launch("gemm");
+}
+int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
+                  const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int32_t n, int32_t W, int32_t H,
+                  lstur_stream stream) {
+  if (!xw || !gmask || !u_zr_packed || !u_h_packed || !hs || !zs || !rs || !hhs || H > 512)
+    return fail(LSTUR_ERR_ARG, "gru fwd: bad argument");
+  launch_gru_fwd(xw, gmask, h0, u_zr_packed, u_h_packed, hs, zs, rs, hhs, n, W, H, (hipStream_t)stream);
+  return check_launch("gru_fwd");
+}
+int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, const float* hs, const float* zs, const float* rs,
+                  const float* hhs, const float* ut_zr_packed, const float* ut_h_packed, float* dgates, float* rh,
+                  float* hprev, float* dh0, int32_t n, int32_t W, int32_t H, lstur_stream stream) {
+  if (!dh_last || !gmask || !hs || !zs || !rs || !hhs || !ut_zr_packed || !ut_h_packed || !dgates || !rh || !hprev ||
+      !dh0 || H > 512)
+    return fail(LSTUR_ERR_ARG, "gru bwd: bad argument");
+  launch_gru_bwd(dh_last, gmask, hs, zs, rs, hhs, ut_zr_packed, ut_h_packed, dgates, rh, hprev, dh0, n, W, H,
+                 (hipStream_t)stream);
+  return check_launch("gru_bwd");
+}
+int lstur_score_softmax_ce(const float* u, const float* d, float* logits, float* probs, float* loss_i, float* correct_i,
+                           float* du, float* dd, int32_t n, int32_t K1, int32_t U, float inv_n, lstur_stream stream) {
+  if (!u || !d || !logits || !probs || !loss_i || !correct_i || K1 > 64) return fail(LSTUR_ERR_ARG, "score: bad argument");
+  launch_score(u, d, logits, probs, loss_i, correct_i, du, dd, n, K1, U, inv_n, (hipStream_t)stream);
+  return check_launch("score");
+}
+int lstur_adam_flat(float* p, const float* g, float* m, float* v, size_t count, float lr_t, float beta1, float beta2,
+                    float eps, lstur_stream stream) {
+  if (!p || !g || !m || !v) return fail(LSTUR_ERR_ARG, "adam: NULL");
+  launch_adam_flat(p, g, m, v, count, lr_t, beta1, beta2, eps, (hipStream_t)stream);
+  return check_launch("adam_flat");
+}
+
+}  // extern "C"

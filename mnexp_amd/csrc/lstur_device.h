@@ -1,0 +1,49 @@
+// Device-side helpers shared by the gfx950 kernels of liblstur_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LSTUR_EPS 1e-7f  // keras.backend.epsilon()
+
+namespace lstur {
+
+// ---- counter-based dropout hash (restated in oracle/lstur_oracle.py: dropout_keep) ---------
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+__host__ __device__ __forceinline__ uint32_t dropout_key(uint32_t seed, uint32_t step, uint32_t stream) {
+  uint32_t k = fmix32(seed + 0x9E3779B9u * (stream + 1u));
+  return fmix32(k ^ (step * 0x7FEB352Du + 0x165667B1u));
+}
+__host__ __device__ __forceinline__ uint32_t dropout_thresh(float p) { return (uint32_t)(p * 16777216.0f); }
+// keep element idx?  (thresh == 0 keeps everything)
+__device__ __forceinline__ bool keep_elem(uint32_t key, uint32_t idx, uint32_t thresh) {
+  return (fmix32(idx * 0x9E3779B1u + key) >> 8) >= thresh;
+}
+
+// ---- wave (64 lanes) reductions ---------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float hard_sigmoid(float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.0f), 1.0f); }
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+}  // namespace lstur

@@ -1,0 +1,85 @@
+// Host-side launcher prototypes (one per kernel family); implemented in the *.hip files,
+// orchestrated by lstur_capi.hip.  All launch on the given stream and never synchronise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+namespace lstur {
+
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int ceil16(int a) { return (a + 15) & ~15; }
+
+// floats of slack the padded embedding buffer carries past its last row so that MFMA operand
+// loads running past k*D (K padded to 16 / 64) stay inside the allocation.
+constexpr int kEmbSlack = 256;
+
+// ---- misc.hip ----------------------------------------------------------------------------------
+void launch_gather(const float* table, const int32_t* ids, float* out, int n_titles, int T, int D,
+                   int pad_l, int pad_r, float drop, uint32_t key, hipStream_t s);
+void launch_expand_titles(const int32_t* table, const int32_t* doc_ids, int32_t* out, int n, int T,
+                          hipStream_t s);
+size_t pack_b_floats(int K, int N);
+void launch_pack_b(const float* B, int ldb, int K, int N, float* packed, hipStream_t s);
+void launch_pack_b_t(const float* Bt, int ldb, int K, int N, float* packed, hipStream_t s);
+// out[r][c] = in[c][r]  (in is [rows_in, cols_in] with leading dim ld_in)
+void launch_transpose(const float* in, int ld_in, int rows_in, int cols_in, float* out, hipStream_t s);
+void launch_colsum(const float* x, int rows, int cols, int ld, float* out, float scale, hipStream_t s);
+void launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1,
+                      float b2, float eps, hipStream_t s);
+// dense Adam sweep of the user table; slot[row] = index into gsum or -1
+void launch_adam_table(float* p, float* m, float* v, const int32_t* slot, const float* gsum, int n_rows,
+                       int dim, float lr_t, float b1, float b2, float eps, hipStream_t s);
+// dedupe rows -> slot map + summed grads (ascending sample order); first[i] scratch int32 [n]
+void launch_user_grad_combine(const int32_t* rows, const float* g, int n, int dim, int32_t* first,
+                              float* gsum, int32_t* slot, hipStream_t s);
+void launch_user_slot_clear(const int32_t* rows, int n, int32_t* slot, hipStream_t s);
+void launch_fill_i32(int32_t* p, int32_t v, size_t n, hipStream_t s);
+// history mask (ComputeMasking) applied to doc vectors + GRU step mask:  hv[b,w,:] *= any(ids != 0);
+// gmask[b,w] = any(hv != 0)
+void launch_hist_mask(const int32_t* hist_ids, float* hv, uint8_t* hmask, uint8_t* gmask, int nW, int T,
+                      int U, hipStream_t s);
+void launch_scale_rows_u8(float* x, const uint8_t* mask, int rows, int cols, hipStream_t s);
+void launch_gather_rows(const float* table, const int32_t* rows, float* out, int n, int dim, hipStream_t s);
+// concat: out[b, :a_cols] = a[b], out[b, a_cols:] = bm[b]
+void launch_concat2(const float* a, int a_cols, const float* bm, int b_cols, float* out, int n, hipStream_t s);
+void launch_split2(const float* in, int a_cols, int b_cols, float* a, float* bm, int n, hipStream_t s);
+void launch_score(const float* u, const float* d, float* logits, float* probs, float* loss_i, float* correct_i,
+                  float* du, float* dd, int n, int K1, int U, float inv_n, hipStream_t s);
+void launch_predict_score(const float* u, const float* d, float* scores, int n, int U, hipStream_t s);
+// stats[0] = mean(loss_i), stats[1] = mean(correct_i)
+void launch_mean2(const float* a, const float* b, int n, float* stats, hipStream_t s);
+
+// ---- conv.hip ----------------------------------------------------------------------------------
+void launch_conv_fwd(const float* emb, const float* w_packed, const float* bias, const int32_t* ids,
+                     float* out, int n_titles, int T, int D, int ksize, int F, hipStream_t s);
+size_t conv_wgrad_scratch_bytes(int D, int ksize, int F);
+void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scratch, int n_titles, int T,
+                       int D, int ksize, int F, hipStream_t s);
+
+// ---- attpool.hip -------------------------------------------------------------------------------
+void launch_attpool_fwd(const float* c, const float* att_w, const float* att_b, float* pooled, float* a,
+                        float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s);
+int attpool_bwd_parts(int n_titles);
+void launch_attpool_bwd(const float* c, const float* att_w, const float* a, const float* w,
+                        const float* dpooled, float* dc, float* parts, int n_titles, int T, int F, float drop,
+                        uint32_t key, hipStream_t s);
+
+// ---- gemm.hip ----------------------------------------------------------------------------------
+size_t gemm_scratch_bytes(int M, int N, int K);
+void launch_gemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, float* C, int ldc,
+                 const float* bias, int M, int N, int K, float alpha, void* scratch, hipStream_t s);
+
+// ---- gru.hip -----------------------------------------------------------------------------------
+// u_zr_packed = pack_b(U[:, :2H]), u_h_packed = pack_b(U[:, 2H:]);  requires H <= 512
+void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
+                    const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int n, int W, int H,
+                    hipStream_t s);
+void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, const float* hs, const float* zs,
+                    const float* rs, const float* hhs, const float* ut_zr_packed, const float* ut_h_packed,
+                    float* dgates, float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s);
+
+}  // namespace lstur

@@ -1,0 +1,462 @@
+// HBM-bound and glue kernels of the LSTUR path (gfx950): embedding gather (+dropout), operand
+// packing, reductions, Keras-Adam (flat bucket and dense user-table sweep), scorer/softmax/CE.
+#include "lstur_device.h"
+#include "lstur_internal.h"
+
+namespace lstur {
+
+// ---------------------------------------------------------------------------------------------
+// Word-embedding gather -> zero-padded per-title layout [N_t][pad_l + T + pad_r][D]
+//   (keras.layers.Embedding + Dropout, reference task/paper.py:132-147; pad id 0 is gathered too)
+// One 16-byte access per lane on both sides: a table row (D*4 B, 1200 B at D=300) is read by
+// D/4 consecutive lanes, so every wave instruction covers whole 64-B segments of a row.
+// ---------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ table,
+                                                     const int32_t* __restrict__ ids,
+                                                     float4* __restrict__ out, uint32_t total4, int T, int Tp,
+                                                     int D4, int pad_l, uint32_t thresh, uint32_t key,
+                                                     float scale) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+    uint32_t row = i / (uint32_t)D4;
+    uint32_t c4 = i - row * (uint32_t)D4;
+    uint32_t n = row / (uint32_t)Tp;
+    int t = (int)(row - n * (uint32_t)Tp) - pad_l;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < T) {
+      uint32_t tok = n * (uint32_t)T + (uint32_t)t;
+      int id = ids[tok];
+      v = table[(size_t)id * D4 + c4];
+      if (DROP) {
+        uint32_t e = (tok * (uint32_t)D4 + c4) * 4u;
+        v.x = keep_elem(key, e + 0u, thresh) ? v.x * scale : 0.f;
+        v.y = keep_elem(key, e + 1u, thresh) ? v.y * scale : 0.f;
+        v.z = keep_elem(key, e + 2u, thresh) ? v.z * scale : 0.f;
+        v.w = keep_elem(key, e + 3u, thresh) ? v.w * scale : 0.f;
+      }
+    }
+    out[i] = v;
+  }
+}
+
+void launch_gather(const float* table, const int32_t* ids, float* out, int n_titles, int T, int D, int pad_l,
+                   int pad_r, float drop, uint32_t key, hipStream_t s) {
+  int Tp = T + pad_l + pad_r, D4 = D / 4;
+  size_t total4 = (size_t)n_titles * Tp * D4;
+  if (total4 == 0) return;
+  int blocks = (int)std::min<size_t>(cdivz(total4, 256), 256 * 16);
+  if (drop > 0.f)
+    hipLaunchKernelGGL(gather_kernel<true>, dim3(blocks), dim3(256), 0, s, (const float4*)table, ids,
+                       (float4*)out, (uint32_t)total4, T, Tp, D4, pad_l, dropout_thresh(drop), key,
+                       1.0f / (1.0f - drop));
+  else
+    hipLaunchKernelGGL(gather_kernel<false>, dim3(blocks), dim3(256), 0, s, (const float4*)table, ids,
+                       (float4*)out, (uint32_t)total4, T, Tp, D4, pad_l, 0u, 0u, 1.0f);
+}
+
+// doc ids -> token ids through the resident title table
+__global__ void expand_titles_kernel(const int32_t* __restrict__ table, const int32_t* __restrict__ doc_ids,
+                                     int32_t* __restrict__ out, int total, int T) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int n = i / T, t = i - n * T;
+  out[i] = table[(size_t)doc_ids[n] * T + t];
+}
+void launch_expand_titles(const int32_t* table, const int32_t* doc_ids, int32_t* out, int n, int T,
+                          hipStream_t s) {
+  int total = n * T;
+  if (total) hipLaunchKernelGGL(expand_titles_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, table, doc_ids, out, total, T);
+}
+
+// ---------------------------------------------------------------------------------------------
+// B[K,N] -> MFMA operand image P[ceil(K/16)][ceil16(N)][16]:  P[ch][n][kk] = B[ch*16+kk][n]
+// A lane (c, kq) of mfma_f32_16x16x4 then reads ONE float4 P[ch][n0+c][4kq..4kq+3] and feeds
+// element s to MFMA s of the chunk (the k order inside a chunk is permuted identically on the
+// A side, which reads float4s along k).
+// ---------------------------------------------------------------------------------------------
+size_t pack_b_floats(int K, int N) { return (size_t)cdiv(K, 16) * ceil16(N) * 16; }
+
+template <bool TRANS>
+__global__ void pack_b_kernel(const float* __restrict__ B, int ldb, int K, int N, int Np, float* __restrict__ P,
+                              size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int n = (int)(i % Np);
+  size_t r = i / Np;
+  int kk = (int)(r % 16);
+  int ch = (int)(r / 16);
+  int k = ch * 16 + kk;
+  float v = 0.f;
+  if (k < K && n < N) v = TRANS ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
+  P[((size_t)ch * Np + n) * 16 + kk] = v;
+}
+void launch_pack_b(const float* B, int ldb, int K, int N, float* packed, hipStream_t s) {
+  size_t total = pack_b_floats(K, N);
+  if (total)
+    hipLaunchKernelGGL(pack_b_kernel<false>, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, B, ldb, K, N,
+                       ceil16(N), packed, total);
+}
+// same image for B = Bt^T where Bt is stored [N rows, K cols] with leading dim ldb
+void launch_pack_b_t(const float* Bt, int ldb, int K, int N, float* packed, hipStream_t s) {
+  size_t total = pack_b_floats(K, N);
+  if (total)
+    hipLaunchKernelGGL(pack_b_kernel<true>, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, Bt, ldb, K, N,
+                       ceil16(N), packed, total);
+}
+
+__global__ void transpose_kernel(const float* __restrict__ in, int ld_in, int rows, int cols,
+                                 float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    int r = r0 + j, c = c0 + threadIdx.x;
+    tile[j][threadIdx.x] = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    int c = c0 + j, r = r0 + threadIdx.x;
+    if (c < cols && r < rows) out[(size_t)c * rows + r] = tile[threadIdx.x][j];
+  }
+}
+void launch_transpose(const float* in, int ld_in, int rows_in, int cols_in, float* out, hipStream_t s) {
+  if (rows_in == 0 || cols_in == 0) return;
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols_in, 32), cdiv(rows_in, 32)), dim3(32, 8), 0, s, in, ld_in,
+                     rows_in, cols_in, out);
+}
+
+// out[j] = scale * sum_i x[i, j]   (fixed summation order -> bitwise reproducible)
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, int rows, int cols, int ld,
+                                                      float* __restrict__ out, float scale) {
+  __shared__ float red[16][64];
+  int c = blockIdx.x * 64 + threadIdx.x;
+  float acc = 0.f;
+  if (c < cols)
+    for (int r = threadIdx.y; r < rows; r += 16) acc += x[(size_t)r * ld + c];
+  red[threadIdx.y][threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.y == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+    out[c] = t * scale;
+  }
+}
+void launch_colsum(const float* x, int rows, int cols, int ld, float* out, float scale, hipStream_t s) {
+  if (cols) hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(64, 16), 0, s, x, rows, cols, ld, out, scale);
+}
+
+// ---------------------------------------------------------------------------------------------
+// keras.optimizers.Adam (Keras 2.2.4; reference task/paper.py:657):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr_t * m / (sqrt(v) + eps)
+// with lr_t = lr sqrt(1-b2^t)/(1-b1^t) computed by the caller.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr_t, float b1, float b2,
+                                      float eps) {
+  m = b1 * m + (1.0f - b1) * g;
+  v = b2 * v + (1.0f - b2) * (g * g);
+  p = p - lr_t * m / (sqrtf(v) + eps);
+}
+
+__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam1(pi, g[i], mi, vi, lr_t, b1, b2, eps);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+void launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
+                      float eps, hipStream_t s) {
+  if (!n) return;
+  int blocks = (int)std::min<size_t>(cdivz(n, 256), 4096);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps);
+}
+
+// Dense sweep of the user table: TF-1 Keras densifies the embedding gradient, so every row's m and v
+// decay and every row moves each step.  HBM-bound: 3 reads + 3 writes / elem.
+template <int VEC>
+__global__ __launch_bounds__(256) void adam_table_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                         float* __restrict__ v, const int32_t* __restrict__ slot,
+                                                         const float* __restrict__ gsum, size_t total, int dimv,
+                                                         float lr_t, float b1, float b2, float eps) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t row = i / dimv;
+    int c = (int)(i - row * dimv);
+    int sl = slot[row];
+    if (VEC == 4) {
+      float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sl >= 0) g = ((const float4*)gsum)[(size_t)sl * dimv + c];
+      adam1(pp.x, g.x, mm.x, vv.x, lr_t, b1, b2, eps);
+      adam1(pp.y, g.y, mm.y, vv.y, lr_t, b1, b2, eps);
+      adam1(pp.z, g.z, mm.z, vv.z, lr_t, b1, b2, eps);
+      adam1(pp.w, g.w, mm.w, vv.w, lr_t, b1, b2, eps);
+      ((float4*)p)[i] = pp;
+      ((float4*)m)[i] = mm;
+      ((float4*)v)[i] = vv;
+    } else {
+      float pp = p[i], mm = m[i], vv = v[i];
+      float g = sl >= 0 ? gsum[(size_t)sl * dimv + c] : 0.f;
+      adam1(pp, g, mm, vv, lr_t, b1, b2, eps);
+      p[i] = pp;
+      m[i] = mm;
+      v[i] = vv;
+    }
+  }
+}
+void launch_adam_table(float* p, float* m, float* v, const int32_t* slot, const float* gsum, int n_rows, int dim,
+                       float lr_t, float b1, float b2, float eps, hipStream_t s) {
+  if (!n_rows) return;
+  if (dim % 4 == 0) {
+    size_t total = (size_t)n_rows * (dim / 4);
+    int blocks = (int)std::min<size_t>(cdivz(total, 256), 256 * 32);
+    hipLaunchKernelGGL(adam_table_kernel<4>, dim3(blocks), dim3(256), 0, s, p, m, v, slot, gsum, total, dim / 4,
+                       lr_t, b1, b2, eps);
+  } else {
+    size_t total = (size_t)n_rows * dim;
+    int blocks = (int)std::min<size_t>(cdivz(total, 256), 256 * 32);
+    hipLaunchKernelGGL(adam_table_kernel<1>, dim3(blocks), dim3(256), 0, s, p, m, v, slot, gsum, total, dim, lr_t,
+                       b1, b2, eps);
+  }
+}
+
+// first[i] = smallest j with rows[j] == rows[i]
+__global__ void first_occurrence_kernel(const int32_t* __restrict__ rows, int n, int32_t* __restrict__ first) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int r = rows[i], f = i;
+  for (int j = 0; j < i; ++j)
+    if (rows[j] == r) {
+      f = j;
+      break;
+    }
+  first[i] = f;
+}
+// gsum[i,:] = sum over j (ascending) with first[j] == i of g[j,:]   (only for first occurrences)
+__global__ void combine_rows_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ first,
+                                    const float* __restrict__ g, int n, int dim, float* __restrict__ gsum,
+                                    int32_t* __restrict__ slot) {
+  int i = blockIdx.x;
+  if (first[i] != i) return;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+    float acc = g[(size_t)i * dim + c];
+    for (int j = i + 1; j < n; ++j)
+      if (first[j] == i) acc += g[(size_t)j * dim + c];
+    gsum[(size_t)i * dim + c] = acc;
+  }
+  if (threadIdx.x == 0) slot[rows[i]] = i;
+}
+void launch_user_grad_combine(const int32_t* rows, const float* g, int n, int dim, int32_t* first, float* gsum,
+                              int32_t* slot, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(first_occurrence_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, rows, n, first);
+  hipLaunchKernelGGL(combine_rows_kernel, dim3(n), dim3(64), 0, s, rows, first, g, n, dim, gsum, slot);
+}
+__global__ void slot_clear_kernel(const int32_t* __restrict__ rows, int n, int32_t* __restrict__ slot) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) slot[rows[i]] = -1;
+}
+void launch_user_slot_clear(const int32_t* rows, int n, int32_t* slot, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(slot_clear_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, rows, n, slot);
+}
+__global__ void fill_i32_kernel(int32_t* p, int32_t v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill_i32(int32_t* p, int32_t v, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)std::min<size_t>(cdivz(n, 256), 4096)), dim3(256), 0, s, p, v, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// models.ComputeMasking(0) on the clicked titles + multiply (reference models.py:20-30,
+// task/paper.py:644-645) and the user encoder's Masking() step mask (paper.py:592).  One wave per
+// history slot.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hist_mask_kernel(const int32_t* __restrict__ ids, float* __restrict__ hv,
+                                                        uint8_t* __restrict__ hmask, uint8_t* __restrict__ gmask,
+                                                        int nW, int T, int U) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= nW) return;
+  bool any_id = false;
+  for (int t = lane; t < T; t += 64) any_id |= ids[(size_t)row * T + t] != 0;
+  bool hm = __any(any_id);
+  bool nz = false;
+  for (int c = lane; c < U; c += 64) {
+    float v = hv[(size_t)row * U + c];
+    v = hm ? v : 0.f;
+    hv[(size_t)row * U + c] = v;
+    nz |= v != 0.f;
+  }
+  bool gm = __any(nz);
+  if (lane == 0) {
+    hmask[row] = hm;
+    gmask[row] = gm;
+  }
+}
+void launch_hist_mask(const int32_t* hist_ids, float* hv, uint8_t* hmask, uint8_t* gmask, int nW, int T, int U,
+                      hipStream_t s) {
+  if (nW) hipLaunchKernelGGL(hist_mask_kernel, dim3(cdiv(nW, 4)), dim3(256), 0, s, hist_ids, hv, hmask, gmask, nW, T, U);
+}
+
+__global__ void scale_rows_u8_kernel(float* __restrict__ x, const uint8_t* __restrict__ mask, size_t total, int cols) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total && !mask[i / cols]) x[i] = 0.f;
+}
+void launch_scale_rows_u8(float* x, const uint8_t* mask, int rows, int cols, hipStream_t s) {
+  size_t total = (size_t)rows * cols;
+  if (total) hipLaunchKernelGGL(scale_rows_u8_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, x, mask, total, cols);
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ rows,
+                                   float* __restrict__ out, int n, int dim) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * dim) return;
+  int b = i / dim, c = i - b * dim;
+  out[i] = table[(size_t)rows[b] * dim + c];
+}
+void launch_gather_rows(const float* table, const int32_t* rows, float* out, int n, int dim, hipStream_t s) {
+  if (n * dim) hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n * dim, 256)), dim3(256), 0, s, table, rows, out, n, dim);
+}
+
+__global__ void concat2_kernel(const float* __restrict__ a, int ac, const float* __restrict__ b, int bc,
+                               float* __restrict__ out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int w = ac + bc;
+  if (i >= n * w) return;
+  int r = i / w, c = i - r * w;
+  out[i] = c < ac ? a[(size_t)r * ac + c] : b[(size_t)r * bc + (c - ac)];
+}
+void launch_concat2(const float* a, int a_cols, const float* bm, int b_cols, float* out, int n, hipStream_t s) {
+  int total = n * (a_cols + b_cols);
+  if (total) hipLaunchKernelGGL(concat2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, a, a_cols, bm, b_cols, out, n);
+}
+__global__ void split2_kernel(const float* __restrict__ in, int ac, int bc, float* __restrict__ a,
+                              float* __restrict__ b, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int w = ac + bc;
+  if (i >= n * w) return;
+  int r = i / w, c = i - r * w;
+  if (c < ac)
+    a[(size_t)r * ac + c] = in[i];
+  else
+    b[(size_t)r * bc + (c - ac)] = in[i];
+}
+void launch_split2(const float* in, int a_cols, int b_cols, float* a, float* bm, int n, hipStream_t s) {
+  int total = n * (a_cols + b_cols);
+  if (total) hipLaunchKernelGGL(split2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, in, a_cols, b_cols, a, bm, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dot scorer over the 1+K candidates + softmax + Keras categorical_crossentropy on probabilities
+// (reference task/paper.py:446-447, 460-464, 658) with label [1,0,..,0], and the gradient wrt u, d.
+// One wave per sample.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxCands = 64;
+
+__global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ u, const float* __restrict__ d,
+                                                    float* __restrict__ logits, float* __restrict__ probs,
+                                                    float* __restrict__ loss_i, float* __restrict__ correct_i,
+                                                    float* __restrict__ du, float* __restrict__ dd, int n, int K1,
+                                                    int U, float inv_n) {
+  __shared__ float zs[4][kMaxCands];
+  int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int b = blockIdx.x * 4 + wv;
+  if (b >= n) return;
+  const float* ub = u + (size_t)b * U;
+  const float* db = d + (size_t)b * K1 * U;
+  for (int j = 0; j < K1; ++j) {
+    float acc = 0.f;
+    for (int c = lane; c < U; c += 64) acc += ub[c] * db[(size_t)j * U + c];
+    acc = wave_sum(acc);
+    if (lane == 0) zs[wv][j] = acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float zmax = -INFINITY;
+  for (int j = 0; j < K1; ++j) zmax = fmaxf(zmax, zs[wv][j]);
+  float esum = 0.f;
+  for (int j = 0; j < K1; ++j) esum += expf(zs[wv][j] - zmax);
+  float S = 0.f, p0 = 0.f, pmax = 0.f;
+  for (int j = 0; j < K1; ++j) {
+    float pj = expf(zs[wv][j] - zmax) / esum;
+    S += pj;
+    if (j == 0) p0 = pj;
+    pmax = fmaxf(pmax, pj);
+  }
+  float q0 = p0 / S;
+  float cq0 = fminf(fmaxf(q0, LSTUR_EPS), 1.0f - LSTUR_EPS);
+  bool inside = (q0 >= LSTUR_EPS) && (q0 <= 1.0f - LSTUR_EPS);
+  float gq0 = inside ? -1.0f / cq0 : 0.f;
+  // dL/dp_j = gq_j / S - (gq0 p0) / S^2 ; dz_j = p_j (dp_j - sum_i dp_i p_i)
+  float common = (gq0 * p0) / (S * S);
+  float dot = 0.f;
+  for (int j = 0; j < K1; ++j) {
+    float pj = expf(zs[wv][j] - zmax) / esum;
+    float dpj = (j == 0 ? gq0 / S : 0.f) - common;
+    dot += dpj * pj;
+  }
+  if (lane == 0) {
+    loss_i[b] = -logf(cq0);
+    correct_i[b] = (p0 >= pmax) ? 1.f : 0.f;
+  }
+  for (int j = lane; j < K1; j += 64) {
+    logits[(size_t)b * K1 + j] = zs[wv][j];
+    probs[(size_t)b * K1 + j] = expf(zs[wv][j] - zmax) / esum;
+  }
+  if (du == nullptr) return;
+  for (int c = lane; c < U; c += 64) {
+    float uc = ub[c], acc = 0.f;
+    for (int j = 0; j < K1; ++j) {
+      float pj = expf(zs[wv][j] - zmax) / esum;
+      float dpj = (j == 0 ? gq0 / S : 0.f) - common;
+      float dz = pj * (dpj - dot) * inv_n;
+      acc += dz * db[(size_t)j * U + c];
+      dd[((size_t)b * K1 + j) * U + c] = dz * uc;
+    }
+    du[(size_t)b * U + c] = acc;
+  }
+}
+void launch_score(const float* u, const float* d, float* logits, float* probs, float* loss_i, float* correct_i,
+                  float* du, float* dd, int n, int K1, int U, float inv_n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(score_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, u, d, logits, probs, loss_i, correct_i, du, dd, n, K1, U, inv_n);
+}
+
+__global__ __launch_bounds__(256) void predict_score_kernel(const float* __restrict__ u, const float* __restrict__ d,
+                                                            float* __restrict__ scores, int n, int U) {
+  int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= n) return;
+  float acc = 0.f;
+  for (int c = lane; c < U; c += 64) acc += u[(size_t)b * U + c] * d[(size_t)b * U + c];
+  acc = wave_sum(acc);
+  if (lane == 0) scores[b] = 1.0f / (1.0f + expf(-acc));
+}
+void launch_predict_score(const float* u, const float* d, float* scores, int n, int U, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(predict_score_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, u, d, scores, n, U);
+}
+
+__global__ __launch_bounds__(256) void mean2_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
+                                                    float* __restrict__ stats) {
+  __shared__ float ra[4], rb[4];
+  float sa = 0.f, sb = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    sa += a[i];
+    sb += b[i];
+  }
+  sa = wave_sum(sa);
+  sb = wave_sum(sb);
+  if ((threadIdx.x & 63) == 0) {
+    ra[threadIdx.x >> 6] = sa;
+    rb[threadIdx.x >> 6] = sb;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stats[0] = (ra[0] + ra[1] + ra[2] + ra[3]) / (float)n;
+    stats[1] = (rb[0] + rb[1] + rb[2] + rb[3]) / (float)n;
+  }
+}
+void launch_mean2(const float* a, const float* b, int n, float* stats, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(mean2_kernel, dim3(1), dim3(256), 0, s, a, b, n, stats);
+}
+
+}  // namespace lstur

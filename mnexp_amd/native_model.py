@@ -1,0 +1,326 @@
+"""Keras-like model object backed by liblstur_hip.so (HIP kernels for gfx950).
+
+Stands in for the ``keras.Model`` that ``Seq2VecPaperSoftmaxId._build_model`` compiles
+(/root/reference/task/paper.py:635-665) and exposes exactly what the reference's callers use:
+``fit_generator`` / ``evaluate_generator`` (main.py:73-87), ``predict`` (task/seq2vec.py:206),
+``metrics_names``, ``optimizer.lr`` (task/paper.py:498-499).  PyTorch-ROCm supplies device
+memory, the stream and (under data parallelism) RCCL collectives; all arithmetic of the model
+runs in the library.  There is no CPU path.
+"""
+import ctypes as C
+import logging
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+
+class History:
+    def __init__(self):
+        self.history = {}
+
+
+class _Optimizer:
+    """Carrier of the learning rate (``model.optimizer.lr`` get/set, task/paper.py:498-499)."""
+
+    def __init__(self, lr):
+        self.lr = float(lr)
+        self.iterations = 0
+
+
+def _glorot(rng, shape, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def _orthogonal(rng, rows, cols):
+    a = rng.normal(0.0, 1.0, size=(rows, cols))
+    u, _, vt = np.linalg.svd(a, full_matrices=False)
+    q = u if u.shape == (rows, cols) else vt
+    return np.ascontiguousarray(q[:rows, :cols], dtype=np.float32)
+
+
+class NativeModel:
+    metrics_names = ['loss', 'categorical_accuracy']
+
+    def __init__(self, word_emb, n_users, batch_size, window, title_len, negative_samples, filters, kernel,
+                 user_dim, arch='igru', dropout=0.2, lr=1e-3, seed=0, device=None, title_table=None,
+                 dist_group=None):
+        if not torch.cuda.is_available():
+            raise _lib.LsturError('no GPU visible: the native LSTUR model has no CPU fallback')
+        self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        word_emb = np.ascontiguousarray(word_emb, dtype=np.float32)
+        V, D = word_emb.shape
+        self.W, self.T, self.K1, self.B = window, title_len, negative_samples + 1, batch_size
+        self.arch = arch
+        self.cfg = _lib.make_cfg(batch_size, window, title_len, self.K1, V, D, filters, kernel, user_dim,
+                                 max(1, n_users), arch, dropout, seed)
+        self.sizes = _lib.query_sizes(self.cfg)
+        self.layout = _lib.param_layout(self.cfg)
+        H, Ue = self.sizes.gru_dim, self.sizes.user_emb_dim
+        self.shapes = dict(conv_w=(kernel, D, filters), conv_b=(filters,), att_w=(filters,), att_b=(1,),
+                           dense_w=(filters, user_dim), dense_b=(user_dim,), gru_w=(user_dim, 3 * H),
+                           gru_u=(H, 3 * H), gru_b=(3 * H,), con_w=(H + Ue, user_dim), con_b=(user_dim,),
+                           user_emb=(max(1, n_users), Ue), word_emb=(V, D))
+        dev = self.device
+        f32 = torch.float32
+        self.word_emb = torch.from_numpy(word_emb).to(dev)
+        self.dense_param = torch.zeros(self.sizes.dense, dtype=f32, device=dev)
+        self.dense_grad = torch.zeros(self.sizes.dense, dtype=f32, device=dev)
+        self.dense_m = torch.zeros(self.sizes.dense, dtype=f32, device=dev)
+        self.dense_v = torch.zeros(self.sizes.dense, dtype=f32, device=dev)
+        self.user_emb = torch.zeros(self.sizes.user_emb, dtype=f32, device=dev)
+        self.user_m = torch.zeros(self.sizes.user_emb, dtype=f32, device=dev)
+        self.user_v = torch.zeros(self.sizes.user_emb, dtype=f32, device=dev)
+        self.workspace = torch.zeros(self.sizes.workspace_bytes + 256, dtype=torch.uint8, device=dev)
+        ws_ptr = (self.workspace.data_ptr() + 255) // 256 * 256
+        self.stats = torch.zeros(2, dtype=f32, device=dev)
+        self.stats_acc = torch.zeros(2, dtype=f32, device=dev)
+        bufs = _lib.Buffers(self.word_emb.data_ptr(), self.dense_param.data_ptr(), self.dense_grad.data_ptr(),
+                            self.dense_m.data_ptr(), self.dense_v.data_ptr(), self.user_emb.data_ptr(),
+                            self.user_m.data_ptr(), self.user_v.data_ptr(), ws_ptr, self.sizes.workspace_bytes)
+        self._ctx = C.c_void_p()
+        check(lib.lstur_create(C.byref(self.cfg), C.byref(bufs), C.byref(self._ctx)), 'lstur_create')
+        self.optimizer = _Optimizer(lr)
+        self.step = 0                       # dropout stream / fit step counter
+        self.dist_group = dist_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(dist_group)
+        self.title_table = None
+        if title_table is not None:
+            self.set_title_table(title_table)
+        self._init_weights(np.random.RandomState(seed))
+
+    # ---- construction from a task handler ----------------------------------------
+    @classmethod
+    def from_task(cls, task, user_count):
+        cfg = task.config
+        from . import utils
+        if getattr(cfg, 'news_encoder', 'cnnatt') != 'cnnatt':
+            raise _lib.LsturError('only the cnnatt news encoder is on the native path')
+        if getattr(cfg, 'score_model', 'dot') != 'dot':
+            raise _lib.LsturError('only the dot scorer is on the native path')
+        if getattr(cfg, 'textual_embedding_trainable', False):
+            raise _lib.LsturError('--textual-embedding-trainable is not on the native path yet')
+        emb = utils.load_textual_embedding(cfg.title_embedding_input, cfg.textual_embedding_dim)
+        vmax = int(task.docs.title_table.max())
+        if vmax >= emb.shape[0]:
+            raise IndexError('title token id {} outside the {}-row word table'.format(vmax, emb.shape[0]))
+        filters, kernel = cfg.title_filter_shape
+        return cls(emb, user_count, cfg.batch_size, cfg.window_size, cfg.title_shape, cfg.negative_samples,
+                   int(filters), int(kernel), cfg.user_embedding_dim, arch=cfg.arch, dropout=cfg.dropout,
+                   lr=cfg.learning_rate, seed=int(getattr(cfg, 'seed', 0) or 0),
+                   title_table=task.docs.title_table)
+
+    def test_view(self):
+        """The reference swaps ``model``/``test_model`` around evaluation (task/paper.py:502,524); here one
+        object serves both roles because ``predict`` already has the test model's semantics."""
+        return self
+
+    # ---- weights -------------------------------------------------------------------
+    def _init_weights(self, rng):
+        """Keras initialisers of the layers the reference instantiates: glorot_uniform kernels, zero
+        biases, orthogonal recurrent kernel, uniform(+-0.05) embedding."""
+        s = self.shapes
+        k, D, F = s['conv_w']
+        U = s['dense_w'][1]
+        H = s['gru_u'][0]
+        w = dict(conv_w=_glorot(rng, s['conv_w'], k * D, k * F), conv_b=np.zeros(F, np.float32),
+                 att_w=_glorot(rng, s['att_w'], F, 1), att_b=np.zeros(1, np.float32),
+                 dense_w=_glorot(rng, s['dense_w'], F, U), dense_b=np.zeros(U, np.float32),
+                 gru_w=_glorot(rng, s['gru_w'], U, 3 * H), gru_u=_orthogonal(rng, H, 3 * H),
+                 gru_b=np.zeros(3 * H, np.float32),
+                 user_emb=rng.uniform(-0.05, 0.05, size=s['user_emb']).astype(np.float32))
+        if self.arch == 'gru':
+            w['con_w'] = _glorot(rng, s['con_w'], s['con_w'][0], U)
+            w['con_b'] = np.zeros(U, np.float32)
+        self.set_weights(w)
+
+    def param_names(self):
+        return [n for n, _, _ in self.layout] + ['user_emb']
+
+    def set_weights(self, weights):
+        """weights: dict name -> ndarray (any subset of param_names() + 'word_emb')."""
+        for name, arr in weights.items():
+            a = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)).to(self.device)
+            if name == 'user_emb':
+                self.user_emb.copy_(a)
+            elif name == 'word_emb':
+                self.word_emb.view(-1).copy_(a)
+            else:
+                off, cnt = self._slot(name)
+                if a.numel() != cnt:
+                    raise ValueError('{}: expected {} values, got {}'.format(name, cnt, a.numel()))
+                self.dense_param[off:off + cnt].copy_(a)
+
+    def _slot(self, name):
+        for n, off, cnt in self.layout:
+            if n == name:
+                return off, cnt
+        raise KeyError(name)
+
+    def _get(self, flat, name):
+        if name == 'user_emb':
+            return self.user_emb.cpu().numpy().reshape(self.shapes['user_emb'])
+        off, cnt = self._slot(name)
+        return flat[off:off + cnt].cpu().numpy().reshape(self.shapes[name])
+
+    def get_weights(self):
+        return {n: self._get(self.dense_param, n) for n in self.param_names()}
+
+    def get_grads(self):
+        """Dense gradients of the last train step by name (+ 'user_rows', 'user_row_grads')."""
+        g = {n: self._get(self.dense_grad, n) for n, _, _ in self.layout}
+        rows, grads, n = C.c_void_p(), C.c_void_p(), C.c_int32()
+        check(lib.lstur_user_grad(self._ctx, C.byref(rows), C.byref(grads), C.byref(n)), 'lstur_user_grad')
+        Ue = self.sizes.user_emb_dim
+        g['user_rows'] = self._peek_ptr(rows.value, n.value, torch.int32).cpu().numpy()
+        g['user_row_grads'] = self._peek_ptr(grads.value, n.value * Ue, torch.float32).cpu().numpy().reshape(n.value, Ue)
+        return g
+
+    def _peek_ptr(self, ptr, count, dtype):
+        esz = 4
+        base = self.workspace.data_ptr()
+        off = ptr - base
+        return self.workspace[off:off + count * esz].view(dtype)
+
+    def peek(self, name):
+        ptr, cnt = C.c_void_p(), C.c_size_t()
+        check(lib.lstur_peek(self._ctx, name.encode(), C.byref(ptr), C.byref(cnt)), 'lstur_peek')
+        return self._peek_ptr(ptr.value, cnt.value, torch.float32).clone()
+
+    def set_title_table(self, table):
+        self.title_table = torch.from_numpy(np.ascontiguousarray(table, dtype=np.int32)).to(self.device)
+        check(lib.lstur_set_title_table(self._ctx, self.title_table.data_ptr(), self.title_table.shape[0]),
+              'lstur_set_title_table')
+
+    # ---- device staging -------------------------------------------------------------
+    def _dev_i32(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.int32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.int32)).to(self.device, non_blocking=True)
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def _split_reference_x(self, X, k1):
+        """Reference X list -> (user, hist[n,W,T], cands[n,k1,T]) int32 device tensors.
+        X = [user int64[n] (or [n,1]), clicked f64[n,W,T], k1 x cand f64[n,T]] (task/seq2vec.py:182-206)."""
+        if len(X) != 2 + k1:
+            raise ValueError('expected {} input arrays, got {}'.format(2 + k1, len(X)))
+        user = self._dev_i32(np.asarray(X[0]).reshape(-1))
+        hist = self._dev_i32(X[1])
+        cands = self._dev_i32(np.stack([np.asarray(x) for x in X[2:]], axis=1))
+        return user, hist, cands
+
+    # ---- training ---------------------------------------------------------------------
+    def _train_step(self, user, hist, cands, ids_form):
+        n = int(user.shape[0])
+        fn = lib.lstur_forward_backward_ids if ids_form else lib.lstur_forward_backward
+        s = self._stream()
+        check(fn(self._ctx, user.data_ptr(), hist.data_ptr(), cands.data_ptr(), n, self.step, 1.0 / self.world,
+                 self.stats.data_ptr(), s), 'lstur_forward_backward')
+        self.optimizer.iterations += 1
+        t = self.optimizer.iterations
+        if self.world > 1:
+            rows, grads = self._allreduce_grads(n)
+            check(lib.lstur_adam_step(self._ctx, self.optimizer.lr, t, rows.data_ptr(), grads.data_ptr(),
+                                      int(rows.shape[0]), s), 'lstur_adam_step')
+        else:
+            check(lib.lstur_adam_step(self._ctx, self.optimizer.lr, t, None, None, 0, s), 'lstur_adam_step')
+        self.step += 1
+        self.stats_acc += self.stats
+
+    def _allreduce_grads(self, n):
+        """Data parallelism over RCCL: ONE all-reduce of the flat dense-gradient bucket (already scaled by
+        1/world in the library) + an all-gather of the sparse user-row gradients."""
+        import torch.distributed as dist
+        dist.all_reduce(self.dense_grad, group=self.dist_group)
+        rows, grads, cnt = C.c_void_p(), C.c_void_p(), C.c_int32()
+        check(lib.lstur_user_grad(self._ctx, C.byref(rows), C.byref(grads), C.byref(cnt)), 'lstur_user_grad')
+        Ue = self.sizes.user_emb_dim
+        my_rows = self._peek_ptr(rows.value, n, torch.int32)
+        my_grads = self._peek_ptr(grads.value, n * Ue, torch.float32)
+        all_rows = torch.empty(self.world * n, dtype=torch.int32, device=self.device)
+        all_grads = torch.empty(self.world * n * Ue, dtype=torch.float32, device=self.device)
+        dist.all_gather_into_tensor(all_rows, my_rows.contiguous(), group=self.dist_group)
+        dist.all_gather_into_tensor(all_grads, my_grads.contiguous(), group=self.dist_group)
+        return all_rows, all_grads
+
+    def train_on_batch(self, X, Y=None):
+        user, hist, cands = self._split_reference_x(X, self.K1)
+        self._train_step(user, hist, cands, False)
+
+    def train_on_ids(self, user, hist_ids, cand_ids):
+        self._train_step(self._dev_i32(user), self._dev_i32(hist_ids), self._dev_i32(cand_ids), True)
+
+    def fit_generator(self, generator, steps_per_epoch, epochs=1, initial_epoch=0, verbose=2, ids_form=False,
+                      **_ignored):
+        """One ``train_on_batch`` per generator item (Keras fit_generator semantics, main.py:73-78)."""
+        hist = History()
+        for epoch in range(initial_epoch, epochs):
+            self.stats_acc.zero_()
+            for _ in range(steps_per_epoch):
+                X, Y = next(generator)
+                if ids_form:
+                    self.train_on_ids(*X)
+                else:
+                    self.train_on_batch(X, Y)
+            loss, acc = (self.stats_acc / steps_per_epoch).tolist()
+            hist.history.setdefault('loss', []).append(loss)
+            hist.history.setdefault('categorical_accuracy', []).append(acc)
+            if verbose:
+                logging.info('Epoch %d/%d - loss: %.4f - categorical_accuracy: %.4f', epoch + 1, epochs, loss, acc)
+        return hist
+
+    def evaluate_generator(self, generator, steps, verbose=0, ids_form=False, **_ignored):
+        acc = torch.zeros(2, dtype=torch.float32, device=self.device)
+        total = 0
+        for _ in range(steps):
+            X, Y = next(generator)
+            if ids_form:
+                raise NotImplementedError('evaluate on id-form batches: expand with the title table first')
+            user, hist, cands = self._split_reference_x(X, self.K1)
+            n = int(user.shape[0])
+            check(lib.lstur_evaluate(self._ctx, user.data_ptr(), hist.data_ptr(), cands.data_ptr(), n,
+                                     self.stats.data_ptr(), self._stream()), 'lstur_evaluate')
+            acc += self.stats * n
+            total += n
+        return (acc / max(total, 1)).tolist()
+
+    # ---- inference ------------------------------------------------------------------------
+    def _predict(self, user, hist, cand, ids_form):
+        n = int(user.shape[0])
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        cap = self.sizes.max_predict_rows
+        fn = lib.lstur_predict_ids if ids_form else lib.lstur_predict
+        for s0 in range(0, n, cap):
+            s1 = min(n, s0 + cap)
+            check(fn(self._ctx, user[s0:s1].data_ptr(), hist[s0:s1].contiguous().data_ptr(),
+                     cand[s0:s1].contiguous().data_ptr(), s1 - s0, out[s0:s1].data_ptr(), self._stream()),
+                  'lstur_predict')
+        return out.cpu().numpy().reshape(-1, 1)
+
+    def predict(self, X, **_ignored):
+        """test_model.predict: X = [user[n], clicked[n,W,T], candidate[n,T]] -> [n,1] sigmoid(u.d)."""
+        user, hist, cands = self._split_reference_x(X, 1)
+        return self._predict(user, hist, cands[:, 0].contiguous(), False)
+
+    predict_on_batch = predict
+
+    def predict_ids(self, user, hist_ids, cand_ids):
+        c = self._dev_i32(cand_ids).reshape(len(user), -1)[:, 0].contiguous()
+        return self._predict(self._dev_i32(user), self._dev_i32(hist_ids), c, True)
+
+    def __del__(self):
+        try:
+            if getattr(self, '_ctx', None):
+                lib.lstur_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass

@@ -1,0 +1,143 @@
+"""GPU parity of the whole native LSTUR step against the CPU oracle (through the C-ABI).
+
+Tolerance: fp32 logits within 1e-3 relative (BASELINE.json north_star); gradients and updated
+parameters are held to 2e-3 of the tensor's max-abs plus a small absolute floor (fp32 kernels vs the
+fp64 oracle).  Index / mask work (dropout masks, padding masks) must match exactly, which is checked
+through values that would be visibly wrong otherwise (dropout on, ragged titles, padded histories).
+"""
+import numpy as np
+import pytest
+
+from conftest import make_batch
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs an MI355X')
+
+
+def rel_close(got, ref, tol=2e-3, name=''):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = np.abs(ref).max() + 1e-12
+    err = np.abs(got - ref).max()
+    assert err <= tol * scale + 1e-7, '{}: max err {:.3e} vs scale {:.3e}'.format(name, err, scale)
+
+
+def build(arch, dims, B, W, T, K1, drop, seed=5):
+    from oracle import lstur_oracle as O
+    from mnexp_amd.native_model import NativeModel
+    rng = np.random.default_rng(seed)
+    p = O.init_params(rng, arch=arch, dtype=np.float64, **dims)
+    for n in ('conv_b', 'att_b', 'dense_b', 'gru_b'):
+        p[n] = rng.normal(0, 0.1, size=p[n].shape)
+    model = NativeModel(p['word_emb'], dims['N_u'], B, W, T, K1 - 1, dims['F'], dims['k'], dims['U'], arch=arch,
+                        dropout=drop, lr=1e-3, seed=77)
+    model.set_weights({n: p[n] for n in p if n != 'word_emb'})
+    return O, p, model, rng
+
+
+TINY = dict(V=60, D=12, F=16, k=3, U=8, N_u=11)
+MID = dict(V=500, D=48, F=80, k=3, U=40, N_u=64)
+ODD = dict(V=90, D=20, F=23, k=5, U=18, N_u=9)      # F, U not multiples of 16; k = 5
+
+
+@pytest.mark.parametrize('arch', ['igru', 'gru', 'hgru'])
+@pytest.mark.parametrize('dims,B,W,T,K1,drop', [
+    (TINY, 5, 4, 7, 3, 0.0),
+    (TINY, 5, 4, 7, 3, 0.25),
+    (MID, 19, 9, 11, 5, 0.2),
+    (ODD, 7, 3, 6, 2, 0.0),
+])
+def test_forward_backward_matches_oracle(arch, dims, B, W, T, K1, drop):
+    _need_gpu()
+    O, p, model, rng = build(arch, dims, B, W, T, K1, drop)
+    user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
+    user[1] = user[0]
+    hist[2] = 0                                    # a sample whose whole history is padding
+    model.step = 3
+    ref = O.forward_backward(p, arch, user, hist, cands, drop_p=drop, seed=77, step=3)
+    import ctypes as C
+    from mnexp_amd._lib import lib, check
+    u, h, c = model._dev_i32(user), model._dev_i32(hist), model._dev_i32(cands)
+    check(lib.lstur_forward_backward(model._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), B, 3, 1.0,
+                                     model.stats.data_ptr(), model._stream()), 'fb')
+    torch.cuda.synchronize()
+    loss, acc = model.stats.tolist()
+    logits = model.peek('logits').cpu().numpy().reshape(B, K1)
+    np.testing.assert_allclose(logits, ref['logits'], rtol=1e-3, atol=1e-5)
+    assert abs(loss - ref['loss']) <= 1e-4 * max(1.0, abs(ref['loss']))
+    assert abs(acc - ref['acc']) < 1e-6
+    rel_close(model.peek('doc_vec').cpu().numpy().reshape(-1, dims['U']), ref['doc_vec'], 1e-3, 'doc_vec')
+    g = model.get_grads()
+    for n in O.dense_param_names(arch):
+        rel_close(g[n], ref['grads'][n], 2e-3, n)
+    assert np.array_equal(g['user_rows'], user)
+    rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
+
+
+@pytest.mark.parametrize('arch', ['igru', 'gru'])
+def test_three_adam_steps_track_oracle(arch):
+    _need_gpu()
+    dims, B, W, T, K1 = MID, 16, 6, 9, 5
+    O, p, model, rng = build(arch, dims, B, W, T, K1, 0.2)
+    p32 = {n: a.astype(np.float32) for n, a in p.items()}
+    names = O.dense_param_names(arch) + ['user_emb']
+    opt = O.Adam(p32, names, lr=1e-3)
+    for step in range(3):
+        user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
+        user[3] = user[0]
+        O.train_step(p32, arch, opt, user, hist, cands, drop_p=0.2, seed=77, step=step)
+        X = [user.astype(np.int64), hist.astype(np.float64)] + [cands[:, j].astype(np.float64) for j in range(K1)]
+        model.train_on_batch(X, None)
+    torch.cuda.synchronize()
+    w = model.get_weights()
+    for n in names:
+        # after 3 Adam steps every touched weight moved by ~3e-3; the update must agree to a few %
+        moved = np.abs(p32[n].astype(np.float64) - p[n]).max()
+        err = np.abs(w[n].astype(np.float64) - p32[n]).max()
+        assert err <= 0.05 * moved + 2e-6, (n, err, moved)
+
+
+def test_predict_and_evaluate_match_oracle():
+    _need_gpu()
+    dims, B, W, T, K1 = MID, 16, 6, 9, 5
+    O, p, model, rng = build('igru', dims, B, W, T, K1, 0.2)
+    n = 37                                           # > max_predict_rows -> chunked
+    user, hist, cands = make_batch(rng, n, W, T, 1, dims['V'], dims['N_u'])
+    X = [user.astype(np.int64), hist.astype(np.float64), cands[:, 0].astype(np.float64)]
+    got = model.predict(X)
+    ref = O.predict(p, 'igru', user, hist, cands[:, 0])
+    assert got.shape == (n, 1)
+    np.testing.assert_allclose(got[:, 0], ref, rtol=1e-3, atol=1e-6)
+    model.set_title_table(np.arange(dims['V'] * T, dtype=np.int32).reshape(dims['V'], T) % dims['V'])
+    tt = model.title_table.cpu().numpy()
+    hid = rng.integers(0, dims['V'], size=(n, W)).astype(np.int32)
+    cid = rng.integers(0, dims['V'], size=(n, 1)).astype(np.int32)
+    got2 = model.predict_ids(user, hid, cid)
+    ref2 = O.predict(p, 'igru', user, tt[hid], tt[cid[:, 0]])
+    np.testing.assert_allclose(got2[:, 0], ref2, rtol=1e-3, atol=1e-6)
+    # evaluate_generator: no dropout, mean loss / accuracy
+    user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
+    Xb = [user.astype(np.int64), hist.astype(np.float64)] + [cands[:, j].astype(np.float64) for j in range(K1)]
+    loss, acc = model.evaluate_generator(iter([(Xb, None)]), 1)
+    ref = O.forward_backward(p, 'igru', user, hist, cands, drop_p=0.0, want_grads=False)
+    assert abs(loss - ref['loss']) < 1e-4 and abs(acc - ref['acc']) < 1e-6
+
+
+def test_errors_are_reported_not_thrown_across_the_abi():
+    _need_gpu()
+    from mnexp_amd import _lib
+    dims, B, W, T, K1 = TINY, 4, 3, 5, 2
+    O, p, model, rng = build('igru', dims, B, W, T, K1, 0.0)
+    user, hist, cands = make_batch(rng, B + 1, W, T, K1, dims['V'], dims['N_u'])
+    X = [user.astype(np.int64), hist.astype(np.float64)] + [cands[:, j].astype(np.float64) for j in range(K1)]
+    with pytest.raises(_lib.LsturError, match='max_batch'):
+        model.train_on_batch(X, None)
+    with pytest.raises(_lib.LsturError, match='multiple of 4'):
+        _lib.query_sizes(_lib.make_cfg(4, 3, 5, 2, 10, 6, 8, 3, 8, 4))
