@@ -1,0 +1,185 @@
+"""LSTUR training throughput on MI355X: training impressions/sec (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = forward + backward + (N > 1: RCCL all-reduce of the dense-gradient bucket and all-gather
+of the sparse user-row gradients) + Keras-Adam over the dense bucket and the whole user table, on one
+batch of synthetic doc-id samples that is already resident in HBM.  Default workload = BASELINE.json
+configs[1]: LSTUR-ini (arch igru), 300-d word embeddings, title_len 30, hist_len 50, 1+4 candidates,
+batch 64 per GPU (weak scaling), dropout 0.2 (reference default), 50k users / 20k docs / 50k vocab.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1] / configs[2]
+    'lstur_ini_b64': dict(arch='igru', B=64, W=50, T=30, K1=5, D=300, F=400, k=3, U=200, V=50000, N_u=50000, N_d=20000),
+    'lstur_con_b64': dict(arch='gru', B=64, W=50, T=30, K1=5, D=300, F=400, k=3, U=200, V=50000, N_u=50000, N_d=20000),
+    # BASELINE.json configs[3]
+    'lstur_ini_b512_1Musers': dict(arch='igru', B=512, W=50, T=30, K1=5, D=300, F=400, k=3, U=200, V=100000,
+                                   N_u=1000000, N_d=200000),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy ceiling)
+
+
+def synth_inputs(wl, rng, n_batches):
+    """Synthetic resident inputs: title table [N_d, T] (ragged, zero padded, doc 0 = pad), word table,
+    and n_batches of (user, hist_ids, cand_ids) with ~10 % front-padded histories."""
+    T, N_d, V = wl['T'], wl['N_d'], wl['V']
+    titles = rng.integers(1, V, size=(N_d, T), dtype=np.int32)
+    lens = rng.integers(5, T + 6, size=N_d)
+    titles[np.arange(T)[None, :] >= lens[:, None]] = 0
+    titles[0] = 0
+    word = rng.normal(0.0, 0.1, size=(V, wl['D'])).astype(np.float32)
+    word[0] = 0.0
+    batches = []
+    for _ in range(n_batches):
+        user = rng.integers(0, wl['N_u'], size=wl['B'], dtype=np.int32)
+        hist = rng.integers(1, N_d, size=(wl['B'], wl['W']), dtype=np.int32)
+        npad = np.where(rng.random(wl['B']) < 0.1, rng.integers(1, wl['W'], size=wl['B']), 0)
+        hist[np.arange(wl['W'])[None, :] < npad[:, None]] = 0
+        cands = rng.integers(1, N_d, size=(wl['B'], wl['K1']), dtype=np.int32)
+        batches.append((user, hist, cands))
+    return titles, word, batches
+
+
+def cpu_baseline(wl, titles, word, batches, budget_s=20.0):
+    """The NumPy oracle (kind 'port'; the reference's Keras/TF stack cannot run here) timed on the host
+    cores for a bounded number of full training steps of the SAME workload in fp32."""
+    from oracle import lstur_oracle as O
+    rng = np.random.default_rng(0)
+    p = O.init_params(rng, V=wl['V'], D=wl['D'], F=wl['F'], k=wl['k'], U=wl['U'], N_u=wl['N_u'], arch=wl['arch'],
+                      word_emb=word, dtype=np.float32)
+    opt = O.Adam(p, O.dense_param_names(wl['arch']) + ['user_emb'], lr=1e-3)
+    try:
+        import threadpoolctl
+        threads = max(i['num_threads'] for i in threadpoolctl.threadpool_info() if i.get('user_api') == 'blas')
+    except Exception:
+        threads = os.cpu_count()
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        user, hist, cands = batches[steps % len(batches)]
+        O.train_step(p, wl['arch'], opt, user, titles[hist], titles[cands], drop_p=0.2, seed=0, step=steps)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 8:
+            break
+    return dict(value=steps * wl['B'] / el, unit='impressions/s', cores=int(threads), kind='port',
+                sample='%d full training steps (fwd+bwd+Adam, fp32 NumPy/BLAS) of the same workload, %.1f s'
+                       % (steps, el), host_cpus=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='lstur_ini_b64', choices=sorted(WORKLOADS))
+    ap.add_argument('--dropout', type=float, default=0.2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='skip the HIP-event brackets around kernels')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mnexp_amd.native_model import NativeModel
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)' % (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    wl = WORKLOADS[args.workload]
+    rng = np.random.default_rng(1234 + rank)
+    titles, word, _ = synth_inputs(wl, np.random.default_rng(1234), 0)   # identical tables on every rank
+    _, _, batches = synth_inputs(wl, rng, 32)                            # per-rank sample stream
+    model = NativeModel(word, wl['N_u'], wl['B'], wl['W'], wl['T'], wl['K1'] - 1, wl['F'], wl['k'], wl['U'],
+                        arch=wl['arch'], dropout=args.dropout, lr=1e-3, seed=7, device='cuda:%d' % local,
+                        title_table=titles)
+    dev = [(model._dev_i32(u), model._dev_i32(h), model._dev_i32(c)) for u, h, c in batches]
+    torch.cuda.synchronize()
+
+    def run(nsteps, offset):
+        for i in range(nsteps):
+            u, h, c = dev[(offset + i) % len(dev)]
+            model._train_step(u, h, c, True)
+
+    run(args.warmup, 0)
+    torch.cuda.synchronize()
+    if not args.no_profile:
+        model.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    loss, acc = (model.stats_acc / max(1, model.step)).tolist()
+
+    prof = {} if args.no_profile else model.profile_read()
+    model.profile(False)
+    if rank == 0:
+        n_tok = wl['B'] * (wl['W'] + wl['K1']) * wl['T']
+        conv_flop = 2.0 * n_tok * wl['k'] * wl['D'] * wl['F']             # 720 kFLOP/token at the defaults
+        gather_bytes = n_tok * (4 + 2 * 4 * wl['D'])                       # 2404 B/token stand-alone
+        kern = {k: dict(avg_us=1e3 * ms / max(1, n), launches=n) for k, (ms, n) in prof.items()}
+        roofline = None
+        roofline_gather = None
+        if prof:
+            dom = max(('conv_fwd', 'conv_wgrad'), key=lambda k: kern[k]['avg_us'])
+            ach = conv_flop / (kern[dom]['avg_us'] * 1e-6) / 1e12
+            roofline = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                            avg_us=round(kern[dom]['avg_us'], 1), flop_per_launch=conv_flop)
+            gb = gather_bytes / (kern['gather']['avg_us'] * 1e-6) / 1e9
+            roofline_gather = dict(kernel='gather', bound='hbm', achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                                   frac=round(gb / PEAK_HBM_GBS, 4), traffic=None,
+                                   avg_us=round(kern['gather']['avg_us'], 1), bytes_per_launch=gather_bytes)
+        out = {
+            'metric': 'training impressions/sec', 'value': round(world * wl['B'] * args.steps / el, 1),
+            'unit': 'impressions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * el / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'arch': wl['arch'], 'batch_per_gpu': wl['B'],
+                       'global_batch': wl['B'] * world, 'hist_len': wl['W'], 'title_len': wl['T'],
+                       'candidates': wl['K1'], 'word_dim': wl['D'], 'filters': wl['F'], 'user_dim': wl['U'],
+                       'n_users': wl['N_u'], 'n_docs': wl['N_d'], 'vocab': wl['V'], 'dropout': args.dropout,
+                       'parallelism': 'dp%d' % world, 'optimizer': 'keras-adam (dense user-table sweep)'},
+            'roofline': roofline, 'roofline_gather': roofline_gather,
+            'kernels_us': {k: round(v['avg_us'], 1) for k, v in sorted(kern.items())},
+            'train_loss': round(loss, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(wl, titles, word, batches)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

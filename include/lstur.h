@@ -145,6 +145,14 @@ int lstur_predict_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_i
 int lstur_evaluate(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands,
                    int32_t n, float* stats, lstur_stream stream);
 
+/* Measurement (bench.py): when enabled, each kernel family of the step is bracketed by HIP events on
+ * the launch stream.  lstur_profile(ctx, 1) also resets the counters.  lstur_profile_read SYNCHRONISES on
+ * the recorded events (the only call that does) and returns the summed duration and launch count of the
+ * index-th family; it returns 1 past the last family.  Families: gather, conv_fwd, attpool_fwd, gru_fwd,
+ * gru_bwd, attpool_bwd, conv_wgrad, adam_user_table, forward_total, backward_total. */
+int lstur_profile(lstur_ctx* ctx, int enable);
+int lstur_profile_read(lstur_ctx* ctx, int index, const char** name, float* total_ms, int32_t* launches);
+
 /* Debug/inspection: device pointers to intermediates of the last call (valid until the next call).
  * names: "doc_vec" [N_t,U], "user_vec" [n,U], "logits" [n,K1], "probs" [n,K1], "conv_out" [N_t,T,F],
  *        "att_w" [N_t,T], "emb" [N_t,T+k-1,D] */

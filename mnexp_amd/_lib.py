@@ -55,6 +55,8 @@ SIGNATURES = {
     'lstur_predict': (_I, [_P, _P, _P, _P, _I, _P, _P]),
     'lstur_predict_ids': (_I, [_P, _P, _P, _P, _I, _P, _P]),
     'lstur_evaluate': (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    'lstur_profile': (_I, [_P, _I]),
+    'lstur_profile_read': (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_F), C.POINTER(_I)]),
     'lstur_peek': (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_Z)]),
     'lstur_gather_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _P]),
     'lstur_conv1d_relu_mask_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

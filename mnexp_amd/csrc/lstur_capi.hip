@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -203,7 +204,22 @@ void carve(const Dims& d, void* base, Workspace* w) {
 
 }  // namespace
 
+struct ProfKernel {
+  const char* name;
+  std::vector<hipEvent_t> start, stop;
+  size_t used = 0;
+};
+
 struct lstur_ctx {
+  bool prof_on = false;
+  std::deque<ProfKernel> prof;  // deque: nested ProfScopes hold pointers across push_back
+  ProfKernel* prof_slot(const char* name) {
+    for (auto& k : prof)
+      if (!strcmp(k.name, name)) return &k;
+    prof.push_back(ProfKernel());
+    prof.back().name = name;
+    return &prof.back();
+  }
   lstur_cfg cfg;
   Dims d;
   lstur_buffers buf;
@@ -234,6 +250,38 @@ int check_launch(const char* what) {
   return LSTUR_OK;
 }
 
+// HIP-event bracket around one kernel family on the launch stream (only when profiling is enabled)
+struct ProfScope {
+  lstur_ctx* c;
+  ProfKernel* k = nullptr;
+  hipStream_t s;
+  ProfScope(lstur_ctx* ctx, const char* name, hipStream_t st) : c(ctx), s(st) {
+    if (!c->prof_on) return;
+    k = c->prof_slot(name);
+    if (k->used == k->start.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        k = nullptr;
+        return;
+      }
+      k->start.push_back(a);
+      k->stop.push_back(b);
+    }
+    (void)hipEventRecord(k->start[k->used], s);
+  }
+  ~ProfScope() {
+    if (k) {
+      (void)hipEventRecord(k->stop[k->used], s);
+      k->used++;
+    }
+  }
+};
+#define PROF(name, stmt)            \
+  do {                              \
+    ProfScope _ps(c, name, s);      \
+    stmt;                           \
+  } while (0)
+
 void lazy_init(lstur_ctx* c, hipStream_t s) {
   if (c->lazy_init_done) return;
   const Dims& d = c->d;
@@ -257,9 +305,10 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   launch_pack_b(gu + 2 * d.H, 3 * d.H, d.H, d.H, w.u_h_p, s);
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
-  launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s);
-  launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, s);
-  launch_attpool_fwd(w.conv, c->P("att_w"), c->P("att_b"), w.pooled, w.att_a, w.att_wt, nt, d.T, d.F, drop, key1, s);
+  PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
+  PROF("conv_fwd", launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, s));
+  PROF("attpool_fwd", launch_attpool_fwd(w.conv, c->P("att_w"), c->P("att_b"), w.pooled, w.att_a, w.att_wt, nt, d.T, d.F,
+                                         drop, key1, s));
   launch_gemm(w.pooled, d.F, 0, c->P("dense_w"), d.U, 0, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, 1.f,
               w.gemm_scratch, s);
   // user encoder (paper.py:584-633)
@@ -268,8 +317,8 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   launch_gather_rows(c->buf.user_emb, user, w.uvec, n, d.Ue, s);
   launch_gemm(w.docvec, d.U, 0, c->P("gru_w"), 3 * d.H, 0, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, 1.f,
               w.gemm_scratch, s);
-  launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.u_zr_p, w.u_h_p, w.hs, w.zs, w.rs,
-                 w.hhs, n, d.W, d.H, s);
+  PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.u_zr_p, w.u_h_p, w.hs,
+                                 w.zs, w.rs, w.hhs, n, d.W, d.H, s));
   (void)hipMemcpy2DAsync(w.hlast, (size_t)d.H * 4, w.hs + (size_t)d.W * d.H, (size_t)(d.W + 1) * d.H * 4,
                          (size_t)d.H * 4, n, hipMemcpyDeviceToDevice, s);
   if (d.arch == LSTUR_ARCH_IGRU) {
@@ -309,8 +358,8 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
   const float* gu = c->P("gru_u");
   launch_pack_b_t(gu, 3 * d.H, 2 * d.H, d.H, w.ut_zr_p, s);          // (U[:, :2H])^T  as [2H x H]
   launch_pack_b_t(gu + 2 * d.H, 3 * d.H, d.H, d.H, w.ut_h_p, s);     // (U[:, 2H:])^T  as [H x H]
-  launch_gru_bwd(dhl, w.gmask, w.hs, w.zs, w.rs, w.hhs, w.ut_zr_p, w.ut_h_p, w.dgates, w.rh, w.hprev,
-                 d.arch == LSTUR_ARCH_IGRU ? w.duser : w.dh0, n, d.W, d.H, s);
+  PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.hs, w.zs, w.rs, w.hhs, w.ut_zr_p, w.ut_h_p, w.dgates, w.rh, w.hprev,
+                                 d.arch == LSTUR_ARCH_IGRU ? w.duser : w.dh0, n, d.W, d.H, s));
   // GRU parameter gradients
   launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
               w.gemm_scratch, s);
@@ -327,12 +376,13 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
   launch_gemm(w.pooled, d.F, 1, w.ddocvec, d.U, 0, c->G("dense_w"), d.U, nullptr, d.F, d.U, nt, 1.f, w.gemm_scratch, s);
   launch_colsum(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, s);
   launch_gemm(w.ddocvec, d.U, 0, c->P("dense_w"), d.U, 1, w.dpooled, d.F, nullptr, nt, d.F, d.U, 1.f, w.gemm_scratch, s);
-  launch_attpool_bwd(w.conv, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, nt, d.T, d.F, drop, key1, s);
+  PROF("attpool_bwd", launch_attpool_bwd(w.conv, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, nt, d.T,
+                                         d.F, drop, key1, s));
   const int np = attpool_bwd_parts(nt), ldp = 2 * d.F + 1;
   launch_colsum(w.parts, np, d.F, ldp, c->G("att_w"), 1.f, s);
   launch_colsum(w.parts + d.F, np, d.F, ldp, c->G("conv_b"), 1.f, s);
   launch_colsum(w.parts + 2 * d.F, np, 1, ldp, c->G("att_b"), 1.f, s);
-  launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, s);
+  PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, s));
 }
 
 int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n, int k1, bool ids_form, hipStream_t s) {
@@ -358,13 +408,13 @@ int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   int rc = stage_titles(c, hist, cands, n, d.K1, ids_form, s);
   if (rc) return rc;
   Workspace& w = c->ws;
-  run_forward(c, user, n, d.K1, training, step, s);
+  PROF("forward_total", run_forward(c, user, n, d.K1, training, step, s));
   const int nW = n * d.W;
   launch_score(w.uservec, w.docvec + (size_t)nW * d.U, w.logits, w.probs, w.loss_i, w.correct_i,
                backward ? w.du : nullptr, backward ? w.ddocvec + (size_t)nW * d.U : nullptr, n, d.K1, d.U,
                grad_scale / (float)n, s);
   if (stats) launch_mean2(w.loss_i, w.correct_i, n, stats, s);
-  if (backward) run_backward(c, n, step, s);
+  if (backward) PROF("backward_total", run_backward(c, n, step, s));
   return check_launch(backward ? "forward_backward" : "evaluate");
 }
 
@@ -467,6 +517,12 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
 }
 
 int lstur_destroy(lstur_ctx* ctx) {
+  if (ctx)
+    for (auto& k : ctx->prof)
+      for (size_t i = 0; i < k.start.size(); ++i) {
+        (void)hipEventDestroy(k.start[i]);
+        (void)hipEventDestroy(k.stop[i]);
+      }
   delete ctx;
   return LSTUR_OK;
 }
@@ -516,8 +572,11 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
   launch_adam_flat(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v, ctx->dense_total,
                    lr_t, c.beta1, c.beta2, c.eps, s);
   launch_user_grad_combine(rows, row_grads, n_rows, d.Ue, ctx->ws.first, ctx->ws.gsum, ctx->ws.slot, s);
-  launch_adam_table(ctx->buf.user_emb, ctx->buf.user_m, ctx->buf.user_v, ctx->ws.slot, ctx->ws.gsum, d.Nu, d.Ue, lr_t,
-                    c.beta1, c.beta2, c.eps, s);
+  {
+    ProfScope _ps(ctx, "adam_user_table", s);
+    launch_adam_table(ctx->buf.user_emb, ctx->buf.user_m, ctx->buf.user_v, ctx->ws.slot, ctx->ws.gsum, d.Nu, d.Ue,
+                      lr_t, c.beta1, c.beta2, c.eps, s);
+  }
   launch_user_slot_clear(rows, n_rows, ctx->ws.slot, s);
   return check_launch("adam_step");
 }
@@ -529,6 +588,30 @@ int lstur_predict(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, cons
 int lstur_predict_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_ids, const int32_t* cand_ids, int32_t n,
                       float* scores, lstur_stream stream) {
   return predict_impl(ctx, user, hist_ids, cand_ids, n, scores, (hipStream_t)stream, true);
+}
+
+int lstur_profile(lstur_ctx* ctx, int enable) {
+  if (!ctx) return fail(LSTUR_ERR_ARG, "ctx is NULL");
+  ctx->prof_on = enable != 0;
+  for (auto& k : ctx->prof) k.used = 0;
+  return LSTUR_OK;
+}
+
+int lstur_profile_read(lstur_ctx* ctx, int index, const char** name, float* total_ms, int32_t* launches) {
+  if (!ctx || index < 0) return fail(LSTUR_ERR_ARG, "bad profile index");
+  if (index >= (int)ctx->prof.size()) return 1;  // past the end
+  ProfKernel& k = ctx->prof[index];
+  float tot = 0.f;
+  for (size_t i = 0; i < k.used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(k.stop[i]) != hipSuccess || hipEventElapsedTime(&ms, k.start[i], k.stop[i]) != hipSuccess)
+      return fail(LSTUR_ERR_HIP, "hipEventElapsedTime failed");
+    tot += ms;
+  }
+  if (name) *name = k.name;
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int32_t)k.used;
+  return LSTUR_OK;
 }
 
 int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* count) {

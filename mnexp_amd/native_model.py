@@ -193,6 +193,23 @@ class NativeModel:
         check(lib.lstur_peek(self._ctx, name.encode(), C.byref(ptr), C.byref(cnt)), 'lstur_peek')
         return self._peek_ptr(ptr.value, cnt.value, torch.float32).clone()
 
+    def profile(self, enable=True):
+        """Bracket each kernel family with HIP events on the launch stream (bench.py roofline figures)."""
+        check(lib.lstur_profile(self._ctx, 1 if enable else 0), 'lstur_profile')
+
+    def profile_read(self):
+        """{family: (total_ms, launches)}; synchronises on the recorded events."""
+        out, i = {}, 0
+        while True:
+            name, ms, cnt = C.c_char_p(), C.c_float(), C.c_int32()
+            rc = lib.lstur_profile_read(self._ctx, i, C.byref(name), C.byref(ms), C.byref(cnt))
+            if rc == 1:
+                break
+            check(rc, 'lstur_profile_read')
+            out[name.value.decode()] = (ms.value, cnt.value)
+            i += 1
+        return out
+
     def set_title_table(self, table):
         self.title_table = torch.from_numpy(np.ascontiguousarray(table, dtype=np.int32)).to(self.device)
         check(lib.lstur_set_title_table(self._ctx, self.title_table.data_ptr(), self.title_table.shape[0]),

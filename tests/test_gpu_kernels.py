@@ -1,0 +1,182 @@
+"""Per-kernel GPU parity through the C-ABI entry points (include/lstur.h), at the BASELINE.json shapes
+(D=300, T=30, F=400, k=3, U=200) where the specialised kernels (25-tile conv forward, 15-wave kernel
+gradient) are selected, plus bit-exact checks of the integer/mask work."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs an MI355X')
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pack_b(B):
+    from mnexp_amd._lib import lib, check
+    K, N = B.shape
+    out = torch.zeros(lib.lstur_pack_b_floats(K, N), dtype=torch.float32, device='cuda')
+    check(lib.lstur_pack_b(B.data_ptr(), B.stride(0), K, N, out.data_ptr(), stream()))
+    return out
+
+
+def test_gather_is_bit_exact_with_dropout_and_padding():
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    from oracle import lstur_oracle as O
+    rng = np.random.default_rng(0)
+    V, D, N, T, k = 5000, 300, 200, 30, 3
+    table = rng.normal(size=(V, D)).astype(np.float32)
+    ids = rng.integers(0, V, size=(N, T)).astype(np.int32)
+    ids[:, 20:] = 0
+    for drop in (0.0, 0.2):
+        key = O.dropout_key(9, 4, 0)
+        out = torch.full((N, T + 2, D), 7.0, dtype=torch.float32, device='cuda')
+        table_d, ids_d = dev(table), dev(ids)      # keep operands alive: a freed temporary's block is reused at once
+        check(lib.lstur_gather_f32(table_d.data_ptr(), ids_d.data_ptr(), out.data_ptr(), N, T, D, 1, 1, drop, key, stream()))
+        ref = table[ids]
+        if drop:
+            keep = O.dropout_keep(key, N * T * D, drop).reshape(N, T, D)
+            ref = ref * keep * np.float32(1.0 / (1.0 - drop))
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:, 1:-1], ref.astype(np.float32))
+        assert not got[:, 0].any() and not got[:, -1].any()
+
+
+@pytest.mark.parametrize('N', [3, 130])
+def test_conv_fwd_and_wgrad_at_baseline_shapes(N):
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    rng = np.random.default_rng(1)
+    D, T, F, k = 300, 30, 400, 3
+    E = rng.normal(0, 0.3, size=(N, T, D)).astype(np.float32)
+    ids = rng.integers(0, 50, size=(N, T)).astype(np.int32)
+    ids[:, 25:] = 0
+    Wc = rng.normal(0, 0.05, size=(k, D, F)).astype(np.float32)
+    b = rng.normal(0, 0.1, size=F).astype(np.float32)
+    Ep = np.zeros((N, T + 2, D), np.float32)
+    Ep[:, 1:-1] = E
+    Epd = torch.zeros(N * (T + 2) * D + 256, dtype=torch.float32, device='cuda')
+    Epd[:N * (T + 2) * D] = dev(Ep).view(-1)
+    Wd = dev(Wc.reshape(k * D, F))
+    Wp = pack_b(Wd)
+    out = torch.empty(N * T, F, dtype=torch.float32, device='cuda')
+    b_d, ids_d = dev(b), dev(ids)
+    check(lib.lstur_conv1d_relu_mask_fwd(Epd.data_ptr(), Wp.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(),
+                                         out.data_ptr(), N, T, D, k, F, stream()))
+    x = torch.nn.functional.pad(dev(E).double().transpose(1, 2), (1, 1))
+    ref = torch.relu(torch.nn.functional.conv1d(x, dev(Wc).double().permute(2, 1, 0), dev(b).double()))
+    ref = ref.transpose(1, 2) * (dev(ids) != 0).unsqueeze(-1)
+    err = (out.view(N, T, F).double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+    assert (out.view(N, T, F)[dev(ids) == 0] == 0).all()
+
+    dC = rng.normal(size=(N * T, F)).astype(np.float32)
+    dw = torch.empty(k * D, F, dtype=torch.float32, device='cuda')
+    scratch = torch.empty(lib.lstur_conv1d_wgrad_scratch(D, k, F), dtype=torch.uint8, device='cuda')
+    dC_d = dev(dC)
+    check(lib.lstur_conv1d_wgrad(Epd.data_ptr(), dC_d.data_ptr(), dw.data_ptr(), scratch.data_ptr(), N, T, D, k, F, stream()))
+    Ep_d = dev(Ep)
+    cols = torch.stack([Ep_d[:, j:j + T] for j in range(k)], dim=2).reshape(N * T, k * D).double()
+    ref_dw = cols.t() @ dC_d.double()
+    err = (dw.double() - ref_dw).abs().max().item()
+    assert err < 2e-5 * ref_dw.abs().max().item(), err
+
+
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(3520, 200, 400), (200, 600, 3200), (37, 19, 70), (64, 64, 2048)])
+def test_gemm_variants(ta, tb, M, N, K):
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    g = torch.Generator(device='cuda').manual_seed(0)
+    A = torch.randn((K, M) if ta else (M, K), device='cuda', generator=g)
+    B = torch.randn((N, K) if tb else (K, N), device='cuda', generator=g)
+    bias = torch.randn(N, device='cuda', generator=g)
+    Cm = torch.empty(M, N, device='cuda')
+    scratch = torch.empty(max(1, lib.lstur_gemm_scratch(M, N, K)), dtype=torch.uint8, device='cuda')
+    check(lib.lstur_gemm_f32(A.data_ptr(), A.stride(0), ta, B.data_ptr(), B.stride(0), tb, Cm.data_ptr(), N,
+                             bias.data_ptr(), M, N, K, 0.5, scratch.data_ptr(), stream()))
+    ref = 0.5 * ((A.t() if ta else A).double() @ (B.t() if tb else B).double()) + bias.double()
+    err = (Cm.double() - ref).abs().max().item()
+    assert err < 1e-5 * ref.abs().max().item() + 1e-6, err
+
+
+def test_gru_at_baseline_width_against_oracle():
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    from oracle import lstur_oracle as O
+    rng = np.random.default_rng(2)
+    n, W, H, U = 21, 12, 200, 200
+    p = dict(gru_w=rng.normal(0, 0.1, (U, 3 * H)), gru_u=O.orthogonal(rng, H, 3 * H), gru_b=rng.normal(0, 0.1, 3 * H))
+    x = rng.normal(0, 0.5, (n, W, U))
+    gmask = rng.random((n, W)) > 0.3
+    gmask[0] = False
+    h0 = rng.normal(0, 0.05, (n, H))
+    h_ref, cache = O.gru_fwd(p, x, gmask, h0)
+    xw = (x.reshape(n * W, U) @ p['gru_w'] + p['gru_b']).astype(np.float32)
+    Ud = dev(p['gru_u'].astype(np.float32))
+    uzr, uh = pack_b(Ud[:, :2 * H]), pack_b(Ud[:, 2 * H:])
+    hs = torch.empty(n, W + 1, H, device='cuda')
+    zs, rs, hhs = (torch.empty(n, W, H, device='cuda') for _ in range(3))
+    gm = dev(gmask.astype(np.uint8))
+    xw_d, h0_d = dev(xw), dev(h0.astype(np.float32))
+    check(lib.lstur_gru_fwd(xw_d.data_ptr(), gm.data_ptr(), h0_d.data_ptr(), uzr.data_ptr(),
+                            uh.data_ptr(), hs.data_ptr(), zs.data_ptr(), rs.data_ptr(), hhs.data_ptr(), n, W, H, stream()))
+    np.testing.assert_allclose(hs[:, W].cpu().numpy(), h_ref, rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(hs.cpu().numpy(), cache['hs'], rtol=1e-3, atol=2e-5)
+    assert np.array_equal(hs[0, W].cpu().numpy(), h0[0].astype(np.float32))   # fully masked row carries h0 bit-exactly
+
+    dh = rng.normal(0, 1.0, (n, H))
+    g_ref, dx_ref, dh0_ref = O.gru_bwd(p, cache, dh)
+    utzr = torch.zeros(lib.lstur_pack_b_floats(2 * H, H), device='cuda')
+    uth = torch.zeros(lib.lstur_pack_b_floats(H, H), device='cuda')
+    check(lib.lstur_pack_bt(Ud.data_ptr(), 3 * H, 2 * H, H, utzr.data_ptr(), stream()))
+    check(lib.lstur_pack_bt(Ud[:, 2 * H:].data_ptr(), 3 * H, H, H, uth.data_ptr(), stream()))
+    dg = torch.empty(n, W, 3 * H, device='cuda')
+    rh, hp = torch.empty(n, W, H, device='cuda'), torch.empty(n, W, H, device='cuda')
+    dh0 = torch.empty(n, H, device='cuda')
+    dh_d = dev(dh.astype(np.float32))
+    check(lib.lstur_gru_bwd(dh_d.data_ptr(), gm.data_ptr(), hs.data_ptr(), zs.data_ptr(),
+                            rs.data_ptr(), hhs.data_ptr(), utzr.data_ptr(), uth.data_ptr(), dg.data_ptr(), rh.data_ptr(),
+                            hp.data_ptr(), dh0.data_ptr(), n, W, H, stream()))
+    np.testing.assert_allclose(dh0.cpu().numpy(), dh0_ref, rtol=2e-3, atol=2e-5)
+    dgn = dg.cpu().numpy().reshape(n * W, 3 * H).astype(np.float64)
+    np.testing.assert_allclose(dgn.sum(0), g_ref['gru_b'], rtol=2e-3, atol=1e-4)
+    dU = np.zeros((H, 3 * H))
+    dU[:, :2 * H] = hp.cpu().numpy().reshape(n * W, H).astype(np.float64).T @ dgn[:, :2 * H]
+    dU[:, 2 * H:] = rh.cpu().numpy().reshape(n * W, H).astype(np.float64).T @ dgn[:, 2 * H:]
+    np.testing.assert_allclose(dU, g_ref['gru_u'], rtol=2e-3, atol=2e-4)
+
+
+def test_full_step_at_baseline_shapes_small_batch():
+    """LSTUR-ini at D=300/T=30/F=400/U=200 with a batch small enough for the NumPy oracle."""
+    _need_gpu()
+    from test_gpu_model import build, rel_close
+    from conftest import make_batch
+    from mnexp_amd._lib import lib, check
+    dims = dict(V=2000, D=300, F=400, k=3, U=200, N_u=50)
+    B, W, T, K1 = 6, 10, 30, 5
+    O, p, model, rng = build('igru', dims, B, W, T, K1, 0.2)
+    user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
+    ref = O.forward_backward(p, 'igru', user, hist, cands, drop_p=0.2, seed=77, step=0)
+    u, h, c = model._dev_i32(user), model._dev_i32(hist), model._dev_i32(cands)
+    check(lib.lstur_forward_backward(model._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), B, 0, 1.0,
+                                     model.stats.data_ptr(), model._stream()))
+    torch.cuda.synchronize()
+    logits = model.peek('logits').cpu().numpy().reshape(B, K1)
+    np.testing.assert_allclose(logits, ref['logits'], rtol=1e-3, atol=1e-5)
+    g = model.get_grads()
+    for n in O.dense_param_names('igru'):
+        rel_close(g[n], ref['grads'][n], 2e-3, n)
+    rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')

@@ -73,7 +73,9 @@ def test_forward_backward_matches_oracle(arch, dims, B, W, T, K1, drop):
     np.testing.assert_allclose(logits, ref['logits'], rtol=1e-3, atol=1e-5)
     assert abs(loss - ref['loss']) <= 1e-4 * max(1.0, abs(ref['loss']))
     assert abs(acc - ref['acc']) < 1e-6
-    rel_close(model.peek('doc_vec').cpu().numpy().reshape(-1, dims['U']), ref['doc_vec'], 1e-3, 'doc_vec')
+    ref_doc = ref['doc_vec'].copy()                # the library masks padded history slots in place
+    ref_doc[:B * W] *= (hist != 0).any(-1).reshape(-1, 1)
+    rel_close(model.peek('doc_vec').cpu().numpy().reshape(-1, dims['U']), ref_doc, 1e-3, 'doc_vec')
     g = model.get_grads()
     for n in O.dense_param_names(arch):
         rel_close(g[n], ref['grads'][n], 2e-3, n)
