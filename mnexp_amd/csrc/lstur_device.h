@@ -42,6 +42,18 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float hard_sigmoid(float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.0f), 1.0f); }
 
+// ---- buffer (SRSRC) loads: wave-uniform base in SGPRs + ONE 32-bit per-lane offset + a scalar offset.
+// Keeps streamed-operand addressing out of the VGPR file (a 64-bit flat pointer per stream otherwise);
+// out-of-range reads return 0.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0);
+  return *(float4*)&v;
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
