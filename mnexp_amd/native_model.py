@@ -256,18 +256,14 @@ class NativeModel:
     def _allreduce_grads(self, n):
         """Data parallelism over RCCL: ONE all-reduce of the flat dense-gradient bucket (already scaled by
         1/world in the library) + an all-gather of the sparse user-row gradients."""
-        import torch.distributed as dist
-        dist.all_reduce(self.dense_grad, group=self.dist_group)
+        from . import dist as D
+        D.allreduce_bucket(self.dense_grad, self.dist_group, prescaled=True)
         rows, grads, cnt = C.c_void_p(), C.c_void_p(), C.c_int32()
         check(lib.lstur_user_grad(self._ctx, C.byref(rows), C.byref(grads), C.byref(cnt)), 'lstur_user_grad')
         Ue = self.sizes.user_emb_dim
         my_rows = self._peek_ptr(rows.value, n, torch.int32)
-        my_grads = self._peek_ptr(grads.value, n * Ue, torch.float32)
-        all_rows = torch.empty(self.world * n, dtype=torch.int32, device=self.device)
-        all_grads = torch.empty(self.world * n * Ue, dtype=torch.float32, device=self.device)
-        dist.all_gather_into_tensor(all_rows, my_rows.contiguous(), group=self.dist_group)
-        dist.all_gather_into_tensor(all_grads, my_grads.contiguous(), group=self.dist_group)
-        return all_rows, all_grads
+        my_grads = self._peek_ptr(grads.value, n * Ue, torch.float32).view(n, Ue)
+        return D.allgather_rows(my_rows, my_grads, self.dist_group)
 
     def train_on_batch(self, X, Y=None):
         user, hist, cands = self._split_reference_x(X, self.K1)

@@ -174,4 +174,10 @@ class Seq2VecPaperSoftmaxId(Seq2VecPaperSoftmax):
     has_user = True
 
     def _users(self):
-        return enumerate(self.data)
+        """(user id, impressions) of the users this rank owns: all of them single-process, users
+        r, r+N, ... under data parallelism (mnexp_amd/dist.py)."""
+        from .. import dist
+        w, r = dist.world_size(), dist.rank()
+        if w == 1:
+            return enumerate(self.data)
+        return ((u, self.data[u]) for u in dist.shard_users(len(self.data), r, w))

@@ -1,0 +1,95 @@
+"""Data-parallel host logic on CPU: world_size-2 gloo, with the oracle standing in for the GPU compute.
+Checks that (1) averaging per-rank gradients of half batches through dist.allreduce_bucket equals the
+global-batch gradient, (2) all-gathered sparse user rows reproduce the global densified gradient with
+duplicates across ranks, (3) replicas stay bit-identical after the update, (4) users are partitioned."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+DIMS = dict(V=60, D=12, F=16, k=3, U=8, N_u=11)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from conftest import make_batch
+    from mnexp_amd import dist as D
+    from oracle import lstur_oracle as O
+    rng = np.random.default_rng(3)
+    p = O.init_params(rng, arch='igru', dtype=np.float64, **DIMS)
+    B, W, T, K1 = 8, 4, 7, 3
+    user, hist, cands = make_batch(rng, B, W, T, K1, DIMS['V'], DIMS['N_u'])
+    user[B // 2] = user[0]                       # the same user on both ranks
+    names = O.dense_param_names('igru')
+    # --- single-process reference on the global batch
+    ref = O.forward_backward(p, 'igru', user, hist, cands)
+    ref_user = O.densify_user_grad(*p['user_emb'].shape, ref['user_rows'], ref['user_row_grads'], np.float64)
+    # --- this rank's half, gradient of the LOCAL mean pre-scaled by 1/world (what the library does)
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+    loc = O.forward_backward(p, 'igru', user[sl], hist[sl], cands[sl])
+    flat = torch.from_numpy(np.concatenate([loc['grads'][n].ravel() for n in names]) / world)
+    D.allreduce_bucket(flat, prescaled=True)
+    got = flat.numpy()
+    want = np.concatenate([ref['grads'][n].ravel() for n in names])
+    assert np.abs(got - want).max() < 1e-12
+    rows = torch.from_numpy(loc['user_rows'].astype(np.int32))
+    rg = torch.from_numpy(loc['user_row_grads'] / world)
+    all_rows, all_grads = D.allgather_rows(rows, rg)
+    assert all_rows.shape[0] == B and np.array_equal(all_rows.numpy(), user)
+    dense = O.densify_user_grad(*p['user_emb'].shape, all_rows.numpy(), all_grads.numpy(), np.float64)
+    assert np.abs(dense - ref_user).max() < 1e-12
+    # --- identical update on every rank
+    g = {n: a for n, a in zip(names, np.split(got, np.cumsum([p[n].size for n in names])[:-1]))}
+    g = {n: g[n].reshape(p[n].shape) for n in names}
+    g['user_emb'] = dense
+    opt = O.Adam(p, names + ['user_emb'])
+    opt.step(p, g)
+    dev = D.replica_checksum([torch.from_numpy(p[n]) for n in names + ['user_emb']])
+    assert float(dev.max()) == 0.0
+    owned = list(D.shard_users(DIMS['N_u'], rank, world))
+    t = torch.zeros(DIMS['N_u'], dtype=torch.int64)
+    t[owned] = 1
+    dist.all_reduce(t)
+    assert bool((t == 1).all())                  # a partition: every user on exactly one rank
+    out.put((rank, 'ok'))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_equivalence():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
+
+
+def test_task_shards_users_across_ranks(monkeypatch):
+    from test_data_path import make_config, GOLD
+    from mnexp_amd import dist as D, task
+    cfg = make_config(os.path.join(GOLD, 'tiny'))
+    h = task.get(cfg)
+    seen = []
+    for r in range(3):
+        monkeypatch.setattr(D, 'world_size', lambda group=None: 3)
+        monkeypatch.setattr(D, 'rank', lambda group=None, r=r: r)
+        seen.append([u for u, _ in h._users()])
+    assert sorted(sum(seen, [])) == list(range(len(h.data)))
+    assert seen[1][:3] == [1, 4, 7]

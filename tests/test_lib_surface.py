@@ -1,0 +1,84 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/lstur.h declares, sizes
+and parameter layout are queryable without a GPU, and creating a context without a GPU FAILS LOUDLY
+(there is no CPU fallback in the product path)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from mnexp_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'lstur.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(lstur_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(_lib.lib, s), 'not exported: ' + s
+        assert s in _lib.SIGNATURES, 'no ctypes signature: ' + s
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_sizes_and_layout_without_gpu():
+    cfg = _lib.make_cfg(64, 50, 30, 5, 50000, 300, 400, 3, 200, 50000, 'igru', 0.2)
+    s = _lib.query_sizes(cfg)
+    assert s.word_emb == 50000 * 300 and s.user_emb == 50000 * 200
+    assert s.user_emb_dim == 200 and s.gru_dim == 200 and s.max_predict_rows == 64 * 55 // 51
+    lay = _lib.param_layout(cfg)
+    assert [n for n, _, _ in lay] == ['conv_w', 'conv_b', 'att_w', 'att_b', 'dense_w', 'dense_b', 'gru_w', 'gru_u', 'gru_b']
+    counts = dict((n, c) for n, _, c in lay)
+    assert counts == dict(conv_w=900 * 400, conv_b=400, att_w=400, att_b=1, dense_w=400 * 200, dense_b=200,
+                          gru_w=200 * 600, gru_u=200 * 600, gru_b=600)
+    assert sum(counts.values()) == 681601                      # 681 601 dense floats at U=200
+    offs = [o for _, o, _ in lay]
+    assert offs == sorted(offs) and all(o % 64 == 0 for o in offs)
+    assert s.dense >= lay[-1][1] + lay[-1][2]
+    lay_con = _lib.param_layout(_lib.make_cfg(8, 5, 8, 5, 100, 16, 16, 3, 8, 10, 'gru'))
+    assert [n for n, _, _ in lay_con][-2:] == ['con_w', 'con_b']
+    h = _lib.query_sizes(_lib.make_cfg(8, 5, 8, 5, 100, 16, 16, 3, 8, 10, 'hgru'))
+    assert h.user_emb_dim == 4 and h.gru_dim == 4
+
+
+def test_bad_configs_are_rejected_with_a_message():
+    with pytest.raises(_lib.LsturError, match='multiple of 4'):
+        _lib.query_sizes(_lib.make_cfg(4, 3, 5, 2, 10, 6, 8, 3, 8, 4))
+    with pytest.raises(_lib.LsturError, match='even'):
+        _lib.query_sizes(_lib.make_cfg(4, 3, 5, 2, 10, 8, 8, 3, 7, 4, 'hgru'))
+    with pytest.raises(_lib.LsturError, match='not supported'):
+        _lib.make_cfg(4, 3, 5, 2, 10, 8, 8, 3, 8, 4, 'dgru')
+    off, cnt = C.c_size_t(), C.c_size_t()
+    cfg = _lib.make_cfg(4, 3, 5, 2, 10, 8, 8, 3, 8, 4)
+    assert _lib.lib.lstur_param(C.byref(cfg), b'nope', C.byref(off), C.byref(cnt)) == -1
+    assert b'nope' in _lib.lib.lstur_last_error()
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from mnexp_amd.native_model import NativeModel
+    import numpy as np
+    with pytest.raises(_lib.LsturError, match='no CPU fallback'):
+        NativeModel(np.zeros((10, 8), np.float32), 4, 4, 3, 5, 1, 8, 3, 8)
+    cfg = _lib.make_cfg(4, 3, 5, 2, 10, 8, 8, 3, 8, 4)
+    bufs = _lib.Buffers(*([256] * 9), 1 << 20)
+    ctx = C.c_void_p()
+    rc = _lib.lib.lstur_create(C.byref(cfg), C.byref(bufs), C.byref(ctx))
+    assert rc == -4 and b'no CPU fallback' in _lib.lib.lstur_last_error()
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'mnexp_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f
