@@ -205,7 +205,7 @@ int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int3
 /* Masked Keras-2.2.4 GRU over W steps (paper.py:592,597-613; K.rnn mask semantics).
  *   xw [n,W,3H] input projection incl. bias; gmask uint8 [n,W]; h0 [n,H] or NULL (zeros)
  *   u_zr_packed = lstur_pack_b(gru_u[:, :2H]); u_h_packed = lstur_pack_b(gru_u[:, 2H:])  (ldb = 3H)
- *   outputs hs [n,W+1,H], z/r/hh [n,W,H];  H <= 512 */
+ *   outputs hs [n,W+1,H], z/r/hh [n,W,H];  H <= 256 */
 int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
                   const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int32_t n, int32_t W,
                   int32_t H, lstur_stream stream);

@@ -12,188 +12,244 @@
 // exactly one wave, so LDS staging would be pure overhead.  The step is latency-bound, so fragment loads
 // run a few chunks ahead of the MFMAs in a register ring and each step's gate inputs are fetched
 // before its products start.
+#include <stdlib.h>
+
 #include "lstur_device.h"
 #include "lstur_internal.h"
 
 namespace lstur {
 
-constexpr int GW = 8;      // waves per workgroup
-constexpr int GLOADS = 8;  // float4 B-fragment loads in flight per wave (ring depth = GLOADS / tiles)
+constexpr int GW = 8;  // waves per workgroup
 
-// One pass of C (static) column tiles first, first+GW, ...: acc[j] = A_lds[16 x K] . Bpacked[:, tile j].
-// Branch-free inside: the tile count is a template parameter, so the MFMA stream has no predication.
+// ring depth for a wave that owns C column tiles: ~12 float4 fragment loads in flight per wave
+__host__ __device__ constexpr int ring_depth(int C) { return C >= 4 ? 3 : (C == 3 ? 4 : (C == 2 ? 6 : 8)); }
+
+// Register ring of packed-B fragments for C tiles (first, first+GW, ...) of one operand image.
 template <int C>
-__device__ __forceinline__ void gemm_pass(const float* __restrict__ arow, __amdgpu_buffer_rsrc_t brs, uint32_t voff,
-                                          int chstride, int nchunk, int first, f32x4* acc) {
-  constexpr int GDEPTH = (GLOADS + C - 1) / C;
-  float4 ring[GDEPTH][C];
+struct FragRing {
+  static constexpr int D = ring_depth(C);
+  float4 r[D][C];
+  __amdgpu_buffer_rsrc_t rs;
+  uint32_t voff;      // per-lane byte offset inside a 16x16 fragment block
+  int chstride;       // floats per K chunk of the image
+  int first;          // first tile of this wave
+  __device__ __forceinline__ void bind(const float* img, int np, int nchunk, int first_tile, int lane,
+                                       bool nostream = false) {
+    chstride = np * 16;
+    // nostream: timing-only build with a zero-record descriptor (every fragment load returns 0 at once)
+    rs = make_rsrc(img, nostream ? 0u : (uint32_t)nchunk * (uint32_t)chstride * 4u);
+    voff = ((lane & 15) * 16 + (lane >> 4) * 4) * 4;
+    first = first_tile;
+  }
+  // scalar byte offset of (chunk, tile j); reads past the image return 0 (buffer range check)
+  __device__ __forceinline__ uint32_t soff(int ch, int j) const {
+    return (uint32_t)(ch * chstride + (first + j * GW) * 256) * 4u;
+  }
+  __device__ __forceinline__ void prefetch() {   // chunks 0..D-1
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int j = 0; j < C; ++j) r[d][j] = buf_load4(rs, voff, soff(d, j));
+  }
+};
+
+// acc[j] = A_lds[16 x K] . image[:, tile j]; the ring must hold chunks 0..D-1 on entry (prefetch()).
+// Branch-free MFMA stream: tile count and ring depth are template parameters.  NCH > 0 fixes the number
+// of K chunks at compile time: the chunk loop is then straight-line code (static ring slots, loads and LDS
+// reads scheduled ahead of the MFMAs with counted waits); NCH == 0 keeps a runtime loop for other widths.
+template <int C, int NCH>
+__device__ __forceinline__ void gemm_run(FragRing<C>& ring, const float* __restrict__ arow, int nchunk, f32x4* acc) {
+  constexpr int D = FragRing<C>::D;
 #pragma unroll
   for (int j = 0; j < C; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // scalar byte offset of (chunk ch, tile first + j*GW); past-the-end reads return 0 and are never used
-  auto soff = [&](int ch, int j) { return (uint32_t)(ch * chstride + (first + j * GW) * 256) * 4u; };
+  if constexpr (NCH > 0) {
+    float4 a = *(const float4*)(arow);
 #pragma unroll
-  for (int d = 0; d < GDEPTH; ++d) {
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int d = ch % D;
+      float4 an = a;
+      if (ch + 1 < NCH) an = *(const float4*)(arow + (ch + 1) * 16);
+      float4 b[C];
 #pragma unroll
-    for (int j = 0; j < C; ++j) ring[d][j] = buf_load4(brs, voff, soff(d, j));
-  }
-  for (int ch0 = 0; ch0 < nchunk; ch0 += GDEPTH) {
+      for (int j = 0; j < C; ++j) b[j] = ring.r[d][j];
+      if (ch + D < NCH) {
 #pragma unroll
-    for (int d = 0; d < GDEPTH; ++d) {
-      const int ch = ch0 + d;
-      if (ch < nchunk) {
-        float4 a = *(const float4*)(arow + ch * 16);
-        float4 b[C];
+        for (int j = 0; j < C; ++j) ring.r[d][j] = buf_load4(ring.rs, ring.voff, ring.soff(ch + D, j));
+      }
 #pragma unroll
-        for (int j = 0; j < C; ++j) b[j] = ring[d][j];
+      for (int j = 0; j < C; ++j) acc[j] = mfma16(a.x, b[j].x, acc[j]);
 #pragma unroll
-        for (int j = 0; j < C; ++j) ring[d][j] = buf_load4(brs, voff, soff(ch + GDEPTH, j));
-        // consecutive MFMAs go to different accumulators (dependent-issue latency 40 > issue 32 cycles)
+      for (int j = 0; j < C; ++j) acc[j] = mfma16(a.y, b[j].y, acc[j]);
 #pragma unroll
-        for (int j = 0; j < C; ++j) acc[j] = mfma16(a.x, b[j].x, acc[j]);
+      for (int j = 0; j < C; ++j) acc[j] = mfma16(a.z, b[j].z, acc[j]);
 #pragma unroll
-        for (int j = 0; j < C; ++j) acc[j] = mfma16(a.y, b[j].y, acc[j]);
+      for (int j = 0; j < C; ++j) acc[j] = mfma16(a.w, b[j].w, acc[j]);
+      a = an;
+    }
+  } else {
+    for (int ch0 = 0; ch0 < nchunk; ch0 += D) {
 #pragma unroll
-        for (int j = 0; j < C; ++j) acc[j] = mfma16(a.z, b[j].z, acc[j]);
+      for (int d = 0; d < D; ++d) {
+        const int ch = ch0 + d;
+        if (ch < nchunk) {
+          float4 a = *(const float4*)(arow + ch * 16);
+          float4 b[C];
 #pragma unroll
-        for (int j = 0; j < C; ++j) acc[j] = mfma16(a.w, b[j].w, acc[j]);
+          for (int j = 0; j < C; ++j) b[j] = ring.r[d][j];
+#pragma unroll
+          for (int j = 0; j < C; ++j) ring.r[d][j] = buf_load4(ring.rs, ring.voff, ring.soff(ch + D, j));
+          // consecutive MFMAs go to different accumulators (dependent-issue latency 40 > issue 32 cycles)
+#pragma unroll
+          for (int j = 0; j < C; ++j) acc[j] = mfma16(a.x, b[j].x, acc[j]);
+#pragma unroll
+          for (int j = 0; j < C; ++j) acc[j] = mfma16(a.y, b[j].y, acc[j]);
+#pragma unroll
+          for (int j = 0; j < C; ++j) acc[j] = mfma16(a.z, b[j].z, acc[j]);
+#pragma unroll
+          for (int j = 0; j < C; ++j) acc[j] = mfma16(a.w, b[j].w, acc[j]);
+        }
       }
     }
   }
 }
 
-// acc[i] = A_lds[16 x K] . Bpacked[:, tile(i)]   for the tiles wave wv owns (wv, wv+GW, ...), MAXT in {2, 4, 8}
-template <int MAXT>
-__device__ __forceinline__ void wave_gemm16(const float* __restrict__ a_lds, int lda, const float* __restrict__ bp,
-                                            int np, int nchunk, int ntiles, int wv, int lane, f32x4* acc) {
-  const int c = lane & 15, kq = lane >> 4;
-  const float* arow = a_lds + c * lda + kq * 4;
-  const int chstride = np * 16;
-  const __amdgpu_buffer_rsrc_t brs = make_rsrc(bp, (uint32_t)nchunk * chstride * 4u);
-  const uint32_t voff = (c * 16 + kq * 4) * 4;   // per-lane part; the rest of every address is wave-uniform
-#pragma unroll
-  for (int p = 0; p < (MAXT + 3) / 4; ++p) {
-    constexpr int kPassMax = MAXT < 4 ? MAXT : 4;
-    const int first = wv + p * 4 * GW;
-    int cnt = first < ntiles ? (ntiles - first + GW - 1) / GW : 0;   // wave-uniform
-    cnt = cnt > kPassMax ? kPassMax : cnt;
-    if (kPassMax >= 4 && cnt == 4)
-      gemm_pass<4>(arow, brs, voff, chstride, nchunk, first, acc + p * 4);
-    else if (kPassMax >= 3 && cnt == 3)
-      gemm_pass<3>(arow, brs, voff, chstride, nchunk, first, acc + p * 4);
-    else if (cnt == 2)
-      gemm_pass<2>(arow, brs, voff, chstride, nchunk, first, acc + p * 4);
-    else if (cnt == 1)
-      gemm_pass<1>(arow, brs, voff, chstride, nchunk, first, acc + p * 4);
-  }
-}
+struct GruFwdArgs {
+  const float* xw; const uint8_t* gmask; const float* h0; const float* u_zr; const float* u_h;
+  float* hs; float* zs; float* rs; float* hhs; int n, W, H, nostream;
+};
 
-template <int MAXT>
-__global__ __launch_bounds__(GW * 64) void gru_fwd_kernel(const float* __restrict__ xw,
-                                                          const uint8_t* __restrict__ gmask,
-                                                          const float* __restrict__ h0,
-                                                          const float* __restrict__ u_zr,  // packed [H x 2H]
-                                                          const float* __restrict__ u_h,   // packed [H x H]
-                                                          float* __restrict__ hs, float* __restrict__ zs,
-                                                          float* __restrict__ rs, float* __restrict__ hhs, int n,
-                                                          int W, int H) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// Whole time loop for a wave that owns C1 tiles of the z|r product and C2 tiles of the candidate product.
+template <int C1, int C2, int NCH>
+__device__ __forceinline__ void gru_fwd_body(const GruFwdArgs& g, float* smem, int wv, int lane) {
+  const int H = g.H, W = g.W, n = g.n;
   const int nch = cdiv(H, 16), Hp = nch * 16, LDH = Hp + 4;
-  const int N1 = 2 * H, NP1 = ceil16(N1), NT1 = NP1 / 16, NT2 = Hp / 16;
+  const int N1 = 2 * H, NP1 = ceil16(N1);
   float* hL = smem;
   float* rhL = hL + 16 * LDH;
   float* zL = rhL + 16 * LDH;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar addressing of fragments
-  const int c = lane & 15, rq = lane >> 4;
+  const int c = lane & 15, rq = lane >> 4, kq = lane >> 4;
   const int b0 = blockIdx.x * 16;
+  const uint32_t uW = W, uH = H, uH3 = 3 * H;   // wrapping 32-bit index math keeps addresses cheap
 
-  for (int i = tid; i < 3 * 16 * LDH; i += GW * 64) smem[i] = 0.f;
-  __syncthreads();
-  for (int i = tid; i < 16 * H; i += GW * 64) {
-    int row = i / H, col = i - row * H, b = b0 + row;
-    float v = (h0 && b < n) ? h0[(size_t)b * H + col] : 0.f;
-    hL[row * LDH + col] = v;
-    if (b < n) hs[(size_t)b * (W + 1) * H + col] = v;
-  }
-  __syncthreads();
+  constexpr int C2R = C2 > 0 ? C2 : 1;      // a wave without candidate tiles keeps a dummy ring (never run)
+  FragRing<C1> ring1;
+  FragRing<C2R> ring2;
+  ring1.bind(g.u_zr, NP1, nch, wv, lane, g.nostream != 0);
+  ring2.bind(g.u_h, Hp, nch, wv, lane, g.nostream != 0);
+  ring1.prefetch();
 
-  f32x4 acc[MAXT];
-  float xin[MAXT][4];
-  // unsigned (wrapping) index arithmetic: keeps every address a 32-bit offset until its use, so no
-  // 64-bit loop-invariant pointer per element is hoisted out of the time loop (VGPR blow-up otherwise)
-  const uint32_t uW = W, uH = H, uH3 = 3 * H;
+  const float* a1 = hL + c * LDH + kq * 4;
+  const float* a2 = rhL + c * LDH + kq * 4;
+  f32x4 acc1[C1], acc2[C2R];
+  float x1[C1][4], x2[C2R][4], mk[4];
   for (int t = 0; t < W; ++t) {
     const uint32_t ut = t;
     // ---- phase 1: z | r ----
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
+    for (int i = 0; i < C1; ++i) {
       int col = (wv + i * GW) * 16 + c;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int b = b0 + rq * 4 + j;
-        xin[i][j] = (col < N1 && b < n) ? xw[((uint32_t)b * uW + ut) * uH3 + (uint32_t)col] : 0.f;
+        x1[i][j] = (col < N1 && b < n) ? g.xw[((uint32_t)b * uW + ut) * uH3 + (uint32_t)col] : 0.f;
       }
     }
-    wave_gemm16<MAXT>(hL, LDH, u_zr, NP1, nch, NT1, wv, lane, acc);
+    gemm_run<C1, NCH>(ring1, a1, nch, acc1);
+    if (C2 > 0) ring2.prefetch();     // candidate-product fragments fly during the gate epilogue + barrier
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      int tile = wv + i * GW;
-      int col = tile * 16 + c;
-      if (tile >= NT1 || col >= N1) continue;
+    for (int i = 0; i < C1; ++i) {
+      int col = (wv + i * GW) * 16 + c;
+      if (col >= N1) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int row = rq * 4 + j, b = b0 + row;
         if (b >= n) continue;
         uint32_t bt = (uint32_t)b * uW + ut;
-        float g = hard_sigmoid(acc[i][j] + xin[i][j]);
+        float gt = hard_sigmoid(acc1[i][j] + x1[i][j]);
         if (col < H) {
-          zL[row * LDH + col] = g;
-          zs[bt * uH + (uint32_t)col] = g;
+          zL[row * LDH + col] = gt;
+          g.zs[bt * uH + (uint32_t)col] = gt;
         } else {
           int k = col - H;
-          rs[bt * uH + (uint32_t)k] = g;
-          rhL[row * LDH + k] = g * hL[row * LDH + k];
+          g.rs[bt * uH + (uint32_t)k] = gt;
+          rhL[row * LDH + k] = gt * hL[row * LDH + k];
         }
       }
     }
-    // candidate inputs + mask for phase 2 (issued before the barrier so they fly during it)
-    float mk[4];
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
+    for (int i = 0; i < C2; ++i) {
       int col = (wv + i * GW) * 16 + c;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int b = b0 + rq * 4 + j;
-        xin[i][j] = (col < H && b < n) ? xw[((uint32_t)b * uW + ut) * uH3 + 2u * uH + (uint32_t)col] : 0.f;
+        x2[i][j] = (col < H && b < n) ? g.xw[((uint32_t)b * uW + ut) * uH3 + 2u * uH + (uint32_t)col] : 0.f;
       }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int b = b0 + rq * 4 + j;
-      mk[j] = (b < n && gmask[(uint32_t)b * uW + ut]) ? 1.f : 0.f;
+      mk[j] = (b < n && g.gmask[(uint32_t)b * uW + ut]) ? 1.f : 0.f;
     }
     __syncthreads();
     // ---- phase 2: candidate + state update ----
-    wave_gemm16<MAXT>(rhL, LDH, u_h, Hp, nch, NT2, wv, lane, acc);
+    if (C2 > 0) gemm_run<C2R, NCH>(ring2, a2, nch, acc2);
+    if (t + 1 < W) ring1.prefetch();  // next step's z|r fragments fly during the update + barrier
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      int tile = wv + i * GW;
-      int col = tile * 16 + c;
-      if (tile >= NT2 || col >= H) continue;
+    for (int i = 0; i < C2; ++i) {
+      int col = (wv + i * GW) * 16 + c;
+      if (col >= H) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int row = rq * 4 + j, b = b0 + row;
         if (b >= n) continue;
         uint32_t bt = (uint32_t)b * uW + ut;
-        float hh = tanhf(acc[i][j] + xin[i][j]);
+        float hh = tanhf(acc2[i][j] + x2[i][j]);
         float z = zL[row * LDH + col], hp = hL[row * LDH + col];
         float hn = z * hp + (1.0f - z) * hh;
         float ho = mk[j] != 0.f ? hn : hp;  // K.rnn: masked step carries the previous state/output
-        hhs[bt * uH + (uint32_t)col] = hh;
-        hs[((uint32_t)b * (uW + 1u) + ut + 1u) * uH + (uint32_t)col] = ho;
+        g.hhs[bt * uH + (uint32_t)col] = hh;
+        g.hs[((uint32_t)b * (uW + 1u) + ut + 1u) * uH + (uint32_t)col] = ho;
         hL[row * LDH + col] = ho;
       }
     }
+    __syncthreads();
+  }
+}
+
+// number of tiles wave wv owns out of ntiles dealt round-robin over GW waves
+__device__ __forceinline__ int tiles_of(int wv, int ntiles) { return wv < ntiles ? (ntiles - wv + GW - 1) / GW : 0; }
+
+__global__ __launch_bounds__(GW * 64) void gru_fwd_kernel(GruFwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = g.H, W = g.W, n = g.n;
+  const int nch = cdiv(H, 16), Hp = nch * 16, LDH = Hp + 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar addressing of fragments
+  const int b0 = blockIdx.x * 16;
+  float* hL = smem;
+  for (int i = tid; i < 3 * 16 * LDH; i += GW * 64) smem[i] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < 16 * H; i += GW * 64) {
+    int row = i / H, col = i - row * H, b = b0 + row;
+    float v = (g.h0 && b < n) ? g.h0[(size_t)b * H + col] : 0.f;
+    hL[row * LDH + col] = v;
+    if (b < n) g.hs[(size_t)b * (W + 1) * H + col] = v;
+  }
+  __syncthreads();
+  // static (tile-count) specialisation per wave: every wave runs the same number of barriers
+  const int c1 = tiles_of(wv, ceil16(2 * H) / 16), c2 = tiles_of(wv, Hp / 16);
+#define LSTUR_FWD_CASE(A, B)                                              \
+  if (c1 == A && c2 == B) {                                               \
+    if (nch == 13) return gru_fwd_body<A, B, 13>(g, smem, wv, lane);      \
+    return gru_fwd_body<A, B, 0>(g, smem, wv, lane);                      \
+  }
+  LSTUR_FWD_CASE(4, 2) LSTUR_FWD_CASE(3, 2) LSTUR_FWD_CASE(3, 1) LSTUR_FWD_CASE(4, 1) LSTUR_FWD_CASE(2, 1)
+  LSTUR_FWD_CASE(1, 1) LSTUR_FWD_CASE(2, 2) LSTUR_FWD_CASE(1, 0) LSTUR_FWD_CASE(2, 0) LSTUR_FWD_CASE(3, 0)
+  LSTUR_FWD_CASE(4, 0) LSTUR_FWD_CASE(1, 2)
+#undef LSTUR_FWD_CASE
+  // a wave without tiles (tiny H) still has to meet the barriers
+  for (int t = 0; t < W; ++t) {
+    __syncthreads();
     __syncthreads();
   }
 }
@@ -209,70 +265,62 @@ __global__ __launch_bounds__(GW * 64) void gru_fwd_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float hs_grad(float g) { return (g > 0.f && g < 1.f) ? 0.2f : 0.f; }
 
-template <int MAXT>
-__global__ __launch_bounds__(GW * 64) void gru_bwd_kernel(const float* __restrict__ dh_last,
-                                                          const uint8_t* __restrict__ gmask,
-                                                          const float* __restrict__ hs, const float* __restrict__ zs,
-                                                          const float* __restrict__ rs, const float* __restrict__ hhs,
-                                                          const float* __restrict__ ut_zr,  // packed [2H x H]
-                                                          const float* __restrict__ ut_h,   // packed [H x H]
-                                                          float* __restrict__ dgates, float* __restrict__ rh,
-                                                          float* __restrict__ hprev, float* __restrict__ dh0, int n,
-                                                          int W, int H) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+struct GruBwdArgs {
+  const float* dh_last; const uint8_t* gmask; const float* hs; const float* zs; const float* rs; const float* hhs;
+  const float* ut_zr; const float* ut_h; float* dgates; float* rh; float* hprev; float* dh0; int n, W, H;
+};
+
+// Every wave owns the same C column tiles (of H hidden units) in all three phases: lane (c, rq) of tile
+// `tile` holds rows rq*4+j, col tile*16+c -- so the element-wise work needs no extra LDS round trip.
+template <int C, int NCH, int NCH2>
+__device__ __forceinline__ void gru_bwd_body(const GruBwdArgs& g, float* smem, int wv, int lane) {
+  const int H = g.H, W = g.W, n = g.n;
   const int nch = cdiv(H, 16), Hp = nch * 16, LDH = Hp + 4;
-  const int N1 = 2 * H, nch2 = cdiv(N1, 16), LD2 = nch2 * 16 + 4, NT = Hp / 16;
+  const int N1 = 2 * H, nch2 = cdiv(N1, 16), LD2 = nch2 * 16 + 4;
   float* dhL = smem;               // [16][LDH] gradient wrt current state
   float* nL = dhL + 16 * LDH;      // [16][LDH] partial dh_prev
   float* g2L = nL + 16 * LDH;      // [16][LDH] dpre_h
   float* g1L = g2L + 16 * LDH;     // [16][LD2] dpre_z | dpre_r
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar addressing of fragments
-  const int c = lane & 15, rq = lane >> 4;
+  const int c = lane & 15, rq = lane >> 4, kq = lane >> 4;
   const int b0 = blockIdx.x * 16;
-  const int total_lds = 3 * 16 * LDH + 16 * LD2;
+  const uint32_t uW = W, uH = H, uH3 = 3 * H;
 
-  for (int i = tid; i < total_lds; i += GW * 64) smem[i] = 0.f;
-  __syncthreads();
-  for (int i = tid; i < 16 * H; i += GW * 64) {
-    int row = i / H, col = i - row * H, b = b0 + row;
-    dhL[row * LDH + col] = b < n ? dh_last[(size_t)b * H + col] : 0.f;
-  }
-  __syncthreads();
+  FragRing<C> ringh, ringzr;
+  ringh.bind(g.ut_h, Hp, nch, wv, lane);
+  ringzr.bind(g.ut_zr, Hp, nch2, wv, lane);
+  ringh.prefetch();
+  const float* a2 = g2L + c * LDH + kq * 4;
+  const float* a1 = g1L + c * LD2 + kq * 4;
 
-  // Every wave owns the same (row, col) elements in all three phases: lane (c, rq) of tile `tile`
-  // holds rows rq*4+j, col tile*16+c -- so the element-wise work needs no extra LDS round trip.
-  f32x4 acc[MAXT];
-  float zv[MAXT][4], rv[MAXT][4], hv[MAXT][4], pv[MAXT][4], mk[4];
-  const uint32_t uW = W, uH = H, uH3 = 3 * H;  // wrapping 32-bit index math (see gru_fwd_kernel)
+  f32x4 acc[C];
+  float zv[C][4], rv[C][4], hv[C][4], pv[C][4], mk[4];
   for (int t = W - 1; t >= 0; --t) {
     const uint32_t ut = t;
-    // ---- fetch this step's saved activations for the elements this lane owns ----
+    // ---- this step's saved activations for the elements this lane owns ----
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int b = b0 + rq * 4 + j;
-      mk[j] = (b < n && gmask[(uint32_t)b * uW + ut]) ? 1.f : 0.f;
+      mk[j] = (b < n && g.gmask[(uint32_t)b * uW + ut]) ? 1.f : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
+    for (int i = 0; i < C; ++i) {
       int col = (wv + i * GW) * 16 + c;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int b = b0 + rq * 4 + j;
         bool ok = col < H && b < n;
         uint32_t bt = ((uint32_t)b * uW + ut) * uH + (uint32_t)col;
-        zv[i][j] = ok ? zs[bt] : 0.f;
-        rv[i][j] = ok ? rs[bt] : 0.f;
-        hv[i][j] = ok ? hhs[bt] : 0.f;
-        pv[i][j] = ok ? hs[((uint32_t)b * (uW + 1u) + ut) * uH + (uint32_t)col] : 0.f;
+        zv[i][j] = ok ? g.zs[bt] : 0.f;
+        rv[i][j] = ok ? g.rs[bt] : 0.f;
+        hv[i][j] = ok ? g.hhs[bt] : 0.f;
+        pv[i][j] = ok ? g.hs[((uint32_t)b * (uW + 1u) + ut) * uH + (uint32_t)col] : 0.f;
       }
     }
     // ---- (a) element-wise part that does not need drh ----
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      int tile = wv + i * GW;
-      int col = tile * 16 + c;
-      if (tile >= NT || col >= H) continue;
+    for (int i = 0; i < C; ++i) {
+      int col = (wv + i * GW) * 16 + c;
+      if (col >= H) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int row = rq * 4 + j, b = b0 + row;
@@ -286,21 +334,21 @@ __global__ __launch_bounds__(GW * 64) void gru_bwd_kernel(const float* __restric
         nL[row * LDH + col] = (mk[j] != 0.f ? 0.f : dh) + dhn * z;
         if (b < n) {
           uint32_t bt = (uint32_t)b * uW + ut;
-          dgates[bt * uH3 + (uint32_t)col] = dpz;
-          dgates[bt * uH3 + 2u * uH + (uint32_t)col] = dph;
-          hprev[bt * uH + (uint32_t)col] = hp;
-          rh[bt * uH + (uint32_t)col] = rv[i][j] * hp;
+          g.dgates[bt * uH3 + (uint32_t)col] = dpz;
+          g.dgates[bt * uH3 + 2u * uH + (uint32_t)col] = dph;
+          g.hprev[bt * uH + (uint32_t)col] = hp;
+          g.rh[bt * uH + (uint32_t)col] = rv[i][j] * hp;
         }
       }
     }
     __syncthreads();
     // ---- (b) drh = dpre_h . U_h^T ----
-    wave_gemm16<MAXT>(g2L, LDH, ut_h, Hp, nch, NT, wv, lane, acc);
+    gemm_run<C, NCH>(ringh, a2, nch, acc);
+    ringzr.prefetch();
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      int tile = wv + i * GW;
-      int col = tile * 16 + c;
-      if (tile >= NT || col >= H) continue;
+    for (int i = 0; i < C; ++i) {
+      int col = (wv + i * GW) * 16 + c;
+      if (col >= H) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int row = rq * 4 + j, b = b0 + row;
@@ -309,17 +357,17 @@ __global__ __launch_bounds__(GW * 64) void gru_bwd_kernel(const float* __restric
         float dpr = drh * hp * hs_grad(r);
         g1L[row * LD2 + H + col] = dpr;
         nL[row * LDH + col] += drh * r;
-        if (b < n) dgates[((uint32_t)b * uW + ut) * uH3 + uH + (uint32_t)col] = dpr;
+        if (b < n) g.dgates[((uint32_t)b * uW + ut) * uH3 + uH + (uint32_t)col] = dpr;
       }
     }
     __syncthreads();
     // ---- (c) dh_prev = part + [dpre_z | dpre_r] . U_zr^T ----
-    wave_gemm16<MAXT>(g1L, LD2, ut_zr, Hp, nch2, NT, wv, lane, acc);
+    gemm_run<C, NCH2>(ringzr, a1, nch2, acc);
+    if (t > 0) ringh.prefetch();
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      int tile = wv + i * GW;
-      int col = tile * 16 + c;
-      if (tile >= NT || col >= H) continue;
+    for (int i = 0; i < C; ++i) {
+      int col = (wv + i * GW) * 16 + c;
+      if (col >= H) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int row = rq * 4 + j;
@@ -328,9 +376,43 @@ __global__ __launch_bounds__(GW * 64) void gru_bwd_kernel(const float* __restric
     }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(GW * 64) void gru_bwd_kernel(GruBwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = g.H, W = g.W, n = g.n;
+  const int nch = cdiv(H, 16), Hp = nch * 16, LDH = Hp + 4;
+  const int LD2 = cdiv(2 * H, 16) * 16 + 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b0 = blockIdx.x * 16;
+  float* dhL = smem;
+  for (int i = tid; i < 3 * 16 * LDH + 16 * LD2; i += GW * 64) smem[i] = 0.f;
+  __syncthreads();
   for (int i = tid; i < 16 * H; i += GW * 64) {
     int row = i / H, col = i - row * H, b = b0 + row;
-    if (b < n) dh0[(size_t)b * H + col] = dhL[row * LDH + col];
+    dhL[row * LDH + col] = b < n ? g.dh_last[(size_t)b * H + col] : 0.f;
+  }
+  __syncthreads();
+  const int cnt = tiles_of(wv, Hp / 16);
+  if (cnt == 2 && nch == 13)
+    gru_bwd_body<2, 13, 25>(g, smem, wv, lane);
+  else if (cnt == 1 && nch == 13)
+    gru_bwd_body<1, 13, 25>(g, smem, wv, lane);
+  else if (cnt == 2)
+    gru_bwd_body<2, 0, 0>(g, smem, wv, lane);
+  else if (cnt == 1)
+    gru_bwd_body<1, 0, 0>(g, smem, wv, lane);
+  else
+    for (int t = 0; t < W; ++t) {
+      __syncthreads();
+      __syncthreads();
+      __syncthreads();
+    }
+  __syncthreads();
+  for (int i = tid; i < 16 * H; i += GW * 64) {
+    int row = i / H, col = i - row * H, b = b0 + row;
+    if (b < n) g.dh0[(size_t)b * H + col] = dhL[row * LDH + col];
   }
 }
 
@@ -347,18 +429,11 @@ void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, cons
   if (!n) return;
   int Hp = ceil16(H), LDH = Hp + 4;
   size_t lds = (size_t)3 * 16 * LDH * sizeof(float);
-  int tiles_per_wave = cdiv(ceil16(2 * H) / 16, GW);
-  if (tiles_per_wave <= 4) {
-    static size_t cur = 0;
-    set_lds_attr((const void*)gru_fwd_kernel<4>, lds, &cur);
-    hipLaunchKernelGGL(gru_fwd_kernel<4>, dim3(cdiv(n, 16)), dim3(GW * 64), lds, s, xw, gmask, h0, u_zr_packed,
-                       u_h_packed, hs, zs, rs, hhs, n, W, H);
-  } else {
-    static size_t cur = 0;
-    set_lds_attr((const void*)gru_fwd_kernel<8>, lds, &cur);
-    hipLaunchKernelGGL(gru_fwd_kernel<8>, dim3(cdiv(n, 16)), dim3(GW * 64), lds, s, xw, gmask, h0, u_zr_packed,
-                       u_h_packed, hs, zs, rs, hhs, n, W, H);
-  }
+  static size_t cur = 0;
+  set_lds_attr((const void*)gru_fwd_kernel, lds, &cur);
+  static const int nostream = getenv("LSTUR_GRU_NOSTREAM") ? 1 : 0;   // measurement knob, results are wrong when set
+  GruFwdArgs a{xw, gmask, h0, u_zr_packed, u_h_packed, hs, zs, rs, hhs, n, W, H, nostream};
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(n, 16)), dim3(GW * 64), lds, s, a);
 }
 
 void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, const float* hs, const float* zs, const float* rs,
@@ -367,18 +442,10 @@ void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, const float* hs,
   if (!n) return;
   int Hp = ceil16(H), LDH = Hp + 4, LD2 = ceil16(2 * H) + 4;
   size_t lds = (size_t)(3 * 16 * LDH + 16 * LD2) * sizeof(float);
-  int tiles_per_wave = cdiv(Hp / 16, GW);
-  if (tiles_per_wave <= 2) {
-    static size_t cur = 0;
-    set_lds_attr((const void*)gru_bwd_kernel<2>, lds, &cur);
-    hipLaunchKernelGGL(gru_bwd_kernel<2>, dim3(cdiv(n, 16)), dim3(GW * 64), lds, s, dh_last, gmask, hs, zs, rs, hhs,
-                       ut_zr_packed, ut_h_packed, dgates, rh, hprev, dh0, n, W, H);
-  } else {
-    static size_t cur = 0;
-    set_lds_attr((const void*)gru_bwd_kernel<4>, lds, &cur);
-    hipLaunchKernelGGL(gru_bwd_kernel<4>, dim3(cdiv(n, 16)), dim3(GW * 64), lds, s, dh_last, gmask, hs, zs, rs, hhs,
-                       ut_zr_packed, ut_h_packed, dgates, rh, hprev, dh0, n, W, H);
-  }
+  static size_t cur = 0;
+  set_lds_attr((const void*)gru_bwd_kernel, lds, &cur);
+  GruBwdArgs a{dh_last, gmask, hs, zs, rs, hhs, ut_zr_packed, ut_h_packed, dgates, rh, hprev, dh0, n, W, H};
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(n, 16)), dim3(GW * 64), lds, s, a);
 }
 
 }  // namespace lstur

@@ -77,8 +77,8 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
   }
   d->H = d->arch == LSTUR_ARCH_HGRU ? d->U / 2 : d->U;
   d->Ue = d->arch == LSTUR_ARCH_HGRU ? d->U / 2 : d->U;
-  if (d->H > 512) {
-    *why = "GRU width must be <= 512";
+  if (d->H > 256) {
+    *why = "GRU width must be <= 256";
     return false;
   }
   d->Tp = d->T + d->k - 1;
@@ -122,7 +122,7 @@ struct Workspace {
   float* cat; float* dcat; float* uservec; float* duser; float* du; float* logits; float* probs; float* loss_i;
   float* correct_i; float* parts; float* conv_wp; float* u_zr_p; float* u_h_p; float* ut_zr_p; float* ut_h_p;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; int32_t* first; float* gsum; int32_t* slot;
-  int32_t* user_rows; float* scores; size_t bytes;
+  int32_t* user_rows; float* scores; float* colsum_scratch; size_t bytes;
 };
 
 size_t max_gemm_scratch(const Dims& d) {
@@ -199,6 +199,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->slot = (int32_t*)take((size_t)d.Nu * 4);
   w->user_rows = (int32_t*)take(nc * 4);
   w->scores = (float*)take(nc * f4);
+  w->colsum_scratch = (float*)take((size_t)kColsumSlices * std::max(std::max(3 * d.H, d.U), 2 * d.F + 1) * f4);
   w->bytes = off;
 }
 
@@ -346,7 +347,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
   if (d.arch == LSTUR_ARCH_GRU) {
     launch_gemm(w.cat, d.H + d.Ue, 1, w.du, d.U, 0, c->G("con_w"), d.U, nullptr, d.H + d.Ue, d.U, n, 1.f,
                 w.gemm_scratch, s);
-    launch_colsum(w.du, n, d.U, d.U, c->G("con_b"), 1.f, s);
+    launch_colsum2(w.du, n, d.U, d.U, c->G("con_b"), 1.f, w.colsum_scratch, s);
     launch_gemm(w.du, d.U, 0, c->P("con_w"), d.U, 1, w.dcat, d.H + d.Ue, nullptr, n, d.H + d.Ue, d.U, 1.f,
                 w.gemm_scratch, s);
     launch_split2(w.dcat, d.H, d.Ue, w.dhlast, w.duser, n, s);
@@ -363,7 +364,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
   // GRU parameter gradients
   launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
               w.gemm_scratch, s);
-  launch_colsum(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, s);
+  launch_colsum2(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, w.colsum_scratch, s);
   launch_gemm(w.hprev, d.H, 1, w.dgates, 3 * d.H, 0, c->G("gru_u"), 3 * d.H, nullptr, d.H, 2 * d.H, nW, 1.f,
               w.gemm_scratch, s);
   launch_gemm(w.rh, d.H, 1, w.dgates + 2 * d.H, 3 * d.H, 0, c->G("gru_u") + 2 * d.H, 3 * d.H, nullptr, d.H, d.H, nW,
@@ -374,14 +375,14 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
   launch_scale_rows_u8(w.ddocvec, w.hmask, nW, d.U, s);
   // news encoder backward (candidate rows of ddocvec were written by the scorer)
   launch_gemm(w.pooled, d.F, 1, w.ddocvec, d.U, 0, c->G("dense_w"), d.U, nullptr, d.F, d.U, nt, 1.f, w.gemm_scratch, s);
-  launch_colsum(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, s);
+  launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch, s);
   launch_gemm(w.ddocvec, d.U, 0, c->P("dense_w"), d.U, 1, w.dpooled, d.F, nullptr, nt, d.F, d.U, 1.f, w.gemm_scratch, s);
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, nt, d.T,
                                          d.F, drop, key1, s));
   const int np = attpool_bwd_parts(nt), ldp = 2 * d.F + 1;
-  launch_colsum(w.parts, np, d.F, ldp, c->G("att_w"), 1.f, s);
-  launch_colsum(w.parts + d.F, np, d.F, ldp, c->G("conv_b"), 1.f, s);
-  launch_colsum(w.parts + 2 * d.F, np, 1, ldp, c->G("att_b"), 1.f, s);
+  launch_colsum2(w.parts, np, d.F, ldp, c->G("att_w"), 1.f, w.colsum_scratch, s);
+  launch_colsum2(w.parts + d.F, np, d.F, ldp, c->G("conv_b"), 1.f, w.colsum_scratch, s);
+  launch_colsum2(w.parts + 2 * d.F, np, 1, ldp, c->G("att_b"), 1.f, w.colsum_scratch, s);
   PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, s));
 }
 
@@ -705,7 +706,7 @@ int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int3
 int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
                   const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int32_t n, int32_t W, int32_t H,
                   lstur_stream stream) {
-  if (!xw || !gmask || !u_zr_packed || !u_h_packed || !hs || !zs || !rs || !hhs || H > 512)
+  if (!xw || !gmask || !u_zr_packed || !u_h_packed || !hs || !zs || !rs || !hhs || H > 256)
     return fail(LSTUR_ERR_ARG, "gru fwd: bad argument");
   launch_gru_fwd(xw, gmask, h0, u_zr_packed, u_h_packed, hs, zs, rs, hhs, n, W, H, (hipStream_t)stream);
   return check_launch("gru_fwd");
@@ -714,7 +715,7 @@ int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, const float* hs, c
                   const float* hhs, const float* ut_zr_packed, const float* ut_h_packed, float* dgates, float* rh,
                   float* hprev, float* dh0, int32_t n, int32_t W, int32_t H, lstur_stream stream) {
   if (!dh_last || !gmask || !hs || !zs || !rs || !hhs || !ut_zr_packed || !ut_h_packed || !dgates || !rh || !hprev ||
-      !dh0 || H > 512)
+      !dh0 || H > 256)
     return fail(LSTUR_ERR_ARG, "gru bwd: bad argument");
   launch_gru_bwd(dh_last, gmask, hs, zs, rs, hhs, ut_zr_packed, ut_h_packed, dgates, rh, hprev, dh0, n, W, H,
                  (hipStream_t)stream);

@@ -28,6 +28,9 @@ void launch_pack_b_t(const float* Bt, int ldb, int K, int N, float* packed, hipS
 // out[r][c] = in[c][r]  (in is [rows_in, cols_in] with leading dim ld_in)
 void launch_transpose(const float* in, int ld_in, int rows_in, int cols_in, float* out, hipStream_t s);
 void launch_colsum(const float* x, int rows, int cols, int ld, float* out, float scale, hipStream_t s);
+constexpr int kColsumSlices = 64;
+void launch_colsum2(const float* x, int rows, int cols, int ld, float* out, float scale, float* scratch,
+                    hipStream_t s);
 void launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1,
                       float b2, float eps, hipStream_t s);
 // dense Adam sweep of the user table; slot[row] = index into gsum or -1
@@ -74,7 +77,7 @@ void launch_gemm(const float* A, int lda, int ta, const float* B, int ldb, int t
                  const float* bias, int M, int N, int K, float alpha, void* scratch, hipStream_t s);
 
 // ---- gru.hip -----------------------------------------------------------------------------------
-// u_zr_packed = pack_b(U[:, :2H]), u_h_packed = pack_b(U[:, 2H:]);  requires H <= 512
+// u_zr_packed = pack_b(U[:, :2H]), u_h_packed = pack_b(U[:, 2H:]);  requires H <= 256
 void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
                     const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int n, int W, int H,
                     hipStream_t s);

@@ -125,24 +125,37 @@ void launch_transpose(const float* in, int ld_in, int rows_in, int cols_in, floa
 }
 
 // out[j] = scale * sum_i x[i, j]   (fixed summation order -> bitwise reproducible)
+// grid = (column blocks of 64, row slices); each block sums its row slice into part[slice][col].
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, int rows, int cols, int ld,
-                                                      float* __restrict__ out, float scale) {
+                                                      float* __restrict__ out, float scale, int rows_per_slice) {
   __shared__ float red[16][64];
   int c = blockIdx.x * 64 + threadIdx.x;
+  int r0 = blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
   float acc = 0.f;
   if (c < cols)
-    for (int r = threadIdx.y; r < rows; r += 16) acc += x[(size_t)r * ld + c];
+    for (int r = r0 + threadIdx.y; r < r1; r += 16) acc += x[(size_t)r * ld + c];
   red[threadIdx.y][threadIdx.x] = acc;
   __syncthreads();
   if (threadIdx.y == 0 && c < cols) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
-    out[c] = t * scale;
+    out[(size_t)blockIdx.y * cols + c] = t * scale;
   }
 }
 void launch_colsum(const float* x, int rows, int cols, int ld, float* out, float scale, hipStream_t s) {
-  if (cols) hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(64, 16), 0, s, x, rows, cols, ld, out, scale);
+  if (cols) hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), 1), dim3(64, 16), 0, s, x, rows, cols, ld, out, scale, rows);
+}
+// two-stage variant for tall inputs: scratch holds kColsumSlices x cols partial sums
+void launch_colsum2(const float* x, int rows, int cols, int ld, float* out, float scale, float* scratch,
+                    hipStream_t s) {
+  if (!cols) return;
+  if (rows < 256 || !scratch) return launch_colsum(x, rows, cols, ld, out, scale, s);
+  int slices = std::min(kColsumSlices, cdiv(rows, 32));
+  int rps = cdiv(rows, slices);
+  slices = cdiv(rows, rps);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), slices), dim3(64, 16), 0, s, x, rows, cols, ld, scratch, 1.0f, rps);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), 1), dim3(64, 16), 0, s, scratch, slices, cols, cols, out, scale, slices);
 }
 
 // ---------------------------------------------------------------------------------------------
