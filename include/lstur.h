@@ -166,30 +166,39 @@ int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* coun
 int lstur_gather_f32(const float* table, const int32_t* ids, float* out, int32_t n_titles, int32_t title_len,
                      int32_t dim, int32_t pad_left, int32_t pad_right, float drop, uint32_t key,
                      lstur_stream stream);
+/* Stable list of the non-pad tokens of a batch: vidx[0 .. *count) = ascending flat indices i with ids[i] != 0.
+ * The conv output of a pad token is multiplied by 0 (paper.py:150-155) and its gradient is 0, so the two conv
+ * contractions may run over this list only (identical results).  scratch: lstur_valid_tokens_scratch bytes. */
+size_t lstur_valid_tokens_scratch(int32_t n_tokens);
+int lstur_valid_tokens(const int32_t* ids, int32_t n_tokens, int32_t* vidx, int32_t* count, int32_t* scratch,
+                       lstur_stream stream);
 /* Conv1D('same', relu) * (id != 0)  (paper.py:146-155) on the padded embedding layout.
- * w_packed from lstur_pack_b(conv_w as [k*D, F]). */
+ * w_packed from lstur_pack_b(conv_w as [k*D, F]).  emb_padded needs 256 floats of zero slack at its end.
+ * vidx/vcount (device, may both be NULL = all rows): only the listed output rows are computed and written. */
 int lstur_conv1d_relu_mask_fwd(const float* emb_padded, const float* w_packed, const float* bias,
                                const int32_t* ids, float* out, int32_t n_titles, int32_t title_len,
-                               int32_t dim, int32_t ksize, int32_t filters, lstur_stream stream);
+                               int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx,
+                               const int32_t* vcount, lstur_stream stream);
 /* Conv1D kernel gradient: dW[k*D,F] = im2col(emb)^T . dOut ; scratch >= lstur_conv1d_wgrad_scratch() bytes. */
 size_t lstur_conv1d_wgrad_scratch(int32_t dim, int32_t ksize, int32_t filters);
 int lstur_conv1d_wgrad(const float* emb_padded, const float* dout, float* dw, void* scratch,
                        int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters,
-                       lstur_stream stream);
+                       const int32_t* vidx, const int32_t* vcount, lstur_stream stream);
 /* Pack a row-major B[K,N] (leading dim ldb) into the MFMA operand image [ceil(K/16)][ceil16(N)][16]. */
 size_t lstur_pack_b_floats(int32_t K, int32_t N);
 int lstur_pack_b(const float* B, int32_t ldb, int32_t K, int32_t N, float* packed, lstur_stream stream);
 /* Same image for B = Bt^T, Bt stored row-major [N, K] with leading dim ldb. */
 int lstur_pack_bt(const float* Bt, int32_t ldb, int32_t K, int32_t N, float* packed, lstur_stream stream);
 /* Masking + Dropout + SimpleAttentionMaskSupport (paper.py:157-158, models.py:474-489).
- * conv_out [N_t,T,F] -> pooled [N_t,F]; saves att_tanh [N_t,T], att_weight [N_t,T]. */
-int lstur_attpool_fwd(const float* conv_out, const float* att_w, const float* att_b, float* pooled,
-                      float* att_tanh, float* att_weight, int32_t n_titles, int32_t title_len,
+ * conv_out [N_t,T,F] -> pooled [N_t,F]; saves att_tanh [N_t,T], att_weight [N_t,T].
+ * ids (may be NULL): rows of pad tokens are taken as zero without being read (they are zero by definition). */
+int lstur_attpool_fwd(const float* conv_out, const int32_t* ids, const float* att_w, const float* att_b,
+                      float* pooled, float* att_tanh, float* att_weight, int32_t n_titles, int32_t title_len,
                       int32_t filters, float drop, uint32_t key, lstur_stream stream);
 /* Backward of the above + ReLU'; dconv [N_t,T,F]; partial sums [n_part, 2F+1] reduced by the caller
  * through lstur_colsum: layout per row = datt_w[F] | dconv_b[F] | datt_b. */
 int32_t lstur_attpool_bwd_parts(int32_t n_titles);
-int lstur_attpool_bwd(const float* conv_out, const float* att_w, const float* att_tanh,
+int lstur_attpool_bwd(const float* conv_out, const int32_t* ids, const float* att_w, const float* att_tanh,
                       const float* att_weight, const float* dpooled, float* dconv, float* parts,
                       int32_t n_titles, int32_t title_len, int32_t filters, float drop, uint32_t key,
                       lstur_stream stream);

@@ -59,15 +59,17 @@ SIGNATURES = {
     'lstur_profile_read': (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_F), C.POINTER(_I)]),
     'lstur_peek': (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_Z)]),
     'lstur_gather_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _P]),
-    'lstur_conv1d_relu_mask_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'lstur_valid_tokens_scratch': (_Z, [_I]),
+    'lstur_valid_tokens': (_I, [_P, _I, _P, _P, _P, _P]),
+    'lstur_conv1d_relu_mask_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'lstur_conv1d_wgrad_scratch': (_Z, [_I, _I, _I]),
-    'lstur_conv1d_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'lstur_conv1d_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'lstur_pack_b_floats': (_Z, [_I, _I]),
     'lstur_pack_b': (_I, [_P, _I, _I, _I, _P, _P]),
     'lstur_pack_bt': (_I, [_P, _I, _I, _I, _P, _P]),
-    'lstur_attpool_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _P]),
+    'lstur_attpool_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _P]),
     'lstur_attpool_bwd_parts': (_I, [_I]),
-    'lstur_attpool_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _P]),
+    'lstur_attpool_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _P]),
     'lstur_colsum': (_I, [_P, _I, _I, _I, _P, _F, _P]),
     'lstur_gemm_scratch': (_Z, [_I, _I, _I]),
     'lstur_gemm_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),

@@ -11,15 +11,25 @@
 
 namespace lstur {
 
-__device__ __forceinline__ void load_title_tile(const float* __restrict__ src, float* __restrict__ xs, int TF) {
-  if ((TF & 3) == 0) {
-    for (int i = threadIdx.x; i < TF / 4; i += blockDim.x) ((float4*)xs)[i] = ((const float4*)src)[i];
+// Title tile [T][F] -> LDS.  Rows of pad tokens (id == 0) are zero by construction (the conv output is
+// multiplied by (id != 0)); with ids given they are not read at all (the conv kernels skip them too).
+__device__ __forceinline__ void load_title_tile(const float* __restrict__ src, const int32_t* __restrict__ ids,
+                                                float* __restrict__ xs, int T, int F) {
+  if ((F & 3) == 0) {
+    const int F4 = F / 4;
+    for (int i = threadIdx.x; i < T * F4; i += blockDim.x) {
+      int t = i / F4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!ids || ids[t] != 0) v = ((const float4*)src)[i];
+      ((float4*)xs)[i] = v;
+    }
   } else {
-    for (int i = threadIdx.x; i < TF; i += blockDim.x) xs[i] = src[i];
+    for (int i = threadIdx.x; i < T * F; i += blockDim.x) xs[i] = (!ids || ids[i / F] != 0) ? src[i] : 0.f;
   }
 }
 
 __global__ __launch_bounds__(256) void attpool_fwd_kernel(const float* __restrict__ c,
+                                                          const int32_t* __restrict__ ids,
                                                           const float* __restrict__ att_w,
                                                           const float* __restrict__ att_b,
                                                           float* __restrict__ pooled, float* __restrict__ a_out,
@@ -31,7 +41,7 @@ __global__ __launch_bounds__(256) void attpool_fwd_kernel(const float* __restric
   float* as = es + T;         // [T] tanh
   const int n = blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  load_title_tile(c + (size_t)n * T * F, xs, T * F);
+  load_title_tile(c + (size_t)n * T * F, ids ? ids + (size_t)n * T : nullptr, xs, T, F);
   __syncthreads();
   const float b = att_b[0];
   for (int t = wv; t < T; t += 4) {
@@ -71,8 +81,8 @@ __global__ __launch_bounds__(256) void attpool_fwd_kernel(const float* __restric
   }
 }
 
-void launch_attpool_fwd(const float* c, const float* att_w, const float* att_b, float* pooled, float* a, float* w,
-                        int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s) {
+void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
+                        float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s) {
   if (!n_titles) return;
   size_t lds = ((size_t)T * F + 2 * T) * sizeof(float);
   static size_t attr = 0;
@@ -82,7 +92,7 @@ void launch_attpool_fwd(const float* c, const float* att_w, const float* att_b, 
   }
   uint32_t thresh = drop > 0.f ? dropout_thresh(drop) : 0u;
   float scale = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
-  hipLaunchKernelGGL(attpool_fwd_kernel, dim3(n_titles), dim3(256), lds, s, c, att_w, att_b, pooled, a, w, T, F,
+  hipLaunchKernelGGL(attpool_fwd_kernel, dim3(n_titles), dim3(256), lds, s, c, ids, att_w, att_b, pooled, a, w, T, F,
                      thresh, key, scale);
 }
 
@@ -98,6 +108,7 @@ constexpr int kFPT = 4;  // columns per thread (F <= 1024)
 int attpool_bwd_parts(int n_titles) { return n_titles < 1024 ? (n_titles > 0 ? n_titles : 1) : 1024; }
 
 __global__ __launch_bounds__(256) void attpool_bwd_kernel(const float* __restrict__ c,
+                                                          const int32_t* __restrict__ ids,
                                                           const float* __restrict__ att_w,
                                                           const float* __restrict__ a_in,
                                                           const float* __restrict__ w_in,
@@ -110,6 +121,7 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const float* __restric
   float* ws = dp + F;          // [T]
   float* av = ws + T;          // [T]
   float* dwv = av + T;         // [T] -> ds
+  float* vr = dwv + T;         // [T] 1 = row is a real token (dconv row is written)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float gaw[kFPT], gcb[kFPT], kf[kFPT];
 #pragma unroll
@@ -123,11 +135,13 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const float* __restric
 
   for (int n = blockIdx.x; n < n_titles; n += gridDim.x) {
     __syncthreads();  // previous title's LDS reads done
-    load_title_tile(c + (size_t)n * T * F, xs, T * F);
+    const int32_t* idn = ids ? ids + (size_t)n * T : nullptr;
+    load_title_tile(c + (size_t)n * T * F, idn, xs, T, F);
     for (int f = threadIdx.x; f < F; f += 256) dp[f] = dpooled[(size_t)n * F + f];
     for (int t = threadIdx.x; t < T; t += 256) {
       ws[t] = w_in[(size_t)n * T + t];
       av[t] = a_in[(size_t)n * T + t];
+      vr[t] = (!idn || idn[t] != 0) ? 1.f : 0.f;
     }
     __syncthreads();
     for (int t = wv; t < T; t += 4) {
@@ -167,7 +181,7 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const float* __restric
           gaw[i] += ds * xv;
           float d = xv > 0.f ? dx * scale : 0.f;
           gcb[i] += d;
-          dcn[t * F + f] = d;
+          if (vr[t] != 0.f) dcn[t * F + f] = d;   // pad rows are never read by the kernel gradient
         }
       }
     }
@@ -186,11 +200,11 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const float* __restric
   if (threadIdx.x == 0) pr[2 * F] = gab;
 }
 
-void launch_attpool_bwd(const float* c, const float* att_w, const float* a, const float* w, const float* dpooled,
-                        float* dc, float* parts, int n_titles, int T, int F, float drop, uint32_t key,
-                        hipStream_t s) {
+void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
+                        const float* dpooled, float* dc, float* parts, int n_titles, int T, int F, float drop,
+                        uint32_t key, hipStream_t s) {
   if (!n_titles) return;
-  size_t lds = ((size_t)T * F + F + 3 * T) * sizeof(float);
+  size_t lds = ((size_t)T * F + F + 4 * T) * sizeof(float);
   static size_t attr = 0;
   if (lds > 65536 && lds > attr) {
     (void)hipFuncSetAttribute((const void*)attpool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -198,7 +212,7 @@ void launch_attpool_bwd(const float* c, const float* att_w, const float* a, cons
   }
   uint32_t thresh = drop > 0.f ? dropout_thresh(drop) : 0u;
   float scale = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
-  hipLaunchKernelGGL(attpool_bwd_kernel, dim3(attpool_bwd_parts(n_titles)), dim3(256), lds, s, c, att_w, a, w,
+  hipLaunchKernelGGL(attpool_bwd_kernel, dim3(attpool_bwd_parts(n_titles)), dim3(256), lds, s, c, ids, att_w, a, w,
                      dpooled, dc, parts, n_titles, T, F, thresh, key, scale);
 }
 

@@ -27,19 +27,21 @@ __global__ __launch_bounds__(WAVES * 64) void conv_fwd_kernel(const float* __res
                                                               const float* __restrict__ bias,
                                                               const int32_t* __restrict__ ids,
                                                               float* __restrict__ C, int M, int T, int Tp, int D,
-                                                              int F, int Fp, int nchunk) {
-  static_assert(NTW >= 1 && WAVES >= 1, "tile shape");
+                                                              int F, int Fp, int nchunk,
+                                                              const int32_t* __restrict__ vidx,
+                                                              const int32_t* __restrict__ vcount) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CH = NTW * 256;  // floats per packed chunk of this column group
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, kq = lane >> 4;
   const int tile0 = blockIdx.y * NTW;  // first column tile of this group
-  const int m0 = (blockIdx.x * WAVES + wv) * 16;
 
-  // A row of this lane (clamped so tail rows read valid memory; their results are not stored)
-  int mr = min(m0 + c, M - 1);
-  int n = mr / T, t = mr - n * T;
-  const float* arow = E + ((size_t)n * Tp + t) * D + kq * 4;
+  // persistent row range of this workgroup over the (compacted) output rows
+  const int count = vcount ? vcount[0] : M;
+  const int per = ((count + (int)gridDim.x - 1) / (int)gridDim.x + 15) & ~15;
+  const int r_begin = blockIdx.x * per;
+  const int r_end = min(count, r_begin + per);
 
   const float* wsrc = Wp + (size_t)tile0 * 256;  // + ch * Fp * 16
   constexpr int NV4 = CH / 4;                    // float4 per chunk
@@ -64,80 +66,103 @@ __global__ __launch_bounds__(WAVES * 64) void conv_fwd_kernel(const float* __res
     }
   };
 
-  f32x4 acc[NTW];
-#pragma unroll
-  for (int i = 0; i < NTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int base = r_begin; base < r_end; base += WAVES * 16) {
+    const int m0 = base + wv * 16;
+    const bool active = m0 < r_end;   // wave-uniform; idle waves still stage W and meet the barriers
+    // A row of this lane (clamped so tail rows read valid memory; their results are not stored)
+    int r = min(m0 + c, r_end - 1);
+    int mr = vidx ? vidx[r] : r;
+    int n = mr / T, t = mr - n * T;
+    const float* arow = E + ((size_t)n * Tp + t) * D + kq * 4;
 
-  load_w(0);
-  store_w(0);
-  float4 a_cur = *(const float4*)(arow);
-  __syncthreads();
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const int buf = ch & 1;
-    float4 a_nxt = a_cur;
-    if (ch + 1 < nchunk) {
-      load_w(ch + 1);
-      a_nxt = *(const float4*)(arow + (ch + 1) * 16);
-    }
-    const float* bs = smem + buf * CH + c * 16 + kq * 4;
-    // groups of G tiles: consecutive MFMAs hit different accumulators (dependent-issue latency 40 cycles
-    // against a 32-cycle issue interval would otherwise leave the matrix pipe idle 20 % of the time)
-    constexpr int G = (NTW % 5 == 0) ? 5 : (NTW % 4 == 0 ? 4 : 1);
-#pragma unroll
-    for (int g0 = 0; g0 < NTW; g0 += G) {
-      float4 b[G];
-#pragma unroll
-      for (int j = 0; j < G; ++j) b[j] = *(const float4*)(bs + (g0 + j) * 256);
-#pragma unroll
-      for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.x, b[j].x, acc[g0 + j]);
-#pragma unroll
-      for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.y, b[j].y, acc[g0 + j]);
-#pragma unroll
-      for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.z, b[j].z, acc[g0 + j]);
-#pragma unroll
-      for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.w, b[j].w, acc[g0 + j]);
-    }
-    if (ch + 1 < nchunk) store_w(buf ^ 1);
-    a_cur = a_nxt;
+    __syncthreads();  // previous row block's LDS reads are done
+    load_w(0);
+    store_w(0);
+    float4 a_cur = *(const float4*)(arow);
     __syncthreads();
-  }
 
-  // epilogue: + bias, ReLU, * (id != 0)   (paper.py:146, 150-155)
-  const int rq = lane >> 4;
-  float keep[4];
-  int rows[4];
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int buf = ch & 1;
+      float4 a_nxt = a_cur;
+      if (ch + 1 < nchunk) {
+        load_w(ch + 1);
+        a_nxt = *(const float4*)(arow + (ch + 1) * 16);
+      }
+      if (active) {
+        const float* bs = smem + buf * CH + c * 16 + kq * 4;
+        // groups of G tiles: consecutive MFMAs hit different accumulators (dependent-issue latency 40
+        // cycles against a 32-cycle issue interval would otherwise idle the matrix pipe)
+        constexpr int G = (NTW % 5 == 0) ? 5 : (NTW % 4 == 0 ? 4 : 1);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    rows[j] = m0 + rq * 4 + j;
-    keep[j] = (rows[j] < M && ids[rows[j]] != 0) ? 1.f : 0.f;
-  }
+        for (int g0 = 0; g0 < NTW; g0 += G) {
+          float4 b[G];
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) {
-    int col = (tile0 + nt) * 16 + c;
-    if (col < F) {
-      float bv = bias[col];
+          for (int j = 0; j < G; ++j) b[j] = *(const float4*)(bs + (g0 + j) * 256);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (rows[j] < M) C[(size_t)rows[j] * F + col] = fmaxf(acc[nt][j] + bv, 0.f) * keep[j];
+          for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.x, b[j].x, acc[g0 + j]);
+#pragma unroll
+          for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.y, b[j].y, acc[g0 + j]);
+#pragma unroll
+          for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.z, b[j].z, acc[g0 + j]);
+#pragma unroll
+          for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.w, b[j].w, acc[g0 + j]);
+        }
+      }
+      if (ch + 1 < nchunk) store_w(buf ^ 1);
+      a_cur = a_nxt;
+      __syncthreads();
+    }
+
+    // epilogue: + bias, ReLU, * (id != 0)   (paper.py:146, 150-155)
+    if (active) {
+      const int rq = lane >> 4;
+      float keep[4];
+      int rows[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int rr = m0 + rq * 4 + j;
+        bool ok = rr < r_end;
+        int mm = ok ? (vidx ? vidx[rr] : rr) : -1;
+        rows[j] = mm;
+        keep[j] = (ok && ids[mm] != 0) ? 1.f : 0.f;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        int col = (tile0 + nt) * 16 + c;
+        if (col < F) {
+          float bv = bias[col];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (rows[j] >= 0) C[(size_t)rows[j] * F + col] = fmaxf(acc[nt][j] + bv, 0.f) * keep[j];
+        }
+      }
     }
   }
 }
 
 void launch_conv_fwd(const float* emb, const float* w_packed, const float* bias, const int32_t* ids, float* out,
-                     int n_titles, int T, int D, int ksize, int F, hipStream_t s) {
+                     int n_titles, int T, int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount,
+                     hipStream_t s) {
   int M = n_titles * T;
   if (M == 0) return;
   int Tp = T + ksize - 1, KD = ksize * D, Fp = ceil16(F), nchunk = cdiv(KD, 16), ntiles = Fp / 16;
   if (ntiles == 25) {
     constexpr int NTW = 25, WAVES = 8;
-    hipLaunchKernelGGL((conv_fwd_kernel<NTW, WAVES>), dim3(cdiv(M, WAVES * 16), 1), dim3(WAVES * 64),
-                       2 * NTW * 256 * sizeof(float), s, emb, w_packed, bias, ids, out, M, T, Tp, D, F, Fp, nchunk);
+    int grid = std::min(cdiv(M, WAVES * 16), 256);  // one 8-wave workgroup per CU, persistent over its rows
+    hipLaunchKernelGGL((conv_fwd_kernel<NTW, WAVES>), dim3(grid, 1), dim3(WAVES * 64),
+                       2 * NTW * 256 * sizeof(float), s, emb, w_packed, bias, ids, out, M, T, Tp, D, F, Fp, nchunk,
+                       vidx, vcount);
   } else {
     constexpr int NTW = 4, WAVES = 4;
-    hipLaunchKernelGGL((conv_fwd_kernel<NTW, WAVES>), dim3(cdiv(M, WAVES * 16), cdiv(ntiles, NTW)),
-                       dim3(WAVES * 64), 2 * NTW * 256 * sizeof(float), s, emb, w_packed, bias, ids, out, M, T, Tp,
-                       D, F, Fp, nchunk);
+    int gy = cdiv(ntiles, NTW);
+    int grid = std::min(cdiv(M, WAVES * 16), std::max(1, 1024 / gy));
+    hipLaunchKernelGGL((conv_fwd_kernel<NTW, WAVES>), dim3(grid, gy), dim3(WAVES * 64),
+                       2 * NTW * 256 * sizeof(float), s, emb, w_packed, bias, ids, out, M, T, Tp, D, F, Fp, nchunk,
+                       vidx, vcount);
   }
 }
 
@@ -154,7 +179,9 @@ template <int WK, int WN, int CT, int TK>
 __global__ __launch_bounds__(WK * WN * 64) void conv_wgrad_kernel(const float* __restrict__ E,
                                                                   const float* __restrict__ dC,
                                                                   float* __restrict__ part, int M, int T, int Tp,
-                                                                  int D, int KD, int F, int tok_per_split) {
+                                                                  int D, int KD, int F,
+                                                                  const int32_t* __restrict__ vidx,
+                                                                  const int32_t* __restrict__ vcount) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTH = WK * WN * 64;
   constexpr int AW = 64 * WK;        // A tile width (kk)
@@ -165,8 +192,11 @@ __global__ __launch_bounds__(WK * WN * 64) void conv_wgrad_kernel(const float* _
   const int i16 = lane & 15, kq = lane >> 4;
   const int kk0 = blockIdx.x * AW;
   const int f0 = blockIdx.z * BW;
+  // contraction range of this split over the (compacted) token list
+  const int count = vcount ? vcount[0] : M;
+  const int tok_per_split = (((count + (int)gridDim.y - 1) / (int)gridDim.y) + TK - 1) / TK * TK;
   const int tok_begin = blockIdx.y * tok_per_split;
-  const int tok_end = min(M, tok_begin + tok_per_split);
+  const int tok_end = min(count, tok_begin + tok_per_split);
 
   const bool fvec = (F & 3) == 0;
   constexpr int A4 = TK * AW / 4, B4 = TK * BW / 4;
@@ -179,7 +209,8 @@ __global__ __launch_bounds__(WK * WN * 64) void conv_wgrad_kernel(const float* _
       int idx = tid + p * NTH;
       if (idx < A4) {
         int r = idx / (AW / 4), x4 = idx - r * (AW / 4);
-        int m = min(tok0 + r, M - 1);  // tail rows: valid address; their dC row is zero
+        int tk = min(tok0 + r, count - 1);  // tail rows: valid address; their dC row is zero
+        int m = vidx ? vidx[max(tk, 0)] : max(tk, 0);
         int n = m / T, t = m - n * T;
         sa[p] = *(const float4*)(E + ((size_t)n * Tp + t) * D + kk0 + x4 * 4);
       }
@@ -189,9 +220,10 @@ __global__ __launch_bounds__(WK * WN * 64) void conv_wgrad_kernel(const float* _
       int idx = tid + p * NTH;
       if (idx < B4) {
         int r = idx / (BW / 4), y4 = idx - r * (BW / 4);
-        int m = tok0 + r, f = f0 + y4 * 4;
+        int tk = tok0 + r, f = f0 + y4 * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < tok_end) {
+        if (tk < tok_end) {
+          int m = vidx ? vidx[tk] : tk;
           const float* src = dC + (size_t)m * F + f;
           if (fvec && f + 3 < F) {
             v = *(const float4*)src;
@@ -305,13 +337,11 @@ size_t conv_wgrad_scratch_bytes(int D, int ksize, int F) {
 }
 
 void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
-                       int ksize, int F, hipStream_t s) {
+                       int ksize, int F, const int32_t* vidx, const int32_t* vcount, hipStream_t s) {
   int M = n_titles * T, Tp = T + ksize - 1, KD = ksize * D;
   WgradGeom g = wgrad_geom(D, ksize, F);
   constexpr int TK = 16;
-  int nsplit = std::min(g.nsplit, std::max(1, cdiv(M, TK)));
-  int tps = cdiv(cdiv(M, nsplit), TK) * TK;
-  nsplit = cdiv(M, tps);
+  int nsplit = std::min(g.nsplit, std::max(1, cdiv(M, TK)));   // splits beyond the token list write zero slabs
   float* part = (float*)scratch;
   if (g.big) {
     constexpr int WK = 3, WN = 5, CT = 5;
@@ -323,12 +353,12 @@ void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scr
       attr_set = true;
     }
     hipLaunchKernelGGL((conv_wgrad_kernel<WK, WN, CT, TK>), dim3(g.kblocks, nsplit, g.fblocks), dim3(WK * WN * 64),
-                       lds, s, emb, dout, part, M, T, Tp, D, KD, F, tps);
+                       lds, s, emb, dout, part, M, T, Tp, D, KD, F, vidx, vcount);
   } else {
     constexpr int WK = 2, WN = 2, CT = 2;
     size_t lds = 2 * TK * (64 * WK + 16 * CT * WN) * sizeof(float);
     hipLaunchKernelGGL((conv_wgrad_kernel<WK, WN, CT, TK>), dim3(g.kblocks, nsplit, g.fblocks), dim3(WK * WN * 64),
-                       lds, s, emb, dout, part, M, T, Tp, D, KD, F, tps);
+                       lds, s, emb, dout, part, M, T, Tp, D, KD, F, vidx, vcount);
   }
   size_t count = (size_t)KD * F;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdivz(count, 256)), dim3(256), 0, s, part, nsplit, count, dw);

@@ -122,7 +122,8 @@ struct Workspace {
   float* cat; float* dcat; float* uservec; float* duser; float* du; float* logits; float* probs; float* loss_i;
   float* correct_i; float* parts; float* conv_wp; float* u_zr_p; float* u_h_p; float* ut_zr_p; float* ut_h_p;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; int32_t* first; float* gsum; int32_t* slot;
-  int32_t* user_rows; float* scores; float* colsum_scratch; size_t bytes;
+  int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch;
+  size_t bytes;
 };
 
 size_t max_gemm_scratch(const Dims& d) {
@@ -200,6 +201,9 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->user_rows = (int32_t*)take(nc * 4);
   w->scores = (float*)take(nc * f4);
   w->colsum_scratch = (float*)take((size_t)kColsumSlices * std::max(std::max(3 * d.H, d.U), 2 * d.F + 1) * f4);
+  w->vidx = (int32_t*)take(nt * d.T * 4);
+  w->vcount = (int32_t*)take(256);
+  w->vscratch = (int32_t*)take(compact_scratch_ints((int)(nt * d.T)) * 4);
   w->bytes = off;
 }
 
@@ -306,9 +310,11 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   launch_pack_b(gu + 2 * d.H, 3 * d.H, d.H, d.H, w.u_h_p, s);
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
+  launch_compact_valid(w.ids, nt * d.T, w.vidx, w.vcount, w.vscratch, s);   // non-pad tokens of this batch
   PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
-  PROF("conv_fwd", launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, s));
-  PROF("attpool_fwd", launch_attpool_fwd(w.conv, c->P("att_w"), c->P("att_b"), w.pooled, w.att_a, w.att_wt, nt, d.T, d.F,
+  PROF("conv_fwd", launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
+                                   w.vcount, s));
+  PROF("attpool_fwd", launch_attpool_fwd(w.conv, w.ids, c->P("att_w"), c->P("att_b"), w.pooled, w.att_a, w.att_wt, nt, d.T, d.F,
                                          drop, key1, s));
   launch_gemm(w.pooled, d.F, 0, c->P("dense_w"), d.U, 0, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, 1.f,
               w.gemm_scratch, s);
@@ -377,13 +383,14 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
   launch_gemm(w.pooled, d.F, 1, w.ddocvec, d.U, 0, c->G("dense_w"), d.U, nullptr, d.F, d.U, nt, 1.f, w.gemm_scratch, s);
   launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch, s);
   launch_gemm(w.ddocvec, d.U, 0, c->P("dense_w"), d.U, 1, w.dpooled, d.F, nullptr, nt, d.F, d.U, 1.f, w.gemm_scratch, s);
-  PROF("attpool_bwd", launch_attpool_bwd(w.conv, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, nt, d.T,
+  PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, nt, d.T,
                                          d.F, drop, key1, s));
   const int np = attpool_bwd_parts(nt), ldp = 2 * d.F + 1;
   launch_colsum2(w.parts, np, d.F, ldp, c->G("att_w"), 1.f, w.colsum_scratch, s);
   launch_colsum2(w.parts + d.F, np, d.F, ldp, c->G("conv_b"), 1.f, w.colsum_scratch, s);
   launch_colsum2(w.parts + 2 * d.F, np, 1, ldp, c->G("att_b"), 1.f, w.colsum_scratch, s);
-  PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, s));
+  PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
+                                       w.vidx, w.vcount, s));
 }
 
 int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n, int k1, bool ids_form, hipStream_t s) {
@@ -645,20 +652,30 @@ int lstur_gather_f32(const float* table, const int32_t* ids, float* out, int32_t
   launch_gather(table, ids, out, n_titles, title_len, dim, pad_left, pad_right, drop, key, (hipStream_t)stream);
   return check_launch("gather");
 }
+int lstur_valid_tokens(const int32_t* ids, int32_t n_tokens, int32_t* vidx, int32_t* count, int32_t* scratch,
+                       lstur_stream stream) {
+  if (!ids || !vidx || !count || !scratch) return fail(LSTUR_ERR_ARG, "valid_tokens: NULL");
+  launch_compact_valid(ids, n_tokens, vidx, count, scratch, (hipStream_t)stream);
+  return check_launch("valid_tokens");
+}
+size_t lstur_valid_tokens_scratch(int32_t n_tokens) { return compact_scratch_ints(n_tokens) * sizeof(int32_t); }
 int lstur_conv1d_relu_mask_fwd(const float* emb_padded, const float* w_packed, const float* bias, const int32_t* ids,
                                float* out, int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize,
-                               int32_t filters, lstur_stream stream) {
+                               int32_t filters, const int32_t* vidx, const int32_t* vcount, lstur_stream stream) {
   if (!emb_padded || !w_packed || !bias || !ids || !out || dim % 4) return fail(LSTUR_ERR_ARG, "conv fwd: bad argument");
-  launch_conv_fwd(emb_padded, w_packed, bias, ids, out, n_titles, title_len, dim, ksize, filters, (hipStream_t)stream);
+  launch_conv_fwd(emb_padded, w_packed, bias, ids, out, n_titles, title_len, dim, ksize, filters, vidx, vcount,
+                  (hipStream_t)stream);
   return check_launch("conv_fwd");
 }
 size_t lstur_conv1d_wgrad_scratch(int32_t dim, int32_t ksize, int32_t filters) {
   return conv_wgrad_scratch_bytes(dim, ksize, filters);
 }
 int lstur_conv1d_wgrad(const float* emb_padded, const float* dout, float* dw, void* scratch, int32_t n_titles,
-                       int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, lstur_stream stream) {
+                       int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx,
+                       const int32_t* vcount, lstur_stream stream) {
   if (!emb_padded || !dout || !dw || !scratch || dim % 4) return fail(LSTUR_ERR_ARG, "conv wgrad: bad argument");
-  launch_conv_wgrad(emb_padded, dout, dw, scratch, n_titles, title_len, dim, ksize, filters, (hipStream_t)stream);
+  launch_conv_wgrad(emb_padded, dout, dw, scratch, n_titles, title_len, dim, ksize, filters, vidx, vcount,
+                    (hipStream_t)stream);
   return check_launch("conv_wgrad");
 }
 size_t lstur_pack_b_floats(int32_t K, int32_t N) { return pack_b_floats(K, N); }
@@ -672,21 +689,21 @@ int lstur_pack_bt(const float* Bt, int32_t ldb, int32_t K, int32_t N, float* pac
   launch_pack_b_t(Bt, ldb, K, N, packed, (hipStream_t)stream);
   return check_launch("pack_bt");
 }
-int lstur_attpool_fwd(const float* conv_out, const float* att_w, const float* att_b, float* pooled, float* att_tanh,
-                      float* att_weight, int32_t n_titles, int32_t title_len, int32_t filters, float drop, uint32_t key,
-                      lstur_stream stream) {
+int lstur_attpool_fwd(const float* conv_out, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
+                      float* att_tanh, float* att_weight, int32_t n_titles, int32_t title_len, int32_t filters,
+                      float drop, uint32_t key, lstur_stream stream) {
   if (!conv_out || !att_w || !att_b || !pooled || !att_tanh || !att_weight) return fail(LSTUR_ERR_ARG, "attpool: NULL");
-  launch_attpool_fwd(conv_out, att_w, att_b, pooled, att_tanh, att_weight, n_titles, title_len, filters, drop, key,
+  launch_attpool_fwd(conv_out, ids, att_w, att_b, pooled, att_tanh, att_weight, n_titles, title_len, filters, drop, key,
                      (hipStream_t)stream);
   return check_launch("attpool_fwd");
 }
 int32_t lstur_attpool_bwd_parts(int32_t n_titles) { return attpool_bwd_parts(n_titles); }
-int lstur_attpool_bwd(const float* conv_out, const float* att_w, const float* att_tanh, const float* att_weight,
-                      const float* dpooled, float* dconv, float* parts, int32_t n_titles, int32_t title_len,
+int lstur_attpool_bwd(const float* conv_out, const int32_t* ids, const float* att_w, const float* att_tanh,
+                      const float* att_weight, const float* dpooled, float* dconv, float* parts, int32_t n_titles, int32_t title_len,
                       int32_t filters, float drop, uint32_t key, lstur_stream stream) {
   if (!conv_out || !att_w || !att_tanh || !att_weight || !dpooled || !dconv || !parts || filters > 1024)
     return fail(LSTUR_ERR_ARG, "attpool bwd: bad argument");
-  launch_attpool_bwd(conv_out, att_w, att_tanh, att_weight, dpooled, dconv, parts, n_titles, title_len, filters, drop,
+  launch_attpool_bwd(conv_out, ids, att_w, att_tanh, att_weight, dpooled, dconv, parts, n_titles, title_len, filters, drop,
                      key, (hipStream_t)stream);
   return check_launch("attpool_bwd");
 }

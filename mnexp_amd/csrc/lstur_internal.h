@@ -22,6 +22,9 @@ void launch_gather(const float* table, const int32_t* ids, float* out, int n_tit
                    int pad_l, int pad_r, float drop, uint32_t key, hipStream_t s);
 void launch_expand_titles(const int32_t* table, const int32_t* doc_ids, int32_t* out, int n, int T,
                           hipStream_t s);
+// stable list of non-pad tokens: vidx[0..*count) ; scratch = compact_scratch_ints(n) int32
+size_t compact_scratch_ints(int n);
+void launch_compact_valid(const int32_t* ids, int n, int32_t* vidx, int32_t* count, int32_t* scratch, hipStream_t s);
 size_t pack_b_floats(int K, int N);
 void launch_pack_b(const float* B, int ldb, int K, int N, float* packed, hipStream_t s);
 void launch_pack_b_t(const float* Bt, int ldb, int K, int N, float* packed, hipStream_t s);
@@ -57,17 +60,20 @@ void launch_predict_score(const float* u, const float* d, float* scores, int n, 
 void launch_mean2(const float* a, const float* b, int n, float* stats, hipStream_t s);
 
 // ---- conv.hip ----------------------------------------------------------------------------------
+// vidx/vcount (nullable): compacted list of output rows to compute (others are left untouched)
 void launch_conv_fwd(const float* emb, const float* w_packed, const float* bias, const int32_t* ids,
-                     float* out, int n_titles, int T, int D, int ksize, int F, hipStream_t s);
+                     float* out, int n_titles, int T, int D, int ksize, int F, const int32_t* vidx,
+                     const int32_t* vcount, hipStream_t s);
 size_t conv_wgrad_scratch_bytes(int D, int ksize, int F);
 void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scratch, int n_titles, int T,
-                       int D, int ksize, int F, hipStream_t s);
+                       int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount, hipStream_t s);
 
 // ---- attpool.hip -------------------------------------------------------------------------------
-void launch_attpool_fwd(const float* c, const float* att_w, const float* att_b, float* pooled, float* a,
-                        float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s);
+// ids (nullable): rows with id == 0 are taken as zero without reading c / writing dc
+void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
+                        float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s);
 int attpool_bwd_parts(int n_titles);
-void launch_attpool_bwd(const float* c, const float* att_w, const float* a, const float* w,
+void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, int n_titles, int T, int F, float drop,
                         uint32_t key, hipStream_t s);
 

@@ -69,6 +69,86 @@ void launch_expand_titles(const int32_t* table, const int32_t* doc_ids, int32_t*
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stable compaction of the non-pad tokens: vidx[0..count) = ascending flat token indices with id != 0.
+// The conv output of a pad token is multiplied by (id != 0) (reference task/paper.py:150-155) and its
+// gradient is zero, so both conv contractions run over this list only; results are unchanged.
+// Three tiny launches (count / scan / write) keep the order deterministic.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCompactBlock = 1024;  // ids per block (256 threads x 4)
+
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) {
+  __shared__ int wsum[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int k = 0; k < wv; ++k) base += wsum[k];
+  *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void compact_count_kernel(const int32_t* __restrict__ ids, int n,
+                                                            int32_t* __restrict__ block_counts) {
+  int i0 = blockIdx.x * kCompactBlock + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c += (i0 + k < n && ids[i0 + k] != 0) ? 1 : 0;
+  int total;
+  block_exclusive_scan_256(c, &total);
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void compact_scan_kernel(int32_t* __restrict__ block_counts, int nblocks,
+                                                           int32_t* __restrict__ count_out) {
+  // exclusive scan of block_counts in place (single block, chunks of 256)
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nblocks; b0 += 256) {
+    int i = b0 + threadIdx.x;
+    int v = i < nblocks ? block_counts[i] : 0;
+    int total;
+    int ex = block_exclusive_scan_256(v, &total);
+    int c0 = carry;
+    if (i < nblocks) block_counts[i] = c0 + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c0 + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) count_out[0] = carry;
+}
+__global__ __launch_bounds__(256) void compact_write_kernel(const int32_t* __restrict__ ids, int n,
+                                                            const int32_t* __restrict__ block_offsets,
+                                                            int32_t* __restrict__ vidx) {
+  int i0 = blockIdx.x * kCompactBlock + threadIdx.x * 4;
+  bool v[4];
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = i0 + k < n && ids[i0 + k] != 0;
+    c += v[k] ? 1 : 0;
+  }
+  int total;
+  int pos = block_offsets[blockIdx.x] + block_exclusive_scan_256(c, &total);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (v[k]) vidx[pos++] = i0 + k;
+}
+size_t compact_scratch_ints(int n) { return (size_t)cdiv(n, kCompactBlock); }
+void launch_compact_valid(const int32_t* ids, int n, int32_t* vidx, int32_t* count, int32_t* scratch, hipStream_t s) {
+  if (n <= 0) return;
+  int nb = cdiv(n, kCompactBlock);
+  hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(256), 0, s, ids, n, scratch);
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(256), 0, s, scratch, nb, count);
+  hipLaunchKernelGGL(compact_write_kernel, dim3(nb), dim3(256), 0, s, ids, n, scratch, vidx);
+}
+
+// ---------------------------------------------------------------------------------------------
 // B[K,N] -> MFMA operand image P[ceil(K/16)][ceil16(N)][16]:  P[ch][n][kk] = B[ch*16+kk][n]
 // A lane (c, kq) of mfma_f32_16x16x4 then reads ONE float4 P[ch][n0+c][4kq..4kq+3] and feeds
 // element s to MFMA s of the chunk (the k order inside a chunk is permuted identically on the

@@ -74,7 +74,7 @@ def test_conv_fwd_and_wgrad_at_baseline_shapes(N):
     out = torch.empty(N * T, F, dtype=torch.float32, device='cuda')
     b_d, ids_d = dev(b), dev(ids)
     check(lib.lstur_conv1d_relu_mask_fwd(Epd.data_ptr(), Wp.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(),
-                                         out.data_ptr(), N, T, D, k, F, stream()))
+                                         out.data_ptr(), N, T, D, k, F, None, None, stream()))
     x = torch.nn.functional.pad(dev(E).double().transpose(1, 2), (1, 1))
     ref = torch.relu(torch.nn.functional.conv1d(x, dev(Wc).double().permute(2, 1, 0), dev(b).double()))
     ref = ref.transpose(1, 2) * (dev(ids) != 0).unsqueeze(-1)
@@ -86,11 +86,36 @@ def test_conv_fwd_and_wgrad_at_baseline_shapes(N):
     dw = torch.empty(k * D, F, dtype=torch.float32, device='cuda')
     scratch = torch.empty(lib.lstur_conv1d_wgrad_scratch(D, k, F), dtype=torch.uint8, device='cuda')
     dC_d = dev(dC)
-    check(lib.lstur_conv1d_wgrad(Epd.data_ptr(), dC_d.data_ptr(), dw.data_ptr(), scratch.data_ptr(), N, T, D, k, F, stream()))
+    check(lib.lstur_conv1d_wgrad(Epd.data_ptr(), dC_d.data_ptr(), dw.data_ptr(), scratch.data_ptr(), N, T, D, k, F,
+                                 None, None, stream()))
     Ep_d = dev(Ep)
     cols = torch.stack([Ep_d[:, j:j + T] for j in range(k)], dim=2).reshape(N * T, k * D).double()
     ref_dw = cols.t() @ dC_d.double()
     err = (dw.double() - ref_dw).abs().max().item()
+    assert err < 2e-5 * ref_dw.abs().max().item(), err
+
+    # --- the same two contractions over the compacted list of non-pad tokens (what the training step runs)
+    vidx = torch.full((N * T,), -1, dtype=torch.int32, device='cuda')
+    vcount = torch.zeros(1, dtype=torch.int32, device='cuda')
+    vs = torch.zeros(max(1, lib.lstur_valid_tokens_scratch(N * T) // 4), dtype=torch.int32, device='cuda')
+    check(lib.lstur_valid_tokens(ids_d.data_ptr(), N * T, vidx.data_ptr(), vcount.data_ptr(), vs.data_ptr(), stream()))
+    want = np.flatnonzero(ids.reshape(-1)).astype(np.int32)
+    assert int(vcount.item()) == len(want) and np.array_equal(vidx[:len(want)].cpu().numpy(), want)   # bit-exact, stable
+    out2 = torch.full((N * T, F), -7.0, dtype=torch.float32, device='cuda')
+    check(lib.lstur_conv1d_relu_mask_fwd(Epd.data_ptr(), Wp.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(),
+                                         out2.data_ptr(), N, T, D, k, F, vidx.data_ptr(), vcount.data_ptr(), stream()))
+    valid = dev(ids.reshape(-1) != 0)
+    assert torch.equal(out2[valid], out[valid])              # same rows, bit-identical
+    assert (out2[~valid] == -7.0).all()                       # pad rows untouched
+    dC_m = dC_d * valid.unsqueeze(-1)                         # true gradients are zero on pad rows
+    dw_ref2 = torch.empty_like(dw)
+    check(lib.lstur_conv1d_wgrad(Epd.data_ptr(), dC_m.data_ptr(), dw_ref2.data_ptr(), scratch.data_ptr(), N, T, D, k, F,
+                                 None, None, stream()))
+    dC_g = torch.where(valid.unsqueeze(-1), dC_d, torch.full_like(dC_d, float('nan')))   # pad rows must not be read
+    dw2 = torch.empty_like(dw)
+    check(lib.lstur_conv1d_wgrad(Epd.data_ptr(), dC_g.data_ptr(), dw2.data_ptr(), scratch.data_ptr(), N, T, D, k, F,
+                                 vidx.data_ptr(), vcount.data_ptr(), stream()))
+    err = (dw2.double() - dw_ref2.double()).abs().max().item()
     assert err < 2e-5 * ref_dw.abs().max().item(), err
 
 
