@@ -44,7 +44,7 @@ def shard_users(n_users, rank_, world):
 
 def allreduce_bucket(flat_grad, group=None, prescaled=True):
     """Sum the dense-gradient bucket over ranks; divide by the world size unless already pre-scaled."""
-    if world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return flat_grad
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     if not prescaled:
@@ -56,7 +56,7 @@ def allgather_rows(rows, row_grads, group=None):
     """rows int32[n], row_grads fp32[n, Ue] -> concatenation over ranks in rank order (duplicates kept:
     the optimizer sums them in ascending order, the same on every rank -> replicas stay bit-identical)."""
     w = world_size(group)
-    if w == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return rows, row_grads
     n, ue = row_grads.shape
     all_rows = torch.empty(w * n, dtype=rows.dtype, device=rows.device)

@@ -90,6 +90,8 @@ class NativeModel:
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(dist_group)
+        # test hook: run the RCCL collectives even with one rank (exercises the exact DP call sequence)
+        self.force_collectives = False
         self.title_table = None
         if title_table is not None:
             self.set_title_table(title_table)
@@ -244,7 +246,7 @@ class NativeModel:
                  self.stats.data_ptr(), s), 'lstur_forward_backward')
         self.optimizer.iterations += 1
         t = self.optimizer.iterations
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             rows, grads = self._allreduce_grads(n)
             check(lib.lstur_adam_step(self._ctx, self.optimizer.lr, t, rows.data_ptr(), grads.data_ptr(),
                                       int(rows.shape[0]), s), 'lstur_adam_step')

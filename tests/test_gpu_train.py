@@ -94,3 +94,35 @@ def test_click_entry_point(tmp_path):
         '--user-embedding-dim', '8', '--textual-embedding-dim', '16', '--name', 'x'], catch_exceptions=False)
     assert r.exit_code == 0, r.output
     assert os.path.exists(os.path.join(str(tmp_path), 'logx.txt'))
+
+
+def test_dp_call_sequence_on_one_rank_nccl():
+    """The data-parallel step (RCCL all-reduce of the flat bucket + all-gather of the sparse user rows +
+    Adam over the gathered rows) with a 1-rank 'nccl' group must equal the plain single-GPU step."""
+    _need_gpu()
+    import torch.distributed as dist
+    from conftest import make_batch
+    from test_gpu_model import build, MID
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        dims, B, W, T, K1 = MID, 16, 6, 9, 5
+        outs = []
+        for force in (False, True):
+            O, p, model, rng = build('igru', dims, B, W, T, K1, 0.2)
+            model.force_collectives = force
+            for step in range(2):
+                user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
+                user[3] = user[0]
+                X = [user.astype(np.int64), hist.astype(np.float64)] + [cands[:, j].astype(np.float64) for j in range(K1)]
+                model.train_on_batch(X, None)
+            torch.cuda.synchronize()
+            outs.append(model.get_weights())
+        for n in outs[0]:
+            assert np.array_equal(outs[0][n], outs[1][n]), n
+    finally:
+        if created:
+            dist.destroy_process_group()
