@@ -196,12 +196,12 @@ int lstur_attpool_fwd(const float* conv_out, const int32_t* ids, const float* at
                       float* pooled, float* att_tanh, float* att_weight, int32_t n_titles, int32_t title_len,
                       int32_t filters, float drop, uint32_t key, lstur_stream stream);
 /* Backward of the above + ReLU'; dconv [N_t,T,F]; partial sums [n_part, 2F+1] reduced by the caller
- * through lstur_colsum: layout per row = datt_w[F] | dconv_b[F] | datt_b. */
+ * through lstur_colsum: layout per row = datt_w[F] | dconv_b[F] | datt_b.  row_scratch: N_t*T floats. */
 int32_t lstur_attpool_bwd_parts(int32_t n_titles);
 int lstur_attpool_bwd(const float* conv_out, const int32_t* ids, const float* att_w, const float* att_tanh,
                       const float* att_weight, const float* dpooled, float* dconv, float* parts,
-                      int32_t n_titles, int32_t title_len, int32_t filters, float drop, uint32_t key,
-                      lstur_stream stream);
+                      float* row_scratch, int32_t n_titles, int32_t title_len, int32_t filters, float drop,
+                      uint32_t key, lstur_stream stream);
 /* out[j] (+)= sum_i x[i, j]   (bias gradients, partial-sum reduction) */
 int lstur_colsum(const float* x, int32_t rows, int32_t cols, int32_t ld, float* out, float scale,
                  lstur_stream stream);

@@ -69,7 +69,7 @@ SIGNATURES = {
     'lstur_pack_bt': (_I, [_P, _I, _I, _I, _P, _P]),
     'lstur_attpool_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _P]),
     'lstur_attpool_bwd_parts': (_I, [_I]),
-    'lstur_attpool_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _P]),
+    'lstur_attpool_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _P]),
     'lstur_colsum': (_I, [_P, _I, _I, _I, _P, _F, _P]),
     'lstur_gemm_scratch': (_Z, [_I, _I, _I]),
     'lstur_gemm_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),

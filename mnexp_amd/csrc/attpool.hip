@@ -4,216 +4,289 @@
 // (task/paper.py:157-158, models.py:474-489):
 //   mask_t = any_f(c[t,f] != 0);  x = dropout(c);  a_t = tanh(x_t . k + b);
 //   e_t = exp(a_t) * mask_t;  w_t = e_t / (sum_t e_t + 1e-7);  pooled_f = sum_t x[t,f] w_t
-// No max-subtraction (tanh-bounded), an all-masked title pools to 0.  One title tile [T][F] lives in
-// LDS; row reductions are wavefront-shuffle reductions, the pool is a column pass.
+// No max-subtraction (tanh-bounded), an all-masked title pools to 0.
+//
+// HBM-bound streaming kernels, no LDS tiles and no block barriers on the hot path:
+//   forward : att_score (one wave per token row: x.k by wavefront shuffle)  ->  att_pool (one thread per
+//             (title, 4 filters): normalises the T weights and accumulates the pooled row)
+//   backward: att_bwd_dw (wave per token: dw_t = dp . x_t) -> att_bwd_ds (thread per title) ->
+//             att_bwd_dc (persistent blocks over token ranges: dconv rows + parameter-gradient partials
+//             kept in registers).
+// Rows of pad tokens (id == 0) are zero by construction and are neither read nor written when `ids` is given
+// (the conv kernels skip them too).  Dropout masks are re-derived from the counter hash in every pass.
 #include "lstur_device.h"
 #include "lstur_internal.h"
 
 namespace lstur {
 
-// Title tile [T][F] -> LDS.  Rows of pad tokens (id == 0) are zero by construction (the conv output is
-// multiplied by (id != 0)); with ids given they are not read at all (the conv kernels skip them too).
-__device__ __forceinline__ void load_title_tile(const float* __restrict__ src, const int32_t* __restrict__ ids,
-                                                float* __restrict__ xs, int T, int F) {
-  if ((F & 3) == 0) {
-    const int F4 = F / 4;
-    for (int i = threadIdx.x; i < T * F4; i += blockDim.x) {
-      int t = i / F4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!ids || ids[t] != 0) v = ((const float4*)src)[i];
-      ((float4*)xs)[i] = v;
+__device__ __forceinline__ float4 drop4(float4 v, uint32_t key, uint32_t e, uint32_t thresh, float scale) {
+  if (thresh) {
+    v.x = keep_elem(key, e + 0u, thresh) ? v.x * scale : 0.f;
+    v.y = keep_elem(key, e + 1u, thresh) ? v.y * scale : 0.f;
+    v.z = keep_elem(key, e + 2u, thresh) ? v.z * scale : 0.f;
+    v.w = keep_elem(key, e + 3u, thresh) ? v.w * scale : 0.f;
+  }
+  return v;
+}
+
+// ---- forward 1: per-token score.  a[row] = tanh(x.k + b), e[row] = exp(a) * any(c != 0) ------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict__ c, const int32_t* __restrict__ ids,
+                                                        const float* __restrict__ att_w,
+                                                        const float* __restrict__ att_b, float* __restrict__ a_out,
+                                                        float* __restrict__ e_out, int rows, int F, uint32_t thresh,
+                                                        uint32_t key, float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  if (ids && ids[row] == 0) {
+    if (lane == 0) {
+      a_out[row] = 0.f;
+      e_out[row] = 0.f;
+    }
+    return;
+  }
+  const float* src = c + (size_t)row * F;
+  const uint32_t e0 = (uint32_t)row * (uint32_t)F;
+  float s = 0.f;
+  bool nz = false;
+  if (VEC == 4) {
+    for (int f4 = lane; f4 < F / 4; f4 += 64) {
+      float4 v = ((const float4*)src)[f4];
+      nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+      v = drop4(v, key, e0 + f4 * 4, thresh, scale);
+      float4 k = ((const float4*)att_w)[f4];
+      s += v.x * k.x + v.y * k.y + v.z * k.z + v.w * k.w;
     }
   } else {
-    for (int i = threadIdx.x; i < T * F; i += blockDim.x) xs[i] = (!ids || ids[i / F] != 0) ? src[i] : 0.f;
+    for (int f = lane; f < F; f += 64) {
+      float v = src[f];
+      nz |= v != 0.f;
+      if (thresh) v = keep_elem(key, e0 + f, thresh) ? v * scale : 0.f;
+      s += v * att_w[f];
+    }
+  }
+  s = wave_sum(s);
+  bool m = __any(nz);
+  if (lane == 0) {
+    float a = tanhf(s + att_b[0]);
+    a_out[row] = a;
+    e_out[row] = m ? expf(a) : 0.f;
   }
 }
 
-__global__ __launch_bounds__(256) void attpool_fwd_kernel(const float* __restrict__ c,
-                                                          const int32_t* __restrict__ ids,
-                                                          const float* __restrict__ att_w,
-                                                          const float* __restrict__ att_b,
-                                                          float* __restrict__ pooled, float* __restrict__ a_out,
-                                                          float* __restrict__ w_out, int T, int F, uint32_t thresh,
-                                                          uint32_t key, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;           // [T][F]
-  float* es = smem + T * F;   // [T] masked exp
-  float* as = es + T;         // [T] tanh
+// ---- forward 2: per-title normalisation + pool.  `w` holds e on entry, the attention weights on exit -------
+template <int VEC>
+__global__ __launch_bounds__(128) void att_pool_kernel(const float* __restrict__ c, float* __restrict__ w,
+                                                       float* __restrict__ pooled, int T, int F, uint32_t thresh,
+                                                       uint32_t key, float scale) {
   const int n = blockIdx.x;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  load_title_tile(c + (size_t)n * T * F, ids ? ids + (size_t)n * T : nullptr, xs, T, F);
-  __syncthreads();
-  const float b = att_b[0];
-  for (int t = wv; t < T; t += 4) {
-    float* row = xs + t * F;
-    bool nz = false;
-    float s = 0.f;
-    uint32_t e0 = ((uint32_t)n * T + t) * (uint32_t)F;
-    for (int f = lane; f < F; f += 64) {
-      float v = row[f];
-      nz |= v != 0.f;
-      if (thresh) {
-        v = keep_elem(key, e0 + f, thresh) ? v * scale : 0.f;
-        row[f] = v;
-      }
-      s += v * att_w[f];
-    }
-    s = wave_sum(s);
-    bool m = __any(nz);
-    if (lane == 0) {
-      float a = tanhf(s + b);
-      as[t] = a;
-      es[t] = m ? expf(a) : 0.f;
-    }
-  }
-  __syncthreads();
+  float* wn = w + (size_t)n * T;
   float S = 0.f;
-  for (int t = 0; t < T; ++t) S += es[t];
+  for (int t = 0; t < T; ++t) S += wn[t];
   const float inv = 1.0f / (S + LSTUR_EPS);
-  for (int f = threadIdx.x; f < F; f += 256) {
-    float acc = 0.f;
-    for (int t = 0; t < T; ++t) acc += xs[t * F + f] * (es[t] * inv);
-    pooled[(size_t)n * F + f] = acc;
+  const float* cn = c + (size_t)n * T * F;
+  const int cols = VEC == 4 ? F / 4 : F;
+  for (int j = threadIdx.x; j < cols; j += 128) {
+    if (VEC == 4) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t = 0; t < T; ++t) {
+        float wt = wn[t] * inv;
+        if (wt != 0.f) {   // masked / pad rows carry weight 0 and may hold unwritten memory
+          float4 v = ((const float4*)(cn + (size_t)t * F))[j];
+          v = drop4(v, key, ((uint32_t)n * T + t) * (uint32_t)F + j * 4, thresh, scale);
+          acc.x += v.x * wt;
+          acc.y += v.y * wt;
+          acc.z += v.z * wt;
+          acc.w += v.w * wt;
+        }
+      }
+      ((float4*)(pooled + (size_t)n * F))[j] = acc;
+    } else {
+      float acc = 0.f;
+      for (int t = 0; t < T; ++t) {
+        float wt = wn[t] * inv;
+        if (wt != 0.f) {
+          float v = cn[(size_t)t * F + j];
+          if (thresh) v = keep_elem(key, ((uint32_t)n * T + t) * (uint32_t)F + j, thresh) ? v * scale : 0.f;
+          acc += v * wt;
+        }
+      }
+      pooled[(size_t)n * F + j] = acc;
+    }
   }
-  for (int t = threadIdx.x; t < T; t += 256) {
-    a_out[(size_t)n * T + t] = as[t];
-    w_out[(size_t)n * T + t] = es[t] * inv;
-  }
+  __syncthreads();  // every thread has read the e values
+  for (int t = threadIdx.x; t < T; t += 128) wn[t] = wn[t] * inv;
 }
 
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
                         float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s) {
   if (!n_titles) return;
-  size_t lds = ((size_t)T * F + 2 * T) * sizeof(float);
-  static size_t attr = 0;
-  if (lds > 65536 && lds > attr) {
-    (void)hipFuncSetAttribute((const void*)attpool_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = lds;
-  }
   uint32_t thresh = drop > 0.f ? dropout_thresh(drop) : 0u;
   float scale = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
-  hipLaunchKernelGGL(attpool_fwd_kernel, dim3(n_titles), dim3(256), lds, s, c, ids, att_w, att_b, pooled, a, w, T, F,
-                     thresh, key, scale);
+  int rows = n_titles * T;
+  if (F % 4 == 0) {
+    hipLaunchKernelGGL(att_score_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, c, ids, att_w, att_b, a, w, rows, F,
+                       thresh, key, scale);
+    hipLaunchKernelGGL(att_pool_kernel<4>, dim3(n_titles), dim3(128), 0, s, c, w, pooled, T, F, thresh, key, scale);
+  } else {
+    hipLaunchKernelGGL(att_score_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, s, c, ids, att_w, att_b, a, w, rows, F,
+                       thresh, key, scale);
+    hipLaunchKernelGGL(att_pool_kernel<1>, dim3(n_titles), dim3(128), 0, s, c, w, pooled, T, F, thresh, key, scale);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Backward through pool, attention, dropout and the ReLU of the conv output.
 //   dw_t = sum_f dp_f x_tf ; ds_t = (dw_t - sum_t' dw_t' w_t') w_t (1 - a_t^2)
 //   dx_tf = dp_f w_t + ds_t k_f ; dc_tf = dx_tf * keep*scale * [c_tf > 0]
-// Parameter-gradient partial sums are kept in registers across the titles a workgroup visits and
-// written once: parts[wg] = datt_w[F] | dconv_b[F] | datt_b.
+// parts[block] = datt_w[F] | dconv_b[F] | datt_b  (reduced by the caller with colsum).
 // ---------------------------------------------------------------------------------------------
-constexpr int kFPT = 4;  // columns per thread (F <= 1024)
+template <int VEC>
+__global__ __launch_bounds__(256) void att_bwd_dw_kernel(const float* __restrict__ c, const float* __restrict__ w,
+                                                         const float* __restrict__ dpooled, float* __restrict__ dw,
+                                                         int rows, int T, int F, uint32_t thresh, uint32_t key,
+                                                         float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  if (w[row] == 0.f) {   // masked / pad row: contributes nothing and may hold unwritten memory
+    if (lane == 0) dw[row] = 0.f;
+    return;
+  }
+  const int n = row / T;
+  const float* src = c + (size_t)row * F;
+  const float* dp = dpooled + (size_t)n * F;
+  const uint32_t e0 = (uint32_t)row * (uint32_t)F;
+  float s = 0.f;
+  if (VEC == 4) {
+    for (int f4 = lane; f4 < F / 4; f4 += 64) {
+      float4 v = drop4(((const float4*)src)[f4], key, e0 + f4 * 4, thresh, scale);
+      float4 d = ((const float4*)dp)[f4];
+      s += v.x * d.x + v.y * d.y + v.z * d.z + v.w * d.w;
+    }
+  } else {
+    for (int f = lane; f < F; f += 64) {
+      float v = src[f];
+      if (thresh) v = keep_elem(key, e0 + f, thresh) ? v * scale : 0.f;
+      s += v * dp[f];
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) dw[row] = s;
+}
+
+// dw (in) -> ds (out, in place)
+__global__ void att_bwd_ds_kernel(float* __restrict__ dw, const float* __restrict__ w, const float* __restrict__ a,
+                                  int n_titles, int T) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_titles) return;
+  float* d = dw + (size_t)n * T;
+  const float* wn = w + (size_t)n * T;
+  const float* an = a + (size_t)n * T;
+  float sum = 0.f;
+  for (int t = 0; t < T; ++t) sum += d[t] * wn[t];
+  for (int t = 0; t < T; ++t) {
+    float av = an[t];
+    d[t] = (d[t] - sum) * wn[t] * (1.0f - av * av);
+  }
+}
 
 int attpool_bwd_parts(int n_titles) { return n_titles < 1024 ? (n_titles > 0 ? n_titles : 1) : 1024; }
 
-__global__ __launch_bounds__(256) void attpool_bwd_kernel(const float* __restrict__ c,
-                                                          const int32_t* __restrict__ ids,
-                                                          const float* __restrict__ att_w,
-                                                          const float* __restrict__ a_in,
-                                                          const float* __restrict__ w_in,
-                                                          const float* __restrict__ dpooled, float* __restrict__ dc,
-                                                          float* __restrict__ parts, int n_titles, int T, int F,
-                                                          uint32_t thresh, uint32_t key, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;            // [T][F]
-  float* dp = xs + T * F;      // [F]
-  float* ws = dp + F;          // [T]
-  float* av = ws + T;          // [T]
-  float* dwv = av + T;         // [T] -> ds
-  float* vr = dwv + T;         // [T] 1 = row is a real token (dconv row is written)
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float gaw[kFPT], gcb[kFPT], kf[kFPT];
-#pragma unroll
-  for (int i = 0; i < kFPT; ++i) {
-    gaw[i] = 0.f;
-    gcb[i] = 0.f;
-    int f = threadIdx.x + i * 256;
-    kf[i] = f < F ? att_w[f] : 0.f;
-  }
-  float gab = 0.f;
-
-  for (int n = blockIdx.x; n < n_titles; n += gridDim.x) {
-    __syncthreads();  // previous title's LDS reads done
-    const int32_t* idn = ids ? ids + (size_t)n * T : nullptr;
-    load_title_tile(c + (size_t)n * T * F, idn, xs, T, F);
-    for (int f = threadIdx.x; f < F; f += 256) dp[f] = dpooled[(size_t)n * F + f];
-    for (int t = threadIdx.x; t < T; t += 256) {
-      ws[t] = w_in[(size_t)n * T + t];
-      av[t] = a_in[(size_t)n * T + t];
-      vr[t] = (!idn || idn[t] != 0) ? 1.f : 0.f;
-    }
-    __syncthreads();
-    for (int t = wv; t < T; t += 4) {
-      float* row = xs + t * F;
-      float s = 0.f;
-      uint32_t e0 = ((uint32_t)n * T + t) * (uint32_t)F;
-      for (int f = lane; f < F; f += 64) {
-        float v = row[f];
-        if (thresh) {
-          v = keep_elem(key, e0 + f, thresh) ? v * scale : 0.f;
-          row[f] = v;
-        }
-        s += dp[f] * v;
-      }
-      s = wave_sum(s);
-      if (lane == 0) dwv[t] = s;
-    }
-    __syncthreads();
-    float sumdw = 0.f;
-    for (int t = 0; t < T; ++t) sumdw += dwv[t] * ws[t];
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 256) {
-      float a = av[t];
-      dwv[t] = (dwv[t] - sumdw) * ws[t] * (1.0f - a * a);  // ds_t
-    }
-    __syncthreads();
-    float* dcn = dc + (size_t)n * T * F;
-#pragma unroll
-    for (int i = 0; i < kFPT; ++i) {
-      int f = threadIdx.x + i * 256;
-      if (f < F) {
-        float dpf = dp[f];
-        for (int t = 0; t < T; ++t) {
-          float xv = xs[t * F + f];
-          float ds = dwv[t];
-          float dx = dpf * ws[t] + ds * kf[i];
-          gaw[i] += ds * xv;
-          float d = xv > 0.f ? dx * scale : 0.f;
-          gcb[i] += d;
-          if (vr[t] != 0.f) dcn[t * F + f] = d;   // pad rows are never read by the kernel gradient
-        }
-      }
-    }
-    if (threadIdx.x == 0)
-      for (int t = 0; t < T; ++t) gab += dwv[t];
-  }
+template <int VEC>
+__global__ __launch_bounds__(128) void att_bwd_dc_kernel(const float* __restrict__ c, const int32_t* __restrict__ ids,
+                                                         const float* __restrict__ att_w, const float* __restrict__ w,
+                                                         const float* __restrict__ ds,
+                                                         const float* __restrict__ dpooled, float* __restrict__ dc,
+                                                         float* __restrict__ parts, int rows, int T, int F,
+                                                         uint32_t thresh, uint32_t key, float scale) {
+  const int cols = VEC == 4 ? F / 4 : F;
+  const int per = (rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
   float* pr = parts + (size_t)blockIdx.x * (2 * F + 1);
-#pragma unroll
-  for (int i = 0; i < kFPT; ++i) {
-    int f = threadIdx.x + i * 256;
-    if (f < F) {
-      pr[f] = gaw[i];
-      pr[F + f] = gcb[i];
+  for (int j = threadIdx.x; j < cols; j += 128) {
+    if (VEC == 4) {
+      float4 kf = ((const float4*)att_w)[j];
+      float4 gaw = make_float4(0.f, 0.f, 0.f, 0.f), gcb = gaw;
+      for (int row = r0; row < r1; ++row) {
+        if (ids && ids[row] == 0) continue;
+        const float wt = w[row], dst = ds[row];
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wt != 0.f) {   // masked rows: x * 0 -- their dconv row is exactly 0
+          const int n = row / T;
+          float4 x = drop4(((const float4*)(c + (size_t)row * F))[j], key, (uint32_t)row * (uint32_t)F + j * 4, thresh,
+                           scale);
+          float4 dp = ((const float4*)(dpooled + (size_t)n * F))[j];
+          gaw.x += dst * x.x;
+          gaw.y += dst * x.y;
+          gaw.z += dst * x.z;
+          gaw.w += dst * x.w;
+          o.x = x.x > 0.f ? (dp.x * wt + dst * kf.x) * scale : 0.f;
+          o.y = x.y > 0.f ? (dp.y * wt + dst * kf.y) * scale : 0.f;
+          o.z = x.z > 0.f ? (dp.z * wt + dst * kf.z) * scale : 0.f;
+          o.w = x.w > 0.f ? (dp.w * wt + dst * kf.w) * scale : 0.f;
+          gcb.x += o.x;
+          gcb.y += o.y;
+          gcb.z += o.z;
+          gcb.w += o.w;
+        }
+        ((float4*)(dc + (size_t)row * F))[j] = o;
+      }
+      pr[j * 4 + 0] = gaw.x;
+      pr[j * 4 + 1] = gaw.y;
+      pr[j * 4 + 2] = gaw.z;
+      pr[j * 4 + 3] = gaw.w;
+      pr[F + j * 4 + 0] = gcb.x;
+      pr[F + j * 4 + 1] = gcb.y;
+      pr[F + j * 4 + 2] = gcb.z;
+      pr[F + j * 4 + 3] = gcb.w;
+    } else {
+      float kf = att_w[j], gaw = 0.f, gcb = 0.f;
+      for (int row = r0; row < r1; ++row) {
+        if (ids && ids[row] == 0) continue;
+        const float wt = w[row], dst = ds[row];
+        float o = 0.f;
+        if (wt != 0.f) {
+          const int n = row / T;
+          float x = c[(size_t)row * F + j];
+          if (thresh) x = keep_elem(key, (uint32_t)row * (uint32_t)F + j, thresh) ? x * scale : 0.f;
+          gaw += dst * x;
+          o = x > 0.f ? (dpooled[(size_t)n * F + j] * wt + dst * kf) * scale : 0.f;
+          gcb += o;
+        }
+        dc[(size_t)row * F + j] = o;
+      }
+      pr[j] = gaw;
+      pr[F + j] = gcb;
     }
   }
-  if (threadIdx.x == 0) pr[2 * F] = gab;
+  if (threadIdx.x == 0) {
+    float gab = 0.f;
+    for (int row = r0; row < r1; ++row) gab += ds[row];   // ds is 0 on masked / pad rows
+    pr[2 * F] = gab;
+  }
 }
 
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
-                        const float* dpooled, float* dc, float* parts, int n_titles, int T, int F, float drop,
-                        uint32_t key, hipStream_t s) {
+                        const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
+                        float drop, uint32_t key, hipStream_t s) {
   if (!n_titles) return;
-  size_t lds = ((size_t)T * F + F + 4 * T) * sizeof(float);
-  static size_t attr = 0;
-  if (lds > 65536 && lds > attr) {
-    (void)hipFuncSetAttribute((const void*)attpool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = lds;
-  }
   uint32_t thresh = drop > 0.f ? dropout_thresh(drop) : 0u;
   float scale = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
-  hipLaunchKernelGGL(attpool_bwd_kernel, dim3(attpool_bwd_parts(n_titles)), dim3(256), lds, s, c, ids, att_w, a, w,
-                     dpooled, dc, parts, n_titles, T, F, thresh, key, scale);
+  const int rows = n_titles * T;
+  const int nparts = attpool_bwd_parts(n_titles);
+  if (F % 4 == 0) {
+    hipLaunchKernelGGL(att_bwd_dw_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, c, w, dpooled, row_scratch, rows, T, F,
+                       thresh, key, scale);
+    hipLaunchKernelGGL(att_bwd_ds_kernel, dim3(cdiv(n_titles, 128)), dim3(128), 0, s, row_scratch, w, a, n_titles, T);
+    hipLaunchKernelGGL(att_bwd_dc_kernel<4>, dim3(nparts), dim3(128), 0, s, c, ids, att_w, w, row_scratch, dpooled, dc,
+                       parts, rows, T, F, thresh, key, scale);
+  } else {
+    hipLaunchKernelGGL(att_bwd_dw_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, s, c, w, dpooled, row_scratch, rows, T, F,
+                       thresh, key, scale);
+    hipLaunchKernelGGL(att_bwd_ds_kernel, dim3(cdiv(n_titles, 128)), dim3(128), 0, s, row_scratch, w, a, n_titles, T);
+    hipLaunchKernelGGL(att_bwd_dc_kernel<1>, dim3(nparts), dim3(128), 0, s, c, ids, att_w, w, row_scratch, dpooled, dc,
+                       parts, rows, T, F, thresh, key, scale);
+  }
 }
 
 }  // namespace lstur

@@ -122,7 +122,7 @@ struct Workspace {
   float* cat; float* dcat; float* uservec; float* duser; float* du; float* logits; float* probs; float* loss_i;
   float* correct_i; float* parts; float* conv_wp; float* u_zr_p; float* u_h_p; float* ut_zr_p; float* ut_h_p;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; int32_t* first; float* gsum; int32_t* slot;
-  int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch;
+  int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds;
   size_t bytes;
 };
 
@@ -203,6 +203,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->colsum_scratch = (float*)take((size_t)kColsumSlices * std::max(std::max(3 * d.H, d.U), 2 * d.F + 1) * f4);
   w->vidx = (int32_t*)take(nt * d.T * 4);
   w->vcount = (int32_t*)take(256);
+  w->att_ds = (float*)take(nt * d.T * f4);
   w->vscratch = (int32_t*)take(compact_scratch_ints((int)(nt * d.T)) * 4);
   w->bytes = off;
 }
@@ -383,8 +384,8 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
   launch_gemm(w.pooled, d.F, 1, w.ddocvec, d.U, 0, c->G("dense_w"), d.U, nullptr, d.F, d.U, nt, 1.f, w.gemm_scratch, s);
   launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch, s);
   launch_gemm(w.ddocvec, d.U, 0, c->P("dense_w"), d.U, 1, w.dpooled, d.F, nullptr, nt, d.F, d.U, 1.f, w.gemm_scratch, s);
-  PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, nt, d.T,
-                                         d.F, drop, key1, s));
+  PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, w.att_ds,
+                                         nt, d.T, d.F, drop, key1, s));
   const int np = attpool_bwd_parts(nt), ldp = 2 * d.F + 1;
   launch_colsum2(w.parts, np, d.F, ldp, c->G("att_w"), 1.f, w.colsum_scratch, s);
   launch_colsum2(w.parts + d.F, np, d.F, ldp, c->G("conv_b"), 1.f, w.colsum_scratch, s);
@@ -699,12 +700,14 @@ int lstur_attpool_fwd(const float* conv_out, const int32_t* ids, const float* at
 }
 int32_t lstur_attpool_bwd_parts(int32_t n_titles) { return attpool_bwd_parts(n_titles); }
 int lstur_attpool_bwd(const float* conv_out, const int32_t* ids, const float* att_w, const float* att_tanh,
-                      const float* att_weight, const float* dpooled, float* dconv, float* parts, int32_t n_titles, int32_t title_len,
-                      int32_t filters, float drop, uint32_t key, lstur_stream stream) {
-  if (!conv_out || !att_w || !att_tanh || !att_weight || !dpooled || !dconv || !parts || filters > 1024)
+                      const float* att_weight, const float* dpooled, float* dconv, float* parts, float* row_scratch,
+                      int32_t n_titles, int32_t title_len, int32_t filters, float drop, uint32_t key,
+                      lstur_stream stream) {
+  if (!conv_out || !att_w || !att_tanh || !att_weight || !dpooled || !dconv || !parts || !row_scratch ||
+      filters > 1024)
     return fail(LSTUR_ERR_ARG, "attpool bwd: bad argument");
-  launch_attpool_bwd(conv_out, ids, att_w, att_tanh, att_weight, dpooled, dconv, parts, n_titles, title_len, filters, drop,
-                     key, (hipStream_t)stream);
+  launch_attpool_bwd(conv_out, ids, att_w, att_tanh, att_weight, dpooled, dconv, parts, row_scratch, n_titles,
+                     title_len, filters, drop, key, (hipStream_t)stream);
   return check_launch("attpool_bwd");
 }
 int lstur_colsum(const float* x, int32_t rows, int32_t cols, int32_t ld, float* out, float scale, lstur_stream stream) {

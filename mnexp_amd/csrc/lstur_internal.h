@@ -73,9 +73,10 @@ void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scr
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
                         float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s);
 int attpool_bwd_parts(int n_titles);
+// row_scratch: n_titles*T floats (dw -> ds)
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
-                        const float* dpooled, float* dc, float* parts, int n_titles, int T, int F, float drop,
-                        uint32_t key, hipStream_t s);
+                        const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
+                        float drop, uint32_t key, hipStream_t s);
 
 // ---- gemm.hip ----------------------------------------------------------------------------------
 size_t gemm_scratch_bytes(int M, int N, int K);
