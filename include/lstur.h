@@ -211,17 +211,22 @@ size_t lstur_gemm_scratch(int32_t M, int32_t N, int32_t K);
 int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int32_t ldb, int32_t tb,
                    float* C, int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K,
                    float alpha, void* scratch, lstur_stream stream);
+/* Operand images of the recurrent matrix gru_u [H,3H] (z|r|h) for the two GRU kernels, written in one launch.
+ * lstur_gru_pack_floats(H) = total floats; u_zr and ut_zr take 2/6 each, u_h and ut_h 1/6 each.  Gate columns
+ * are padded per gate to Hp = ceil16(H) so that no 16-column MFMA tile straddles two gates. */
+size_t lstur_gru_pack_floats(int32_t H);
+int lstur_gru_pack_u(const float* gru_u, int32_t H, float* u_zr, float* u_h, float* ut_h, float* ut_zr,
+                     lstur_stream stream);
 /* Masked Keras-2.2.4 GRU over W steps (paper.py:592,597-613; K.rnn mask semantics).
  *   xw [n,W,3H] input projection incl. bias; gmask uint8 [n,W]; h0 [n,H] or NULL (zeros)
- *   u_zr_packed = lstur_pack_b(gru_u[:, :2H]); u_h_packed = lstur_pack_b(gru_u[:, 2H:])  (ldb = 3H)
- *   outputs hs [n,W+1,H], z/r/hh [n,W,H];  H <= 256 */
+ *   outputs hs [n,W+1,H], z/r/hh [n,W,H];  H <= 256.
+ * EVERY per-sample buffer (xw, gmask, hs, zs, rs, hhs, and dgates/rh/hprev below) must be allocated for
+ * ceil16(n) samples: the kernels process whole 16-sample row tiles without masking the tail rows. */
 int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
                   const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int32_t n, int32_t W,
                   int32_t H, lstur_stream stream);
 /* BPTT: dh_last [n,H] -> dgates [n,W,3H], rh [n,W,H] (= r * h_prev, operand of dU_h),
- *   hprev [n,W,H] (= h_{t-1}, operand of dU_zr), dh0 [n,H].
- *   ut_zr_packed = lstur_pack_bt(gru_u, 3H, 2H, H)      (U[:, :2H]^T as [2H, H])
- *   ut_h_packed  = lstur_pack_bt(gru_u + 2H, 3H, H, H)  (U[:, 2H:]^T as [H, H]) */
+ *   hprev [n,W,H] (= h_{t-1}, operand of dU_zr), dh0 [n,H]. */
 int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, const float* hs, const float* zs,
                   const float* rs, const float* hhs, const float* ut_zr_packed, const float* ut_h_packed,
                   float* dgates, float* rh, float* hprev, float* dh0, int32_t n, int32_t W, int32_t H,

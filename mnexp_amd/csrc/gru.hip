@@ -21,8 +21,8 @@ namespace lstur {
 
 constexpr int GW = 8;  // waves per workgroup
 
-// ring depth for a wave that owns C column tiles: ~12 float4 fragment loads in flight per wave
-__host__ __device__ constexpr int ring_depth(int C) { return C >= 4 ? 3 : (C == 3 ? 4 : (C == 2 ? 6 : 8)); }
+// ring depth for a wave that owns C column tiles: ~8 float4 fragment loads in flight per wave
+__host__ __device__ constexpr int ring_depth(int C) { return C >= 4 ? 2 : (C == 3 ? 3 : (C == 2 ? 4 : 6)); }
 
 // Register ring of packed-B fragments for C tiles (first, first+GW, ...) of one operand image.
 template <int C>
@@ -115,104 +115,159 @@ __device__ __forceinline__ void gemm_run(FragRing<C>& ring, const float* __restr
 
 struct GruFwdArgs {
   const float* xw; const uint8_t* gmask; const float* h0; const float* u_zr; const float* u_h;
-  float* hs; float* zs; float* rs; float* hhs; int n, W, H, nostream;
+  float* hs; float* zs; float* rs; float* hhs; int n, W, H, dbg;
 };
 
+// Layout contract of the GRU kernels (see lstur_gru_pack_u / include/lstur.h):
+//   * every per-sample buffer holds ceil16(n) sample rows (the last row tile is processed unmasked);
+//   * gate columns are padded per gate to Hp = ceil16(H): the z|r image has N = 2*Hp columns (z at [0,H),
+//     r at [Hp, Hp+H)), so no 16-column tile straddles two gates and every epilogue is uniform per tile.
+//
 // Whole time loop for a wave that owns C1 tiles of the z|r product and C2 tiles of the candidate product.
 template <int C1, int C2, int NCH>
 __device__ __forceinline__ void gru_fwd_body(const GruFwdArgs& g, float* smem, int wv, int lane) {
-  const int H = g.H, W = g.W, n = g.n;
+  const int H = g.H, W = g.W;
   const int nch = cdiv(H, 16), Hp = nch * 16, LDH = Hp + 4;
-  const int N1 = 2 * H, NP1 = ceil16(N1);
   float* hL = smem;
   float* rhL = hL + 16 * LDH;
   float* zL = rhL + 16 * LDH;
   const int c = lane & 15, rq = lane >> 4, kq = lane >> 4;
-  const int b0 = blockIdx.x * 16;
-  const uint32_t uW = W, uH = H, uH3 = 3 * H;   // wrapping 32-bit index math keeps addresses cheap
+  const uint32_t rowb = blockIdx.x * 16 + rq * 4;            // first of this lane's 4 sample rows
+  const uint32_t uW = W, uH = H, uH3 = 3 * H, WH = uW * uH, WH3 = uW * uH3, W1H = (uW + 1u) * uH;
+  const bool nostream = (g.dbg & 1) != 0;
 
   constexpr int C2R = C2 > 0 ? C2 : 1;      // a wave without candidate tiles keeps a dummy ring (never run)
   FragRing<C1> ring1;
   FragRing<C2R> ring2;
-  ring1.bind(g.u_zr, NP1, nch, wv, lane, g.nostream != 0);
-  ring2.bind(g.u_h, Hp, nch, wv, lane, g.nostream != 0);
+  ring1.bind(g.u_zr, 2 * Hp, nch, wv, lane, nostream);
+  ring2.bind(g.u_h, Hp, nch, wv, lane, nostream);
   ring1.prefetch();
+
+  // per-lane invariants of the tiles this wave owns (hidden index clamped so every load is in range;
+  // stores / LDS writes of lanes past H are predicated off -- padding columns of the state stay 0)
+  bool isr[C1], ok1[C1], ok2[C2R];
+  uint32_t xo1[C1], go1[C1], xo2[C2R], go2[C2R], ho2[C2R];
+  int l1[C1], l2[C2R];
+#pragma unroll
+  for (int i = 0; i < C1; ++i) {
+    const int tcol = (wv + i * GW) * 16;
+    isr[i] = tcol >= Hp;                                      // wave-uniform: tile of r gates
+    const int hc = tcol - (isr[i] ? Hp : 0) + c;
+    ok1[i] = hc < H;
+    const int hcc = min(hc, H - 1);
+    xo1[i] = rowb * WH3 + (isr[i] ? uH : 0u) + (uint32_t)hcc;
+    go1[i] = rowb * WH + (uint32_t)hcc;
+    l1[i] = rq * 4 * LDH + hcc;
+  }
+#pragma unroll
+  for (int i = 0; i < C2R; ++i) {
+    const int hc = (wv + i * GW) * 16 + c;
+    ok2[i] = C2 > 0 && hc < H;
+    const int hcc = min(hc, H - 1);
+    xo2[i] = rowb * WH3 + 2u * uH + (uint32_t)hcc;
+    go2[i] = rowb * WH + (uint32_t)hcc;
+    ho2[i] = rowb * W1H + (uint32_t)hcc;
+    l2[i] = rq * 4 * LDH + hcc;
+  }
+  const uint32_t mo = rowb * uW;
 
   const float* a1 = hL + c * LDH + kq * 4;
   const float* a2 = rhL + c * LDH + kq * 4;
   f32x4 acc1[C1], acc2[C2R];
   float x1[C1][4], x2[C2R][4], mk[4];
+  unsigned long long c0 = 0, r0 = 0;    // diagnostic build only (dbg bit 4): in-kernel clock
+  if (g.dbg & 16) {
+    c0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  unsigned long long st[6] = {0, 0, 0, 0, 0, 0};   // diagnostic build only (dbg bit 5): per-segment shader cycles
+  const bool stamp = (g.dbg & 32) != 0;
+#define LSTUR_STAMP(k)                                   \
+  if (stamp) {                                           \
+    unsigned long long now = __builtin_amdgcn_s_memtime(); \
+    st[k] += now - last;                                 \
+    last = now;                                          \
+  }
   for (int t = 0; t < W; ++t) {
     const uint32_t ut = t;
+    const float* xw_t = g.xw + ut * uH3;
+    unsigned long long last = stamp ? __builtin_amdgcn_s_memtime() : 0;
     // ---- phase 1: z | r ----
 #pragma unroll
-    for (int i = 0; i < C1; ++i) {
-      int col = (wv + i * GW) * 16 + c;
+    for (int i = 0; i < C1; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int b = b0 + rq * 4 + j;
-        x1[i][j] = (col < N1 && b < n) ? g.xw[((uint32_t)b * uW + ut) * uH3 + (uint32_t)col] : 0.f;
-      }
-    }
+      for (int j = 0; j < 4; ++j) x1[i][j] = xw_t[xo1[i] + j * WH3];
     gemm_run<C1, NCH>(ring1, a1, nch, acc1);
+    LSTUR_STAMP(0)
     if (C2 > 0) ring2.prefetch();     // candidate-product fragments fly during the gate epilogue + barrier
+    float* zs_t = g.zs + ut * uH;
+    float* rs_t = g.rs + ut * uH;
 #pragma unroll
     for (int i = 0; i < C1; ++i) {
-      int col = (wv + i * GW) * 16 + c;
-      if (col >= N1) continue;
+      if (ok1[i]) {
+        if (!isr[i]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int row = rq * 4 + j, b = b0 + row;
-        if (b >= n) continue;
-        uint32_t bt = (uint32_t)b * uW + ut;
-        float gt = hard_sigmoid(acc1[i][j] + x1[i][j]);
-        if (col < H) {
-          zL[row * LDH + col] = gt;
-          g.zs[bt * uH + (uint32_t)col] = gt;
+          for (int j = 0; j < 4; ++j) {
+            float gt = hard_sigmoid(acc1[i][j] + x1[i][j]);
+            zL[l1[i] + j * LDH] = gt;
+            zs_t[go1[i] + j * WH] = gt;
+          }
         } else {
-          int k = col - H;
-          g.rs[bt * uH + (uint32_t)k] = gt;
-          rhL[row * LDH + k] = gt * hL[row * LDH + k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float gt = hard_sigmoid(acc1[i][j] + x1[i][j]);
+            rs_t[go1[i] + j * WH] = gt;
+            rhL[l1[i] + j * LDH] = gt * hL[l1[i] + j * LDH];
+          }
         }
       }
     }
+    // candidate inputs + mask for phase 2 (issued before the barrier so they fly during it)
+    if (C2 > 0) {
 #pragma unroll
-    for (int i = 0; i < C2; ++i) {
-      int col = (wv + i * GW) * 16 + c;
+      for (int i = 0; i < C2R; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int b = b0 + rq * 4 + j;
-        x2[i][j] = (col < H && b < n) ? g.xw[((uint32_t)b * uW + ut) * uH3 + 2u * uH + (uint32_t)col] : 0.f;
-      }
+        for (int j = 0; j < 4; ++j) x2[i][j] = xw_t[xo2[i] + j * WH3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mk[j] = g.gmask[mo + j * uW + ut] ? 1.f : 0.f;
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int b = b0 + rq * 4 + j;
-      mk[j] = (b < n && g.gmask[(uint32_t)b * uW + ut]) ? 1.f : 0.f;
-    }
+    LSTUR_STAMP(1)
     __syncthreads();
+    LSTUR_STAMP(2)
     // ---- phase 2: candidate + state update ----
     if (C2 > 0) gemm_run<C2R, NCH>(ring2, a2, nch, acc2);
+    LSTUR_STAMP(3)
     if (t + 1 < W) ring1.prefetch();  // next step's z|r fragments fly during the update + barrier
+    if (C2 > 0) {
+      float* hhs_t = g.hhs + ut * uH;
+      float* hs_t1 = g.hs + (ut + 1u) * uH;
 #pragma unroll
-    for (int i = 0; i < C2; ++i) {
-      int col = (wv + i * GW) * 16 + c;
-      if (col >= H) continue;
+      for (int i = 0; i < C2R; ++i) {
+        if (ok2[i]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int row = rq * 4 + j, b = b0 + row;
-        if (b >= n) continue;
-        uint32_t bt = (uint32_t)b * uW + ut;
-        float hh = tanhf(acc2[i][j] + x2[i][j]);
-        float z = zL[row * LDH + col], hp = hL[row * LDH + col];
-        float hn = z * hp + (1.0f - z) * hh;
-        float ho = mk[j] != 0.f ? hn : hp;  // K.rnn: masked step carries the previous state/output
-        g.hhs[bt * uH + (uint32_t)col] = hh;
-        g.hs[((uint32_t)b * (uW + 1u) + ut + 1u) * uH + (uint32_t)col] = ho;
-        hL[row * LDH + col] = ho;
+          for (int j = 0; j < 4; ++j) {
+            float hh = tanhf(acc2[i][j] + x2[i][j]);
+            float z = zL[l2[i] + j * LDH], hp = hL[l2[i] + j * LDH];
+            float hn = z * hp + (1.0f - z) * hh;
+            float ho = mk[j] != 0.f ? hn : hp;  // K.rnn: masked step carries the previous state/output
+            hhs_t[go2[i] + j * WH] = hh;
+            hs_t1[ho2[i] + j * W1H] = ho;
+            hL[l2[i] + j * LDH] = ho;
+          }
+        }
       }
     }
+    LSTUR_STAMP(4)
     __syncthreads();
+    LSTUR_STAMP(5)
+  }
+#undef LSTUR_STAMP
+  if (stamp && lane == 0 && blockIdx.x == 0)
+    for (int k = 0; k < 6; ++k) g.rs[wv * 8 + k] = (float)st[k];
+  if ((g.dbg & 16) && wv == 0 && lane == 0 && blockIdx.x == 0) {
+    unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    g.zs[0] = (float)(c1 - c0);   // shader cycles
+    g.zs[1] = (float)(r1 - r0);   // 100 MHz ticks
   }
 }
 
@@ -233,11 +288,11 @@ __global__ __launch_bounds__(GW * 64) void gru_fwd_kernel(GruFwdArgs g) {
     int row = i / H, col = i - row * H, b = b0 + row;
     float v = (g.h0 && b < n) ? g.h0[(size_t)b * H + col] : 0.f;
     hL[row * LDH + col] = v;
-    if (b < n) g.hs[(size_t)b * (W + 1) * H + col] = v;
+    g.hs[(size_t)b * (W + 1) * H + col] = v;
   }
   __syncthreads();
   // static (tile-count) specialisation per wave: every wave runs the same number of barriers
-  const int c1 = tiles_of(wv, ceil16(2 * H) / 16), c2 = tiles_of(wv, Hp / 16);
+  const int c1 = tiles_of(wv, 2 * Hp / 16), c2 = tiles_of(wv, Hp / 16);
 #define LSTUR_FWD_CASE(A, B)                                              \
   if (c1 == A && c2 == B) {                                               \
     if (nch == 13) return gru_fwd_body<A, B, 13>(g, smem, wv, lane);      \
@@ -274,16 +329,16 @@ struct GruBwdArgs {
 // `tile` holds rows rq*4+j, col tile*16+c -- so the element-wise work needs no extra LDS round trip.
 template <int C, int NCH, int NCH2>
 __device__ __forceinline__ void gru_bwd_body(const GruBwdArgs& g, float* smem, int wv, int lane) {
-  const int H = g.H, W = g.W, n = g.n;
+  const int H = g.H, W = g.W;
   const int nch = cdiv(H, 16), Hp = nch * 16, LDH = Hp + 4;
-  const int N1 = 2 * H, nch2 = cdiv(N1, 16), LD2 = nch2 * 16 + 4;
+  const int nch2 = 2 * nch, LD2 = 2 * Hp + 4;      // K of the last product is gate-padded: z at [0,H), r at [Hp,Hp+H)
   float* dhL = smem;               // [16][LDH] gradient wrt current state
   float* nL = dhL + 16 * LDH;      // [16][LDH] partial dh_prev
   float* g2L = nL + 16 * LDH;      // [16][LDH] dpre_h
   float* g1L = g2L + 16 * LDH;     // [16][LD2] dpre_z | dpre_r
   const int c = lane & 15, rq = lane >> 4, kq = lane >> 4;
-  const int b0 = blockIdx.x * 16;
-  const uint32_t uW = W, uH = H, uH3 = 3 * H;
+  const uint32_t rowb = blockIdx.x * 16 + rq * 4;
+  const uint32_t uW = W, uH = H, uH3 = 3 * H, WH = uW * uH, WH3 = uW * uH3, W1H = (uW + 1u) * uH;
 
   FragRing<C> ringh, ringzr;
   ringh.bind(g.ut_h, Hp, nch, wv, lane);
@@ -292,52 +347,58 @@ __device__ __forceinline__ void gru_bwd_body(const GruBwdArgs& g, float* smem, i
   const float* a2 = g2L + c * LDH + kq * 4;
   const float* a1 = g1L + c * LD2 + kq * 4;
 
+  bool ok[C];
+  uint32_t go[C], ho[C], dgo[C];
+  int l[C], lz[C];
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    const int hc = (wv + i * GW) * 16 + c;
+    ok[i] = hc < H;
+    const int hcc = min(hc, H - 1);
+    go[i] = rowb * WH + (uint32_t)hcc;
+    ho[i] = rowb * W1H + (uint32_t)hcc;
+    dgo[i] = rowb * WH3 + (uint32_t)hcc;
+    l[i] = rq * 4 * LDH + hcc;
+    lz[i] = rq * 4 * LD2 + hcc;
+  }
+  const uint32_t mo = rowb * uW;
+
   f32x4 acc[C];
   float zv[C][4], rv[C][4], hv[C][4], pv[C][4], mk[4];
   for (int t = W - 1; t >= 0; --t) {
     const uint32_t ut = t;
+    const uint32_t tH = ut * uH;
     // ---- this step's saved activations for the elements this lane owns ----
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int b = b0 + rq * 4 + j;
-      mk[j] = (b < n && g.gmask[(uint32_t)b * uW + ut]) ? 1.f : 0.f;
-    }
+    for (int j = 0; j < 4; ++j) mk[j] = g.gmask[mo + j * uW + ut] ? 1.f : 0.f;
 #pragma unroll
-    for (int i = 0; i < C; ++i) {
-      int col = (wv + i * GW) * 16 + c;
+    for (int i = 0; i < C; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int b = b0 + rq * 4 + j;
-        bool ok = col < H && b < n;
-        uint32_t bt = ((uint32_t)b * uW + ut) * uH + (uint32_t)col;
-        zv[i][j] = ok ? g.zs[bt] : 0.f;
-        rv[i][j] = ok ? g.rs[bt] : 0.f;
-        hv[i][j] = ok ? g.hhs[bt] : 0.f;
-        pv[i][j] = ok ? g.hs[((uint32_t)b * (uW + 1u) + ut) * uH + (uint32_t)col] : 0.f;
+        zv[i][j] = g.zs[go[i] + j * WH + tH];
+        rv[i][j] = g.rs[go[i] + j * WH + tH];
+        hv[i][j] = g.hhs[go[i] + j * WH + tH];
+        pv[i][j] = g.hs[ho[i] + j * W1H + tH];
       }
-    }
     // ---- (a) element-wise part that does not need drh ----
+    float* dg_t = g.dgates + ut * uH3;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-      int col = (wv + i * GW) * 16 + c;
-      if (col >= H) continue;
+      if (ok[i]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int row = rq * 4 + j, b = b0 + row;
-        float dh = dhL[row * LDH + col];
-        float dhn = mk[j] != 0.f ? dh : 0.f;
-        float z = zv[i][j], hh = hv[i][j], hp = pv[i][j];
-        float dph = dhn * (1.0f - z) * (1.0f - hh * hh);
-        float dpz = dhn * (hp - hh) * hs_grad(z);
-        g2L[row * LDH + col] = dph;
-        g1L[row * LD2 + col] = dpz;
-        nL[row * LDH + col] = (mk[j] != 0.f ? 0.f : dh) + dhn * z;
-        if (b < n) {
-          uint32_t bt = (uint32_t)b * uW + ut;
-          g.dgates[bt * uH3 + (uint32_t)col] = dpz;
-          g.dgates[bt * uH3 + 2u * uH + (uint32_t)col] = dph;
-          g.hprev[bt * uH + (uint32_t)col] = hp;
-          g.rh[bt * uH + (uint32_t)col] = rv[i][j] * hp;
+        for (int j = 0; j < 4; ++j) {
+          float dh = dhL[l[i] + j * LDH];
+          float dhn = mk[j] != 0.f ? dh : 0.f;
+          float z = zv[i][j], hh = hv[i][j], hp = pv[i][j];
+          float dph = dhn * (1.0f - z) * (1.0f - hh * hh);
+          float dpz = dhn * (hp - hh) * hs_grad(z);
+          g2L[l[i] + j * LDH] = dph;
+          g1L[lz[i] + j * LD2] = dpz;
+          nL[l[i] + j * LDH] = (mk[j] != 0.f ? 0.f : dh) + dhn * z;
+          dg_t[dgo[i] + j * WH3] = dpz;
+          dg_t[dgo[i] + j * WH3 + 2u * uH] = dph;
+          g.hprev[go[i] + j * WH + tH] = hp;
+          g.rh[go[i] + j * WH + tH] = rv[i][j] * hp;
         }
       }
     }
@@ -347,17 +408,16 @@ __device__ __forceinline__ void gru_bwd_body(const GruBwdArgs& g, float* smem, i
     ringzr.prefetch();
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-      int col = (wv + i * GW) * 16 + c;
-      if (col >= H) continue;
+      if (ok[i]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int row = rq * 4 + j, b = b0 + row;
-        float drh = acc[i][j];
-        float r = rv[i][j], hp = pv[i][j];
-        float dpr = drh * hp * hs_grad(r);
-        g1L[row * LD2 + H + col] = dpr;
-        nL[row * LDH + col] += drh * r;
-        if (b < n) g.dgates[((uint32_t)b * uW + ut) * uH3 + uH + (uint32_t)col] = dpr;
+        for (int j = 0; j < 4; ++j) {
+          float drh = acc[i][j];
+          float r = rv[i][j], hp = pv[i][j];
+          float dpr = drh * hp * hs_grad(r);
+          g1L[lz[i] + j * LD2 + Hp] = dpr;
+          nL[l[i] + j * LDH] += drh * r;
+          dg_t[dgo[i] + j * WH3 + uH] = dpr;
+        }
       }
     }
     __syncthreads();
@@ -366,12 +426,9 @@ __device__ __forceinline__ void gru_bwd_body(const GruBwdArgs& g, float* smem, i
     if (t > 0) ringh.prefetch();
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-      int col = (wv + i * GW) * 16 + c;
-      if (col >= H) continue;
+      if (ok[i]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int row = rq * 4 + j;
-        dhL[row * LDH + col] = nL[row * LDH + col] + acc[i][j];
+        for (int j = 0; j < 4; ++j) dhL[l[i] + j * LDH] = nL[l[i] + j * LDH] + acc[i][j];
       }
     }
     __syncthreads();
@@ -382,7 +439,7 @@ __global__ __launch_bounds__(GW * 64) void gru_bwd_kernel(GruBwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = g.H, W = g.W, n = g.n;
   const int nch = cdiv(H, 16), Hp = nch * 16, LDH = Hp + 4;
-  const int LD2 = cdiv(2 * H, 16) * 16 + 4;
+  const int LD2 = 2 * Hp + 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b0 = blockIdx.x * 16;
@@ -396,9 +453,9 @@ __global__ __launch_bounds__(GW * 64) void gru_bwd_kernel(GruBwdArgs g) {
   __syncthreads();
   const int cnt = tiles_of(wv, Hp / 16);
   if (cnt == 2 && nch == 13)
-    gru_bwd_body<2, 13, 25>(g, smem, wv, lane);
+    gru_bwd_body<2, 13, 26>(g, smem, wv, lane);
   else if (cnt == 1 && nch == 13)
-    gru_bwd_body<1, 13, 25>(g, smem, wv, lane);
+    gru_bwd_body<1, 13, 26>(g, smem, wv, lane);
   else if (cnt == 2)
     gru_bwd_body<2, 0, 0>(g, smem, wv, lane);
   else if (cnt == 1)
@@ -416,6 +473,52 @@ __global__ __launch_bounds__(GW * 64) void gru_bwd_kernel(GruBwdArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// All four operand images of the recurrent matrix U [H, 3H] (z|r|h) in one launch:
+//   u_zr  [nch][2Hp][16]  B = [U_z | 0 | U_r | 0]            (forward z|r product, gates padded to Hp)
+//   u_h   [nch][Hp][16]   B = U_h                            (forward candidate product)
+//   ut_h  [nch][Hp][16]   B = U_h^T                          (BPTT: drh)
+//   ut_zr [2nch][Hp][16]  B = [U_z^T ; 0 ; U_r^T ; 0]        (BPTT: dh_prev, K gate-padded)
+// ---------------------------------------------------------------------------------------------
+size_t gru_pack_floats(int H) {
+  int nch = cdiv(H, 16), Hp = nch * 16;
+  return (size_t)nch * 16 * (2 * Hp + Hp + Hp + 2 * Hp);
+}
+__global__ void gru_pack_kernel(const float* __restrict__ U, int H, float* __restrict__ u_zr, float* __restrict__ u_h,
+                                float* __restrict__ ut_h, float* __restrict__ ut_zr) {
+  const int nch = cdiv(H, 16), Hp = nch * 16, H3 = 3 * H;
+  const int e1 = nch * 2 * Hp * 16, e2 = nch * Hp * 16;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < e1) {   // u_zr: P[ch][n][kk], n in [0, 2Hp)
+    int kk = i & 15, nn = (i >> 4) % (2 * Hp), ch = (i >> 4) / (2 * Hp), k = ch * 16 + kk;
+    int gate = nn >= Hp, hc = nn - gate * Hp;
+    u_zr[i] = (k < H && hc < H) ? U[(size_t)k * H3 + gate * H + hc] : 0.f;
+    return;
+  }
+  i -= e1;
+  if (i < e2) {   // u_h
+    int kk = i & 15, nn = (i >> 4) % Hp, ch = (i >> 4) / Hp, k = ch * 16 + kk;
+    u_h[i] = (k < H && nn < H) ? U[(size_t)k * H3 + 2 * H + nn] : 0.f;
+    return;
+  }
+  i -= e2;
+  if (i < e2) {   // ut_h: B[k][n] = U_h[n][k]
+    int kk = i & 15, nn = (i >> 4) % Hp, ch = (i >> 4) / Hp, k = ch * 16 + kk;
+    ut_h[i] = (k < H && nn < H) ? U[(size_t)nn * H3 + 2 * H + k] : 0.f;
+    return;
+  }
+  i -= e2;
+  if (i < 2 * e2) {   // ut_zr: K = 2Hp gate-padded: B[k][n] = U[n][gate*H + (k - gate*Hp)]
+    int kk = i & 15, nn = (i >> 4) % Hp, ch = (i >> 4) / Hp, k = ch * 16 + kk;
+    int gate = k >= Hp, hc = k - gate * Hp;
+    ut_zr[i] = (hc < H && nn < H) ? U[(size_t)nn * H3 + gate * H + hc] : 0.f;
+  }
+}
+void launch_gru_pack(const float* U, int H, float* u_zr, float* u_h, float* ut_h, float* ut_zr, hipStream_t s) {
+  size_t total = gru_pack_floats(H);
+  hipLaunchKernelGGL(gru_pack_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, U, H, u_zr, u_h, ut_h, ut_zr);
+}
+
 static void set_lds_attr(const void* fn, size_t lds, size_t* cur) {
   if (lds > 65536 && lds > *cur) {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -431,8 +534,8 @@ void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, cons
   size_t lds = (size_t)3 * 16 * LDH * sizeof(float);
   static size_t cur = 0;
   set_lds_attr((const void*)gru_fwd_kernel, lds, &cur);
-  static const int nostream = getenv("LSTUR_GRU_NOSTREAM") ? 1 : 0;   // measurement knob, results are wrong when set
-  GruFwdArgs a{xw, gmask, h0, u_zr_packed, u_h_packed, hs, zs, rs, hhs, n, W, H, nostream};
+  static const int dbg = getenv("LSTUR_GRU_DEBUG") ? atoi(getenv("LSTUR_GRU_DEBUG")) : 0;  // measurement knobs
+  GruFwdArgs a{xw, gmask, h0, u_zr_packed, u_h_packed, hs, zs, rs, hhs, n, W, H, dbg};
   hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(n, 16)), dim3(GW * 64), lds, s, a);
 }
 
@@ -440,7 +543,7 @@ void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, const float* hs,
                     const float* hhs, const float* ut_zr_packed, const float* ut_h_packed, float* dgates, float* rh,
                     float* hprev, float* dh0, int n, int W, int H, hipStream_t s) {
   if (!n) return;
-  int Hp = ceil16(H), LDH = Hp + 4, LD2 = ceil16(2 * H) + 4;
+  int Hp = ceil16(H), LDH = Hp + 4, LD2 = 2 * Hp + 4;
   size_t lds = (size_t)(3 * 16 * LDH + 16 * LD2) * sizeof(float);
   static size_t cur = 0;
   set_lds_attr((const void*)gru_bwd_kernel, lds, &cur);

@@ -85,7 +85,7 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
   d->KD = d->k * d->D;
   d->nt_max = d->B * (d->W + d->K1);
   int pred_rows = d->nt_max / (d->W + 1);
-  d->n_cap = std::max(d->B, pred_rows);
+  d->n_cap = ceil16(std::max(d->B, pred_rows));   // GRU kernels process whole 16-sample row tiles
   d->rows_cap = d->B * 8;
   return true;
 }
@@ -188,10 +188,13 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->correct_i = (float*)take(nc * f4);
   w->parts = (float*)take((size_t)1024 * (2 * d.F + 1) * f4);
   w->conv_wp = (float*)take(pack_b_floats(d.KD, d.F) * f4);
-  w->u_zr_p = (float*)take(pack_b_floats(d.H, 2 * d.H) * f4);
-  w->u_h_p = (float*)take(pack_b_floats(d.H, d.H) * f4);
-  w->ut_zr_p = (float*)take(pack_b_floats(2 * d.H, d.H) * f4);
-  w->ut_h_p = (float*)take(pack_b_floats(d.H, d.H) * f4);
+  {
+    const size_t sixth = gru_pack_floats(d.H) / 6;
+    w->u_zr_p = (float*)take(2 * sixth * f4);
+    w->u_h_p = (float*)take(sixth * f4);
+    w->ut_h_p = (float*)take(sixth * f4);
+    w->ut_zr_p = (float*)take(2 * sixth * f4);
+  }
   w->wgrad_scratch = take(conv_wgrad_scratch_bytes(d.D, d.k, d.F));
   w->gemm_scratch_bytes = max_gemm_scratch(d);
   w->gemm_scratch = take(w->gemm_scratch_bytes);
@@ -306,9 +309,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   lazy_init(c, s);
   // operand images of the weights used by MFMA kernels this step
   launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, s);
-  const float* gu = c->P("gru_u");
-  launch_pack_b(gu, 3 * d.H, d.H, 2 * d.H, w.u_zr_p, s);
-  launch_pack_b(gu + 2 * d.H, 3 * d.H, d.H, d.H, w.u_h_p, s);
+  launch_gru_pack(c->P("gru_u"), d.H, w.u_zr_p, w.u_h_p, w.ut_h_p, w.ut_zr_p, s);
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
   launch_compact_valid(w.ids, nt * d.T, w.vidx, w.vcount, w.vscratch, s);   // non-pad tokens of this batch
@@ -363,9 +364,6 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
     launch_split2(w.du, d.H, d.Ue, w.dhlast, w.duser, n, s);
     dhl = w.dhlast;
   }
-  const float* gu = c->P("gru_u");
-  launch_pack_b_t(gu, 3 * d.H, 2 * d.H, d.H, w.ut_zr_p, s);          // (U[:, :2H])^T  as [2H x H]
-  launch_pack_b_t(gu + 2 * d.H, 3 * d.H, d.H, d.H, w.ut_h_p, s);     // (U[:, 2H:])^T  as [H x H]
   PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.hs, w.zs, w.rs, w.hhs, w.ut_zr_p, w.ut_h_p, w.dgates, w.rh, w.hprev,
                                  d.arch == LSTUR_ARCH_IGRU ? w.duser : w.dh0, n, d.W, d.H, s));
   // GRU parameter gradients
@@ -722,6 +720,13 @@ int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int3
   if (!A || !B || !C) return fail(LSTUR_ERR_ARG, "gemm: NULL");
   launch_gemm(A, lda, ta, B, ldb, tb, C, ldc, bias, M, N, K, alpha, scratch, (hipStream_t)stream);
   return check_launch("gemm");
+}
+size_t lstur_gru_pack_floats(int32_t H) { return gru_pack_floats(H); }
+int lstur_gru_pack_u(const float* gru_u, int32_t H, float* u_zr, float* u_h, float* ut_h, float* ut_zr,
+                     lstur_stream stream) {
+  if (!gru_u || !u_zr || !u_h || !ut_h || !ut_zr || H < 1 || H > 256) return fail(LSTUR_ERR_ARG, "gru pack: bad argument");
+  launch_gru_pack(gru_u, H, u_zr, u_h, ut_h, ut_zr, (hipStream_t)stream);
+  return check_launch("gru_pack");
 }
 int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
                   const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int32_t n, int32_t W, int32_t H,

@@ -84,7 +84,11 @@ void launch_gemm(const float* A, int lda, int ta, const float* B, int ldb, int t
                  const float* bias, int M, int N, int K, float alpha, void* scratch, hipStream_t s);
 
 // ---- gru.hip -----------------------------------------------------------------------------------
-// u_zr_packed = pack_b(U[:, :2H]), u_h_packed = pack_b(U[:, 2H:]);  requires H <= 256
+// Operand images of the recurrent matrix U [H,3H] for the two kernels below (one launch); each image pointer
+// needs its share of gru_pack_floats(H): u_zr 2/6, u_h 1/6, ut_h 1/6, ut_zr 2/6 of the total.
+size_t gru_pack_floats(int H);
+void launch_gru_pack(const float* U, int H, float* u_zr, float* u_h, float* ut_h, float* ut_zr, hipStream_t s);
+// All per-sample buffers must hold ceil16(n) sample rows.  Requires H <= 256.
 void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
                     const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int n, int W, int H,
                     hipStream_t s);

@@ -13,17 +13,9 @@ def run(n, W, H, iters=20):
     gm = torch.ones(n, W, dtype=torch.uint8, device='cuda')
     h0 = torch.randn(n, H, device='cuda', generator=g) * 0.05
     Um = torch.randn(H, 3 * H, device='cuda', generator=g) * 0.07
-    def pack(B, trans=False, K=None, N=None):
-        if not trans:
-            K, N = B.shape
-            out = torch.zeros(lib.lstur_pack_b_floats(K, N), device='cuda')
-            check(lib.lstur_pack_b(B.data_ptr(), B.stride(0), K, N, out.data_ptr(), stream()))
-        else:
-            out = torch.zeros(lib.lstur_pack_b_floats(K, N), device='cuda')
-            check(lib.lstur_pack_bt(B.data_ptr(), 3 * H, K, N, out.data_ptr(), stream()))
-        return out
-    uzr, uh = pack(Um[:, :2 * H]), pack(Um[:, 2 * H:])
-    utzr, uth = pack(Um, True, 2 * H, H), pack(Um[:, 2 * H:], True, H, H)
+    sixth = lib.lstur_gru_pack_floats(H) // 6
+    uzr, uh, uth, utzr = (torch.zeros(k * sixth, device='cuda') for k in (2, 1, 1, 2))
+    check(lib.lstur_gru_pack_u(Um.data_ptr(), H, uzr.data_ptr(), uh.data_ptr(), uth.data_ptr(), utzr.data_ptr(), stream()))
     hs = torch.empty(n, W + 1, H, device='cuda'); zs, rs, hhs = (torch.empty(n, W, H, device='cuda') for _ in range(3))
     dg = torch.empty(n, W, 3 * H, device='cuda'); rh = torch.empty(n, W, H, device='cuda'); hp = torch.empty(n, W, H, device='cuda')
     dh0 = torch.empty(n, H, device='cuda'); dh = torch.randn(n, H, device='cuda', generator=g)
@@ -42,10 +34,17 @@ def run(n, W, H, iters=20):
         for _ in range(iters): fn()
         e1.record(); torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / iters * 1e3
+    if int(os.environ.get('LSTUR_GRU_DEBUG', '0')) & 16:
+        fwd(); torch.cuda.synchronize(); cyc, ticks = zs.view(-1)[0].item(), zs.view(-1)[1].item()
+        print('  in-kernel: %.0f shader cycles over %.1f us -> %.3f GHz' % (cyc, ticks / 100.0, cyc / (ticks / 100.0) / 1e3))
+    if int(os.environ.get('LSTUR_GRU_DEBUG', '0')) & 32:
+        fwd(); torch.cuda.synchronize(); v = rs.view(-1)[:64].cpu().numpy().reshape(8, 8)[:, :6] / W
+        print('  per-step cycles per wave: gemm1, epi1, bar1, gemm2, epi2, bar2'); print(v.round(0))
     return res
 
 if __name__ == '__main__':
-    for (n, W, H) in [(16, 50, 200), (64, 50, 200), (512, 50, 200), (64, 50, 128), (64, 50, 256)]:
+    cfgs = [(64, 50, 200)] if len(sys.argv) > 1 else [(16, 50, 200), (64, 50, 200), (512, 50, 200), (64, 50, 128), (64, 50, 256)]
+    for (n, W, H) in cfgs:
         r = run(n, W, H)
         print('n=%d W=%d H=%d  fwd %.1f us (%.2f us/step)  bwd %.1f us (%.2f us/step)  nostream=%s' % (
-            n, W, H, r['fwd'], r['fwd'] / W, r['bwd'], r['bwd'] / W, os.environ.get('LSTUR_GRU_NOSTREAM')))
+            n, W, H, r['fwd'], r['fwd'] / W, r['bwd'], r['bwd'] / W, os.environ.get('LSTUR_GRU_DEBUG')))
