@@ -154,8 +154,8 @@ int lstur_profile(lstur_ctx* ctx, int enable);
 int lstur_profile_read(lstur_ctx* ctx, int index, const char** name, float* total_ms, int32_t* launches);
 
 /* Debug/inspection: device pointers to intermediates of the last call (valid until the next call).
- * names: "doc_vec" [N_t,U], "user_vec" [n,U], "logits" [n,K1], "probs" [n,K1], "conv_out" [N_t,T,F],
- *        "att_w" [N_t,T], "emb" [N_t,T+k-1,D] */
+ * names: "doc_vec" [N_t,U], "user_vec" [n,U], "logits" [n,K1], "probs" [n,K1], "conv_out" [N_t,T,F] (rows of
+ *        non-pad tokens only), "att_w" [N_t,T], "emb" [N_t,T+k-1,D], "h_last" [n,H], "dgates" [n,W,3H] */
 int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* count);
 
 /* ---- per-kernel entry points (unit parity tests, micro-benchmarks) --------------------------- */
@@ -218,19 +218,19 @@ size_t lstur_gru_pack_floats(int32_t H);
 int lstur_gru_pack_u(const float* gru_u, int32_t H, float* u_zr, float* u_h, float* ut_h, float* ut_zr,
                      lstur_stream stream);
 /* Masked Keras-2.2.4 GRU over W steps (paper.py:592,597-613; K.rnn mask semantics).
- *   xw [n,W,3H] input projection incl. bias; gmask uint8 [n,W]; h0 [n,H] or NULL (zeros)
- *   outputs hs [n,W+1,H], z/r/hh [n,W,H];  H <= 256.
- * EVERY per-sample buffer (xw, gmask, hs, zs, rs, hhs, and dgates/rh/hprev below) must be allocated for
- * ceil16(n) samples: the kernels process whole 16-sample row tiles without masking the tail rows. */
+ *   xw [n,W,3H] input projection incl. bias (row-major, gates z|r|h); gmask uint8 [n,W]; h0 [n,H] or NULL (zeros)
+ *   hlast [n,H] = output of the last step.  tape: lstur_gru_tape_floats(n,W,H) floats of scratch that carries the
+ *   saved activations to lstur_gru_bwd in the MFMA accumulator layout (opaque to the caller).  H <= 256. */
+size_t lstur_gru_tape_floats(int32_t n, int32_t W, int32_t H);
 int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
-                  const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int32_t n, int32_t W,
-                  int32_t H, lstur_stream stream);
-/* BPTT: dh_last [n,H] -> dgates [n,W,3H], rh [n,W,H] (= r * h_prev, operand of dU_h),
- *   hprev [n,W,H] (= h_{t-1}, operand of dU_zr), dh0 [n,H]. */
-int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, const float* hs, const float* zs,
-                  const float* rs, const float* hhs, const float* ut_zr_packed, const float* ut_h_packed,
-                  float* dgates, float* rh, float* hprev, float* dh0, int32_t n, int32_t W, int32_t H,
+                  const float* u_h_packed, float* tape, float* hlast, int32_t n, int32_t W, int32_t H,
                   lstur_stream stream);
+/* BPTT over the tape of the matching lstur_gru_fwd call: dh_last [n,H] ->
+ *   dgates [n,W,3H] (gradient wrt the gate pre-activations z|r|h), rh [n,W,H] (= r * h_prev, operand of dU_h),
+ *   hprev [n,W,H] (= h_{t-1}, operand of dU_zr), dh0 [n,H] (gradient wrt the initial state). */
+int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* ut_zr_packed,
+                  const float* ut_h_packed, float* dgates, float* rh, float* hprev, float* dh0, int32_t n,
+                  int32_t W, int32_t H, lstur_stream stream);
 /* dot scorer + softmax + categorical_crossentropy (paper.py:446-447,463,658) and its gradient.
  *   u [n,U]; d [n,K1,U]; outputs logits/probs [n,K1], loss_i [n], correct_i [n], du [n,U], dd [n,K1,U]
  *   (du/dd may be NULL: forward only).  inv_n scales the gradient (1/batch * grad_scale). */

@@ -12,6 +12,14 @@
 // exactly one wave, so LDS staging would be pure overhead.  The step is latency-bound, so fragment loads
 // run a few chunks ahead of the MFMAs in a register ring and each step's gate inputs are fetched
 // before its products start.
+//
+// Element-wise traffic of the recurrence (gate inputs in, saved activations out, gate gradients out) moves
+// in the MFMA ACCUMULATOR ("fragment") layout: tape[blk][t][tile][lane][4] holds, for lane (c, rq), the 4
+// sample rows rq*4..rq*4+3 of hidden column tile*16+c -- exactly one accumulator register quad.  Every
+// such access is ONE 16-byte, fully coalesced load/store per tile (1 KiB per wave instruction) instead of 4
+// scattered dwords with their own address arithmetic; the epilogues were VALU-issue bound on that arithmetic.
+// Two fully parallel layout kernels convert between the row-major tensors of the rest of the step and the
+// tape (xw -> fragments before the forward recurrence; gate gradients / r*h / h_prev -> row-major after BPTT).
 #include <stdlib.h>
 
 #include "lstur_device.h"
@@ -113,28 +121,96 @@ __device__ __forceinline__ void gemm_run(FragRing<C>& ring, const float* __restr
   }
 }
 
+// ---- fragment tape ------------------------------------------------------------------------------------
+// sections of S = nb * W * NT * 256 floats (nb = ceil(n/16) sample blocks, NT = Hp/16 hidden tiles)
+enum { TP_XZ = 0, TP_XR, TP_XH, TP_Z, TP_R, TP_HH, TP_HP, TP_DZ, TP_DR, TP_DH, TP_RH, TP_SECTIONS };
+size_t gru_tape_floats(int n, int W, int H) {
+  return (size_t)TP_SECTIONS * cdiv(n, 16) * W * (ceil16(H) / 16) * 256;
+}
+__host__ __device__ __forceinline__ size_t tape_section(int n, int W, int H) {
+  return (size_t)cdiv(n, 16) * W * (ceil16(H) / 16) * 256;
+}
+
+// xw [n*W, 3H] (row-major, gates z|r|h) -> tape sections XZ, XR, XH.  One thread per fragment float4.
+__global__ void gru_xw_to_tape_kernel(const float* __restrict__ xw, float* __restrict__ tape, int n, int W, int H,
+                                      size_t S) {
+  const int NT = ceil16(H) / 16;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over 3 * S / 4
+  if (i >= 3 * S / 4) return;
+  const int gate = (int)(i / (S / 4));
+  size_t r = i - (size_t)gate * (S / 4);
+  const int lane = (int)(r & 63);
+  r >>= 6;
+  const int tile = (int)(r % NT);
+  r /= NT;
+  const int t = (int)(r % W), blk = (int)(r / W);
+  const int col = tile * 16 + (lane & 15);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < H) {
+    const int b = blk * 16 + (lane >> 4) * 4;
+    const size_t base = ((size_t)b * W + t) * 3 * H + (size_t)gate * H + col, rs = (size_t)W * 3 * H;
+    if (b + 0 < n) v.x = xw[base];
+    if (b + 1 < n) v.y = xw[base + rs];
+    if (b + 2 < n) v.z = xw[base + 2 * rs];
+    if (b + 3 < n) v.w = xw[base + 3 * rs];
+  }
+  ((float4*)tape)[(size_t)(TP_XZ + gate) * (S / 4) + (i - (size_t)gate * (S / 4))] = v;
+}
+
+// tape sections DZ, DR, DH, RH, HP -> dgates [n*W, 3H], rh [n*W, H], hprev [n*W, H] (row-major)
+__global__ void gru_tape_to_rows_kernel(const float* __restrict__ tape, float* __restrict__ dgates,
+                                        float* __restrict__ rh, float* __restrict__ hprev, int n, int W, int H,
+                                        size_t S) {
+  const int NT = ceil16(H) / 16;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over S / 4 fragment quads
+  if (i >= S / 4) return;
+  size_t r = i;
+  const int lane = (int)(r & 63);
+  r >>= 6;
+  const int tile = (int)(r % NT);
+  r /= NT;
+  const int t = (int)(r % W), blk = (int)(r / W);
+  const int col = tile * 16 + (lane & 15);
+  if (col >= H) return;
+  const float4* tp = (const float4*)tape;
+  const float4 dz = tp[(size_t)TP_DZ * (S / 4) + i], dr = tp[(size_t)TP_DR * (S / 4) + i],
+               dh = tp[(size_t)TP_DH * (S / 4) + i], rhv = tp[(size_t)TP_RH * (S / 4) + i],
+               hp = tp[(size_t)TP_HP * (S / 4) + i];
+  const int b = blk * 16 + (lane >> 4) * 4;
+  const float dzv[4] = {dz.x, dz.y, dz.z, dz.w}, drv[4] = {dr.x, dr.y, dr.z, dr.w}, dhv[4] = {dh.x, dh.y, dh.z, dh.w},
+              rv[4] = {rhv.x, rhv.y, rhv.z, rhv.w}, pv[4] = {hp.x, hp.y, hp.z, hp.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (b + j < n) {
+      const size_t row = (size_t)(b + j) * W + t;
+      dgates[row * 3 * H + col] = dzv[j];
+      dgates[row * 3 * H + H + col] = drv[j];
+      dgates[row * 3 * H + 2 * H + col] = dhv[j];
+      rh[row * H + col] = rv[j];
+      hprev[row * H + col] = pv[j];
+    }
+  }
+}
+
 struct GruFwdArgs {
-  const float* xw; const uint8_t* gmask; const float* h0; const float* u_zr; const float* u_h;
-  float* hs; float* zs; float* rs; float* hhs; int n, W, H, dbg;
+  const uint8_t* gmask; const float* h0; const float* u_zr; const float* u_h; float* tape; float* hlast;
+  int n, W, H, dbg;
 };
 
-// Layout contract of the GRU kernels (see lstur_gru_pack_u / include/lstur.h):
-//   * every per-sample buffer holds ceil16(n) sample rows (the last row tile is processed unmasked);
-//   * gate columns are padded per gate to Hp = ceil16(H): the z|r image has N = 2*Hp columns (z at [0,H),
-//     r at [Hp, Hp+H)), so no 16-column tile straddles two gates and every epilogue is uniform per tile.
+// Gate columns of the z|r operand image are padded per gate to Hp = ceil16(H) (N = 2*Hp: z at [0,H), r at
+// [Hp, Hp+H)), so no 16-column tile straddles two gates and every epilogue is uniform per tile.
 //
 // Whole time loop for a wave that owns C1 tiles of the z|r product and C2 tiles of the candidate product.
 template <int C1, int C2, int NCH>
 __device__ __forceinline__ void gru_fwd_body(const GruFwdArgs& g, float* smem, int wv, int lane) {
-  const int H = g.H, W = g.W;
-  const int nch = cdiv(H, 16), Hp = nch * 16, LDH = Hp + 4;
+  const int H = g.H, W = g.W, n = g.n;
+  const int nch = cdiv(H, 16), Hp = nch * 16, LDH = Hp + 4, NT = nch;
   float* hL = smem;
   float* rhL = hL + 16 * LDH;
   float* zL = rhL + 16 * LDH;
   const int c = lane & 15, rq = lane >> 4, kq = lane >> 4;
-  const uint32_t rowb = blockIdx.x * 16 + rq * 4;            // first of this lane's 4 sample rows
-  const uint32_t uW = W, uH = H, uH3 = 3 * H, WH = uW * uH, WH3 = uW * uH3, W1H = (uW + 1u) * uH;
   const bool nostream = (g.dbg & 1) != 0;
+  const size_t S = tape_section(n, W, H);
 
   constexpr int C2R = C2 > 0 ? C2 : 1;      // a wave without candidate tiles keeps a dummy ring (never run)
   FragRing<C1> ring1;
@@ -143,38 +219,36 @@ __device__ __forceinline__ void gru_fwd_body(const GruFwdArgs& g, float* smem, i
   ring2.bind(g.u_h, Hp, nch, wv, lane, nostream);
   ring1.prefetch();
 
-  // per-lane invariants of the tiles this wave owns (hidden index clamped so every load is in range;
-  // stores / LDS writes of lanes past H are predicated off -- padding columns of the state stay 0)
+  // tiles of this wave: z|r product tile T1 = wv + i*GW in [0, 2*NT): gate = T1 >= NT, hidden tile = T1 - gate*NT
   bool isr[C1], ok1[C1], ok2[C2R];
-  uint32_t xo1[C1], go1[C1], xo2[C2R], go2[C2R], ho2[C2R];
-  int l1[C1], l2[C2R];
+  int ht1[C1], l1[C1], l2[C2R];
 #pragma unroll
   for (int i = 0; i < C1; ++i) {
-    const int tcol = (wv + i * GW) * 16;
-    isr[i] = tcol >= Hp;                                      // wave-uniform: tile of r gates
-    const int hc = tcol - (isr[i] ? Hp : 0) + c;
-    ok1[i] = hc < H;
-    const int hcc = min(hc, H - 1);
-    xo1[i] = rowb * WH3 + (isr[i] ? uH : 0u) + (uint32_t)hcc;
-    go1[i] = rowb * WH + (uint32_t)hcc;
-    l1[i] = rq * 4 * LDH + hcc;
+    const int T1 = wv + i * GW;
+    isr[i] = T1 >= NT;                                        // wave-uniform
+    ht1[i] = T1 - (isr[i] ? NT : 0);
+    const int hc = ht1[i] * 16 + c;
+    ok1[i] = hc < H;                                          // lanes past H: LDS padding columns stay 0
+    l1[i] = rq * 4 * LDH + min(hc, Hp - 1);
   }
 #pragma unroll
   for (int i = 0; i < C2R; ++i) {
     const int hc = (wv + i * GW) * 16 + c;
     ok2[i] = C2 > 0 && hc < H;
-    const int hcc = min(hc, H - 1);
-    xo2[i] = rowb * WH3 + 2u * uH + (uint32_t)hcc;
-    go2[i] = rowb * WH + (uint32_t)hcc;
-    ho2[i] = rowb * W1H + (uint32_t)hcc;
-    l2[i] = rq * 4 * LDH + hcc;
+    l2[i] = rq * 4 * LDH + min(hc, Hp - 1);
   }
-  const uint32_t mo = rowb * uW;
+  // mask rows of this lane (clamped: rows past n are never read back)
+  uint32_t mo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) mo[j] = (uint32_t)min((int)blockIdx.x * 16 + rq * 4 + j, n - 1) * (uint32_t)W;
 
+  float4* tp = (float4*)g.tape;
+  const size_t S4 = S / 4;
   const float* a1 = hL + c * LDH + kq * 4;
   const float* a2 = rhL + c * LDH + kq * 4;
   f32x4 acc1[C1], acc2[C2R];
-  float x1[C1][4], x2[C2R][4], mk[4];
+  float4 x1[C1], x2[C2R];
+  float mk[4];
   unsigned long long c0 = 0, r0 = 0;    // diagnostic build only (dbg bit 4): in-kernel clock
   if (g.dbg & 16) {
     c0 = __builtin_amdgcn_s_memtime();
@@ -182,54 +256,50 @@ __device__ __forceinline__ void gru_fwd_body(const GruFwdArgs& g, float* smem, i
   }
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0};   // diagnostic build only (dbg bit 5): per-segment shader cycles
   const bool stamp = (g.dbg & 32) != 0;
-#define LSTUR_STAMP(k)                                   \
-  if (stamp) {                                           \
+#define LSTUR_STAMP(k)                                     \
+  if (stamp) {                                             \
     unsigned long long now = __builtin_amdgcn_s_memtime(); \
-    st[k] += now - last;                                 \
-    last = now;                                          \
+    st[k] += now - last;                                   \
+    last = now;                                            \
   }
   for (int t = 0; t < W; ++t) {
-    const uint32_t ut = t;
-    const float* xw_t = g.xw + ut * uH3;
     unsigned long long last = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    // fragment quad index of (this block, step t, hidden tile 0) + this lane
+    const size_t f0 = ((size_t)blockIdx.x * W + t) * NT * 64 + lane;
     // ---- phase 1: z | r ----
 #pragma unroll
-    for (int i = 0; i < C1; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x1[i][j] = xw_t[xo1[i] + j * WH3];
+    for (int i = 0; i < C1; ++i) x1[i] = tp[(size_t)(isr[i] ? TP_XR : TP_XZ) * S4 + f0 + (size_t)ht1[i] * 64];
     gemm_run<C1, NCH>(ring1, a1, nch, acc1);
     LSTUR_STAMP(0)
     if (C2 > 0) ring2.prefetch();     // candidate-product fragments fly during the gate epilogue + barrier
-    float* zs_t = g.zs + ut * uH;
-    float* rs_t = g.rs + ut * uH;
 #pragma unroll
     for (int i = 0; i < C1; ++i) {
+      float4 gt;
+      gt.x = hard_sigmoid(acc1[i][0] + x1[i].x);
+      gt.y = hard_sigmoid(acc1[i][1] + x1[i].y);
+      gt.z = hard_sigmoid(acc1[i][2] + x1[i].z);
+      gt.w = hard_sigmoid(acc1[i][3] + x1[i].w);
+      tp[(size_t)(isr[i] ? TP_R : TP_Z) * S4 + f0 + (size_t)ht1[i] * 64] = gt;
       if (ok1[i]) {
         if (!isr[i]) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float gt = hard_sigmoid(acc1[i][j] + x1[i][j]);
-            zL[l1[i] + j * LDH] = gt;
-            zs_t[go1[i] + j * WH] = gt;
-          }
+          zL[l1[i]] = gt.x;
+          zL[l1[i] + LDH] = gt.y;
+          zL[l1[i] + 2 * LDH] = gt.z;
+          zL[l1[i] + 3 * LDH] = gt.w;
         } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float gt = hard_sigmoid(acc1[i][j] + x1[i][j]);
-            rs_t[go1[i] + j * WH] = gt;
-            rhL[l1[i] + j * LDH] = gt * hL[l1[i] + j * LDH];
-          }
+          rhL[l1[i]] = gt.x * hL[l1[i]];
+          rhL[l1[i] + LDH] = gt.y * hL[l1[i] + LDH];
+          rhL[l1[i] + 2 * LDH] = gt.z * hL[l1[i] + 2 * LDH];
+          rhL[l1[i] + 3 * LDH] = gt.w * hL[l1[i] + 3 * LDH];
         }
       }
     }
     // candidate inputs + mask for phase 2 (issued before the barrier so they fly during it)
     if (C2 > 0) {
 #pragma unroll
-      for (int i = 0; i < C2R; ++i)
+      for (int i = 0; i < C2R; ++i) x2[i] = tp[(size_t)TP_XH * S4 + f0 + (size_t)(wv + i * GW) * 64];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x2[i][j] = xw_t[xo2[i] + j * WH3];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) mk[j] = g.gmask[mo + j * uW + ut] ? 1.f : 0.f;
+      for (int j = 0; j < 4; ++j) mk[j] = g.gmask[mo[j] + t] ? 1.f : 0.f;
     }
     LSTUR_STAMP(1)
     __syncthreads();
@@ -239,21 +309,24 @@ __device__ __forceinline__ void gru_fwd_body(const GruFwdArgs& g, float* smem, i
     LSTUR_STAMP(3)
     if (t + 1 < W) ring1.prefetch();  // next step's z|r fragments fly during the update + barrier
     if (C2 > 0) {
-      float* hhs_t = g.hhs + ut * uH;
-      float* hs_t1 = g.hs + (ut + 1u) * uH;
 #pragma unroll
       for (int i = 0; i < C2R; ++i) {
+        const float xv[4] = {x2[i].x, x2[i].y, x2[i].z, x2[i].w};
+        float hh[4], hp[4], ho[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hh[j] = tanhf(acc2[i][j] + xv[j]);
+          float z = zL[l2[i] + j * LDH];
+          hp[j] = hL[l2[i] + j * LDH];
+          float hn = z * hp[j] + (1.0f - z) * hh[j];
+          ho[j] = mk[j] != 0.f ? hn : hp[j];  // K.rnn: masked step carries the previous state/output
+        }
+        const size_t fi = f0 + (size_t)(wv + i * GW) * 64;
+        tp[(size_t)TP_HH * S4 + fi] = make_float4(hh[0], hh[1], hh[2], hh[3]);
+        tp[(size_t)TP_HP * S4 + fi] = make_float4(hp[0], hp[1], hp[2], hp[3]);
         if (ok2[i]) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float hh = tanhf(acc2[i][j] + x2[i][j]);
-            float z = zL[l2[i] + j * LDH], hp = hL[l2[i] + j * LDH];
-            float hn = z * hp + (1.0f - z) * hh;
-            float ho = mk[j] != 0.f ? hn : hp;  // K.rnn: masked step carries the previous state/output
-            hhs_t[go2[i] + j * WH] = hh;
-            hs_t1[ho2[i] + j * W1H] = ho;
-            hL[l2[i] + j * LDH] = ho;
-          }
+          for (int j = 0; j < 4; ++j) hL[l2[i] + j * LDH] = ho[j];
         }
       }
     }
@@ -263,11 +336,11 @@ __device__ __forceinline__ void gru_fwd_body(const GruFwdArgs& g, float* smem, i
   }
 #undef LSTUR_STAMP
   if (stamp && lane == 0 && blockIdx.x == 0)
-    for (int k = 0; k < 6; ++k) g.rs[wv * 8 + k] = (float)st[k];
+    for (int k = 0; k < 6; ++k) g.tape[(size_t)TP_DZ * S + wv * 8 + k] = (float)st[k];
   if ((g.dbg & 16) && wv == 0 && lane == 0 && blockIdx.x == 0) {
     unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    g.zs[0] = (float)(c1 - c0);   // shader cycles
-    g.zs[1] = (float)(r1 - r0);   // 100 MHz ticks
+    g.tape[(size_t)TP_DR * S] = (float)(c1 - c0);       // shader cycles
+    g.tape[(size_t)TP_DR * S + 1] = (float)(r1 - r0);   // 100 MHz ticks
   }
 }
 
@@ -286,26 +359,33 @@ __global__ __launch_bounds__(GW * 64) void gru_fwd_kernel(GruFwdArgs g) {
   __syncthreads();
   for (int i = tid; i < 16 * H; i += GW * 64) {
     int row = i / H, col = i - row * H, b = b0 + row;
-    float v = (g.h0 && b < n) ? g.h0[(size_t)b * H + col] : 0.f;
-    hL[row * LDH + col] = v;
-    g.hs[(size_t)b * (W + 1) * H + col] = v;
+    hL[row * LDH + col] = (g.h0 && b < n) ? g.h0[(size_t)b * H + col] : 0.f;
   }
   __syncthreads();
   // static (tile-count) specialisation per wave: every wave runs the same number of barriers
   const int c1 = tiles_of(wv, 2 * Hp / 16), c2 = tiles_of(wv, Hp / 16);
-#define LSTUR_FWD_CASE(A, B)                                              \
-  if (c1 == A && c2 == B) {                                               \
-    if (nch == 13) return gru_fwd_body<A, B, 13>(g, smem, wv, lane);      \
-    return gru_fwd_body<A, B, 0>(g, smem, wv, lane);                      \
+  bool done = false;
+#define LSTUR_FWD_CASE(A, B)                                      \
+  if (!done && c1 == A && c2 == B) {                              \
+    if (nch == 13)                                                \
+      gru_fwd_body<A, B, 13>(g, smem, wv, lane);                  \
+    else                                                          \
+      gru_fwd_body<A, B, 0>(g, smem, wv, lane);                   \
+    done = true;                                                  \
   }
   LSTUR_FWD_CASE(4, 2) LSTUR_FWD_CASE(3, 2) LSTUR_FWD_CASE(3, 1) LSTUR_FWD_CASE(4, 1) LSTUR_FWD_CASE(2, 1)
   LSTUR_FWD_CASE(1, 1) LSTUR_FWD_CASE(2, 2) LSTUR_FWD_CASE(1, 0) LSTUR_FWD_CASE(2, 0) LSTUR_FWD_CASE(3, 0)
   LSTUR_FWD_CASE(4, 0) LSTUR_FWD_CASE(1, 2)
 #undef LSTUR_FWD_CASE
-  // a wave without tiles (tiny H) still has to meet the barriers
-  for (int t = 0; t < W; ++t) {
-    __syncthreads();
-    __syncthreads();
+  if (!done)   // a wave without tiles (tiny H) still has to meet the barriers
+    for (int t = 0; t < W; ++t) {
+      __syncthreads();
+      __syncthreads();
+    }
+  // last state (the loop ends on a barrier, so hL is complete)
+  for (int i = tid; i < 16 * H; i += GW * 64) {
+    int row = i / H, col = i - row * H, b = b0 + row;
+    if (b < n) g.hlast[(size_t)b * H + col] = hL[row * LDH + col];
   }
 }
 
@@ -315,30 +395,29 @@ __global__ __launch_bounds__(GW * 64) void gru_fwd_kernel(GruFwdArgs g) {
 //   dpre_h = dhn (1-z)(1-hh^2) ; dpre_z = dhn (hp-hh) hs'(z)
 //   drh = dpre_h U_h^T ; dpre_r = drh hp hs'(r)
 //   dh_prev = carry + dhn z + drh r + [dpre_z | dpre_r] U_zr^T
-// dgates = [dpre_z | dpre_r | dpre_h], rh = r*hp and hprev = hp are stored (time-major per sample,
-// [n,W,*]) for the weight-gradient GEMMs.
+// [dpre_z | dpre_r | dpre_h], r*hp (and hp, saved by the forward) go to the tape; gru_tape_to_rows_kernel
+// turns them into the row-major operands of the weight-gradient GEMMs.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float hs_grad(float g) { return (g > 0.f && g < 1.f) ? 0.2f : 0.f; }
 
 struct GruBwdArgs {
-  const float* dh_last; const uint8_t* gmask; const float* hs; const float* zs; const float* rs; const float* hhs;
-  const float* ut_zr; const float* ut_h; float* dgates; float* rh; float* hprev; float* dh0; int n, W, H;
+  const float* dh_last; const uint8_t* gmask; float* tape; const float* ut_zr; const float* ut_h; float* dh0;
+  int n, W, H;
 };
 
 // Every wave owns the same C column tiles (of H hidden units) in all three phases: lane (c, rq) of tile
 // `tile` holds rows rq*4+j, col tile*16+c -- so the element-wise work needs no extra LDS round trip.
 template <int C, int NCH, int NCH2>
 __device__ __forceinline__ void gru_bwd_body(const GruBwdArgs& g, float* smem, int wv, int lane) {
-  const int H = g.H, W = g.W;
-  const int nch = cdiv(H, 16), Hp = nch * 16, LDH = Hp + 4;
+  const int H = g.H, W = g.W, n = g.n;
+  const int nch = cdiv(H, 16), Hp = nch * 16, LDH = Hp + 4, NT = nch;
   const int nch2 = 2 * nch, LD2 = 2 * Hp + 4;      // K of the last product is gate-padded: z at [0,H), r at [Hp,Hp+H)
   float* dhL = smem;               // [16][LDH] gradient wrt current state
   float* nL = dhL + 16 * LDH;      // [16][LDH] partial dh_prev
   float* g2L = nL + 16 * LDH;      // [16][LDH] dpre_h
   float* g1L = g2L + 16 * LDH;     // [16][LD2] dpre_z | dpre_r
   const int c = lane & 15, rq = lane >> 4, kq = lane >> 4;
-  const uint32_t rowb = blockIdx.x * 16 + rq * 4;
-  const uint32_t uW = W, uH = H, uH3 = 3 * H, WH = uW * uH, WH3 = uW * uH3, W1H = (uW + 1u) * uH;
+  const size_t S4 = tape_section(n, W, H) / 4;
 
   FragRing<C> ringh, ringzr;
   ringh.bind(g.ut_h, Hp, nch, wv, lane);
@@ -348,59 +427,58 @@ __device__ __forceinline__ void gru_bwd_body(const GruBwdArgs& g, float* smem, i
   const float* a1 = g1L + c * LD2 + kq * 4;
 
   bool ok[C];
-  uint32_t go[C], ho[C], dgo[C];
   int l[C], lz[C];
 #pragma unroll
   for (int i = 0; i < C; ++i) {
     const int hc = (wv + i * GW) * 16 + c;
     ok[i] = hc < H;
-    const int hcc = min(hc, H - 1);
-    go[i] = rowb * WH + (uint32_t)hcc;
-    ho[i] = rowb * W1H + (uint32_t)hcc;
-    dgo[i] = rowb * WH3 + (uint32_t)hcc;
-    l[i] = rq * 4 * LDH + hcc;
-    lz[i] = rq * 4 * LD2 + hcc;
+    l[i] = rq * 4 * LDH + min(hc, Hp - 1);
+    lz[i] = rq * 4 * LD2 + min(hc, Hp - 1);
   }
-  const uint32_t mo = rowb * uW;
+  uint32_t mo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) mo[j] = (uint32_t)min((int)blockIdx.x * 16 + rq * 4 + j, n - 1) * (uint32_t)W;
 
+  float4* tp = (float4*)g.tape;
   f32x4 acc[C];
-  float zv[C][4], rv[C][4], hv[C][4], pv[C][4], mk[4];
+  float4 zv[C], rv[C], hv[C], pv[C];
+  float mk[4];
   for (int t = W - 1; t >= 0; --t) {
-    const uint32_t ut = t;
-    const uint32_t tH = ut * uH;
+    const size_t f0 = ((size_t)blockIdx.x * W + t) * NT * 64 + lane;
     // ---- this step's saved activations for the elements this lane owns ----
 #pragma unroll
-    for (int j = 0; j < 4; ++j) mk[j] = g.gmask[mo + j * uW + ut] ? 1.f : 0.f;
-#pragma unroll
-    for (int i = 0; i < C; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        zv[i][j] = g.zs[go[i] + j * WH + tH];
-        rv[i][j] = g.rs[go[i] + j * WH + tH];
-        hv[i][j] = g.hhs[go[i] + j * WH + tH];
-        pv[i][j] = g.hs[ho[i] + j * W1H + tH];
-      }
-    // ---- (a) element-wise part that does not need drh ----
-    float* dg_t = g.dgates + ut * uH3;
+    for (int j = 0; j < 4; ++j) mk[j] = g.gmask[mo[j] + t] ? 1.f : 0.f;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-      if (ok[i]) {
+      const size_t fi = f0 + (size_t)(wv + i * GW) * 64;
+      zv[i] = tp[(size_t)TP_Z * S4 + fi];
+      rv[i] = tp[(size_t)TP_R * S4 + fi];
+      hv[i] = tp[(size_t)TP_HH * S4 + fi];
+      pv[i] = tp[(size_t)TP_HP * S4 + fi];
+    }
+    // ---- (a) element-wise part that does not need drh ----
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float dh = dhL[l[i] + j * LDH];
-          float dhn = mk[j] != 0.f ? dh : 0.f;
-          float z = zv[i][j], hh = hv[i][j], hp = pv[i][j];
-          float dph = dhn * (1.0f - z) * (1.0f - hh * hh);
-          float dpz = dhn * (hp - hh) * hs_grad(z);
-          g2L[l[i] + j * LDH] = dph;
-          g1L[lz[i] + j * LD2] = dpz;
-          nL[l[i] + j * LDH] = (mk[j] != 0.f ? 0.f : dh) + dhn * z;
-          dg_t[dgo[i] + j * WH3] = dpz;
-          dg_t[dgo[i] + j * WH3 + 2u * uH] = dph;
-          g.hprev[go[i] + j * WH + tH] = hp;
-          g.rh[go[i] + j * WH + tH] = rv[i][j] * hp;
+    for (int i = 0; i < C; ++i) {
+      const float z[4] = {zv[i].x, zv[i].y, zv[i].z, zv[i].w}, hh[4] = {hv[i].x, hv[i].y, hv[i].z, hv[i].w},
+                  hp[4] = {pv[i].x, pv[i].y, pv[i].z, pv[i].w}, r[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+      float dpz[4], dph[4], rhp[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float dh = dhL[l[i] + j * LDH];
+        float dhn = mk[j] != 0.f ? dh : 0.f;
+        dph[j] = dhn * (1.0f - z[j]) * (1.0f - hh[j] * hh[j]);
+        dpz[j] = dhn * (hp[j] - hh[j]) * hs_grad(z[j]);
+        rhp[j] = r[j] * hp[j];
+        if (ok[i]) {
+          g2L[l[i] + j * LDH] = dph[j];
+          g1L[lz[i] + j * LD2] = dpz[j];
+          nL[l[i] + j * LDH] = (mk[j] != 0.f ? 0.f : dh) + dhn * z[j];
         }
       }
+      const size_t fi = f0 + (size_t)(wv + i * GW) * 64;
+      tp[(size_t)TP_DZ * S4 + fi] = make_float4(dpz[0], dpz[1], dpz[2], dpz[3]);
+      tp[(size_t)TP_DH * S4 + fi] = make_float4(dph[0], dph[1], dph[2], dph[3]);
+      tp[(size_t)TP_RH * S4 + fi] = make_float4(rhp[0], rhp[1], rhp[2], rhp[3]);
     }
     __syncthreads();
     // ---- (b) drh = dpre_h . U_h^T ----
@@ -408,17 +486,18 @@ __device__ __forceinline__ void gru_bwd_body(const GruBwdArgs& g, float* smem, i
     ringzr.prefetch();
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-      if (ok[i]) {
+      const float hp[4] = {pv[i].x, pv[i].y, pv[i].z, pv[i].w}, r[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+      float dpr[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float drh = acc[i][j];
-          float r = rv[i][j], hp = pv[i][j];
-          float dpr = drh * hp * hs_grad(r);
-          g1L[lz[i] + j * LD2 + Hp] = dpr;
-          nL[l[i] + j * LDH] += drh * r;
-          dg_t[dgo[i] + j * WH3 + uH] = dpr;
+      for (int j = 0; j < 4; ++j) {
+        float drh = acc[i][j];
+        dpr[j] = drh * hp[j] * hs_grad(r[j]);
+        if (ok[i]) {
+          g1L[lz[i] + j * LD2 + Hp] = dpr[j];
+          nL[l[i] + j * LDH] += drh * r[j];
         }
       }
+      tp[(size_t)TP_DR * S4 + f0 + (size_t)(wv + i * GW) * 64] = make_float4(dpr[0], dpr[1], dpr[2], dpr[3]);
     }
     __syncthreads();
     // ---- (c) dh_prev = part + [dpre_z | dpre_r] . U_zr^T ----
@@ -527,28 +606,32 @@ static void set_lds_attr(const void* fn, size_t lds, size_t* cur) {
 }
 
 void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
-                    const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int n, int W, int H,
-                    hipStream_t s) {
+                    const float* u_h_packed, float* tape, float* hlast, int n, int W, int H, hipStream_t s) {
   if (!n) return;
   int Hp = ceil16(H), LDH = Hp + 4;
   size_t lds = (size_t)3 * 16 * LDH * sizeof(float);
   static size_t cur = 0;
   set_lds_attr((const void*)gru_fwd_kernel, lds, &cur);
   static const int dbg = getenv("LSTUR_GRU_DEBUG") ? atoi(getenv("LSTUR_GRU_DEBUG")) : 0;  // measurement knobs
-  GruFwdArgs a{xw, gmask, h0, u_zr_packed, u_h_packed, hs, zs, rs, hhs, n, W, H, dbg};
+  const size_t S = tape_section(n, W, H);
+  hipLaunchKernelGGL(gru_xw_to_tape_kernel, dim3((unsigned)cdivz(3 * S / 4, 256)), dim3(256), 0, s, xw, tape, n, W, H, S);
+  GruFwdArgs a{gmask, h0, u_zr_packed, u_h_packed, tape, hlast, n, W, H, dbg};
   hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(n, 16)), dim3(GW * 64), lds, s, a);
 }
 
-void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, const float* hs, const float* zs, const float* rs,
-                    const float* hhs, const float* ut_zr_packed, const float* ut_h_packed, float* dgates, float* rh,
-                    float* hprev, float* dh0, int n, int W, int H, hipStream_t s) {
+void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* ut_zr_packed,
+                    const float* ut_h_packed, float* dgates, float* rh, float* hprev, float* dh0, int n, int W, int H,
+                    hipStream_t s) {
   if (!n) return;
   int Hp = ceil16(H), LDH = Hp + 4, LD2 = 2 * Hp + 4;
   size_t lds = (size_t)(3 * 16 * LDH + 16 * LD2) * sizeof(float);
   static size_t cur = 0;
   set_lds_attr((const void*)gru_bwd_kernel, lds, &cur);
-  GruBwdArgs a{dh_last, gmask, hs, zs, rs, hhs, ut_zr_packed, ut_h_packed, dgates, rh, hprev, dh0, n, W, H};
+  GruBwdArgs a{dh_last, gmask, tape, ut_zr_packed, ut_h_packed, dh0, n, W, H};
   hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(n, 16)), dim3(GW * 64), lds, s, a);
+  const size_t S = tape_section(n, W, H);
+  hipLaunchKernelGGL(gru_tape_to_rows_kernel, dim3((unsigned)cdivz(S / 4, 256)), dim3(256), 0, s, tape, dgates, rh, hprev,
+                     n, W, H, S);
 }
 
 }  // namespace lstur

@@ -117,8 +117,8 @@ std::vector<ParamSlot> param_layout(const Dims& d, size_t* total) {
 // Workspace carving: identical in lstur_query_sizes and lstur_create.
 struct Workspace {
   int32_t* ids; float* emb; float* conv; float* dconv; float* att_a; float* att_wt; float* pooled; float* dpooled;
-  float* docvec; float* ddocvec; uint8_t* hmask; uint8_t* gmask; float* uvec; float* xw; float* hs; float* zs;
-  float* rs; float* hhs; float* dgates; float* rh; float* hprev; float* dh0; float* hlast; float* dhlast;
+  float* docvec; float* ddocvec; uint8_t* hmask; uint8_t* gmask; float* uvec; float* xw; float* gru_tape;
+  float* dgates; float* rh; float* hprev; float* dh0; float* hlast; float* dhlast;
   float* cat; float* dcat; float* uservec; float* duser; float* du; float* logits; float* probs; float* loss_i;
   float* correct_i; float* parts; float* conv_wp; float* u_zr_p; float* u_h_p; float* ut_zr_p; float* ut_h_p;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; int32_t* first; float* gsum; int32_t* slot;
@@ -167,10 +167,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->gmask = (uint8_t*)take(nW);
   w->uvec = (float*)take(nc * d.Ue * f4);
   w->xw = (float*)take(nW * 3 * d.H * f4);
-  w->hs = (float*)take(nc * (d.W + 1) * d.H * f4);
-  w->zs = (float*)take(nW * d.H * f4);
-  w->rs = (float*)take(nW * d.H * f4);
-  w->hhs = (float*)take(nW * d.H * f4);
+  w->gru_tape = (float*)take(gru_tape_floats((int)nc, d.W, d.H) * f4);
   w->dgates = (float*)take(nW * 3 * d.H * f4);
   w->rh = (float*)take(nW * d.H * f4);
   w->hprev = (float*)take(nW * d.H * f4);
@@ -326,10 +323,8 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   launch_gather_rows(c->buf.user_emb, user, w.uvec, n, d.Ue, s);
   launch_gemm(w.docvec, d.U, 0, c->P("gru_w"), 3 * d.H, 0, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, 1.f,
               w.gemm_scratch, s);
-  PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.u_zr_p, w.u_h_p, w.hs,
-                                 w.zs, w.rs, w.hhs, n, d.W, d.H, s));
-  (void)hipMemcpy2DAsync(w.hlast, (size_t)d.H * 4, w.hs + (size_t)d.W * d.H, (size_t)(d.W + 1) * d.H * 4,
-                         (size_t)d.H * 4, n, hipMemcpyDeviceToDevice, s);
+  PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.u_zr_p, w.u_h_p,
+                                 w.gru_tape, w.hlast, n, d.W, d.H, s));
   if (d.arch == LSTUR_ARCH_IGRU) {
     (void)hipMemcpyAsync(w.uservec, w.hlast, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
   } else {
@@ -364,7 +359,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
     launch_split2(w.du, d.H, d.Ue, w.dhlast, w.duser, n, s);
     dhl = w.dhlast;
   }
-  PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.hs, w.zs, w.rs, w.hhs, w.ut_zr_p, w.ut_h_p, w.dgates, w.rh, w.hprev,
+  PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.ut_zr_p, w.ut_h_p, w.dgates, w.rh, w.hprev,
                                  d.arch == LSTUR_ARCH_IGRU ? w.duser : w.dh0, n, d.W, d.H, s));
   // GRU parameter gradients
   launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
@@ -632,7 +627,7 @@ int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* coun
       {"conv_out", w.conv, nt * d.T * d.F}, {"att_w", w.att_wt, nt * d.T},
       {"emb", w.emb, nt * d.Tp * d.D},      {"pooled", w.pooled, nt * d.F},
       {"loss_i", w.loss_i, n},              {"user_grad", w.duser, n * d.Ue},
-      {"dconv", w.dconv, nt * d.T * d.F},   {"hs", w.hs, n * (d.W + 1) * d.H},
+      {"dconv", w.dconv, nt * d.T * d.F},   {"h_last", w.hlast, n * d.H},
       {"dgates", w.dgates, n * d.W * 3 * d.H}, {"ddoc_vec", w.ddocvec, nt * d.U},
   };
   for (auto& e : tab)
@@ -728,22 +723,22 @@ int lstur_gru_pack_u(const float* gru_u, int32_t H, float* u_zr, float* u_h, flo
   launch_gru_pack(gru_u, H, u_zr, u_h, ut_h, ut_zr, (hipStream_t)stream);
   return check_launch("gru_pack");
 }
+size_t lstur_gru_tape_floats(int32_t n, int32_t W, int32_t H) { return gru_tape_floats(n, W, H); }
 int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
-                  const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int32_t n, int32_t W, int32_t H,
+                  const float* u_h_packed, float* tape, float* hlast, int32_t n, int32_t W, int32_t H,
                   lstur_stream stream) {
-  if (!xw || !gmask || !u_zr_packed || !u_h_packed || !hs || !zs || !rs || !hhs || H > 256)
+  if (!xw || !gmask || !u_zr_packed || !u_h_packed || !tape || !hlast || H < 1 || H > 256)
     return fail(LSTUR_ERR_ARG, "gru fwd: bad argument");
-  launch_gru_fwd(xw, gmask, h0, u_zr_packed, u_h_packed, hs, zs, rs, hhs, n, W, H, (hipStream_t)stream);
+  launch_gru_fwd(xw, gmask, h0, u_zr_packed, u_h_packed, tape, hlast, n, W, H, (hipStream_t)stream);
   return check_launch("gru_fwd");
 }
-int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, const float* hs, const float* zs, const float* rs,
-                  const float* hhs, const float* ut_zr_packed, const float* ut_h_packed, float* dgates, float* rh,
-                  float* hprev, float* dh0, int32_t n, int32_t W, int32_t H, lstur_stream stream) {
-  if (!dh_last || !gmask || !hs || !zs || !rs || !hhs || !ut_zr_packed || !ut_h_packed || !dgates || !rh || !hprev ||
-      !dh0 || H > 256)
+int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* ut_zr_packed,
+                  const float* ut_h_packed, float* dgates, float* rh, float* hprev, float* dh0, int32_t n, int32_t W,
+                  int32_t H, lstur_stream stream) {
+  if (!dh_last || !gmask || !tape || !ut_zr_packed || !ut_h_packed || !dgates || !rh || !hprev || !dh0 || H < 1 ||
+      H > 256)
     return fail(LSTUR_ERR_ARG, "gru bwd: bad argument");
-  launch_gru_bwd(dh_last, gmask, hs, zs, rs, hhs, ut_zr_packed, ut_h_packed, dgates, rh, hprev, dh0, n, W, H,
-                 (hipStream_t)stream);
+  launch_gru_bwd(dh_last, gmask, tape, ut_zr_packed, ut_h_packed, dgates, rh, hprev, dh0, n, W, H, (hipStream_t)stream);
   return check_launch("gru_bwd");
 }
 int lstur_score_softmax_ce(const float* u, const float* d, float* logits, float* probs, float* loss_i, float* correct_i,

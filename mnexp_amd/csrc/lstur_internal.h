@@ -88,12 +88,13 @@ void launch_gemm(const float* A, int lda, int ta, const float* B, int ldb, int t
 // needs its share of gru_pack_floats(H): u_zr 2/6, u_h 1/6, ut_h 1/6, ut_zr 2/6 of the total.
 size_t gru_pack_floats(int H);
 void launch_gru_pack(const float* U, int H, float* u_zr, float* u_h, float* ut_h, float* ut_zr, hipStream_t s);
-// All per-sample buffers must hold ceil16(n) sample rows.  Requires H <= 256.
+// tape: gru_tape_floats(n, W, H) floats of scratch in MFMA-fragment layout, shared by forward and BPTT.
+// xw [n*W,3H] row-major; hlast [n,H]; dgates [n*W,3H], rh / hprev [n*W,H] row-major.  Requires H <= 256.
+size_t gru_tape_floats(int n, int W, int H);
 void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
-                    const float* u_h_packed, float* hs, float* zs, float* rs, float* hhs, int n, int W, int H,
+                    const float* u_h_packed, float* tape, float* hlast, int n, int W, int H, hipStream_t s);
+void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* ut_zr_packed,
+                    const float* ut_h_packed, float* dgates, float* rh, float* hprev, float* dh0, int n, int W, int H,
                     hipStream_t s);
-void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, const float* hs, const float* zs,
-                    const float* rs, const float* hhs, const float* ut_zr_packed, const float* ut_h_packed,
-                    float* dgates, float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s);
 
 }  // namespace lstur

@@ -137,12 +137,13 @@ def test_gemm_variants(ta, tb, M, N, K):
     assert err < 1e-5 * ref.abs().max().item() + 1e-6, err
 
 
-def test_gru_at_baseline_width_against_oracle():
+@pytest.mark.parametrize('n,W,H', [(21, 12, 200), (5, 7, 40), (33, 9, 128)])
+def test_gru_against_oracle(n, W, H):
     _need_gpu()
     from mnexp_amd._lib import lib, check
     from oracle import lstur_oracle as O
     rng = np.random.default_rng(2)
-    n, W, H, U = 21, 12, 200, 200
+    U = H
     p = dict(gru_w=rng.normal(0, 0.1, (U, 3 * H)), gru_u=O.orthogonal(rng, H, 3 * H), gru_b=rng.normal(0, 0.1, 3 * H))
     x = rng.normal(0, 0.5, (n, W, U))
     gmask = rng.random((n, W)) > 0.3
@@ -154,36 +155,32 @@ def test_gru_at_baseline_width_against_oracle():
     sixth = lib.lstur_gru_pack_floats(H) // 6
     uzr, uh, uth, utzr = (torch.zeros(k * sixth, device='cuda') for k in (2, 1, 1, 2))
     check(lib.lstur_gru_pack_u(Ud.data_ptr(), H, uzr.data_ptr(), uh.data_ptr(), uth.data_ptr(), utzr.data_ptr(), stream()))
-    npad = (n + 15) // 16 * 16                      # the kernels want ceil16(n) sample rows in every buffer
-    hs = torch.zeros(npad, W + 1, H, device='cuda')
-    zs, rs, hhs = (torch.zeros(npad, W, H, device='cuda') for _ in range(3))
-    gm = torch.zeros(npad, W, dtype=torch.uint8, device='cuda')
-    gm[:n] = dev(gmask.astype(np.uint8))
-    xw_d = torch.zeros(npad, W, 3 * H, device='cuda')
-    xw_d[:n] = dev(xw).view(n, W, 3 * H)
-    h0_d = dev(h0.astype(np.float32))
-    check(lib.lstur_gru_fwd(xw_d.data_ptr(), gm.data_ptr(), h0_d.data_ptr(), uzr.data_ptr(),
-                            uh.data_ptr(), hs.data_ptr(), zs.data_ptr(), rs.data_ptr(), hhs.data_ptr(), n, W, H, stream()))
-    np.testing.assert_allclose(hs[:n, W].cpu().numpy(), h_ref, rtol=1e-3, atol=2e-5)
-    np.testing.assert_allclose(hs[:n].cpu().numpy(), cache['hs'], rtol=1e-3, atol=2e-5)
-    assert np.array_equal(hs[0, W].cpu().numpy(), h0[0].astype(np.float32))   # fully masked row carries h0 bit-exactly
+    tape = torch.zeros(lib.lstur_gru_tape_floats(n, W, H), device='cuda')
+    hlast = torch.empty(n, H, device='cuda')
+    gm = dev(gmask.astype(np.uint8))
+    xw_d, h0_d = dev(xw), dev(h0.astype(np.float32))
+    check(lib.lstur_gru_fwd(xw_d.data_ptr(), gm.data_ptr(), h0_d.data_ptr(), uzr.data_ptr(), uh.data_ptr(),
+                            tape.data_ptr(), hlast.data_ptr(), n, W, H, stream()))
+    np.testing.assert_allclose(hlast.cpu().numpy(), h_ref, rtol=1e-3, atol=2e-5)
+    assert np.array_equal(hlast[0].cpu().numpy(), h0[0].astype(np.float32))   # fully masked row carries h0 bit-exactly
 
     dh = rng.normal(0, 1.0, (n, H))
     g_ref, dx_ref, dh0_ref = O.gru_bwd(p, cache, dh)
-    dg = torch.zeros(npad, W, 3 * H, device='cuda')
-    rh, hp = torch.zeros(npad, W, H, device='cuda'), torch.zeros(npad, W, H, device='cuda')
+    dg = torch.empty(n, W, 3 * H, device='cuda')
+    rh, hp = torch.empty(n, W, H, device='cuda'), torch.empty(n, W, H, device='cuda')
     dh0 = torch.empty(n, H, device='cuda')
     dh_d = dev(dh.astype(np.float32))
-    check(lib.lstur_gru_bwd(dh_d.data_ptr(), gm.data_ptr(), hs.data_ptr(), zs.data_ptr(),
-                            rs.data_ptr(), hhs.data_ptr(), utzr.data_ptr(), uth.data_ptr(), dg.data_ptr(), rh.data_ptr(),
-                            hp.data_ptr(), dh0.data_ptr(), n, W, H, stream()))
+    check(lib.lstur_gru_bwd(dh_d.data_ptr(), gm.data_ptr(), tape.data_ptr(), utzr.data_ptr(), uth.data_ptr(),
+                            dg.data_ptr(), rh.data_ptr(), hp.data_ptr(), dh0.data_ptr(), n, W, H, stream()))
+    np.testing.assert_allclose(hp.cpu().numpy(), cache['hs'][:, :W], rtol=1e-3, atol=2e-5)     # h_{t-1} tape
     np.testing.assert_allclose(dh0.cpu().numpy(), dh0_ref, rtol=2e-3, atol=2e-5)
-    dgn = dg[:n].cpu().numpy().reshape(n * W, 3 * H).astype(np.float64)
+    dgn = dg.cpu().numpy().reshape(n * W, 3 * H).astype(np.float64)
     np.testing.assert_allclose(dgn.sum(0), g_ref['gru_b'], rtol=2e-3, atol=1e-4)
     dU = np.zeros((H, 3 * H))
-    dU[:, :2 * H] = hp[:n].cpu().numpy().reshape(n * W, H).astype(np.float64).T @ dgn[:, :2 * H]
-    dU[:, 2 * H:] = rh[:n].cpu().numpy().reshape(n * W, H).astype(np.float64).T @ dgn[:, 2 * H:]
+    dU[:, :2 * H] = hp.cpu().numpy().reshape(n * W, H).astype(np.float64).T @ dgn[:, :2 * H]
+    dU[:, 2 * H:] = rh.cpu().numpy().reshape(n * W, H).astype(np.float64).T @ dgn[:, 2 * H:]
     np.testing.assert_allclose(dU, g_ref['gru_u'], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose((dgn @ p['gru_w'].T).reshape(n, W, U), dx_ref, rtol=2e-3, atol=2e-5)
 
 
 def test_full_step_at_baseline_shapes_small_batch():

@@ -16,15 +16,16 @@ def run(n, W, H, iters=20):
     sixth = lib.lstur_gru_pack_floats(H) // 6
     uzr, uh, uth, utzr = (torch.zeros(k * sixth, device='cuda') for k in (2, 1, 1, 2))
     check(lib.lstur_gru_pack_u(Um.data_ptr(), H, uzr.data_ptr(), uh.data_ptr(), uth.data_ptr(), utzr.data_ptr(), stream()))
-    hs = torch.empty(n, W + 1, H, device='cuda'); zs, rs, hhs = (torch.empty(n, W, H, device='cuda') for _ in range(3))
+    tape = torch.zeros(lib.lstur_gru_tape_floats(n, W, H), device='cuda')
+    hlast = torch.empty(n, H, device='cuda')
     dg = torch.empty(n, W, 3 * H, device='cuda'); rh = torch.empty(n, W, H, device='cuda'); hp = torch.empty(n, W, H, device='cuda')
     dh0 = torch.empty(n, H, device='cuda'); dh = torch.randn(n, H, device='cuda', generator=g)
     def fwd():
-        check(lib.lstur_gru_fwd(xw.data_ptr(), gm.data_ptr(), h0.data_ptr(), uzr.data_ptr(), uh.data_ptr(), hs.data_ptr(),
-                                zs.data_ptr(), rs.data_ptr(), hhs.data_ptr(), n, W, H, stream()))
+        check(lib.lstur_gru_fwd(xw.data_ptr(), gm.data_ptr(), h0.data_ptr(), uzr.data_ptr(), uh.data_ptr(), tape.data_ptr(),
+                                hlast.data_ptr(), n, W, H, stream()))
     def bwd():
-        check(lib.lstur_gru_bwd(dh.data_ptr(), gm.data_ptr(), hs.data_ptr(), zs.data_ptr(), rs.data_ptr(), hhs.data_ptr(),
-                                utzr.data_ptr(), uth.data_ptr(), dg.data_ptr(), rh.data_ptr(), hp.data_ptr(), dh0.data_ptr(), n, W, H, stream()))
+        check(lib.lstur_gru_bwd(dh.data_ptr(), gm.data_ptr(), tape.data_ptr(), utzr.data_ptr(), uth.data_ptr(), dg.data_ptr(),
+                                rh.data_ptr(), hp.data_ptr(), dh0.data_ptr(), n, W, H, stream()))
     res = {}
     for name, fn in (('fwd', fwd), ('bwd', bwd)):
         for _ in range(3): fn()
@@ -35,10 +36,10 @@ def run(n, W, H, iters=20):
         e1.record(); torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / iters * 1e3
     if int(os.environ.get('LSTUR_GRU_DEBUG', '0')) & 16:
-        fwd(); torch.cuda.synchronize(); cyc, ticks = zs.view(-1)[0].item(), zs.view(-1)[1].item()
+        fwd(); torch.cuda.synchronize(); S = tape.numel() // 11; cyc, ticks = tape[8 * S].item(), tape[8 * S + 1].item()
         print('  in-kernel: %.0f shader cycles over %.1f us -> %.3f GHz' % (cyc, ticks / 100.0, cyc / (ticks / 100.0) / 1e3))
     if int(os.environ.get('LSTUR_GRU_DEBUG', '0')) & 32:
-        fwd(); torch.cuda.synchronize(); v = rs.view(-1)[:64].cpu().numpy().reshape(8, 8)[:, :6] / W
+        fwd(); torch.cuda.synchronize(); S = tape.numel() // 11; v = tape[7 * S:7 * S + 64].cpu().numpy().reshape(8, 8)[:, :6] / W
         print('  per-step cycles per wave: gemm1, epi1, bar1, gemm2, epi2, bar2'); print(v.round(0))
     return res
 
