@@ -27,7 +27,7 @@
 
 namespace lstur {
 
-constexpr int GW = 8;  // waves per workgroup
+constexpr int GW = 16;  // waves per workgroup
 
 // ring depth for a wave that owns C column tiles: ~8 float4 fragment loads in flight per wave
 __host__ __device__ constexpr int ring_depth(int C) { return C >= 4 ? 2 : (C == 3 ? 3 : (C == 2 ? 4 : 6)); }
@@ -373,9 +373,11 @@ __global__ __launch_bounds__(GW * 64) void gru_fwd_kernel(GruFwdArgs g) {
       gru_fwd_body<A, B, 0>(g, smem, wv, lane);                   \
     done = true;                                                  \
   }
-  LSTUR_FWD_CASE(4, 2) LSTUR_FWD_CASE(3, 2) LSTUR_FWD_CASE(3, 1) LSTUR_FWD_CASE(4, 1) LSTUR_FWD_CASE(2, 1)
-  LSTUR_FWD_CASE(1, 1) LSTUR_FWD_CASE(2, 2) LSTUR_FWD_CASE(1, 0) LSTUR_FWD_CASE(2, 0) LSTUR_FWD_CASE(3, 0)
-  LSTUR_FWD_CASE(4, 0) LSTUR_FWD_CASE(1, 2)
+  if constexpr (GW == 8) {   // H <= 256: up to 4 z|r tiles and 2 candidate tiles per wave
+    LSTUR_FWD_CASE(4, 2) LSTUR_FWD_CASE(3, 2) LSTUR_FWD_CASE(3, 1) LSTUR_FWD_CASE(4, 1) LSTUR_FWD_CASE(3, 0)
+    LSTUR_FWD_CASE(4, 0) LSTUR_FWD_CASE(2, 2) LSTUR_FWD_CASE(1, 2)
+  }
+  LSTUR_FWD_CASE(2, 1) LSTUR_FWD_CASE(1, 1) LSTUR_FWD_CASE(1, 0) LSTUR_FWD_CASE(2, 0)
 #undef LSTUR_FWD_CASE
   if (!done)   // a wave without tiles (tiny H) still has to meet the barriers
     for (int t = 0; t < W; ++t) {
@@ -531,12 +533,12 @@ __global__ __launch_bounds__(GW * 64) void gru_bwd_kernel(GruBwdArgs g) {
   }
   __syncthreads();
   const int cnt = tiles_of(wv, Hp / 16);
-  if (cnt == 2 && nch == 13)
-    gru_bwd_body<2, 13, 26>(g, smem, wv, lane);
+  if (GW == 8 && cnt == 2 && nch == 13)
+    gru_bwd_body<(GW == 8 ? 2 : 1), 13, 26>(g, smem, wv, lane);
   else if (cnt == 1 && nch == 13)
     gru_bwd_body<1, 13, 26>(g, smem, wv, lane);
-  else if (cnt == 2)
-    gru_bwd_body<2, 0, 0>(g, smem, wv, lane);
+  else if (GW == 8 && cnt == 2)
+    gru_bwd_body<(GW == 8 ? 2 : 1), 0, 0>(g, smem, wv, lane);
   else if (cnt == 1)
     gru_bwd_body<1, 0, 0>(g, smem, wv, lane);
   else
