@@ -1,6 +1,7 @@
 // General fp32 MFMA GEMM for the small dense layers of the LSTUR path (gfx950):
 //   C[M,N] = alpha * op(A) . op(B) + bias      (Dense(U) paper.py:159, GRU input projection and the
-//   weight/input gradients of both).  64x64 tile, BK = 16, 4 waves x (2x2) v_mfma_f32_16x16x4_f32.
+//   weight/input gradients of both).  64x64 tile, BK = 32, 4 waves x (2x2) v_mfma_f32_16x16x4_f32,
+//   register-staged prefetch of the next tile under the MFMAs of the current one.
 // Weight-gradient shapes (small M*N, long K) are split along K into partial slabs that a second
 // kernel reduces in fixed order (bitwise reproducible, unlike float atomics).
 #include "lstur_device.h"
@@ -8,7 +9,7 @@
 
 namespace lstur {
 
-constexpr int GT = 64, GK = 16, GLD = 80;  // tile, k-step, LDS row stride (80 % 32 == 16: conflict-free b32 reads)
+constexpr int GT = 64, GK = 32, GLD = 80;  // tile, k-step, LDS row stride (80 % 32 == 16: conflict-free b32 reads)
 
 // four consecutive elements base[i0 .. i0+3] with element-level bounds (count valid from i0)
 __device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int valid, bool vec) {
@@ -19,6 +20,44 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int v
   if (valid > 2) v.z = p[2];
   if (valid > 3) v.w = p[3];
   return v;
+}
+
+// One 64 x 32 operand tile = 512 float4, two per thread.  KMAJOR: the operand is stored with k contiguous
+// (A[m][k] or B[n][k]) and is transposed on its way into the k-major LDS image; otherwise (A[k][m] / B[k][n])
+// the image is a straight copy.
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_load(const float* __restrict__ P, int ld, int x0, int xmax, int k0, int kend,
+                                          bool vec, int tid, float4 (&r)[2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + q * 256;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KMAJOR) {
+      const int x = idx >> 3, kg = (idx & 7) * 4;
+      if (x0 + x < xmax) v = load4_guard(P + (size_t)(x0 + x) * ld + k0 + kg, kend - (k0 + kg), vec);
+    } else {
+      const int k = idx >> 4, xg = (idx & 15) * 4;
+      if (k0 + k < kend) v = load4_guard(P + (size_t)(k0 + k) * ld + x0 + xg, xmax - (x0 + xg), vec);
+    }
+    r[q] = v;
+  }
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_store(float (*S)[GLD], int tid, const float4 (&r)[2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + q * 256;
+    if (KMAJOR) {
+      const int x = idx >> 3, kg = (idx & 7) * 4;
+      S[kg + 0][x] = r[q].x;
+      S[kg + 1][x] = r[q].y;
+      S[kg + 2][x] = r[q].z;
+      S[kg + 3][x] = r[q].w;
+    } else {
+      const int k = idx >> 4, xg = (idx & 15) * 4;
+      *(float4*)&S[k][xg] = r[q];
+    }
+  }
 }
 
 template <bool TA, bool TB>
@@ -41,38 +80,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // register-staged pipeline: the next tile's global loads are in flight while this tile's MFMAs run
+  float4 ra[2], rb[2];
+  tile_load<!TA>(A, lda, m0, M, kbeg, kend, vecA, tid, ra);
+  tile_load<TB>(B, ldb, n0, N, kbeg, kend, vecB, tid, rb);
   for (int k0 = kbeg; k0 < kend; k0 += GK) {
-    // ---- stage A tile: As[k][m] ----
-    if (!TA) {  // A[m][k], k contiguous: thread -> (m, 4 k's)
-      int m = tid >> 2, kg = (tid & 3) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + m < M) v = load4_guard(A + (size_t)(m0 + m) * lda + k0 + kg, kend - (k0 + kg), vecA);
-      As[kg + 0][m] = v.x;
-      As[kg + 1][m] = v.y;
-      As[kg + 2][m] = v.z;
-      As[kg + 3][m] = v.w;
-    } else {  // A[k][m], m contiguous: thread -> (k, 4 m's)
-      int k = tid >> 4, mg = (tid & 15) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + k < kend) v = load4_guard(A + (size_t)(k0 + k) * lda + m0 + mg, M - (m0 + mg), vecA);
-      *(float4*)&As[k][mg] = v;
-    }
-    // ---- stage B tile: Bs[k][n] ----
-    if (!TB) {  // B[k][n], n contiguous
-      int k = tid >> 4, ng = (tid & 15) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + k < kend) v = load4_guard(B + (size_t)(k0 + k) * ldb + n0 + ng, N - (n0 + ng), vecB);
-      *(float4*)&Bs[k][ng] = v;
-    } else {  // B[n][k], k contiguous
-      int n = tid >> 2, kg = (tid & 3) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 + n < N) v = load4_guard(B + (size_t)(n0 + n) * ldb + k0 + kg, kend - (k0 + kg), vecB);
-      Bs[kg + 0][n] = v.x;
-      Bs[kg + 1][n] = v.y;
-      Bs[kg + 2][n] = v.z;
-      Bs[kg + 3][n] = v.w;
-    }
+    tile_store<!TA>(As, tid, ra);
+    tile_store<TB>(Bs, tid, rb);
     __syncthreads();
+    if (k0 + GK < kend) {
+      tile_load<!TA>(A, lda, m0, M, k0 + GK, kend, vecA, tid, ra);
+      tile_load<TB>(B, ldb, n0, N, k0 + GK, kend, vecB, tid, rb);
+    }
 #pragma unroll
     for (int s = 0; s < GK / 4; ++s) {
       float a0 = As[s * 4 + kq][wr * 32 + r16];
