@@ -54,6 +54,21 @@ def synth_inputs(wl, rng, n_batches):
     return titles, word, batches
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/;
+    FETCH_SIZE doubled per the gfx950 correction) -- None when no file matches the workload."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(ROOT, 'profiles'))) if os.path.isdir(os.path.join(ROOT, 'profiles')) else []:
+        if name.endswith('pmc_traffic.json'):
+            try:
+                d = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            except Exception:
+                continue
+            if d.get('workload') == workload:
+                best = d
+    return best
+
+
 def cpu_baseline(wl, titles, word, batches, budget_s=20.0):
     """The NumPy oracle (kind 'port'; the reference's Keras/TF stack cannot run here) timed on the host
     cores for a bounded number of full training steps of the SAME workload in fp32."""
@@ -152,17 +167,19 @@ def main():
         kern = {k: dict(avg_us=1e3 * ms / max(1, n), launches=n) for k, (ms, n) in prof.items()}
         roofline = None
         roofline_gather = None
+        pmc = pmc_traffic(args.workload)
+        traffic = (lambda k: pmc['kernels'][k]['traffic_bytes'] if pmc and k in pmc['kernels'] else None)
         if prof:
             dom = max(('conv_fwd', 'conv_wgrad'), key=lambda k: kern[k]['avg_us'])
             ach = conv_flop / (kern[dom]['avg_us'] * 1e-6) / 1e12
             roofline = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic(dom),
                             avg_us=round(kern[dom]['avg_us'], 1), flop_per_launch=conv_flop,
                             non_pad_token_fraction=round(real_tok / n_tok, 4),
                             effective_algorithmic=round(conv_flop_full / (kern[dom]['avg_us'] * 1e-6) / 1e12, 2))
             gb = gather_bytes / (kern['gather']['avg_us'] * 1e-6) / 1e9
             roofline_gather = dict(kernel='gather', bound='hbm', achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                                   frac=round(gb / PEAK_HBM_GBS, 4), traffic=None,
+                                   frac=round(gb / PEAK_HBM_GBS, 4), traffic=traffic('gather'),
                                    avg_us=round(kern['gather']['avg_us'], 1), bytes_per_launch=gather_bytes)
         out = {
             'metric': 'training impressions/sec', 'value': round(world * wl['B'] * args.steps / el, 1),
