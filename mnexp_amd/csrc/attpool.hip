@@ -139,7 +139,8 @@ void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, 
 // Backward through pool, attention, dropout and the ReLU of the conv output.
 //   dw_t = sum_f dp_f x_tf ; ds_t = (dw_t - sum_t' dw_t' w_t') w_t (1 - a_t^2)
 //   dx_tf = dp_f w_t + ds_t k_f ; dc_tf = dx_tf * keep*scale * [c_tf > 0]
-// parts[block] = datt_w[F] | dconv_b[F] | datt_b  (reduced by the caller with colsum).
+// parts[block] holds datt_w[F], dconv_b[F], datt_b at caller-chosen offsets of an ldp-wide row (reduced by the
+// caller with colsum; the training step lays the row out like the gradient bucket: ONE reduction).
 // ---------------------------------------------------------------------------------------------
 template <int VEC>
 __global__ __launch_bounds__(256) void att_bwd_dw_kernel(const float* __restrict__ c, const float* __restrict__ w,
@@ -198,11 +199,14 @@ __global__ __launch_bounds__(128) void att_bwd_dc_kernel(const float* __restrict
                                                          const float* __restrict__ ds,
                                                          const float* __restrict__ dpooled, float* __restrict__ dc,
                                                          float* __restrict__ parts, int rows, int T, int F,
-                                                         uint32_t thresh, uint32_t key, float scale) {
+                                                         uint32_t thresh, uint32_t key, float scale, int ldp,
+                                                         int off_aw, int off_cb, int off_ab) {
   const int cols = VEC == 4 ? F / 4 : F;
   const int per = (rows + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
-  float* pr = parts + (size_t)blockIdx.x * (2 * F + 1);
+  float* pr = parts + (size_t)blockIdx.x * ldp;
+  float* pr_aw = pr + off_aw;   // datt_w[F]
+  float* pr_cb = pr + off_cb;   // dconv_b[F]
   for (int j = threadIdx.x; j < cols; j += 128) {
     if (VEC == 4) {
       float4 kf = ((const float4*)att_w)[j];
@@ -231,14 +235,14 @@ __global__ __launch_bounds__(128) void att_bwd_dc_kernel(const float* __restrict
         }
         ((float4*)(dc + (size_t)row * F))[j] = o;
       }
-      pr[j * 4 + 0] = gaw.x;
-      pr[j * 4 + 1] = gaw.y;
-      pr[j * 4 + 2] = gaw.z;
-      pr[j * 4 + 3] = gaw.w;
-      pr[F + j * 4 + 0] = gcb.x;
-      pr[F + j * 4 + 1] = gcb.y;
-      pr[F + j * 4 + 2] = gcb.z;
-      pr[F + j * 4 + 3] = gcb.w;
+      pr_aw[j * 4 + 0] = gaw.x;
+      pr_aw[j * 4 + 1] = gaw.y;
+      pr_aw[j * 4 + 2] = gaw.z;
+      pr_aw[j * 4 + 3] = gaw.w;
+      pr_cb[j * 4 + 0] = gcb.x;
+      pr_cb[j * 4 + 1] = gcb.y;
+      pr_cb[j * 4 + 2] = gcb.z;
+      pr_cb[j * 4 + 3] = gcb.w;
     } else {
       float kf = att_w[j], gaw = 0.f, gcb = 0.f;
       for (int row = r0; row < r1; ++row) {
@@ -255,20 +259,26 @@ __global__ __launch_bounds__(128) void att_bwd_dc_kernel(const float* __restrict
         }
         dc[(size_t)row * F + j] = o;
       }
-      pr[j] = gaw;
-      pr[F + j] = gcb;
+      pr_aw[j] = gaw;
+      pr_cb[j] = gcb;
     }
   }
   if (threadIdx.x == 0) {
     float gab = 0.f;
     for (int row = r0; row < r1; ++row) gab += ds[row];   // ds is 0 on masked / pad rows
-    pr[2 * F] = gab;
+    pr[off_ab] = gab;
   }
 }
 
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
-                        float drop, uint32_t key, hipStream_t s) {
+                        float drop, uint32_t key, hipStream_t s, int ldp, int off_aw, int off_cb, int off_ab) {
+  if (ldp <= 0) {   // default layout of the public entry point: datt_w[F] | dconv_b[F] | datt_b
+    ldp = 2 * F + 1;
+    off_aw = 0;
+    off_cb = F;
+    off_ab = 2 * F;
+  }
   if (!n_titles) return;
   uint32_t thresh = drop > 0.f ? dropout_thresh(drop) : 0u;
   float scale = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
@@ -279,13 +289,13 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
                        thresh, key, scale);
     hipLaunchKernelGGL(att_bwd_ds_kernel, dim3(cdiv(n_titles, 128)), dim3(128), 0, s, row_scratch, w, a, n_titles, T);
     hipLaunchKernelGGL(att_bwd_dc_kernel<4>, dim3(nparts), dim3(128), 0, s, c, ids, att_w, w, row_scratch, dpooled, dc,
-                       parts, rows, T, F, thresh, key, scale);
+                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab);
   } else {
     hipLaunchKernelGGL(att_bwd_dw_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, s, c, w, dpooled, row_scratch, rows, T, F,
                        thresh, key, scale);
     hipLaunchKernelGGL(att_bwd_ds_kernel, dim3(cdiv(n_titles, 128)), dim3(128), 0, s, row_scratch, w, a, n_titles, T);
     hipLaunchKernelGGL(att_bwd_dc_kernel<1>, dim3(nparts), dim3(128), 0, s, c, ids, att_w, w, row_scratch, dpooled, dc,
-                       parts, rows, T, F, thresh, key, scale);
+                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab);
   }
 }
 

@@ -183,7 +183,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->probs = (float*)take(nc * d.K1 * f4);
   w->loss_i = (float*)take(nc * f4);
   w->correct_i = (float*)take(nc * f4);
-  w->parts = (float*)take((size_t)1024 * (2 * d.F + 1) * f4);
+  w->parts = (float*)take((size_t)1024 * (3 * ((d.F + kParamAlign - 1) / kParamAlign * kParamAlign) + 64) * f4);
   w->conv_wp = (float*)take(pack_b_floats(d.KD, d.F) * f4);
   {
     const size_t sixth = gru_pack_floats(d.H) / 6;
@@ -200,7 +200,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->slot = (int32_t*)take((size_t)d.Nu * 4);
   w->user_rows = (int32_t*)take(nc * 4);
   w->scores = (float*)take(nc * f4);
-  w->colsum_scratch = (float*)take((size_t)kColsumSlices * std::max(std::max(3 * d.H, d.U), 2 * d.F + 1) * f4);
+  w->colsum_scratch = (float*)take((size_t)kColsumSlices * std::max(std::max(3 * d.H, d.U), (int)(3 * ((d.F + kParamAlign - 1) / kParamAlign * kParamAlign) + 64)) * f4);
   w->vidx = (int32_t*)take(nt * d.T * 4);
   w->vcount = (int32_t*)take(256);
   w->att_ds = (float*)take(nt * d.T * f4);
@@ -377,12 +377,12 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
   launch_gemm(w.pooled, d.F, 1, w.ddocvec, d.U, 0, c->G("dense_w"), d.U, nullptr, d.F, d.U, nt, 1.f, w.gemm_scratch, s);
   launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch, s);
   launch_gemm(w.ddocvec, d.U, 0, c->P("dense_w"), d.U, 1, w.dpooled, d.F, nullptr, nt, d.F, d.U, 1.f, w.gemm_scratch, s);
-  PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, w.att_ds,
-                                         nt, d.T, d.F, drop, key1, s));
-  const int np = attpool_bwd_parts(nt), ldp = 2 * d.F + 1;
-  launch_colsum2(w.parts, np, d.F, ldp, c->G("att_w"), 1.f, w.colsum_scratch, s);
-  launch_colsum2(w.parts + d.F, np, d.F, ldp, c->G("conv_b"), 1.f, w.colsum_scratch, s);
-  launch_colsum2(w.parts + 2 * d.F, np, 1, ldp, c->G("att_b"), 1.f, w.colsum_scratch, s);
+  // partial sums laid out like the bucket slice conv_b .. att_b -> one reduction straight into dense_grad
+  const int off_cb = 0, off_aw = (int)(c->G("att_w") - c->G("conv_b")), off_ab = (int)(c->G("att_b") - c->G("conv_b"));
+  const int ldp = off_ab + 1;
+  PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
+                                         w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab));
+  launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch, s);
   PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
                                        w.vidx, w.vcount, s));
 }

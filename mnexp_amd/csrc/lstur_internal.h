@@ -76,7 +76,8 @@ int attpool_bwd_parts(int n_titles);
 // row_scratch: n_titles*T floats (dw -> ds)
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
-                        float drop, uint32_t key, hipStream_t s);
+                        float drop, uint32_t key, hipStream_t s, int ldp = 0, int off_aw = 0, int off_cb = 0,
+                        int off_ab = 0);
 
 // ---- gemm.hip ----------------------------------------------------------------------------------
 size_t gemm_scratch_bytes(int M, int N, int K);

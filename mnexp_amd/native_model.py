@@ -195,6 +195,43 @@ class NativeModel:
         check(lib.lstur_peek(self._ctx, name.encode(), C.byref(ptr), C.byref(cnt)), 'lstur_peek')
         return self._peek_ptr(ptr.value, cnt.value, torch.float32).clone()
 
+    # ---- weight interchange (reference utils.save_model / load_model, utils.py:65-79) -----------------
+    def keras_weight_order(self):
+        """Names in the order ``keras.Model.get_weights()`` lists them for the reference graph: trainable
+        weights layer by layer (doc_encoder: Conv1D kernel/bias, attention kernel/bias, Dense kernel/bias;
+        user_encoder: user Embedding, GRU kernel/recurrent/bias[, concat Dense]), then the frozen word table."""
+        names = ['conv_w', 'conv_b', 'att_w', 'att_b', 'dense_w', 'dense_b', 'user_emb', 'gru_w', 'gru_u', 'gru_b']
+        if self.arch == 'gru':
+            names += ['con_w', 'con_b']
+        return names + ['word_emb']
+
+    def save(self, paths):
+        """(json_path, pkl_path) like utils.save_model: a JSON description + a pickle of the weight list in
+        Keras order and Keras shapes (attention kernel [F,1])."""
+        import json
+        import pickle
+        json_path, pkl_path = paths
+        w = self.get_weights()
+        w['word_emb'] = self.word_emb.cpu().numpy()
+        arrays = [w[n].reshape(-1, 1) if n == 'att_w' else w[n] for n in self.keras_weight_order()]
+        with open(json_path, 'w') as f:
+            json.dump(dict(format='mnexp_amd-lstur-1', arch=self.arch, order=self.keras_weight_order(),
+                           shapes=[list(a.shape) for a in arrays]), f)
+        with open(pkl_path, 'wb') as f:
+            pickle.dump(arrays, f, protocol=pickle.HIGHEST_PROTOCOL)
+
+    def load(self, paths):
+        import json
+        import pickle
+        json_path, pkl_path = paths
+        with open(json_path) as f:
+            meta = json.load(f)
+        if meta.get('arch') != self.arch:
+            raise ValueError('saved model is arch {!r}, this model is {!r}'.format(meta.get('arch'), self.arch))
+        with open(pkl_path, 'rb') as f:      # a file written by save() above
+            arrays = pickle.load(f)
+        self.set_weights({n: np.asarray(a).reshape(self.shapes[n]) for n, a in zip(meta['order'], arrays)})
+
     def profile(self, enable=True):
         """Bracket each kernel family with HIP events on the launch stream (bench.py roofline figures)."""
         check(lib.lstur_profile(self._ctx, 1 if enable else 0), 'lstur_profile')

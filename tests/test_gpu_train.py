@@ -126,3 +126,23 @@ def test_dp_call_sequence_on_one_rank_nccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_save_load_round_trip(tmp_path):
+    _need_gpu()
+    from conftest import make_batch
+    from test_gpu_model import build, MID
+    dims, B, W, T, K1 = MID, 8, 5, 9, 5
+    O, p, model, rng = build('gru', dims, B, W, T, K1, 0.0)
+    paths = (str(tmp_path / 'm.json'), str(tmp_path / 'm.pkl'))
+    model.save(paths)
+    O2, p2, other, _ = build('gru', dims, B, W, T, K1, 0.0, seed=99)     # different weights
+    user, hist, cands = make_batch(rng, 6, W, T, 1, dims['V'], dims['N_u'])
+    X = [user.astype(np.int64), hist.astype(np.float64), cands[:, 0].astype(np.float64)]
+    a = model.predict(X)
+    assert not np.allclose(a, other.predict(X))
+    other.load(paths)
+    assert np.array_equal(a, other.predict(X))
+    import pickle
+    arrays = pickle.load(open(paths[1], 'rb'))
+    assert arrays[2].shape == (dims['F'], 1) and arrays[-1].shape == (dims['V'], dims['D'])   # Keras shapes / order
