@@ -5,7 +5,7 @@ Keeps the reference's entry point and option names (/root/reference/main.py:11-9
         train -t Seq2VecPaperSoftmaxId -a igru -e 2 -b 64 -s 100 -w 50 --title-shape 30 ...
 Every option is also settable as MSN_NEWS_<OPTION> (auto_envvar_prefix).  Added for the native path:
 --seed, --ids (feed doc-id batches and keep titles resident on the GPU instead of expanding them on the
-host).  Under `torch.distributed.run` each rank trains on its own shard of users (rank r takes users
+host), --native-feed (C++ sample feed, bit-identical batches).  Under `torch.distributed.run` each rank trains on its own shard of users (rank r takes users
 r, r+N, ...) with RCCL gradient averaging (mnexp_amd/dist.py).
 """
 import logging
@@ -61,6 +61,8 @@ _TRAIN_OPTIONS = [
     # native-path additions
     (('--seed',), dict(default=0)),
     (('--ids',), dict(is_flag=True, help='feed doc-id batches; titles stay resident on the GPU')),
+    (('--native-feed',), dict(is_flag=True, help='C++ sample feed (liblstur_data.so): the same batches as the Python '
+                                                  'generators for np.random.seed(--seed), implies --ids')),
 ]
 
 
@@ -75,8 +77,13 @@ def run_training(config, task_handler=None):
     evaluate_generator (failures swallowed like the reference), callback_valid, save_model."""
     if task_handler is None:
         task_handler = task.get(config)
-    use_ids = bool(getattr(config, 'ids', False))
-    training_data = task_handler.train_ids if use_ids else task_handler.train
+    native_feed = bool(getattr(config, 'native_feed', False))
+    use_ids = bool(getattr(config, 'ids', False)) or native_feed
+    if native_feed:
+        from .data_native import NativeTrainFeed
+        training_data = NativeTrainFeed(task_handler, seed=int(getattr(config, 'seed', 0) or 0))
+    else:
+        training_data = task_handler.train_ids if use_ids else task_handler.train
     model = None
     for epoch in range(config.epochs):
         logging.info('[+] start epoch {}'.format(epoch))

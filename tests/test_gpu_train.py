@@ -68,12 +68,12 @@ def test_training_tracks_oracle_and_auc_matches(tmp_path):
     assert abs(auc_gpu - auc_cpu) <= 0.002, (auc_gpu, auc_cpu)
 
 
-@pytest.mark.parametrize('arch,ids', [('igru', True), ('gru', False), ('hgru', True)])
+@pytest.mark.parametrize('arch,ids', [('igru', True), ('gru', False), ('hgru', True), ('igru', 'native')])
 def test_cli_train_loop(tmp_path, arch, ids):
     _need_gpu()
     from mnexp_amd.main import run_training
     cfg = _config(tmp_path, arch=arch, epochs=2, training_step=15, validation_step=2, validation_impression=20,
-                  testing_impression=20, dropout=0.2, ids=ids, seed=1)
+                  testing_impression=20, dropout=0.2, ids=bool(ids), native_feed=(ids == 'native'), seed=1)
     np.random.seed(0)
     h = run_training(cfg)
     assert 0.0 <= h.last_metrics['auc'] <= 1.0 and np.isfinite(h.last_metrics['mrr'])
