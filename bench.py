@@ -104,6 +104,7 @@ def main():
     ap.add_argument('--dropout', type=float, default=0.2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip the HIP-event brackets around kernels')
+    ap.add_argument('--force-dp', action='store_true', help='diagnostic: run the RCCL collectives of the data-parallel step even with one rank')
     args = ap.parse_args()
 
     import torch
@@ -116,9 +117,10 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)' % (args.gpus, args.gpus, world))
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        os.environ.setdefault('MASTER_PORT', '29517')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
 
     wl = WORKLOADS[args.workload]
     rng = np.random.default_rng(1234 + rank)
@@ -127,6 +129,7 @@ def main():
     model = NativeModel(word, wl['N_u'], wl['B'], wl['W'], wl['T'], wl['K1'] - 1, wl['F'], wl['k'], wl['U'],
                         arch=wl['arch'], dropout=args.dropout, lr=1e-3, seed=7, device='cuda:%d' % local,
                         title_table=titles)
+    model.force_collectives = args.force_dp
     dev = [(model._dev_i32(u), model._dev_i32(h), model._dev_i32(c)) for u, h, c in batches]
     torch.cuda.synchronize()
 
@@ -200,7 +203,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_dp:
         dist.destroy_process_group()
 
 
