@@ -193,25 +193,31 @@ __global__ void att_bwd_ds_kernel(float* __restrict__ dw, const float* __restric
 
 int attpool_bwd_parts(int n_titles) { return n_titles < 1024 ? (n_titles > 0 ? n_titles : 1) : 1024; }
 
+// RSUB row sub-streams per block (256 threads = RSUB x 128 column slots): more loads in flight per CU for this
+// purely bandwidth-bound pass; the sub-streams' partial sums are combined through LDS in fixed order.
+constexpr int kDcRsub = 2;
+
 template <int VEC>
-__global__ __launch_bounds__(128) void att_bwd_dc_kernel(const float* __restrict__ c, const int32_t* __restrict__ ids,
-                                                         const float* __restrict__ att_w, const float* __restrict__ w,
-                                                         const float* __restrict__ ds,
-                                                         const float* __restrict__ dpooled, float* __restrict__ dc,
-                                                         float* __restrict__ parts, int rows, int T, int F,
-                                                         uint32_t thresh, uint32_t key, float scale, int ldp,
-                                                         int off_aw, int off_cb, int off_ab) {
+__global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
+    const float* __restrict__ c, const int32_t* __restrict__ ids, const float* __restrict__ att_w,
+    const float* __restrict__ w, const float* __restrict__ ds, const float* __restrict__ dpooled,
+    float* __restrict__ dc, float* __restrict__ parts, int rows, int T, int F, uint32_t thresh, uint32_t key,
+    float scale, int ldp, int off_aw, int off_cb, int off_ab) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][F] partials of sub-stream 1
   const int cols = VEC == 4 ? F / 4 : F;
   const int per = (rows + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+  const int rsub = threadIdx.x / 128, tcol = threadIdx.x - rsub * 128;
   float* pr = parts + (size_t)blockIdx.x * ldp;
   float* pr_aw = pr + off_aw;   // datt_w[F]
   float* pr_cb = pr + off_cb;   // dconv_b[F]
-  for (int j = threadIdx.x; j < cols; j += 128) {
+  for (int j0 = 0; j0 < cols; j0 += 128) {   // uniform trip count: the barriers below are block-wide
+    const int j = j0 + tcol;
+    const bool act = j < cols;
     if (VEC == 4) {
-      float4 kf = ((const float4*)att_w)[j];
+      float4 kf = act ? ((const float4*)att_w)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 gaw = make_float4(0.f, 0.f, 0.f, 0.f), gcb = gaw;
-      for (int row = r0; row < r1; ++row) {
+      for (int row = r0 + rsub; act && row < r1; row += kDcRsub) {
         if (ids && ids[row] == 0) continue;
         const float wt = w[row], dst = ds[row];
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -235,17 +241,26 @@ __global__ __launch_bounds__(128) void att_bwd_dc_kernel(const float* __restrict
         }
         ((float4*)(dc + (size_t)row * F))[j] = o;
       }
-      pr_aw[j * 4 + 0] = gaw.x;
-      pr_aw[j * 4 + 1] = gaw.y;
-      pr_aw[j * 4 + 2] = gaw.z;
-      pr_aw[j * 4 + 3] = gaw.w;
-      pr_cb[j * 4 + 0] = gcb.x;
-      pr_cb[j * 4 + 1] = gcb.y;
-      pr_cb[j * 4 + 2] = gcb.z;
-      pr_cb[j * 4 + 3] = gcb.w;
+      if (act && rsub == 1) {
+        ((float4*)red)[j] = gaw;
+        ((float4*)(red + F))[j] = gcb;
+      }
+      __syncthreads();
+      if (act && rsub == 0) {
+        float4 a1 = ((float4*)red)[j], b1 = ((float4*)(red + F))[j];
+        pr_aw[j * 4 + 0] = gaw.x + a1.x;
+        pr_aw[j * 4 + 1] = gaw.y + a1.y;
+        pr_aw[j * 4 + 2] = gaw.z + a1.z;
+        pr_aw[j * 4 + 3] = gaw.w + a1.w;
+        pr_cb[j * 4 + 0] = gcb.x + b1.x;
+        pr_cb[j * 4 + 1] = gcb.y + b1.y;
+        pr_cb[j * 4 + 2] = gcb.z + b1.z;
+        pr_cb[j * 4 + 3] = gcb.w + b1.w;
+      }
+      __syncthreads();
     } else {
-      float kf = att_w[j], gaw = 0.f, gcb = 0.f;
-      for (int row = r0; row < r1; ++row) {
+      float kf = act ? att_w[j] : 0.f, gaw = 0.f, gcb = 0.f;
+      for (int row = r0 + rsub; act && row < r1; row += kDcRsub) {
         if (ids && ids[row] == 0) continue;
         const float wt = w[row], dst = ds[row];
         float o = 0.f;
@@ -259,8 +274,16 @@ __global__ __launch_bounds__(128) void att_bwd_dc_kernel(const float* __restrict
         }
         dc[(size_t)row * F + j] = o;
       }
-      pr_aw[j] = gaw;
-      pr_cb[j] = gcb;
+      if (act && rsub == 1) {
+        red[j] = gaw;
+        red[F + j] = gcb;
+      }
+      __syncthreads();
+      if (act && rsub == 0) {
+        pr_aw[j] = gaw + red[j];
+        pr_cb[j] = gcb + red[F + j];
+      }
+      __syncthreads();
     }
   }
   if (threadIdx.x == 0) {
@@ -288,13 +311,13 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
     hipLaunchKernelGGL(att_bwd_dw_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, c, w, dpooled, row_scratch, rows, T, F,
                        thresh, key, scale);
     hipLaunchKernelGGL(att_bwd_ds_kernel, dim3(cdiv(n_titles, 128)), dim3(128), 0, s, row_scratch, w, a, n_titles, T);
-    hipLaunchKernelGGL(att_bwd_dc_kernel<4>, dim3(nparts), dim3(128), 0, s, c, ids, att_w, w, row_scratch, dpooled, dc,
+    hipLaunchKernelGGL(att_bwd_dc_kernel<4>, dim3(nparts), dim3(128 * kDcRsub), 2 * F * sizeof(float), s, c, ids, att_w, w, row_scratch, dpooled, dc,
                        parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab);
   } else {
     hipLaunchKernelGGL(att_bwd_dw_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, s, c, w, dpooled, row_scratch, rows, T, F,
                        thresh, key, scale);
     hipLaunchKernelGGL(att_bwd_ds_kernel, dim3(cdiv(n_titles, 128)), dim3(128), 0, s, row_scratch, w, a, n_titles, T);
-    hipLaunchKernelGGL(att_bwd_dc_kernel<1>, dim3(nparts), dim3(128), 0, s, c, ids, att_w, w, row_scratch, dpooled, dc,
+    hipLaunchKernelGGL(att_bwd_dc_kernel<1>, dim3(nparts), dim3(128 * kDcRsub), 2 * F * sizeof(float), s, c, ids, att_w, w, row_scratch, dpooled, dc,
                        parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab);
   }
 }
