@@ -21,34 +21,20 @@ namespace lstur {
 // (double buffered, shared by all waves), NTW*4 MFMAs.  The k index inside a chunk is permuted
 // identically on both operands (lane kq supplies k = 4kq+s to MFMA s), which is legal for a sum.
 // ---------------------------------------------------------------------------------------------
-template <int NTW, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void conv_fwd_kernel(const float* __restrict__ E,
-                                                              const float* __restrict__ Wp,
-                                                              const float* __restrict__ bias,
-                                                              const int32_t* __restrict__ ids,
-                                                              float* __restrict__ C, int M, int T, int Tp, int D,
-                                                              int F, int Fp, int nchunk,
-                                                              const int32_t* __restrict__ vidx,
-                                                              const int32_t* __restrict__ vcount) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int CH = NTW * 256;  // floats per packed chunk of this column group
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, kq = lane >> 4;
-  const int tile0 = blockIdx.y * NTW;  // first column tile of this group
-
-  // persistent row range of this workgroup over the (compacted) output rows
-  const int count = vcount ? vcount[0] : M;
-  const int per = ((count + (int)gridDim.x - 1) / (int)gridDim.x + 15) & ~15;
-  const int r_begin = blockIdx.x * per;
-  const int r_end = min(count, r_begin + per);
-
-  const float* wsrc = Wp + (size_t)tile0 * 256;  // + ch * Fp * 16
-  constexpr int NV4 = CH / 4;                    // float4 per chunk
+// One pass over K for NT column tiles [first, first+NT) of 16 output rows: the wave's share of a row block.
+// All waves of the workgroup run the chunk loop together (W staging + barriers); `active` gates the MFMAs and
+// the epilogue only.
+template <int NTW, int WAVES, int NT>
+__device__ __forceinline__ void conv_rows_pass(const float* __restrict__ E, const float* __restrict__ wsrc,
+                                               const float* __restrict__ bias, const int32_t* __restrict__ ids,
+                                               float* __restrict__ C, const int32_t* __restrict__ vidx, float* smem,
+                                               int T, int Tp, int D, int F, int Fp, int nchunk, int valid4, int tile0,
+                                               int m0, int r_end, bool active, int first, int tid, int lane) {
+  constexpr int CH = NTW * 256;
+  constexpr int NV4 = CH / 4;
   constexpr int PER = (NV4 + WAVES * 64 - 1) / (WAVES * 64);
-  const int valid4 = min(NV4, (Fp / 16 - tile0) * 64);  // last column group may be partial
+  const int c = lane & 15, kq = lane >> 4;
   float4 stage[PER];
-
   auto load_w = [&](int ch) {
     const float4* src = (const float4*)(wsrc + (size_t)ch * Fp * 16);
 #pragma unroll
@@ -65,80 +51,127 @@ __global__ __launch_bounds__(WAVES * 64) void conv_fwd_kernel(const float* __res
       if (idx < NV4) dst[idx] = stage[i];
     }
   };
+  // A row of this lane (clamped so tail rows read valid memory; their results are not stored)
+  int r = min(m0 + c, r_end - 1);
+  int mr = vidx ? vidx[r] : r;
+  int n = mr / T, t = mr - n * T;
+  const float* arow = E + ((size_t)n * Tp + t) * D + kq * 4;
 
-  for (int base = r_begin; base < r_end; base += WAVES * 16) {
-    const int m0 = base + wv * 16;
-    const bool active = m0 < r_end;   // wave-uniform; idle waves still stage W and meet the barriers
-    // A row of this lane (clamped so tail rows read valid memory; their results are not stored)
-    int r = min(m0 + c, r_end - 1);
-    int mr = vidx ? vidx[r] : r;
-    int n = mr / T, t = mr - n * T;
-    const float* arow = E + ((size_t)n * Tp + t) * D + kq * 4;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 acc[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();  // previous row block's LDS reads are done
+  load_w(0);
+  store_w(0);
+  float4 a_cur = *(const float4*)(arow);
+  __syncthreads();
 
-    __syncthreads();  // previous row block's LDS reads are done
-    load_w(0);
-    store_w(0);
-    float4 a_cur = *(const float4*)(arow);
-    __syncthreads();
-
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const int buf = ch & 1;
-      float4 a_nxt = a_cur;
-      if (ch + 1 < nchunk) {
-        load_w(ch + 1);
-        a_nxt = *(const float4*)(arow + (ch + 1) * 16);
-      }
-      if (active) {
-        const float* bs = smem + buf * CH + c * 16 + kq * 4;
-        // groups of G tiles: consecutive MFMAs hit different accumulators (dependent-issue latency 40
-        // cycles against a 32-cycle issue interval would otherwise idle the matrix pipe)
-        constexpr int G = (NTW % 5 == 0) ? 5 : (NTW % 4 == 0 ? 4 : 1);
-#pragma unroll
-        for (int g0 = 0; g0 < NTW; g0 += G) {
-          float4 b[G];
-#pragma unroll
-          for (int j = 0; j < G; ++j) b[j] = *(const float4*)(bs + (g0 + j) * 256);
-#pragma unroll
-          for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.x, b[j].x, acc[g0 + j]);
-#pragma unroll
-          for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.y, b[j].y, acc[g0 + j]);
-#pragma unroll
-          for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.z, b[j].z, acc[g0 + j]);
-#pragma unroll
-          for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.w, b[j].w, acc[g0 + j]);
-        }
-      }
-      if (ch + 1 < nchunk) store_w(buf ^ 1);
-      a_cur = a_nxt;
-      __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    float4 a_nxt = a_cur;
+    if (ch + 1 < nchunk) {
+      load_w(ch + 1);
+      a_nxt = *(const float4*)(arow + (ch + 1) * 16);
     }
-
-    // epilogue: + bias, ReLU, * (id != 0)   (paper.py:146, 150-155)
     if (active) {
-      const int rq = lane >> 4;
-      float keep[4];
-      int rows[4];
+      const float* bs = smem + buf * CH + (first * 16 + c) * 16 + kq * 4;
+      // groups of G tiles: consecutive MFMAs hit different accumulators (dependent-issue latency 40
+      // cycles against a 32-cycle issue interval would otherwise idle the matrix pipe)
+      constexpr int G = (NT % 5 == 0) ? 5 : (NT % 4 == 0 ? 4 : (NT == 13 ? 13 : (NT == 7 ? 7 : 1)));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int rr = m0 + rq * 4 + j;
-        bool ok = rr < r_end;
-        int mm = ok ? (vidx ? vidx[rr] : rr) : -1;
-        rows[j] = mm;
-        keep[j] = (ok && ids[mm] != 0) ? 1.f : 0.f;
+      for (int g0 = 0; g0 < NT; g0 += G) {
+        float4 b[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) b[j] = *(const float4*)(bs + (g0 + j) * 256);
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.x, b[j].x, acc[g0 + j]);
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.y, b[j].y, acc[g0 + j]);
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.z, b[j].z, acc[g0 + j]);
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[g0 + j] = mfma16(a_cur.w, b[j].w, acc[g0 + j]);
       }
+    }
+    if (ch + 1 < nchunk) store_w(buf ^ 1);
+    a_cur = a_nxt;
+    __syncthreads();
+  }
+
+  // epilogue: + bias, ReLU, * (id != 0)   (paper.py:146, 150-155)
+  if (active) {
+    const int rq = lane >> 4;
+    float keep[4];
+    int rows[4];
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        int col = (tile0 + nt) * 16 + c;
-        if (col < F) {
-          float bv = bias[col];
+    for (int j = 0; j < 4; ++j) {
+      int rr = m0 + rq * 4 + j;
+      bool ok = rr < r_end;
+      int mm = ok ? (vidx ? vidx[rr] : rr) : -1;
+      rows[j] = mm;
+      keep[j] = (ok && ids[mm] != 0) ? 1.f : 0.f;
+    }
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (rows[j] >= 0) C[(size_t)rows[j] * F + col] = fmaxf(acc[nt][j] + bv, 0.f) * keep[j];
-        }
+    for (int nt = 0; nt < NT; ++nt) {
+      int col = (tile0 + first + nt) * 16 + c;
+      if (first + nt < NTW && col < F) {
+        float bv = bias[col];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (rows[j] >= 0) C[(size_t)rows[j] * F + col] = fmaxf(acc[nt][j] + bv, 0.f) * keep[j];
+      }
+    }
+  }
+}
+
+template <int NTW, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void conv_fwd_kernel(const float* __restrict__ E,
+                                                              const float* __restrict__ Wp,
+                                                              const float* __restrict__ bias,
+                                                              const int32_t* __restrict__ ids,
+                                                              float* __restrict__ C, int M, int T, int Tp, int D,
+                                                              int F, int Fp, int nchunk,
+                                                              const int32_t* __restrict__ vidx,
+                                                              const int32_t* __restrict__ vcount) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CH = NTW * 256;  // floats per packed chunk of this column group
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile0 = blockIdx.y * NTW;  // first column tile of this group
+
+  // persistent row range of this workgroup over the (compacted) output rows
+  const int count = vcount ? vcount[0] : M;
+  const int per = ((count + (int)gridDim.x - 1) / (int)gridDim.x + 15) & ~15;
+  const int r_begin = blockIdx.x * per;
+  const int r_end = min(count, r_begin + per);
+  const float* wsrc = Wp + (size_t)tile0 * 256;  // + ch * Fp * 16
+  const int valid4 = min(CH / 4, (Fp / 16 - tile0) * 64);  // last column group may be partial
+
+  int base = r_begin;
+  // full rounds: one 16-row tile per wave, all NTW column tiles
+  for (; base < r_end && (NTW != 25 || WAVES != 8 || r_end - base > 64); base += WAVES * 16) {
+    const int m0 = base + wv * 16;
+    conv_rows_pass<NTW, WAVES, NTW>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0, m0, r_end,
+                                    m0 < r_end, 0, tid, lane);
+  }
+  // tail of <= 4 row tiles (25-tile / 8-wave configuration): split the column tiles of each row tile over the
+  // idle waves so the last round costs a fraction of a full one instead of a whole wave-round
+  if constexpr (NTW == 25 && WAVES == 8) {
+    if (base < r_end) {
+      const int rt = (r_end - base + 15) / 16;   // 1..4 row tiles left (block-uniform)
+      if (rt == 1) {
+        const int first = wv * 4;                // 8 waves x 4 tiles
+        conv_rows_pass<NTW, WAVES, 4>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0, base,
+                                      r_end, first < NTW, first, tid, lane);
+      } else if (rt == 2) {
+        const int tile = wv >> 2, first = (wv & 3) * 7;   // 4 waves x 7 tiles per row tile
+        conv_rows_pass<NTW, WAVES, 7>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0,
+                                      base + tile * 16, r_end, first < NTW, first, tid, lane);
+      } else {
+        const int tile = wv >> 1, first = (wv & 1) * 13;  // 2 waves x 13 tiles per row tile
+        conv_rows_pass<NTW, WAVES, 13>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0,
+                                       base + tile * 16, r_end, tile < rt && first < NTW, first, tid, lane);
       }
     }
   }
