@@ -41,7 +41,9 @@ enum lstur_status {
 enum lstur_arch {            /* user encoders of Seq2VecPaperSoftmaxId.get_user_encoder, paper.py:584-633 */
   LSTUR_ARCH_IGRU = 0,       /* LSTUR-ini: GRU(U)(x, initial_state=user_vec)            paper.py:612-613 */
   LSTUR_ARCH_GRU = 1,        /* LSTUR-con: Dense(U)(concat[GRU(U)(x), user_vec])        paper.py:596-599 */
-  LSTUR_ARCH_HGRU = 2        /* LSTUR-con: concat[GRU(U/2)(x), Embedding(N_u, U/2)]     paper.py:603-607 */
+  LSTUR_ARCH_HGRU = 2,       /* LSTUR-con: concat[GRU(U/2)(x), Embedding(N_u, U/2)]     paper.py:603-607 */
+  LSTUR_ARCH_NIGRU = 3       /* no user id: GRU(U)(x) from a zero state (paper.py:627-628 `nigru`; `gru` of the
+                                id-less Seq2VecPaperSoftmax, paper.py:206-208); user arguments are ignored     */
 };
 
 typedef struct lstur_cfg {

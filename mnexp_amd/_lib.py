@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblstur_hip.so')
 
-ARCH = {'igru': 0, 'gru': 1, 'hgru': 2}
+ARCH = {'igru': 0, 'gru': 1, 'hgru': 2, 'nigru': 3}
 
 
 class LsturError(RuntimeError):

@@ -63,7 +63,7 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     *why = "filters must be <= 1024";
     return false;
   }
-  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_HGRU) {
+  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_NIGRU) {
     *why = "unknown arch";
     return false;
   }
@@ -325,7 +325,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
               w.gemm_scratch, s);
   PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.u_zr_p, w.u_h_p,
                                  w.gru_tape, w.hlast, n, d.W, d.H, s));
-  if (d.arch == LSTUR_ARCH_IGRU) {
+  if (d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU) {
     (void)hipMemcpyAsync(w.uservec, w.hlast, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
   } else {
     launch_concat2(w.hlast, d.H, w.uvec, d.Ue, w.cat, n, s);
@@ -573,13 +573,15 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
   lazy_init(ctx, s);
   launch_adam_flat(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v, ctx->dense_total,
                    lr_t, c.beta1, c.beta2, c.eps, s);
-  launch_user_grad_combine(rows, row_grads, n_rows, d.Ue, ctx->ws.first, ctx->ws.gsum, ctx->ws.slot, s);
-  {
-    ProfScope _ps(ctx, "adam_user_table", s);
-    launch_adam_table(ctx->buf.user_emb, ctx->buf.user_m, ctx->buf.user_v, ctx->ws.slot, ctx->ws.gsum, d.Nu, d.Ue,
-                      lr_t, c.beta1, c.beta2, c.eps, s);
+  if (d.arch != LSTUR_ARCH_NIGRU) {   // nigru: the user embedding is not part of the graph (paper.py:627-628)
+    launch_user_grad_combine(rows, row_grads, n_rows, d.Ue, ctx->ws.first, ctx->ws.gsum, ctx->ws.slot, s);
+    {
+      ProfScope _ps(ctx, "adam_user_table", s);
+      launch_adam_table(ctx->buf.user_emb, ctx->buf.user_m, ctx->buf.user_v, ctx->ws.slot, ctx->ws.gsum, d.Nu, d.Ue,
+                        lr_t, c.beta1, c.beta2, c.eps, s);
+    }
+    launch_user_slot_clear(rows, n_rows, ctx->ws.slot, s);
   }
-  launch_user_slot_clear(rows, n_rows, ctx->ws.slot, s);
   return check_launch("adam_step");
 }
 

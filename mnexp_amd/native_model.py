@@ -47,7 +47,7 @@ class NativeModel:
 
     def __init__(self, word_emb, n_users, batch_size, window, title_len, negative_samples, filters, kernel,
                  user_dim, arch='igru', dropout=0.2, lr=1e-3, seed=0, device=None, title_table=None,
-                 dist_group=None):
+                 dist_group=None, has_user=True):
         if not torch.cuda.is_available():
             raise _lib.LsturError('no GPU visible: the native LSTUR model has no CPU fallback')
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
@@ -56,6 +56,7 @@ class NativeModel:
         V, D = word_emb.shape
         self.W, self.T, self.K1, self.B = window, title_len, negative_samples + 1, batch_size
         self.arch = arch
+        self.has_user = has_user       # False: id-less task (Seq2VecPaperSoftmax), inputs carry no user column
         self.cfg = _lib.make_cfg(batch_size, window, title_len, self.K1, V, D, filters, kernel, user_dim,
                                  max(1, n_users), arch, dropout, seed)
         self.sizes = _lib.query_sizes(self.cfg)
@@ -113,10 +114,17 @@ class NativeModel:
         if vmax >= emb.shape[0]:
             raise IndexError('title token id {} outside the {}-row word table'.format(vmax, emb.shape[0]))
         filters, kernel = cfg.title_filter_shape
+        arch, has_user = cfg.arch, user_count > 0
+        if not has_user:
+            # Seq2VecPaperSoftmax.get_user_encoder (paper.py:198-221): only its `gru` (a plain masked GRU from a zero
+            # state) is on the native path; it is the graph SoftmaxId calls `nigru`
+            if arch != 'gru':
+                raise _lib.LsturError('id-less task: only -a gru is on the native path (got {!r})'.format(arch))
+            arch = 'nigru'
         return cls(emb, user_count, cfg.batch_size, cfg.window_size, cfg.title_shape, cfg.negative_samples,
-                   int(filters), int(kernel), cfg.user_embedding_dim, arch=cfg.arch, dropout=cfg.dropout,
+                   int(filters), int(kernel), cfg.user_embedding_dim, arch=arch, dropout=cfg.dropout,
                    lr=cfg.learning_rate, seed=int(getattr(cfg, 'seed', 0) or 0),
-                   title_table=task.docs.title_table)
+                   title_table=task.docs.title_table, has_user=has_user)
 
     def test_view(self):
         """The reference swaps ``model``/``test_model`` around evaluation (task/paper.py:502,524); here one
@@ -267,8 +275,10 @@ class NativeModel:
     def _split_reference_x(self, X, k1):
         """Reference X list -> (user, hist[n,W,T], cands[n,k1,T]) int32 device tensors.
         X = [user int64[n] (or [n,1]), clicked f64[n,W,T], k1 x cand f64[n,T]] (task/seq2vec.py:182-206)."""
+        if not self.has_user:
+            X = [np.zeros(len(X[0]), dtype=np.int32)] + list(X)
         if len(X) != 2 + k1:
-            raise ValueError('expected {} input arrays, got {}'.format(2 + k1, len(X)))
+            raise ValueError('expected {} input arrays, got {}'.format(2 + k1 - (not self.has_user), len(X) - (not self.has_user)))
         user = self._dev_i32(np.asarray(X[0]).reshape(-1))
         hist = self._dev_i32(X[1])
         cands = self._dev_i32(np.stack([np.asarray(x) for x in X[2:]], axis=1))
@@ -308,7 +318,11 @@ class NativeModel:
         user, hist, cands = self._split_reference_x(X, self.K1)
         self._train_step(user, hist, cands, False)
 
-    def train_on_ids(self, user, hist_ids, cand_ids):
+    def train_on_ids(self, *ids):
+        """(user, hist_ids, cand_ids), or (hist_ids, cand_ids) for an id-less task."""
+        if not self.has_user:
+            ids = (np.zeros(len(ids[0]), dtype=np.int32),) + tuple(ids)
+        user, hist_ids, cand_ids = ids
         self._train_step(self._dev_i32(user), self._dev_i32(hist_ids), self._dev_i32(cand_ids), True)
 
     def fit_generator(self, generator, steps_per_epoch, epochs=1, initial_epoch=0, verbose=2, ids_form=False,
@@ -365,7 +379,10 @@ class NativeModel:
 
     predict_on_batch = predict
 
-    def predict_ids(self, user, hist_ids, cand_ids):
+    def predict_ids(self, *ids):
+        if not self.has_user:
+            ids = (np.zeros(len(ids[0]), dtype=np.int32),) + tuple(ids)
+        user, hist_ids, cand_ids = ids
         c = self._dev_i32(cand_ids).reshape(len(user), -1)[:, 0].contiguous()
         return self._predict(self._dev_i32(user), self._dev_i32(hist_ids), c, True)
 

@@ -38,7 +38,7 @@ import numpy as np
 
 EPS = 1e-7  # keras.backend.epsilon()
 
-ARCHS = ("igru", "gru", "hgru")
+ARCHS = ("igru", "gru", "hgru", "nigru")
 
 
 # --------------------------------------------------------------------------
@@ -324,6 +324,10 @@ def user_encoder_fwd(p, arch, user, hv, hist_ids):
         h, gc = gru_fwd(p, hvm, gmask, uvec)
         u = h
         extra = None
+    elif arch == "nigru":                           # paper.py:627-628 / 206-208: no user embedding in the graph
+        h, gc = gru_fwd(p, hvm, gmask, np.zeros((len(user), H), dtype=hv.dtype))
+        u = h
+        extra = None
     else:
         h, gc = gru_fwd(p, hvm, gmask, np.zeros((len(user), H), dtype=hv.dtype))
         cat = np.concatenate([h, uvec], axis=1)
@@ -342,6 +346,9 @@ def user_encoder_bwd(p, cache, du):
     if arch == "igru":
         gg, dx, dh0 = gru_bwd(p, gc, du)
         duser = dh0
+    elif arch == "nigru":
+        gg, dx, _ = gru_bwd(p, gc, du)
+        duser = np.zeros_like(du)
     else:
         if arch == "gru":
             g["con_w"] = cache["cat"].T @ du

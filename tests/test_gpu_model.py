@@ -47,7 +47,7 @@ MID = dict(V=500, D=48, F=80, k=3, U=40, N_u=64)
 ODD = dict(V=90, D=20, F=23, k=5, U=18, N_u=9)      # F, U not multiples of 16; k = 5
 
 
-@pytest.mark.parametrize('arch', ['igru', 'gru', 'hgru'])
+@pytest.mark.parametrize('arch', ['igru', 'gru', 'hgru', 'nigru'])
 @pytest.mark.parametrize('dims,B,W,T,K1,drop', [
     (TINY, 5, 4, 7, 3, 0.0),
     (TINY, 5, 4, 7, 3, 0.25),
@@ -80,10 +80,11 @@ def test_forward_backward_matches_oracle(arch, dims, B, W, T, K1, drop):
     for n in O.dense_param_names(arch):
         rel_close(g[n], ref['grads'][n], 2e-3, n)
     assert np.array_equal(g['user_rows'], user)
-    rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
+    if arch != 'nigru':
+        rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
 
 
-@pytest.mark.parametrize('arch', ['igru', 'gru'])
+@pytest.mark.parametrize('arch', ['igru', 'gru', 'nigru'])
 def test_three_adam_steps_track_oracle(arch):
     _need_gpu()
     dims, B, W, T, K1 = MID, 16, 6, 9, 5

@@ -81,6 +81,20 @@ def test_cli_train_loop(tmp_path, arch, ids):
     assert h.model.optimizer.iterations == 30
 
 
+def test_idless_softmax_task(tmp_path):
+    """Seq2VecPaperSoftmax (no user id, paper.py:384-524) with its `gru` user encoder."""
+    _need_gpu()
+    from mnexp_amd.main import run_training
+    cfg = _config(tmp_path, task='Seq2VecPaperSoftmax', arch='gru', epochs=1, training_step=10, validation_step=1,
+                  validation_impression=10, testing_impression=10, dropout=0.2, seed=1)
+    np.random.seed(0)
+    h = run_training(cfg)
+    assert h.model.arch == 'nigru' and 0.0 <= h.last_metrics['auc'] <= 1.0
+    cfg = _config(tmp_path, task='Seq2VecPaperSoftmax', arch='att', epochs=1)
+    with pytest.raises(Exception, match='only -a gru'):
+        run_training(cfg)
+
+
 def test_click_entry_point(tmp_path):
     _need_gpu()
     from click.testing import CliRunner

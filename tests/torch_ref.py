@@ -77,6 +77,8 @@ def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0):
     H = p["gru_u"].shape[0]
     if arch == "igru":
         u = gru(p, hv, gmask, uvec)
+    elif arch == "nigru":
+        u = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
     else:
         h = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
         u = torch.cat([h, uvec], dim=1)
