@@ -7,7 +7,7 @@ Host-side mirror of /root/reference/task/paper.py:
 Everything under ``_build_model`` is replaced by ``mnexp_amd.native_model.NativeModel`` (HIP/gfx950).
 """
 import logging
-from datetime import datetime
+from datetime import datetime, timedelta
 
 import numpy as np
 from sklearn.metrics import roc_auc_score
@@ -181,3 +181,98 @@ class Seq2VecPaperSoftmaxId(Seq2VecPaperSoftmax):
         if w == 1:
             return enumerate(self.data)
         return ((u, self.data[u]) for u in dist.shard_users(len(self.data), r, w))
+
+
+class _ExpiringWindow:
+    """Time-aware click window of the `...Days` tasks (paper.py:669-696, 763-792): an entry is visible until
+    `days` after its click; an expired entry reads as the pad doc 0 IN PLACE (the history keeps its holes)."""
+    __slots__ = ['docs', 'click_history', 'click_history_time', 'delta']
+    zero = datetime.strptime('01/01/2000', '%m/%d/%Y')
+
+    def __init__(self, docs, window_size, delta):
+        self.docs = docs
+        self.delta = timedelta(days=delta)
+        self.click_history = [0] * window_size
+        self.click_history_time = [self.zero] * window_size
+
+    def get_ids(self, time):
+        return np.array([i if t >= time else 0 for i, t in zip(self.click_history, self.click_history_time)],
+                        dtype=np.int32)
+
+    def get_title(self, time):
+        return self.docs.titles_f64[self.get_ids(time)]
+
+    def push(self, doc, time):
+        del self.click_history[0], self.click_history_time[0]
+        self.click_history.append(doc)
+        self.click_history_time.append(time + self.delta)
+
+    @property
+    def window_size(self):
+        return len(self.click_history)
+
+    def count(self, time):
+        return sum(1 for t in self.click_history_time if t >= time)
+
+
+class Seq2VecPaperSoftmaxDays(Seq2VecPaperSoftmax):
+    """History entries expire `config.days` after the click (paper.py:668-750).  Same model as the parent."""
+    Window = _ExpiringWindow
+
+    def _sample_at(self, user, ch, pos, impression, label):
+        cands = [pos] + [int(n) for n in impression.negative_samples(self.config.negative_samples)]
+        head = (user,) if self.has_user else ()
+        return head + (ch.get_ids(impression.time), cands, label)
+
+    def _history_after_training(self, ih1):
+        ch = self.Window(self.docs, self.config.window_size, self.config.days)
+        for impression in ih1:
+            for pos in impression.pos:
+                ch.push(pos, impression.time)
+        return ch
+
+    def train_gen_ids(self):
+        label = self._label()
+        while True:
+            for user, (ih, _) in self._users():
+                if not ih:
+                    continue
+                ch = self.Window(self.docs, self.config.window_size, self.config.days)
+                for impression in ih:
+                    for pos in impression.pos:
+                        if ch.count(impression.time):
+                            yield self._sample_at(user, ch, pos, impression, label)
+                        ch.push(pos, impression.time)
+
+    def valid_gen_ids(self):
+        label = self._label()
+        while True:
+            for user, (ih1, ih2) in self._users():
+                if not (ih1 and ih2):
+                    continue
+                ch = self._history_after_training(ih1)
+                for impression in ih2:
+                    for pos in impression.pos:
+                        yield self._sample_at(user, ch, pos, impression, label)
+                    for pos in impression.pos:
+                        ch.push(pos, impression.time)
+
+    def test_gen_ids(self):
+        for user, (ih1, ih2) in self._users():
+            if not (ih1 and ih2):
+                continue
+            ch = self._history_after_training(ih1)
+            for impression in ih2:
+                hist = ch.get_ids(impression.time)
+                head = (user,) if self.has_user else ()
+                yield ([head + (hist, [p], 1) for p in impression.pos] +
+                       [head + (hist, [n], 0) for n in impression.neg])
+                for pos in impression.pos:
+                    ch.push(pos, impression.time)
+
+
+class Seq2VecPaperSoftmaxDaysId(Seq2VecPaperSoftmaxDays):
+    """`...Days` with the user-id model of Seq2VecPaperSoftmaxId (paper.py:753-881; the vertical / sub-vertical
+    fields its News class also parses are not used by this task's generators or model)."""
+    has_user = True
+    _users = Seq2VecPaperSoftmaxId._users

@@ -105,15 +105,17 @@ def ref_config(settings, data_dir, **kw):
         return settings.Config(base)
 
 
-def capture(handler, n_samples, n_batches, seed):
+def capture(handler, n_samples, n_batches, seed, has_user=True):
     out = {}
+    u = 1 if has_user else 0          # id-less tasks carry no user column
     np.random.seed(seed)
     random.seed(seed)
     gen = handler.train_gen()
     samples = [next(gen) for _ in range(n_samples)]
-    out['train_user'] = np.array([s[0] for s in samples], dtype=np.int64)
-    out['train_clicked'] = np.stack([s[1] for s in samples])
-    out['train_cands'] = np.stack([np.stack(s[2:-1]) for s in samples])
+    if has_user:
+        out['train_user'] = np.array([s[0] for s in samples], dtype=np.int64)
+    out['train_clicked'] = np.stack([s[u] for s in samples])
+    out['train_cands'] = np.stack([np.stack(s[u + 1:-1]) for s in samples])
     out['train_label'] = np.array([s[-1] for s in samples])
 
     np.random.seed(seed + 1)
@@ -121,9 +123,10 @@ def capture(handler, n_samples, n_batches, seed):
     it = handler.train
     for b in range(n_batches):
         X, Y = next(it)
-        out['batch%d_user' % b] = X[0]
-        out['batch%d_clicked' % b] = X[1]
-        out['batch%d_cands' % b] = np.stack(X[2:], axis=1)
+        if has_user:
+            out['batch%d_user' % b] = X[0]
+        out['batch%d_clicked' % b] = X[u]
+        out['batch%d_cands' % b] = np.stack(X[u + 1:], axis=1)
         out['batch%d_y' % b] = Y
     out['rng_after_batches'] = np.random.randint(0, 1 << 30, size=4)
 
@@ -131,19 +134,21 @@ def capture(handler, n_samples, n_batches, seed):
     it = handler.valid
     for b in range(3):
         X, Y = next(it)
-        out['valid%d_user' % b] = X[0]
-        out['valid%d_clicked' % b] = X[1]
-        out['valid%d_cands' % b] = np.stack(X[2:], axis=1)
+        if has_user:
+            out['valid%d_user' % b] = X[0]
+        out['valid%d_clicked' % b] = X[u]
+        out['valid%d_cands' % b] = np.stack(X[u + 1:], axis=1)
         out['valid%d_y' % b] = Y
 
     tests = []
     for i, rows in zip(range(12), handler.test_gen()):
         cols = [np.stack(x) for x in zip(*rows)]
         tests.append(cols)
-        out['test%d_user' % i] = cols[0]
-        out['test%d_clicked' % i] = cols[1]
-        out['test%d_cand' % i] = cols[2]
-        out['test%d_label' % i] = cols[3]
+        if has_user:
+            out['test%d_user' % i] = cols[0]
+        out['test%d_clicked' % i] = cols[u]
+        out['test%d_cand' % i] = cols[u + 1]
+        out['test%d_label' % i] = cols[u + 2]
     out['n_test'] = np.array(len(tests))
     return out
 
@@ -185,6 +190,12 @@ def main():
     out['edge_imp_counts'] = np.array([[len(a), len(b)] for a, b in h.data])
     for k, v in capture(h, 30, 4, seed=5).items():
         out['edge_' + k] = v
+    # --- time-window variants on the tiny set (days = 0.05 so entries do expire inside a user's history)
+    for tname in ('Seq2VecPaperSoftmaxDaysId', 'Seq2VecPaperSoftmaxDays'):
+        cfg = ref_config(ref_settings, tiny, task=tname, days=0.05)
+        h = ref_task.get(cfg)
+        for k, v in capture(h, 120, 4, seed=21, has_user=tname.endswith('Id')).items():
+            out['%s_%s' % (tname, k)] = v
     np.savez_compressed(os.path.join(HERE, 'data_path.npz'), **out)
 
     # --- parser known answers -------------------------------------------------

@@ -157,3 +157,47 @@ def test_unknown_doc_id_fails_at_load(tmp_path):
     cfg = make_config(str(d), **CASES['edge'][0])
     with pytest.raises(KeyError):
         task.get(cfg)
+
+
+@pytest.mark.parametrize('tname,has_user', [('Seq2VecPaperSoftmaxDaysId', True), ('Seq2VecPaperSoftmaxDays', False)])
+def test_time_window_variants(tname, has_user):
+    """History entries expire `days` after the click and read as doc 0 in place (paper.py:668-881)."""
+    cfg = make_config(os.path.join(GOLD, 'tiny'), task=tname, days=0.05)
+    h = task.get(cfg)
+    u = 1 if has_user else 0
+    np.random.seed(21)
+    random.seed(21)
+    gen = h.train_gen_ids()
+    X, Y = h._expand([next(gen) for _ in range(120)])
+    if has_user:
+        same(X[0], G[tname + '_train_user'])
+    same(X[u], G[tname + '_train_clicked'])
+    same(np.stack(X[u + 1:], axis=1), G[tname + '_train_cands'])
+    same(Y, G[tname + '_train_label'])
+    # expiry really happened: with a huge window the same walk yields more samples / fuller histories
+    h_inf = task.get(make_config(os.path.join(GOLD, 'tiny'), task=tname, days=10000))
+    np.random.seed(21)
+    gen = h_inf.train_gen_ids()
+    X_inf, _ = h_inf._expand([next(gen) for _ in range(120)])
+    assert not np.array_equal(X_inf[u], X[u])
+    np.random.seed(22)
+    random.seed(22)
+    it = h.train
+    for b in range(4):
+        X, Y = next(it)
+        if has_user:
+            same(X[0], G['%s_batch%d_user' % (tname, b)])
+        same(X[u], G['%s_batch%d_clicked' % (tname, b)])
+        same(np.stack(X[u + 1:], axis=1), G['%s_batch%d_cands' % (tname, b)])
+    same(np.random.randint(0, 1 << 30, size=4), G[tname + '_rng_after_batches'])
+    np.random.seed(23)
+    it = h.valid
+    for b in range(3):
+        X, Y = next(it)
+        same(X[u], G['%s_valid%d_clicked' % (tname, b)])
+        same(np.stack(X[u + 1:], axis=1), G['%s_valid%d_cands' % (tname, b)])
+    for i, rows in zip(range(int(G[tname + '_n_test'])), h.test_gen_ids()):
+        X, labels = h._expand(rows)
+        same(X[u], G['%s_test%d_clicked' % (tname, i)])
+        same(X[u + 1], G['%s_test%d_cand' % (tname, i)])
+        same(labels, G['%s_test%d_label' % (tname, i)])
