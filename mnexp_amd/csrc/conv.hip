@@ -9,6 +9,8 @@
 //
 // MFMA: v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD).  Operand lane map: A lane l holds
 // A[row l&15][k l>>4], B lane l holds B[k l>>4][col l&15]; C/D lane l, reg j: row (l>>4)*4+j, col l&15.
+#include <stdlib.h>
+
 #include "lstur_device.h"
 #include "lstur_internal.h"
 
@@ -337,6 +339,122 @@ __global__ __launch_bounds__(WK * WN * 64) void conv_wgrad_kernel(const float* _
     }
 }
 
+// Same contraction with LDS-DMA staging (global_load_lds, 16 B per lane): the two operand tiles of the next
+// stage go straight from L2 into LDS -- no staging VGPRs (the register version spilled them at the 128-VGPR
+// limit of a 15-wave workgroup), no ds_write pass.  One wave instruction fills 64 consecutive float4 of the
+// stage image [A 16x192 | B 16x400]; the source address is per lane (row gather through the precomputed
+// per-token offsets), the instructions of a stage are dealt round-robin over the waves.  hipcc makes a wave
+// wait vmcnt(0) before the first ds_read that follows its own LDS-DMA, so a wave's DMA does not overlap its own
+// MFMAs -- the other 14 waves' MFMAs cover it.  (A dedicated loader wave, which keeps every compute wave free of
+// vmcnt waits, measured 2.5x slower: one wave cannot issue 37 gathers per stage fast enough.)
+// F == 16*CT*WN (one column block).
+template <int WK, int WN, int CT, int TK>
+__global__ __launch_bounds__(WK * WN * 64) void conv_wgrad_glds_kernel(
+    const float* __restrict__ E, const float* __restrict__ dC, float* __restrict__ part, int KD, int F,
+    const int32_t* __restrict__ offA, const int32_t* __restrict__ offB, const int32_t* __restrict__ vcount,
+    const float* __restrict__ zeros) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NW = WK * WN;
+  constexpr int AW = 64 * WK, BW = 16 * CT * WN;
+  constexpr int STAGE = TK * (AW + BW);
+  constexpr int A4 = TK * AW / 4, S4 = STAGE / 4;
+  static_assert(A4 % 64 == 0 && S4 % 64 == 0, "stage image must be whole wave-instructions");
+  constexpr int NINST = S4 / 64, PER = (NINST + NW - 1) / NW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wv / WN, wn = wv - wk * WN;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int kk0 = blockIdx.x * AW;
+  const int count = vcount[0];
+  const int tok_per_split = (((count + (int)gridDim.y - 1) / (int)gridDim.y) + TK - 1) / TK * TK;
+  const int tok_begin = blockIdx.y * tok_per_split;
+  const int tok_end = min(count, tok_begin + tok_per_split);
+  const int nstage = (tok_end > tok_begin) ? cdiv(tok_end - tok_begin, TK) : 0;
+
+  auto issue_stage = [&](int tok0, int buf) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int q = wv + i * NW;        // wave-uniform
+      if (q < NINST) {
+        const int idx = q * 64 + lane;
+        const float* src;
+        if (q < A4 / 64) {                // A part: E rows (kk window of the token)
+          const int r = idx / (AW / 4), x4 = idx - r * (AW / 4);
+          const int tk = min(tok0 + r, count - 1);
+          src = E + (size_t)offA[tk] + kk0 + x4 * 4;
+        } else {                          // B part: dC rows; rows past the split's range read zeros
+          const int ib = idx - A4;
+          const int r = ib / (BW / 4), y4 = ib - r * (BW / 4);
+          const int tk = tok0 + r;
+          src = tk < tok_end ? dC + (size_t)offB[tk] + y4 * 4 : zeros;
+        }
+        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(smem + buf * STAGE + q * 256),
+                                         16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[4][CT];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[e][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (nstage > 0) issue_stage(tok_begin, 0);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstage) issue_stage(tok_begin + (st + 1) * TK, buf ^ 1);
+    const float* as = smem + buf * STAGE + wk * 64 + i16 * 4;
+    const float* bs = smem + buf * STAGE + TK * AW + wn * CT * 16 + i16;
+#pragma unroll
+    for (int s4 = 0; s4 < TK / 4; ++s4) {
+      float4 a = *(const float4*)(as + (s4 * 4 + kq) * AW);
+      float b[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) b[ct] = bs[(s4 * 4 + kq) * BW + ct * 16];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        acc[0][ct] = mfma16(a.x, b[ct], acc[0][ct]);
+        acc[1][ct] = mfma16(a.y, b[ct], acc[1][ct]);
+        acc[2][ct] = mfma16(a.z, b[ct], acc[2][ct]);
+        acc[3][ct] = mfma16(a.w, b[ct], acc[3][ct]);
+      }
+    }
+    __syncthreads();   // vmcnt(0): the next stage has landed; every wave is done with this one
+  }
+
+  float* dst = part + (size_t)blockIdx.y * KD * F;
+  const int rq = lane >> 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      int f = (wn * CT + ct) * 16 + i16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int kk = kk0 + wk * 64 + 4 * (rq * 4 + j) + e;
+        if (kk < KD && f < F) dst[(size_t)kk * F + f] = acc[e][ct][j];
+      }
+    }
+}
+
+// per-token source offsets of the compacted list (in floats): offA = row of the padded embedding layout,
+// offB = row of the conv-output-shaped tensors; entries past the count repeat the last valid token
+__global__ void token_offsets_kernel(const int32_t* __restrict__ vidx, const int32_t* __restrict__ vcount, int M, int T,
+                                     int Tp, int D, int F, int32_t* __restrict__ offA, int32_t* __restrict__ offB) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const int count = vcount[0];
+  const int m = vidx[min(i, max(count - 1, 0))];
+  const int n = m / T, t = m - n * T;
+  offA[i] = (n * Tp + t) * D;
+  offB[i] = m * F;
+}
+void launch_token_offsets(const int32_t* vidx, const int32_t* vcount, int M, int T, int Tp, int D, int F, int32_t* offA,
+                          int32_t* offB, hipStream_t s) {
+  if (M > 0) hipLaunchKernelGGL(token_offsets_kernel, dim3(cdiv(M, 256)), dim3(256), 0, s, vidx, vcount, M, T, Tp, D, F, offA, offB);
+}
+
 __global__ void reduce_slabs_kernel(const float* __restrict__ part, int nsplit, size_t count,
                                     float* __restrict__ out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,13 +488,26 @@ size_t conv_wgrad_scratch_bytes(int D, int ksize, int F) {
 }
 
 void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
-                       int ksize, int F, const int32_t* vidx, const int32_t* vcount, hipStream_t s) {
+                       int ksize, int F, const int32_t* vidx, const int32_t* vcount, hipStream_t s, const int32_t* offA,
+                       const int32_t* offB, const float* zeros) {
   int M = n_titles * T, Tp = T + ksize - 1, KD = ksize * D;
   WgradGeom g = wgrad_geom(D, ksize, F);
   constexpr int TK = 16;
   int nsplit = std::min(g.nsplit, std::max(1, cdiv(M, TK)));   // splits beyond the token list write zero slabs
   float* part = (float*)scratch;
-  if (g.big) {
+  static const bool no_glds = getenv("LSTUR_WGRAD_NO_GLDS") != nullptr;   // A/B switch for measurements
+  if (g.big && offA && offB && zeros && vcount && !no_glds) {
+    constexpr int WK = 3, WN = 5, CT = 5;
+    size_t lds = 2 * TK * (64 * WK + 16 * CT * WN) * sizeof(float);
+    static bool attr_set2 = false;
+    if (!attr_set2) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<WK, WN, CT, TK>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set2 = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_glds_kernel<WK, WN, CT, TK>), dim3(g.kblocks, nsplit, 1), dim3(WK * WN * 64), lds, s,
+                       emb, dout, part, KD, F, offA, offB, vcount, zeros);
+  } else if (g.big) {
     constexpr int WK = 3, WN = 5, CT = 5;
     size_t lds = 2 * TK * (64 * WK + 16 * CT * WN) * sizeof(float);
     static bool attr_set = false;

@@ -122,7 +122,7 @@ struct Workspace {
   float* cat; float* dcat; float* uservec; float* duser; float* du; float* logits; float* probs; float* loss_i;
   float* correct_i; float* parts; float* conv_wp; float* u_zr_p; float* u_h_p; float* ut_zr_p; float* ut_h_p;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; int32_t* first; float* gsum; int32_t* slot;
-  int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds;
+  int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
 };
 
@@ -204,6 +204,8 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->vidx = (int32_t*)take(nt * d.T * 4);
   w->vcount = (int32_t*)take(256);
   w->att_ds = (float*)take(nt * d.T * f4);
+  w->offA = (int32_t*)take(nt * d.T * 4);
+  w->offB = (int32_t*)take(nt * d.T * 4);
   w->vscratch = (int32_t*)take(compact_scratch_ints((int)(nt * d.T)) * 4);
   w->bytes = off;
 }
@@ -383,8 +385,10 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
                                          w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab));
   launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch, s);
+  launch_token_offsets(w.vidx, w.vcount, nt * d.T, d.T, d.Tp, d.D, d.F, w.offA, w.offB, s);
   PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
-                                       w.vidx, w.vcount, s));
+                                       w.vidx, w.vcount, s, w.offA, w.offB,
+                                       w.emb + (size_t)d.nt_max * d.Tp * d.D /* zero slack */));
 }
 
 int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n, int k1, bool ids_form, hipStream_t s) {

@@ -65,8 +65,13 @@ void launch_conv_fwd(const float* emb, const float* w_packed, const float* bias,
                      float* out, int n_titles, int T, int D, int ksize, int F, const int32_t* vidx,
                      const int32_t* vcount, hipStream_t s);
 size_t conv_wgrad_scratch_bytes(int D, int ksize, int F);
+// offA/offB/zeros (nullable): per-token float offsets from launch_token_offsets + >= 16 B of zeros; with them
+// the F == 400 configuration stages its operands by LDS-DMA
 void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scratch, int n_titles, int T,
-                       int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount, hipStream_t s);
+                       int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount, hipStream_t s,
+                       const int32_t* offA = nullptr, const int32_t* offB = nullptr, const float* zeros = nullptr);
+void launch_token_offsets(const int32_t* vidx, const int32_t* vcount, int M, int T, int Tp, int D, int F, int32_t* offA,
+                          int32_t* offB, hipStream_t s);
 
 // ---- attpool.hip -------------------------------------------------------------------------------
 // ids (nullable): rows with id == 0 are taken as zero without reading c / writing dc
