@@ -213,26 +213,23 @@ size_t lstur_gemm_scratch(int32_t M, int32_t N, int32_t K);
 int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int32_t ldb, int32_t tb,
                    float* C, int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K,
                    float alpha, void* scratch, lstur_stream stream);
-/* Operand images of the recurrent matrix gru_u [H,3H] (z|r|h) for the two GRU kernels, written in one launch.
- * lstur_gru_pack_floats(H) = total floats; u_zr and ut_zr take 2/6 each, u_h and ut_h 1/6 each.  Gate columns
- * are padded per gate to Hp = ceil16(H) so that no 16-column MFMA tile straddles two gates. */
+/* Operand images of the recurrent matrix gru_u [H,3H] (z|r|h) for the two GRU kernels, written in one launch into
+ * ONE opaque buffer of lstur_gru_pack_floats(H) floats (re-pack after every update of gru_u). */
 size_t lstur_gru_pack_floats(int32_t H);
-int lstur_gru_pack_u(const float* gru_u, int32_t H, float* u_zr, float* u_h, float* ut_h, float* ut_zr,
-                     lstur_stream stream);
+int lstur_gru_pack_u(const float* gru_u, int32_t H, float* packed, lstur_stream stream);
 /* Masked Keras-2.2.4 GRU over W steps (paper.py:592,597-613; K.rnn mask semantics).
  *   xw [n,W,3H] input projection incl. bias (row-major, gates z|r|h); gmask uint8 [n,W]; h0 [n,H] or NULL (zeros)
  *   hlast [n,H] = output of the last step.  tape: lstur_gru_tape_floats(n,W,H) floats of scratch that carries the
- *   saved activations to lstur_gru_bwd in the MFMA accumulator layout (opaque to the caller).  H <= 256. */
+ *   saved activations to lstur_gru_bwd (layout opaque to the caller).  H <= 256; H <= 200 runs the kernels that
+ *   keep the recurrent matrix resident in registers + LDS (set LSTUR_GRU_GENERIC=1 to force the general ones). */
 size_t lstur_gru_tape_floats(int32_t n, int32_t W, int32_t H);
-int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
-                  const float* u_h_packed, float* tape, float* hlast, int32_t n, int32_t W, int32_t H,
-                  lstur_stream stream);
+int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
+                  float* hlast, int32_t n, int32_t W, int32_t H, lstur_stream stream);
 /* BPTT over the tape of the matching lstur_gru_fwd call: dh_last [n,H] ->
  *   dgates [n,W,3H] (gradient wrt the gate pre-activations z|r|h), rh [n,W,H] (= r * h_prev, operand of dU_h),
  *   hprev [n,W,H] (= h_{t-1}, operand of dU_zr), dh0 [n,H] (gradient wrt the initial state). */
-int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* ut_zr_packed,
-                  const float* ut_h_packed, float* dgates, float* rh, float* hprev, float* dh0, int32_t n,
-                  int32_t W, int32_t H, lstur_stream stream);
+int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* packed, float* dgates,
+                  float* rh, float* hprev, float* dh0, int32_t n, int32_t W, int32_t H, lstur_stream stream);
 /* dot scorer + softmax + categorical_crossentropy (paper.py:446-447,463,658) and its gradient.
  *   u [n,U]; d [n,K1,U]; outputs logits/probs [n,K1], loss_i [n], correct_i [n], du [n,U], dd [n,K1,U]
  *   (du/dd may be NULL: forward only).  inv_n scales the gradient (1/batch * grad_scale). */

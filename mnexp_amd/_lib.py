@@ -74,10 +74,10 @@ SIGNATURES = {
     'lstur_gemm_scratch': (_Z, [_I, _I, _I]),
     'lstur_gemm_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),
     'lstur_gru_pack_floats': (_Z, [_I]),
-    'lstur_gru_pack_u': (_I, [_P, _I, _P, _P, _P, _P, _P]),
+    'lstur_gru_pack_u': (_I, [_P, _I, _P, _P]),
     'lstur_gru_tape_floats': (_Z, [_I, _I, _I]),
-    'lstur_gru_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    'lstur_gru_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'lstur_gru_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'lstur_gru_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'lstur_score_softmax_ce': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     'lstur_adam_flat': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P]),
 }

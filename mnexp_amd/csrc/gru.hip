@@ -124,7 +124,7 @@ __device__ __forceinline__ void gemm_run(FragRing<C>& ring, const float* __restr
 // ---- fragment tape ------------------------------------------------------------------------------------
 // sections of S = nb * W * NT * 256 floats (nb = ceil(n/16) sample blocks, NT = Hp/16 hidden tiles)
 enum { TP_XZ = 0, TP_XR, TP_XH, TP_Z, TP_R, TP_HH, TP_HP, TP_DZ, TP_DR, TP_DH, TP_RH, TP_SECTIONS };
-size_t gru_tape_floats(int n, int W, int H) {
+static size_t generic_tape_floats(int n, int W, int H) {
   return (size_t)TP_SECTIONS * cdiv(n, 16) * W * (ceil16(H) / 16) * 256;
 }
 __host__ __device__ __forceinline__ size_t tape_section(int n, int W, int H) {
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(GW * 64) void gru_bwd_kernel(GruBwdArgs g) {
 //   ut_h  [nch][Hp][16]   B = U_h^T                          (BPTT: drh)
 //   ut_zr [2nch][Hp][16]  B = [U_z^T ; 0 ; U_r^T ; 0]        (BPTT: dh_prev, K gate-padded)
 // ---------------------------------------------------------------------------------------------
-size_t gru_pack_floats(int H) {
+static size_t generic_pack_floats(int H) {
   int nch = cdiv(H, 16), Hp = nch * 16;
   return (size_t)nch * 16 * (2 * Hp + Hp + Hp + 2 * Hp);
 }
@@ -595,8 +595,8 @@ __global__ void gru_pack_kernel(const float* __restrict__ U, int H, float* __res
     ut_zr[i] = (hc < H && nn < H) ? U[(size_t)nn * H3 + gate * H + hc] : 0.f;
   }
 }
-void launch_gru_pack(const float* U, int H, float* u_zr, float* u_h, float* ut_h, float* ut_zr, hipStream_t s) {
-  size_t total = gru_pack_floats(H);
+static void generic_pack(const float* U, int H, float* u_zr, float* u_h, float* ut_h, float* ut_zr, hipStream_t s) {
+  size_t total = generic_pack_floats(H);
   hipLaunchKernelGGL(gru_pack_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, U, H, u_zr, u_h, ut_h, ut_zr);
 }
 
@@ -607,8 +607,8 @@ static void set_lds_attr(const void* fn, size_t lds, size_t* cur) {
   }
 }
 
-void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
-                    const float* u_h_packed, float* tape, float* hlast, int n, int W, int H, hipStream_t s) {
+static void generic_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
+                        const float* u_h_packed, float* tape, float* hlast, int n, int W, int H, hipStream_t s) {
   if (!n) return;
   int Hp = ceil16(H), LDH = Hp + 4;
   size_t lds = (size_t)3 * 16 * LDH * sizeof(float);
@@ -621,9 +621,9 @@ void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, cons
   hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(n, 16)), dim3(GW * 64), lds, s, a);
 }
 
-void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* ut_zr_packed,
-                    const float* ut_h_packed, float* dgates, float* rh, float* hprev, float* dh0, int n, int W, int H,
-                    hipStream_t s) {
+static void generic_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* ut_zr_packed,
+                        const float* ut_h_packed, float* dgates, float* rh, float* hprev, float* dh0, int n, int W, int H,
+                        hipStream_t s) {
   if (!n) return;
   int Hp = ceil16(H), LDH = Hp + 4, LD2 = 2 * Hp + 4;
   size_t lds = (size_t)(3 * 16 * LDH + 16 * LD2) * sizeof(float);
@@ -634,6 +634,37 @@ void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, con
   const size_t S = tape_section(n, W, H);
   hipLaunchKernelGGL(gru_tape_to_rows_kernel, dim3((unsigned)cdivz(S / 4, 256)), dim3(256), 0, s, tape, dgates, rh, hprev,
                      n, W, H, S);
+}
+
+// ---- public launchers: fast path (gru4.hip, U resident on chip, H <= 200) or the general kernels above ----------
+// `packed` is one opaque buffer of gru_pack_floats(H) floats written by launch_gru_pack.
+size_t gru_pack_floats(int H) { return gru4_supported(H) ? gru4_pack_floats(H) : generic_pack_floats(H); }
+size_t gru_tape_floats(int n, int W, int H) {
+  return gru4_supported(H) ? gru4_tape_floats(n, W, H) : generic_tape_floats(n, W, H);
+}
+void launch_gru_pack(const float* U, int H, float* packed, hipStream_t s) {
+  if (gru4_supported(H)) return launch_gru4_pack(U, H, packed, s);
+  const size_t sixth = generic_pack_floats(H) / 6;   // u_zr 2/6 | u_h 1/6 | ut_h 1/6 | ut_zr 2/6
+  generic_pack(U, H, packed, packed + 2 * sixth, packed + 3 * sixth, packed + 4 * sixth, s);
+}
+void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
+                    float* hlast, int n, int W, int H, hipStream_t s) {
+  if (!n) return;
+  if (gru4_supported(H)) return launch_gru4_fwd(xw, gmask, h0, packed, tape, hlast, n, W, H, s);
+  const size_t sixth = generic_pack_floats(H) / 6;
+  generic_fwd(xw, gmask, h0, packed, packed + 2 * sixth, tape, hlast, n, W, H, s);
+}
+void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* packed, float* dgates,
+                    float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s) {
+  if (!n) return;
+  if (gru4_supported(H)) return launch_gru4_bwd(dh_last, gmask, tape, packed, dgates, rh, hprev, dh0, n, W, H, s);
+  const size_t sixth = generic_pack_floats(H) / 6;
+  generic_bwd(dh_last, gmask, tape, packed + 4 * sixth, packed + 3 * sixth, dgates, rh, hprev, dh0, n, W, H, s);
+}
+bool gru_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh) {
+  if (!gru4_supported(H)) return false;
+  gru4_tape_rows(tape, n, W, H, hprev, rh);
+  return true;
 }
 
 }  // namespace lstur

@@ -120,7 +120,7 @@ struct Workspace {
   float* docvec; float* ddocvec; uint8_t* hmask; uint8_t* gmask; float* uvec; float* xw; float* gru_tape;
   float* dgates; float* rh; float* hprev; float* dh0; float* hlast; float* dhlast;
   float* cat; float* dcat; float* uservec; float* duser; float* du; float* logits; float* probs; float* loss_i;
-  float* correct_i; float* parts; float* conv_wp; float* u_zr_p; float* u_h_p; float* ut_zr_p; float* ut_h_p;
+  float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; int32_t* first; float* gsum; int32_t* slot;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
@@ -185,13 +185,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->correct_i = (float*)take(nc * f4);
   w->parts = (float*)take((size_t)1024 * (3 * ((d.F + kParamAlign - 1) / kParamAlign * kParamAlign) + 64) * f4);
   w->conv_wp = (float*)take(pack_b_floats(d.KD, d.F) * f4);
-  {
-    const size_t sixth = gru_pack_floats(d.H) / 6;
-    w->u_zr_p = (float*)take(2 * sixth * f4);
-    w->u_h_p = (float*)take(sixth * f4);
-    w->ut_h_p = (float*)take(sixth * f4);
-    w->ut_zr_p = (float*)take(2 * sixth * f4);
-  }
+  w->gru_up = (float*)take(gru_pack_floats(d.H) * f4);
   w->wgrad_scratch = take(conv_wgrad_scratch_bytes(d.D, d.k, d.F));
   w->gemm_scratch_bytes = max_gemm_scratch(d);
   w->gemm_scratch = take(w->gemm_scratch_bytes);
@@ -308,7 +302,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   lazy_init(c, s);
   // operand images of the weights used by MFMA kernels this step
   launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, s);
-  launch_gru_pack(c->P("gru_u"), d.H, w.u_zr_p, w.u_h_p, w.ut_h_p, w.ut_zr_p, s);
+  launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, s);
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
   launch_compact_valid(w.ids, nt * d.T, w.vidx, w.vcount, w.vscratch, s);   // non-pad tokens of this batch
@@ -325,7 +319,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   launch_gather_rows(c->buf.user_emb, user, w.uvec, n, d.Ue, s);
   launch_gemm(w.docvec, d.U, 0, c->P("gru_w"), 3 * d.H, 0, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, 1.f,
               w.gemm_scratch, s);
-  PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.u_zr_p, w.u_h_p,
+  PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.gru_up,
                                  w.gru_tape, w.hlast, n, d.W, d.H, s));
   if (d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU) {
     (void)hipMemcpyAsync(w.uservec, w.hlast, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
@@ -361,15 +355,17 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
     launch_split2(w.du, d.H, d.Ue, w.dhlast, w.duser, n, s);
     dhl = w.dhlast;
   }
-  PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.ut_zr_p, w.ut_h_p, w.dgates, w.rh, w.hprev,
+  float *hprev = w.hprev, *rh = w.rh;   // fast path: both already sit row-major in the tape (no copies)
+  gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
+  PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
                                  d.arch == LSTUR_ARCH_IGRU ? w.duser : w.dh0, n, d.W, d.H, s));
   // GRU parameter gradients
   launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
               w.gemm_scratch, s);
   launch_colsum2(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, w.colsum_scratch, s);
-  launch_gemm(w.hprev, d.H, 1, w.dgates, 3 * d.H, 0, c->G("gru_u"), 3 * d.H, nullptr, d.H, 2 * d.H, nW, 1.f,
+  launch_gemm(hprev, d.H, 1, w.dgates, 3 * d.H, 0, c->G("gru_u"), 3 * d.H, nullptr, d.H, 2 * d.H, nW, 1.f,
               w.gemm_scratch, s);
-  launch_gemm(w.rh, d.H, 1, w.dgates + 2 * d.H, 3 * d.H, 0, c->G("gru_u") + 2 * d.H, 3 * d.H, nullptr, d.H, d.H, nW,
+  launch_gemm(rh, d.H, 1, w.dgates + 2 * d.H, 3 * d.H, 0, c->G("gru_u") + 2 * d.H, 3 * d.H, nullptr, d.H, d.H, nW,
               1.f, w.gemm_scratch, s);
   // d(history doc vectors) = dgates . gru_w^T, masked by the history mask (paper.py:644-645)
   launch_gemm(w.dgates, 3 * d.H, 0, c->P("gru_w"), 3 * d.H, 1, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, 1.f,
@@ -723,28 +719,26 @@ int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int3
   return check_launch("gemm");
 }
 size_t lstur_gru_pack_floats(int32_t H) { return gru_pack_floats(H); }
-int lstur_gru_pack_u(const float* gru_u, int32_t H, float* u_zr, float* u_h, float* ut_h, float* ut_zr,
-                     lstur_stream stream) {
-  if (!gru_u || !u_zr || !u_h || !ut_h || !ut_zr || H < 1 || H > 256) return fail(LSTUR_ERR_ARG, "gru pack: bad argument");
-  launch_gru_pack(gru_u, H, u_zr, u_h, ut_h, ut_zr, (hipStream_t)stream);
+int lstur_gru_pack_u(const float* gru_u, int32_t H, float* packed, lstur_stream stream) {
+  if (!gru_u || !packed || H < 1 || H > 256) return fail(LSTUR_ERR_ARG, "gru pack: bad argument");
+  launch_gru_pack(gru_u, H, packed, (hipStream_t)stream);
   return check_launch("gru_pack");
 }
 size_t lstur_gru_tape_floats(int32_t n, int32_t W, int32_t H) { return gru_tape_floats(n, W, H); }
-int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
-                  const float* u_h_packed, float* tape, float* hlast, int32_t n, int32_t W, int32_t H,
-                  lstur_stream stream) {
-  if (!xw || !gmask || !u_zr_packed || !u_h_packed || !tape || !hlast || H < 1 || H > 256)
+int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
+                  float* hlast, int32_t n, int32_t W, int32_t H, lstur_stream stream) {
+  if (!xw || !gmask || !packed || !tape || !hlast || n < 0 || W < 1 || H < 1 || H > 256 ||
+      (size_t)n * W * 3 * H >= ((size_t)1 << 30))
     return fail(LSTUR_ERR_ARG, "gru fwd: bad argument");
-  launch_gru_fwd(xw, gmask, h0, u_zr_packed, u_h_packed, tape, hlast, n, W, H, (hipStream_t)stream);
+  launch_gru_fwd(xw, gmask, h0, packed, tape, hlast, n, W, H, (hipStream_t)stream);
   return check_launch("gru_fwd");
 }
-int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* ut_zr_packed,
-                  const float* ut_h_packed, float* dgates, float* rh, float* hprev, float* dh0, int32_t n, int32_t W,
-                  int32_t H, lstur_stream stream) {
-  if (!dh_last || !gmask || !tape || !ut_zr_packed || !ut_h_packed || !dgates || !rh || !hprev || !dh0 || H < 1 ||
-      H > 256)
+int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* packed, float* dgates,
+                  float* rh, float* hprev, float* dh0, int32_t n, int32_t W, int32_t H, lstur_stream stream) {
+  if (!dh_last || !gmask || !tape || !packed || !dgates || !rh || !hprev || !dh0 || n < 0 || W < 1 || H < 1 || H > 256 ||
+      (size_t)n * W * 3 * H >= ((size_t)1 << 30))
     return fail(LSTUR_ERR_ARG, "gru bwd: bad argument");
-  launch_gru_bwd(dh_last, gmask, tape, ut_zr_packed, ut_h_packed, dgates, rh, hprev, dh0, n, W, H, (hipStream_t)stream);
+  launch_gru_bwd(dh_last, gmask, tape, packed, dgates, rh, hprev, dh0, n, W, H, (hipStream_t)stream);
   return check_launch("gru_bwd");
 }
 int lstur_score_softmax_ce(const float* u, const float* d, float* logits, float* probs, float* loss_i, float* correct_i,

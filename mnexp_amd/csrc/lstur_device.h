@@ -54,6 +54,16 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t v
   return *(float4*)&v;
 }
 
+// one dword per lane through a buffer descriptor: lanes whose offset is past the descriptor's range (e.g.
+// kBufOob) load 0 and store nothing, so column guards need no exec-mask branches and no address VGPRs
+constexpr uint32_t kBufOob = 0x80000000u;
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff_bytes, (int)soff_bytes, 0));
+}
+__device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, (int)voff_bytes, (int)soff_bytes, 0);
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

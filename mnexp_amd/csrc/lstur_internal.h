@@ -89,18 +89,30 @@ size_t gemm_scratch_bytes(int M, int N, int K);
 void launch_gemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, float* C, int ldc,
                  const float* bias, int M, int N, int K, float alpha, void* scratch, hipStream_t s);
 
-// ---- gru.hip -----------------------------------------------------------------------------------
-// Operand images of the recurrent matrix U [H,3H] for the two kernels below (one launch); each image pointer
-// needs its share of gru_pack_floats(H): u_zr 2/6, u_h 1/6, ut_h 1/6, ut_zr 2/6 of the total.
+// ---- gru.hip / gru4.hip --------------------------------------------------------------------------
+// Operand images of the recurrent matrix U [H,3H]: ONE opaque buffer of gru_pack_floats(H) floats (one launch).
 size_t gru_pack_floats(int H);
-void launch_gru_pack(const float* U, int H, float* u_zr, float* u_h, float* ut_h, float* ut_zr, hipStream_t s);
-// tape: gru_tape_floats(n, W, H) floats of scratch in MFMA-fragment layout, shared by forward and BPTT.
+void launch_gru_pack(const float* U, int H, float* packed, hipStream_t s);
+// tape: gru_tape_floats(n, W, H) floats of scratch shared by forward and BPTT (layout private to the kernels).
 // xw [n*W,3H] row-major; hlast [n,H]; dgates [n*W,3H], rh / hprev [n*W,H] row-major.  Requires H <= 256.
 size_t gru_tape_floats(int n, int W, int H);
-void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* u_zr_packed,
-                    const float* u_h_packed, float* tape, float* hlast, int n, int W, int H, hipStream_t s);
-void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* ut_zr_packed,
-                    const float* ut_h_packed, float* dgates, float* rh, float* hprev, float* dh0, int n, int W, int H,
-                    hipStream_t s);
+void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
+                    float* hlast, int n, int W, int H, hipStream_t s);
+void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* packed, float* dgates,
+                    float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s);
+// On the fast path the forward already leaves hprev and r*hprev row-major inside the tape: returns true and the two
+// pointers (pass them to launch_gru_bwd to skip its copies); false on the general path.
+bool gru_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh);
+
+// gru4.hip (fast path: four sample rows per workgroup, U resident in VGPRs + LDS; H <= 200)
+bool gru4_supported(int H);
+size_t gru4_pack_floats(int H);
+size_t gru4_tape_floats(int n, int W, int H);
+void gru4_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh);
+void launch_gru4_pack(const float* U, int H, float* img, hipStream_t s);
+void launch_gru4_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* img, float* tape, float* hlast,
+                     int n, int W, int H, hipStream_t s);
+void launch_gru4_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* img, float* dgates, float* rh,
+                     float* hprev, float* dh0, int n, int W, int H, hipStream_t s);
 
 }  // namespace lstur

@@ -137,11 +137,17 @@ def test_gemm_variants(ta, tb, M, N, K):
     assert err < 1e-5 * ref.abs().max().item() + 1e-6, err
 
 
-@pytest.mark.parametrize('n,W,H', [(21, 12, 200), (5, 7, 40), (33, 9, 128)])
-def test_gru_against_oracle(n, W, H):
+@pytest.mark.parametrize('generic', [False, True], ids=['resident', 'generic'])
+@pytest.mark.parametrize('n,W,H', [(21, 12, 200), (5, 7, 40), (33, 9, 128), (6, 5, 150), (9, 4, 224)])
+def test_gru_against_oracle(n, W, H, generic, monkeypatch):
+    """Both GRU kernel families (U resident on chip for H <= 200 / the general streaming kernels)."""
     _need_gpu()
     from mnexp_amd._lib import lib, check
     from oracle import lstur_oracle as O
+    if generic:
+        monkeypatch.setenv('LSTUR_GRU_GENERIC', '1')
+    else:
+        monkeypatch.delenv('LSTUR_GRU_GENERIC', raising=False)
     rng = np.random.default_rng(2)
     U = H
     p = dict(gru_w=rng.normal(0, 0.1, (U, 3 * H)), gru_u=O.orthogonal(rng, H, 3 * H), gru_b=rng.normal(0, 0.1, 3 * H))
@@ -152,14 +158,13 @@ def test_gru_against_oracle(n, W, H):
     h_ref, cache = O.gru_fwd(p, x, gmask, h0)
     xw = (x.reshape(n * W, U) @ p['gru_w'] + p['gru_b']).astype(np.float32)
     Ud = dev(p['gru_u'].astype(np.float32))
-    sixth = lib.lstur_gru_pack_floats(H) // 6
-    uzr, uh, uth, utzr = (torch.zeros(k * sixth, device='cuda') for k in (2, 1, 1, 2))
-    check(lib.lstur_gru_pack_u(Ud.data_ptr(), H, uzr.data_ptr(), uh.data_ptr(), uth.data_ptr(), utzr.data_ptr(), stream()))
+    packed = torch.zeros(lib.lstur_gru_pack_floats(H), device='cuda')
+    check(lib.lstur_gru_pack_u(Ud.data_ptr(), H, packed.data_ptr(), stream()))
     tape = torch.zeros(lib.lstur_gru_tape_floats(n, W, H), device='cuda')
     hlast = torch.empty(n, H, device='cuda')
     gm = dev(gmask.astype(np.uint8))
     xw_d, h0_d = dev(xw), dev(h0.astype(np.float32))
-    check(lib.lstur_gru_fwd(xw_d.data_ptr(), gm.data_ptr(), h0_d.data_ptr(), uzr.data_ptr(), uh.data_ptr(),
+    check(lib.lstur_gru_fwd(xw_d.data_ptr(), gm.data_ptr(), h0_d.data_ptr(), packed.data_ptr(),
                             tape.data_ptr(), hlast.data_ptr(), n, W, H, stream()))
     np.testing.assert_allclose(hlast.cpu().numpy(), h_ref, rtol=1e-3, atol=2e-5)
     assert np.array_equal(hlast[0].cpu().numpy(), h0[0].astype(np.float32))   # fully masked row carries h0 bit-exactly
@@ -170,7 +175,7 @@ def test_gru_against_oracle(n, W, H):
     rh, hp = torch.empty(n, W, H, device='cuda'), torch.empty(n, W, H, device='cuda')
     dh0 = torch.empty(n, H, device='cuda')
     dh_d = dev(dh.astype(np.float32))
-    check(lib.lstur_gru_bwd(dh_d.data_ptr(), gm.data_ptr(), tape.data_ptr(), utzr.data_ptr(), uth.data_ptr(),
+    check(lib.lstur_gru_bwd(dh_d.data_ptr(), gm.data_ptr(), tape.data_ptr(), packed.data_ptr(),
                             dg.data_ptr(), rh.data_ptr(), hp.data_ptr(), dh0.data_ptr(), n, W, H, stream()))
     np.testing.assert_allclose(hp.cpu().numpy(), cache['hs'][:, :W], rtol=1e-3, atol=2e-5)     # h_{t-1} tape
     np.testing.assert_allclose(dh0.cpu().numpy(), dh0_ref, rtol=2e-3, atol=2e-5)
