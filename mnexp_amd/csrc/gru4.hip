@@ -6,22 +6,24 @@
 // Why another kernel: the recurrence is a chain of W dependent skinny products [rows x H] . [H x 3H].  With 16
 // sample rows per workgroup (one 16x16x4 MFMA row tile) a B=64 batch fills 4 of 256 CUs and every step re-streams
 // all 480 KB of U from L2 (>= 3 us at 64 B/clk/CU) behind ~6 us of MFMA issue.  Here a workgroup owns FOUR sample
-// rows and computes with v_mfma_f32_4x4x1_16b_f32 in A-broadcast mode (cbsz = 4): lanes 0..3 carry the 4 rows'
-// state for one k, lane l carries U[k][col0 + l], so ONE instruction updates a [4 rows x 64 columns] strip
-// (register j / lane l = row j, column col0 + l; layout probed on hardware by tools/probe_mfma4.hip).  4x more
-// workgroups, and U never moves after the prologue: a wave keeps its 64-column strip of one operand in 200 VGPRs
-// (KQ float4 = 4 k each; 8 waves x 256 VGPRs), what does not fit in registers sits in LDS.  A step issues no
-// global load on its critical path except the prefetched gate inputs.
+// rows and computes with v_mfma_f32_4x4x1_16b_f32 in A-broadcast mode (cbsz = 4): one 4-lane block of A carries the
+// 4 rows' state for one k, lane l carries U[k][col0 + l], so ONE instruction updates a [4 rows x 64 columns] strip
+// (register j / lane l = row j, column col0 + l; layout probed on hardware by tools/probe_mfma4.hip, issue rate
+// 8.4 cycles per instruction by tools/probe_mfma4_rate.hip).  4x more workgroups, and U never moves after the
+// prologue: the workgroup is 4 waves, one per SIMD, so each wave owns the SIMD's whole 512-entry register file
+// (VGPR + AGPR; MFMA reads its B operand from either) and keeps TWO 64-column strips of operand resident (2 x 200
+// registers at H = 200); the strips that do not fit (3 of 11 forward, 4 of 12 backward) are read from LDS images
+// through a register ring.  A step issues no global load on its critical path except the prefetched gate inputs.
 //
-// Forward, per step:   phase 1  [z|r] = hs(xw_zr + h U_zr)     2H columns = G1 strips, waves 0..G1-1 (resident)
-//                      phase 2  hh = tanh(xw_h + (r*h) U_h)    H  columns = G2 strips, waves 4..4+G2-1
-//                               (strip j is resident when wave 4+j has no phase-1 strip, else it is read from LDS)
-// BPTT, per step:      stage 1  drh = dpre_h U_h^T  and  part_z = dpre_z U_z^T      (independent: 2*G2 strips)
-//                      stage 2  dh_prev = ... + dpre_r U_r^T                         (G2 strips)
-//                      8 strips resident (one per wave), the rest (the 8-column tail strips and one full strip) in LDS.
-// State and gate vectors live in LDS in the A-operand image [k/4][row][k%4] (one ds_read_b128 feeds 4 MFMAs).
-// Saved activations / gradients are plain row-major tensors (lane = column => coalesced), so the fragment-layout
-// conversion kernels of the general path are not needed.
+// Forward, per step:   phase 1  [z|r] = hs(xw_zr + h U_zr)     2H columns = G1 strips: wave s owns strips s, s+4
+//                      phase 2  hh = tanh(xw_h + (r*h) U_h)    H  columns = G2 strips, one per wave
+// BPTT, per step:      stage 1  drh = dpre_h U_h^T (waves 0, 2)  and  part_z = dpre_z U_z^T (waves 1, 3)
+//                      stage 2  dh_prev = ... + dpre_r U_r^T     one strip per wave
+// State and gate vectors live in LDS in the A-operand image [k/4][row][k%4]; a wave reads a whole image with 4
+// ds_read_b128 (lane l = k-quad 16i + l/4, row l%4) and selects the quad per MFMA with the ABID field.
+// Saved activations / gradients are plain row-major tensors (lane = column => coalesced), addressed through
+// buffer descriptors (scalar row/step offset + one per-lane column offset; out-of-range columns are dropped by
+// the range check) -- no address VGPRs, no exec-mask branches.
 #include <utility>
 
 #include "lstur_device.h"
@@ -29,8 +31,9 @@
 
 namespace lstur {
 
-constexpr int G4_THREADS = 512;   // 8 waves, 2 per SIMD -> 256 VGPRs per wave
+constexpr int G4_THREADS = 256;   // 4 waves, 1 per SIMD -> 512 registers per wave
 constexpr size_t G4_LDS_MAX = 160 * 1024;
+enum { M_NONE = 0, M_RES = 1, M_LDS = 2 };
 
 // cbsz = 4: ONE 4-lane block of A feeds all 16 blocks; ABID picks which block (lanes 4*ABID .. 4*ABID+3)
 template <int ABID>
@@ -42,7 +45,6 @@ __host__ __device__ __forceinline__ int aidx(int k, int row) { return (k >> 2) *
 
 // The whole A vector of a strip product in registers: lane l of load i holds k-quad 16i + l/4 of row l&3, i.e. the
 // image is read as plain consecutive float4 (1 KiB per wave instruction) and quad q is MFMA block q%16 of load q/16.
-// 4 ds_read_b128 feed all 200 MFMAs of an H = 200 strip; nothing waits on LDS inside the MFMA stream.
 // (Loads past quad KQ-1 run into the LDS region behind the image; those registers are never used.)
 template <int KQ>
 struct AVec {
@@ -54,60 +56,114 @@ struct AVec {
   }
 };
 
-template <int Q, typename B4>
-__device__ __forceinline__ void quad_mfma(const float4& a, const B4& b, f32x4& c0, f32x4& c1) {
-  c0 = mfma4<Q % 16>(a.x, b.x, c0);
-  c1 = mfma4<Q % 16>(a.y, b.y, c1);
-  c0 = mfma4<Q % 16>(a.z, b.z, c0);
-  c1 = mfma4<Q % 16>(a.w, b.w, c1);
-}
+constexpr int LDS_AHEAD = 6;   // k-quads the LDS operand reads run in front of their MFMAs (~120-cycle round trip)
+// Resident k-quads (QR1) of the strip in register slot 1; its last KQ - QR1 quads sit in a per-wave LDS tail
+// [q][64 lanes][4].  (2 x 200 operand registers + the working set of a step do not fit 512 at H = 200.)
+__host__ __device__ constexpr int fwd_slot1(int KQ) { return KQ > 40 ? 40 : KQ; }
+__host__ __device__ constexpr int bwd_slot1(int KQ) { return KQ > 36 ? 36 : KQ; }   // BPTT keeps more values live
 
-// out[row j][strip column of this lane] = sum_k A[j][k] * B[k][col]; B resident in registers
-template <int KQ, size_t... Q>
-__device__ __forceinline__ f32x4 strip_res_impl(const float4 (&ub)[KQ], const AVec<KQ>& a, std::index_sequence<Q...>) {
-  f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-  (quad_mfma<(int)Q>(a.v[Q / 16], ub[Q], c0, c1), ...);
-  return c0 + c1;
+// One k-quad of up to two strips that share the A vector.  Strip 0 is resident in slot 0 (or absent); strip 1 is
+// resident in slot 1 (+ LDS tail), absent, or read from an LDS image (layout below).  LDS operands pass through
+// `ring`, read LDS_AHEAD quads early.  MFMAs of the two strips alternate so that no accumulator is reused within
+// 4 issues.
+template <int KQ, int QR1, int Q, int M0, int M1>
+__device__ __forceinline__ void quad_step(const float4& a, const float4 (&u0)[KQ], const float4 (&u1)[QR1],
+                                          const float* __restrict__ l1, float4 (&ring)[LDS_AHEAD], f32x4 (&c)[4]) {
+  constexpr int QP = Q + LDS_AHEAD;
+  float4 b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool pinned = false;
+  if (M1 == M_RES) {   // l1 = this lane's tail, quad stride 256 floats
+    if (Q < QR1) b1 = u1[Q < QR1 ? Q : 0];
+    else b1 = ring[Q % LDS_AHEAD];
+    if (QP >= QR1 && QP < KQ) ring[QP % LDS_AHEAD] = *(const float4*)(l1 + (QP - QR1) * 256);
+    pinned = QP >= QR1;
+  }
+  if (M1 == M_LDS) {
+    b1 = ring[Q % LDS_AHEAD];
+    if (QP < KQ) ring[QP % LDS_AHEAD] = *(const float4*)(l1 + QP * 4);
+    pinned = true;
+  }
+  if (M0 == M_RES) c[0] = mfma4<Q % 16>(a.x, u0[Q].x, c[0]);
+  if (M1 != M_NONE) c[2] = mfma4<Q % 16>(a.x, b1.x, c[2]);
+  if (M0 == M_RES) c[1] = mfma4<Q % 16>(a.y, u0[Q].y, c[1]);
+  if (M1 != M_NONE) c[3] = mfma4<Q % 16>(a.y, b1.y, c[3]);
+  if (M0 == M_RES) c[0] = mfma4<Q % 16>(a.z, u0[Q].z, c[0]);
+  if (M1 != M_NONE) c[2] = mfma4<Q % 16>(a.z, b1.z, c[2]);
+  if (M0 == M_RES) c[1] = mfma4<Q % 16>(a.w, u0[Q].w, c[1]);
+  if (M1 != M_NONE) c[3] = mfma4<Q % 16>(a.w, b1.w, c[3]);
+  if (pinned) __builtin_amdgcn_sched_barrier(0);   // pin: the read of quad Q+LDS_AHEAD stays in front of quad Q
 }
-template <int KQ>
-__device__ __forceinline__ f32x4 strip_res(const float4 (&ub)[KQ], const float* __restrict__ aimg, int lane) {
+template <int KQ, int QR1, int M0, int M1, size_t... Q>
+__device__ __forceinline__ void strips_impl(const float4 (&u0)[KQ], const float4 (&u1)[QR1],
+                                            const float* __restrict__ l1, const AVec<KQ>& a, f32x4& r0, f32x4& r1,
+                                            std::index_sequence<Q...>) {
+  f32x4 c[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 ring[LDS_AHEAD];
+  if (M1 == M_LDS) {
+#pragma unroll
+    for (int d = 0; d < LDS_AHEAD; ++d) ring[d] = *(const float4*)(l1 + (d < KQ ? d : 0) * 4);
+  }
+  (quad_step<KQ, QR1, (int)Q, M0, M1>(a.v[Q / 16], u0, u1, l1, ring, c), ...);
+  r0 = c[0] + c[1];
+  r1 = c[2] + c[3];
+}
+// r0 = A . strip0, r1 = A . strip1 for the 4 rows (register j) at this lane's strip column.
+// l1: M_RES -> this lane's slot-1 tail; M_LDS -> this lane's column of an LDS operand image.
+template <int KQ, int QR1, int M0, int M1>
+__device__ __forceinline__ void run_strips(const float4 (&u0)[KQ], const float4 (&u1)[QR1],
+                                           const float* __restrict__ l1, const float* __restrict__ aimg, int lane,
+                                           f32x4& r0, f32x4& r1) {
   AVec<KQ> a;
   a.load(aimg, lane);
-  return strip_res_impl<KQ>(ub, a, std::make_index_sequence<KQ>{});
+  strips_impl<KQ, QR1, M0, M1>(u0, u1, l1, a, r0, r1, std::make_index_sequence<KQ>{});
 }
-// B resident for the first QR k-quads, the last KQ-QR read from a per-wave LDS tail [KQ-QR][64 lanes][4] (BPTT at
-// H = 200 needs a few more live registers than the forward: 44 resident quads + 6 in LDS avoids scratch spills)
-template <int KQ, int QR, size_t... Q, size_t... T>
-__device__ __forceinline__ f32x4 strip_mix_impl(const float4 (&ub)[QR], const float* __restrict__ tailL,
-                                                const AVec<KQ>& a, std::index_sequence<Q...>,
-                                                std::index_sequence<T...>) {
-  f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-  (quad_mfma<(int)Q>(a.v[Q / 16], ub[Q], c0, c1), ...);
-  (quad_mfma<(int)(QR + T)>(a.v[(QR + T) / 16], *(const float4*)(tailL + T * 256), c0, c1), ...);
-  return c0 + c1;
+// LDS operand images are column-major [column][KQP][4] with KQP = KQ | 1 quads per column: the k-quads of a lane's
+// column are at immediate offsets (no address arithmetic in the MFMA stream), and an odd quad count per column
+// spreads the 16 lanes of every ds_read_b128 lane group over all 64 banks.
+__host__ __device__ constexpr int kqp(int KQ) { return KQ | 1; }
+
+// tanh through v_exp_f32 / v_rcp_f32: (1 - e) / (1 + e), e = exp(-2|x|); absolute error ~1e-7 (libm tanhf costs
+// ~250 cycles per value in the step epilogue)
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __expf(-2.0f * fabsf(x));
+  const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+  return copysignf(t, x);
 }
-template <int KQ, int QR>
-__device__ __forceinline__ f32x4 strip_mix(const float4 (&ub)[QR], const float* __restrict__ tailL,
-                                           const float* __restrict__ aimg, int lane) {
-  AVec<KQ> a;
-  a.load(aimg, lane);
-  return strip_mix_impl<KQ, QR>(ub, tailL, a, std::make_index_sequence<QR>{}, std::make_index_sequence<KQ - QR>{});
-}
-// B read from an LDS image [KQ][ncols][4] (uL already points at this lane's column)
-template <int KQ, size_t... Q>
-__device__ __forceinline__ f32x4 strip_lds_impl(const float* __restrict__ uL, int qstride, const AVec<KQ>& a,
-                                                std::index_sequence<Q...>) {
-  f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-  (quad_mfma<(int)Q>(a.v[Q / 16], *(const float4*)(uL + (size_t)Q * qstride), c0, c1), ...);
-  return c0 + c1;
-}
-template <int KQ>
-__device__ __forceinline__ f32x4 strip_lds(const float* __restrict__ uL, int qstride, const float* __restrict__ aimg,
-                                           int lane) {
-  AVec<KQ> a;
-  a.load(aimg, lane);
-  return strip_lds_impl<KQ>(uL, qstride, a, std::make_index_sequence<KQ>{});
-}
+__device__ __forceinline__ float hs_grad4(float g) { return (g > 0.f && g < 1.f) ? 0.2f : 0.f; }
+
+// A value that was handed to a global store stays in its register until `keep` is reached: hipcc makes a wave wait
+// for the store's completion before it lets anything overwrite the store's data register, and the registers freed
+// by an epilogue are exactly the ones the next MFMA stream (A vector, accumulators) takes.  Keeping the stored
+// values alive over that stream moves the wait to a point where the store has long been acknowledged.
+__device__ __forceinline__ void keep(float& v) { asm volatile("" : "+v"(v)); }
+
+// Step masks of the 4 rows of this workgroup as wave-uniform bit words (bit i = step base+i), 64 steps at a time:
+// one vector load + ballot per row and chunk instead of a byte load (and its wait) on every step.
+struct RowMasks {
+  unsigned long long bits[4];
+  int chunk;
+  const uint8_t* gm;
+  uint32_t rbase[4];
+  int W, lane;
+  __device__ __forceinline__ void init(const uint8_t* gmask, int b0, int n, int W_, int lane_) {
+    gm = gmask; W = W_; lane = lane_; chunk = -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rbase[j] = (uint32_t)min(b0 + j, n - 1) * (uint32_t)W_;
+  }
+  __device__ __forceinline__ void seek(int t) {   // wave-uniform t
+    if ((t >> 6) == chunk) return;
+    chunk = t >> 6;
+    const int tt = chunk * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint8_t v = tt < W ? gm[rbase[j] + tt] : (uint8_t)0;
+      bits[j] = __ballot(v != 0);
+    }
+  }
+  __device__ __forceinline__ bool at(int j, int t) const { return (bits[j] >> (t & 63)) & 1ull; }
+};
 
 // ---- operand images -----------------------------------------------------------------------------
 // All images are [KQ][N][4] (float4 = 4 consecutive k of one column), zero for k >= H:
@@ -157,129 +213,167 @@ void launch_gru4_pack(const float* U, int H, float* img, hipStream_t s) {
 // tape of the fast path: row-major sections ZR [n*W,2H] | HH [n*W,H] | HP [n*W,H] | RH [n*W,H]
 size_t gru4_tape_floats(int n, int W, int H) { return gru4_kq(H) ? (size_t)5 * n * W * H : 0; }
 
+
 // ---- forward -------------------------------------------------------------------------------------
 struct Gru4Fwd {
   const float* xw; const uint8_t* gmask; const float* h0; const float* izr; const float* ih;
   float* zr; float* hh; float* hp; float* rh; float* hlast;
-  int n, W, H;
+  int n, W, H, dbg;   // dbg: measurement knobs (LSTUR_GRU4_DEBUG): 1 no global stores, 8 per-segment cycle stamps
 };
 
+// Strip plan of the forward kernel (host + device).  [z|r] strip s and s+4 are resident on wave s.  A wave whose
+// second register slot is free (s+4 >= G1) can keep a candidate strip resident: strips 0..nres-1 sit on waves
+// 3, 2, ...; the other candidate strips (hidden columns nres*64 .. H-1, width wl) are LDS-fed on waves 0, 1, ...
+struct FwdPlan {
+  int G1, G2, nres, wl;
+  __host__ __device__ FwdPlan(int H) {
+    G1 = cdiv(2 * H, 64);
+    G2 = cdiv(H, 64);
+    const int nfree = G1 >= 4 ? 8 - G1 : 4;
+    nres = nfree < G2 ? nfree : G2;
+    wl = H - nres * 64 > 0 ? H - nres * 64 : 0;
+  }
+};
 static size_t gru4_fwd_lds(int H, int KQ) {
-  const int G1 = cdiv(2 * H, 64), G2 = cdiv(H, 64);
-  const int NL = std::max(0, std::min(G2, G1 - 4));
-  const size_t floats = (size_t)2 * KQ * 16 + ((4 * H + 3) & ~3) + (size_t)KQ * NL * 64 * 4;
-  const size_t aread = (size_t)KQ * 16 + (size_t)cdiv(KQ, 16) * 256;   // AVec reads whole 1 KiB blocks of the last image
-  return std::max(floats, aread) * sizeof(float);
+  const FwdPlan p(H);
+  return ((size_t)3 * KQ * 16 + 16 + (size_t)kqp(KQ) * p.wl * 4 + (size_t)4 * (KQ - fwd_slot1(KQ)) * 256) * sizeof(float);
 }
 
-// Step masks of the 4 rows of this workgroup as wave-uniform bit words (bit i = step base+i), 64 steps at a time:
-// one vector load + ballot per row and chunk instead of a byte load (and its wait) on every step.
-struct RowMasks {
-  unsigned long long bits[4];
-  int chunk;
-  const uint8_t* gm;
-  uint32_t rbase[4];
-  int W, lane;
-  __device__ __forceinline__ void init(const uint8_t* gmask, int b0, int n, int W_, int lane_) {
-    gm = gmask; W = W_; lane = lane_; chunk = -1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rbase[j] = (uint32_t)min(b0 + j, n - 1) * (uint32_t)W_;
-  }
-  __device__ __forceinline__ void seek(int t) {   // wave-uniform t
-    if ((t >> 6) == chunk) return;
-    chunk = t >> 6;
-    const int tt = chunk * 64 + lane;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint8_t v = tt < W ? gm[rbase[j] + tt] : (uint8_t)0;
-      bits[j] = __ballot(v != 0);
-    }
-  }
-  __device__ __forceinline__ bool at(int j, int t) const { return (bits[j] >> (t & 63)) & 1ull; }
-};
+struct FwdLds { float *hA, *rhA, *zA, *dummy; const float* uL; int wl; const float* tail; };
 
-// Time loop of one wave role.  P1: the wave owns (resident) strip `wv` of [z|r].  P2: 0 = no candidate strip,
-// 1 = candidate strip j2 resident, 2 = candidate strip j2 read from the LDS image.  One straight-line body per role
-// (no per-phase `if (role)` inside the loop), so every wait the compiler places is for an access of this role only.
-// Global traffic goes through buffer descriptors: scalar row/step offset + ONE per-lane column offset (kBufOob for
-// columns past H: loads return 0, stores are dropped) -- no address VGPRs next to the 200 operand registers.
-template <int KQ, bool P1, int P2>
-__device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, float* hA, float* rhA, float* zL, const float* uL,
-                                              int ncl, int wv, int lane, const float4 (&ub)[KQ]) {
+// Time loop of one wave role.  NP1: resident [z|r] strips of this wave (slot 0 = strip wv, slot 1 = strip wv+4).
+// P2: candidate strip M_NONE | M_RES (slot 1) | M_LDS; c2 = its first hidden column, lcol = its first image column.
+template <int KQ, int NP1, int P2>
+__device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L, int wv, int lane, int c2base, int lcol,
+                                              const float4 (&u0)[KQ], const float4 (&u1)[fwd_slot1(KQ)]) {
   const int H = g.H, W = g.W, n = g.n, H2 = 2 * H, H3 = 3 * H;
   const int b0 = blockIdx.x * 4;
   const uint32_t e4 = (uint32_t)n * W * H * 4;   // bytes of an [n*W, H] tensor
   const __amdgpu_buffer_rsrc_t rxw = make_rsrc(g.xw, 3 * e4), rzr = make_rsrc(g.zr, 2 * e4), rhh = make_rsrc(g.hh, e4),
                                rhp = make_rsrc(g.hp, e4), rrh = make_rsrc(g.rh, e4);
-  const int c1 = wv * 64 + lane;            // column of [z|r]
-  const bool v1 = P1 && c1 < H2;
-  const bool isz = c1 < H;
-  const int hc1 = isz ? c1 : c1 - H;
-  const int c2 = (wv - 4) * 64 + lane;      // hidden column of the candidate strip
-  const bool v2 = P2 != 0 && c2 < H;
-  const uint32_t o1 = v1 ? c1 * 4 : kBufOob;                     // [z|r] column (xw, zr)
-  const uint32_t o1r = (v1 && !isz) ? hc1 * 4 : kBufOob;         // r columns -> rh
+  // phase-1 strips: per-lane column, LDS destination of the gate (z -> zA, r*h -> rhA, past 2H -> dummy), h source
+  uint32_t o1[2], o1r[2];
+  float* dst1[2];
+  const float* hsrc[2];
+  bool isr[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int c = (wv + 4 * s) * 64 + lane;
+    const bool v = s < NP1 && c < H2;
+    isr[s] = c >= H;
+    const int hc = isr[s] ? c - H : c;
+    o1[s] = v ? c * 4 : kBufOob;
+    o1r[s] = (v && isr[s]) ? hc * 4 : kBufOob;
+    dst1[s] = v ? (isr[s] ? L.rhA : L.zA) + aidx(hc, 0) : L.dummy;
+    hsrc[s] = L.hA + aidx(v ? hc : 0, 0);
+  }
+  const int c2 = c2base + lane;             // hidden column of the candidate strip
+  const bool v2 = P2 != M_NONE && c2 < H;
   const uint32_t o2 = v2 ? c2 * 4 : kBufOob, o2x = v2 ? (H2 + c2) * 4 : kBufOob;
-  const float* uLl = uL + (size_t)(P2 == 2 ? min(c2, ncl - 1) : 0) * 4;
-    uint32_t rb[4];   // row * W (the launcher keeps n*W*3H below 2^30)
+  const float* zsrc = L.zA + aidx(v2 ? c2 : 0, 0);
+  const float* hsrc2 = L.hA + aidx(v2 ? c2 : 0, 0);
+  float* hdst2 = v2 ? L.hA + aidx(c2, 0) : L.dummy;
+  const float* uLl = L.uL + (size_t)(P2 == M_LDS ? min(lcol + lane, L.wl - 1) : 0) * kqp(KQ) * 4;
+  uint32_t rb[4];   // row * W (the launcher keeps n*W*3H below 2^30)
   bool rok[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    rok[j] = b0 + j < n;
+    rok[j] = b0 + j < n && !(g.dbg & 1);
     rb[j] = (uint32_t)min(b0 + j, n - 1) * (uint32_t)W;
   }
   RowMasks rm;
-  if (P2) rm.init(g.gmask, b0, n, W, lane);
+  if (P2 != M_NONE) rm.init(g.gmask, b0, n, W, lane);
+  // measurement build only (dbg bit 3): per-segment shader cycles of this wave, summed over the steps
+  const bool stamp = g.dbg & 8;
+  unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, last = 0;
+#define LSTUR_STAMP(k)                                     \
+  if (stamp) {                                             \
+    unsigned long long now = __builtin_amdgcn_s_memtime(); \
+    st[k] += now - last;                                   \
+    last = now;                                            \
+  }
+  float k1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, k1r[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float k2h[4] = {0.f, 0.f, 0.f, 0.f}, k2p[4] = {0.f, 0.f, 0.f, 0.f};   // values handed to stores (see keep())
   for (int t = 0; t < W; ++t) {
+    if (stamp) last = __builtin_amdgcn_s_memtime();
     // ---- phase 1: z | r ----
-    if (P1) {
-      float x1[4];
+    if (NP1 > 0) {
+      float x1[2][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x1[j] = buf_load1(rxw, o1, (rb[j] + t) * H3 * 4);
+      for (int s = 0; s < NP1; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x1[s][j] = buf_load1(rxw, o1[s], (rb[j] + t) * H3 * 4);
+      float hv[2][4];   // h at this lane's r columns (read before the stream: one LDS round trip less in the epilogue)
+#pragma unroll
+      for (int s = 0; s < NP1; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hv[s][j] = hsrc[s][j * 4];
       __builtin_amdgcn_sched_barrier(0);   // keep the gate-input loads in front of the MFMA stream
-      const f32x4 acc = strip_res<KQ>(ub, hA, lane);
+      f32x4 acc[2];
+      run_strips<KQ, fwd_slot1(KQ), M_RES, NP1 == 2 ? M_RES : M_NONE>(u0, u1, L.tail, L.hA, lane, acc[0], acc[1]);
+      if (P2 != M_NONE) {   // the previous step's hh / hp stores have long completed
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float gt = hard_sigmoid(acc[j] + x1[j]);
-        if (rok[j]) buf_store1(gt, rzr, o1, (rb[j] + t) * H2 * 4);
-        if (v1) {
-          if (isz) {
-            zL[j * H + hc1] = gt;
-          } else {
-            const float v = gt * hA[aidx(hc1, j)];
-            rhA[aidx(hc1, j)] = v;
-            if (rok[j]) buf_store1(v, rrh, o1r, (rb[j] + t) * H * 4);
-          }
-        }
+        for (int j = 0; j < 4; ++j) { keep(k2h[j]); keep(k2p[j]); }
       }
+      LSTUR_STAMP(0)
+#pragma unroll
+      for (int s = 0; s < NP1; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gt = hard_sigmoid(acc[s][j] + x1[s][j]);
+          const float val = isr[s] ? gt * hv[s][j] : gt;
+          dst1[s][j * 4] = val;
+          k1[s][j] = gt;
+          k1r[s][j] = val;
+          buf_store1(k1[s][j], rzr, rok[j] ? o1[s] : kBufOob, (rb[j] + t) * H2 * 4);
+          buf_store1(k1r[s][j], rrh, rok[j] ? o1r[s] : kBufOob, (rb[j] + t) * H * 4);
+        }
     }
     float x2[4];
-    if (P2) {   // candidate inputs fly over the barrier and the candidate product
+    if (P2 != M_NONE) {   // candidate inputs fly over the barrier and the candidate product
       rm.seek(t);
 #pragma unroll
       for (int j = 0; j < 4; ++j) x2[j] = buf_load1(rxw, o2x, (rb[j] + t) * H3 * 4);
     }
+    LSTUR_STAMP(1)
     __syncthreads();
+    LSTUR_STAMP(2)
     // ---- phase 2: candidate + state update ----
-    if (P2) {
-      const f32x4 acc = P2 == 1 ? strip_res<KQ>(ub, rhA, lane) : strip_lds<KQ>(uLl, ncl * 4, rhA, lane);
-      if (v2) {
+    if (P2 != M_NONE) {
+      float z[4], hp[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float hhv = tanhf(acc[j] + x2[j]);
-          const float z = zL[j * H + c2];
-          const float hp = hA[aidx(c2, j)];
-          const float hn = z * hp + (1.0f - z) * hhv;
-          if (rok[j]) {
-            buf_store1(hhv, rhh, o2, (rb[j] + t) * H * 4);
-            buf_store1(hp, rhp, o2, (rb[j] + t) * H * 4);
-          }
-          hA[aidx(c2, j)] = rm.at(j, t) ? hn : hp;   // K.rnn: a masked step carries the previous state/output
-        }
+      for (int j = 0; j < 4; ++j) {
+        z[j] = zsrc[j * 4];
+        hp[j] = hsrc2[j * 4];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc, unused;
+      run_strips<KQ, fwd_slot1(KQ), M_NONE, P2>(u0, u1, P2 == M_RES ? L.tail : uLl, L.rhA, lane, unused, acc);
+      LSTUR_STAMP(3)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float hhv = fast_tanh(acc[j] + x2[j]);
+        const float hn = z[j] * hp[j] + (1.0f - z[j]) * hhv;
+        hdst2[j * 4] = rm.at(j, t) ? hn : hp[j];   // K.rnn: a masked step carries the previous state/output
+        k2h[j] = hhv;
+        k2p[j] = hp[j];
+        buf_store1(k2h[j], rhh, rok[j] ? o2 : kBufOob, (rb[j] + t) * H * 4);
+        buf_store1(k2p[j], rhp, rok[j] ? o2 : kBufOob, (rb[j] + t) * H * 4);
       }
     }
+    if (NP1 > 0) {   // this step's z / r / r*h stores were issued a whole candidate product ago
+#pragma unroll
+      for (int s = 0; s < NP1; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { keep(k1[s][j]); keep(k1r[s][j]); }
+    }
+    LSTUR_STAMP(4)
     __syncthreads();
+    LSTUR_STAMP(5)
   }
+#undef LSTUR_STAMP
+  if (stamp && lane == 0 && blockIdx.x == 0)
+    for (int k = 0; k < 6; ++k) g.hlast[wv * 8 + k] = (float)st[k];
 }
 
 template <int KQ>
@@ -288,53 +382,64 @@ __global__ __launch_bounds__(G4_THREADS) void gru4_fwd_kernel(Gru4Fwd g) {
   const int H = g.H, n = g.n, H2 = 2 * H;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int G1 = cdiv(H2, 64), G2 = cdiv(H, 64);
-  const int NL = max(0, min(G2, G1 - 4));   // phase-2 strips whose wave also owns a phase-1 strip: fed from LDS
-  const int ncl = NL * 64;
-  float* hA = smem;                         // state, A image
-  float* rhA = hA + KQ * 16;                // r*h, A image
-  float* zL = rhA + KQ * 16;                // z [4][H]
-  float* uL = zL + ((4 * H + 3) & ~3);      // U_h[:, 0:ncl] image [KQ][ncl][4]
+  const FwdPlan P(H);
+  FwdLds L;
+  L.hA = smem;                      // state, A image
+  L.rhA = L.hA + KQ * 16;           // r*h, A image
+  L.zA = L.rhA + KQ * 16;           // z, same layout
+  L.dummy = L.zA + KQ * 16;         // sink for lanes past the last column
+  float* uL = L.dummy + 16;         // U_h[:, nres*64 : H] image [wl][KQP][4]
+  L.uL = uL;
+  L.wl = P.wl;
+  constexpr int QR1 = fwd_slot1(KQ);
+  float* tailL = uL + (size_t)kqp(KQ) * P.wl * 4 + (size_t)wv * (KQ - QR1) * 256 + lane * 4;   // slot-1 tail of this lane
+  L.tail = tailL;
   const int b0 = blockIdx.x * 4;
 
-  for (int i = tid; i < 2 * KQ * 16; i += G4_THREADS) smem[i] = 0.f;
+  for (int i = tid; i < 3 * KQ * 16 + 16; i += G4_THREADS) smem[i] = 0.f;
   __syncthreads();
   for (int i = tid; i < 4 * H; i += G4_THREADS) {
     const int row = i / H, col = i - row * H, b = b0 + row;
-    if (g.h0 && b < n) hA[aidx(col, row)] = g.h0[(size_t)b * H + col];
+    if (g.h0 && b < n) L.hA[aidx(col, row)] = g.h0[(size_t)b * H + col];
   }
-  for (int i = tid; i < KQ * ncl; i += G4_THREADS) {
-    const int q = i / ncl, col = i - q * ncl;
-    ((float4*)uL)[i] = ((const float4*)g.ih)[(size_t)q * H + col];
+  for (int i = tid; i < KQ * P.wl; i += G4_THREADS) {
+    const int q = i / P.wl, col = i - q * P.wl;
+    ((float4*)uL)[col * kqp(KQ) + q] = ((const float4*)g.ih)[(size_t)q * H + P.nres * 64 + col];
   }
 
   // roles (all wave-uniform)
-  const bool p1 = wv < G1;
-  const int j2 = wv - 4;
-  const bool p2 = j2 >= 0 && j2 < G2;
-  const bool p2res = p2 && !p1;
-  float4 ub[KQ];
+  const int np1 = (wv < P.G1) + (wv + 4 < P.G1);
+  int p2 = M_NONE, c2base = 0, lcol = 0;
+  if (wv >= 4 - P.nres) { p2 = M_RES; c2base = (3 - wv) * 64; }
+  else if (wv < P.G2 - P.nres) { p2 = M_LDS; lcol = wv * 64; c2base = (P.nres + wv) * 64; }
+  float4 u0[KQ], u1[QR1];
   {
-    const int c1 = wv * 64 + lane, c2 = j2 * 64 + lane;
-    const float4* src = p1 ? (const float4*)g.izr : (const float4*)g.ih;
-    const int ncol = p1 ? H2 : H;
-    const bool ok = p1 ? c1 < H2 : (p2res && c2 < H);
-    const int col = ok ? (p1 ? c1 : c2) : 0;
+    const int ca = wv * 64 + lane;                 // slot 0: [z|r] strip wv
+    const bool oka = np1 >= 1 && ca < H2;
+    const int cb = p2 == M_RES ? c2base + lane : (wv + 4) * 64 + lane;   // slot 1: [z|r] strip wv+4 or candidate strip
+    const bool okb = p2 == M_RES ? cb < H : (np1 == 2 && cb < H2);
+    const float4* sb = p2 == M_RES ? (const float4*)g.ih : (const float4*)g.izr;
+    const int nb = p2 == M_RES ? H : H2;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
-      float4 v = src[(size_t)q * ncol + col];
-      ub[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 va = ((const float4*)g.izr)[(size_t)q * H2 + (oka ? ca : 0)];
+      float4 vb = sb[(size_t)q * nb + (okb ? cb : 0)];
+      vb = okb ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
+      u0[q] = oka ? va : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < QR1) u1[q < QR1 ? q : 0] = vb;
+      else *(float4*)(tailL + (q - QR1) * 256) = vb;
     }
   }
   __syncthreads();
-  if (p1 && p2) gru4_fwd_loop<KQ, true, 2>(g, hA, rhA, zL, uL, ncl, wv, lane, ub);
-  else if (p1) gru4_fwd_loop<KQ, true, 0>(g, hA, rhA, zL, uL, ncl, wv, lane, ub);
-  else if (p2res) gru4_fwd_loop<KQ, false, 1>(g, hA, rhA, zL, uL, ncl, wv, lane, ub);
-  else gru4_fwd_loop<KQ, false, 0>(g, hA, rhA, zL, uL, ncl, wv, lane, ub);
+#define LSTUR_ROLE(A, B) \
+  if (np1 == A && p2 == B) gru4_fwd_loop<KQ, A, B>(g, L, wv, lane, c2base, lcol, u0, u1); else
+  LSTUR_ROLE(2, M_LDS) LSTUR_ROLE(2, M_NONE) LSTUR_ROLE(1, M_RES) LSTUR_ROLE(1, M_NONE) LSTUR_ROLE(0, M_RES)
+  gru4_fwd_loop<KQ, 0, M_NONE>(g, L, wv, lane, c2base, lcol, u0, u1);
+#undef LSTUR_ROLE
 
   for (int i = tid; i < 4 * H; i += G4_THREADS) {
     const int row = i / H, col = i - row * H, b = b0 + row;
-    if (b < n) g.hlast[(size_t)b * H + col] = hA[aidx(col, row)];
+    if (b < n && !(g.dbg & 8)) g.hlast[(size_t)b * H + col] = L.hA[aidx(col, row)];
   }
 }
 
@@ -343,64 +448,76 @@ __global__ __launch_bounds__(G4_THREADS) void gru4_fwd_kernel(Gru4Fwd g) {
 //   dpre_h = dhn (1-z)(1-hh^2) ; dpre_z = dhn (hp-hh) hs'(z)
 //   drh = dpre_h U_h^T ; dpre_r = drh hp hs'(r)
 //   dh_prev = carry + dhn z + drh r + dpre_z U_z^T + dpre_r U_r^T
+// Strip j of a product covers hidden columns 64j .. 64j+63 (G2 strips).
+//   stage 1: wave 0: drh 0, 1      wave 1: part_z 0, 1      wave 2: drh 2, 3      wave 3: part_z 2, 3
+//   stage 2 (dpre_r U_r^T + the element-wise head of the next step): strip 0 on wave 2, 1 on wave 3, 2 on wave 0,
+//            3 on wave 1
+//   resident: both stage-1 strips of waves 0/1, strip 2 of waves 2/3 (slot 0) and the stage-2 strip of waves 2/3
+//   (slot 1); from LDS: the stage-1 tail strips 3 (columns 192..H-1) and the stage-2 strips 2 and 3.
 struct Gru4Bwd {
   const float* dh_last; const uint8_t* gmask; const float* zr; const float* hh; const float* hp;
   const float* itz; const float* itr; const float* ith;
   float* dgates; float* dh0;
-  int n, W, H;
+  int n, W, H, dbg;
 };
-__device__ __forceinline__ float hs_grad4(float g) { return (g > 0.f && g < 1.f) ? 0.2f : 0.f; }
-
-// strip -> wave tables (strip j of a product covers hidden columns 64j .. 64j+63)
-//   stage 1: drh strips on waves {0,1,2,6}, part_z strips on waves {3,4,5,7}; stage 2: strips on waves {6,7,0,1}.
-//   resident: drh 0..2, part_z 0..2, stage-2 0..1;  LDS: drh 3, part_z 3, stage-2 2 and 3.
-__host__ __device__ constexpr int bwd_resident_quads(int KQ) { return KQ > 44 ? 44 : KQ; }
 static size_t gru4_bwd_lds(int H, int KQ) {
   const int G2 = cdiv(H, 64);
   const int w2 = G2 >= 3 ? std::min(64, H - 128) : 0, w3 = G2 >= 4 ? H - 192 : 0;
-  const size_t floats = (size_t)3 * KQ * 16 + 2 * ((4 * H + 3) & ~3) + (size_t)KQ * 4 * (w2 + 3 * w3) +
-                        (size_t)8 * (KQ - bwd_resident_quads(KQ)) * 256;
-  const size_t aread = (size_t)2 * KQ * 16 + (size_t)cdiv(KQ, 16) * 256;
-  return std::max(floats, aread) * sizeof(float);
+  return ((size_t)5 * KQ * 16 + 16 + (size_t)kqp(KQ) * 4 * (w2 + 3 * w3) + (size_t)4 * (KQ - bwd_slot1(KQ)) * 256) *
+         sizeof(float);
 }
-
-struct Gru4BwdLds {
-  float *dphA, *dpzA, *dprA, *n2, *n3;
-  const float *u1, *u2;     // LDS operand images of this wave's stage-1 / stage-2 strip (lane-adjusted), if LDS-fed
-  int q1, q2;               // their k-quad strides (floats)
-  const float* tail;        // this lane's LDS tail of the resident operand
+struct BwdLds {
+  float *dphA, *dpzA, *dprA, *n2, *n3, *dummy;
+  const float* tail;        // this lane's LDS tail of the slot-1 strip
+  const float *la, *lb;     // LDS operand images of this wave's stage-1 tail strip / stage-2 strip (lane-adjusted)
 };
 
-// Time loop of one wave role.  S1: 0 none | 1 drh resident | 2 part_z resident | 3 drh from LDS | 4 part_z from LDS
-// (strip s1grp);  S2: 0 none | 1 stage-2 strip resident | 2 from LDS (strip s2grp).  The resident operand belongs to
-// S1 when S1 is 1 or 2, else to S2.
-template <int KQ, int S1, int S2>
-__device__ __forceinline__ void gru4_bwd_loop(const Gru4Bwd& g, const Gru4BwdLds& L, int s1grp, int s2grp, int lane,
-                                              const float4 (&ub)[bwd_resident_quads(KQ)]) {
-  constexpr int QR = bwd_resident_quads(KQ);
+// Time loop of one wave role.  KIND 1: the stage-1 strips are drh (A = dpre_h), KIND 2: part_z (A = dpre_z).
+// MA0: M_NONE | M_RES (slot 0) strip ga; MA1: M_NONE | M_RES (slot 1) | M_LDS strip ga+1;
+// MB: stage-2 strip gb, M_NONE | M_RES (slot 1) | M_LDS.
+template <int KQ, int KIND, int MA0, int MA1, int MB>
+__device__ __forceinline__ void gru4_bwd_loop(const Gru4Bwd& g, const BwdLds& L, int ga, int gb, int lane,
+                                              const float4 (&u0)[KQ], const float4 (&u1)[bwd_slot1(KQ)]) {
   const int H = g.H, W = g.W, n = g.n, H2 = 2 * H, H3 = 3 * H;
   const int b0 = blockIdx.x * 4;
   const uint32_t e4 = (uint32_t)n * W * H * 4;   // bytes of an [n*W, H] tensor
   const __amdgpu_buffer_rsrc_t rzr = make_rsrc(g.zr, 2 * e4), rhh = make_rsrc(g.hh, e4), rhp = make_rsrc(g.hp, e4),
                                rdg = make_rsrc(g.dgates, 3 * e4);
-  const int cs1 = s1grp * 64 + lane;           // output column of the stage-1 strip
-  const bool vs1 = S1 != 0 && cs1 < H;
-  const int cs2 = s2grp * 64 + lane;
-  const bool vs2 = S2 != 0 && cs2 < H;
-  const uint32_t o1 = vs1 ? cs1 * 4 : kBufOob, o1r = vs1 ? (H + cs1) * 4 : kBufOob;
-  const uint32_t o2 = vs2 ? cs2 * 4 : kBufOob, o2h = vs2 ? (H2 + cs2) * 4 : kBufOob;
+  constexpr int NA = (MA0 != M_NONE) + (MA1 != M_NONE);
+  // stage-1 strips
+  uint32_t oa[2], oar[2];
+  float *dsta[2], *dstn[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int c = (ga + s) * 64 + lane;
+    const bool v = (s == 0 ? MA0 != M_NONE : MA1 != M_NONE) && c < H;
+    oa[s] = v ? c * 4 : kBufOob;
+    oar[s] = v ? (H + c) * 4 : kBufOob;
+    dsta[s] = v ? L.dprA + aidx(c, 0) : L.dummy;
+    dstn[s] = v ? (KIND == 1 ? L.n2 : L.n3) + aidx(c, 0) : L.dummy;
+  }
+  // stage-2 strip
+  const int cb = gb * 64 + lane;
+  const bool vb = MB != M_NONE && cb < H;
+  const uint32_t ob = vb ? cb * 4 : kBufOob, obh = vb ? (H2 + cb) * 4 : kBufOob;
+  const float* n2s = L.n2 + aidx(vb ? cb : 0, 0);
+  const float* n3s = L.n3 + aidx(vb ? cb : 0, 0);
+  float* dphd = vb ? L.dphA + aidx(cb, 0) : L.dummy;
+  float* dpzd = vb ? L.dpzA + aidx(cb, 0) : L.dummy;
   uint32_t rb[4];   // row * W (the launcher keeps n*W*3H below 2^30)
   bool rok[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    rok[j] = b0 + j < n;
+    rok[j] = b0 + j < n && !(g.dbg & 1);
     rb[j] = (uint32_t)min(b0 + j, n - 1) * (uint32_t)W;
   }
   RowMasks rm;
-  if (S2 != 0) rm.init(g.gmask, b0, n, W, lane);
+  if (MB != M_NONE) rm.init(g.gmask, b0, n, W, lane);
 
   // element-wise head of step t for the (row, column) elements this lane owns in stage 2
   float n1[4] = {0.f, 0.f, 0.f, 0.f};
+  float kz[4] = {0.f, 0.f, 0.f, 0.f}, kh[4] = {0.f, 0.f, 0.f, 0.f};   // values handed to stores (see keep())
+  float kr[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   auto head = [&](int t, const float (&dh)[4], const float (&z)[4], const float (&hh)[4], const float (&hp)[4]) {
     rm.seek(t);
 #pragma unroll
@@ -410,25 +527,23 @@ __device__ __forceinline__ void gru4_bwd_loop(const Gru4Bwd& g, const Gru4BwdLds
       const float dph = dhn * (1.0f - z[j]) * (1.0f - hh[j] * hh[j]);
       const float dpz = dhn * (hp[j] - hh[j]) * hs_grad4(z[j]);
       n1[j] = (m ? 0.f : dh[j]) + dhn * z[j];
-      if (vs2) {
-        L.dphA[aidx(cs2, j)] = dph;
-        L.dpzA[aidx(cs2, j)] = dpz;
-      }
-      if (rok[j]) {
-        buf_store1(dpz, rdg, o2, (rb[j] + t) * H3 * 4);
-        buf_store1(dph, rdg, o2h, (rb[j] + t) * H3 * 4);
-      }
+      dphd[j * 4] = dph;
+      dpzd[j * 4] = dpz;
+      kz[j] = dpz;
+      kh[j] = dph;
+      buf_store1(kz[j], rdg, rok[j] ? ob : kBufOob, (rb[j] + t) * H3 * 4);
+      buf_store1(kh[j], rdg, rok[j] ? obh : kBufOob, (rb[j] + t) * H3 * 4);
     }
   };
-  if (S2 != 0) {
+  if (MB != M_NONE) {
     float dh[4], z[4], hh[4], hp[4];
     const int t = W - 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      dh[j] = (rok[j] && vs2) ? g.dh_last[(size_t)(b0 + j) * H + cs2] : 0.f;
-      z[j] = buf_load1(rzr, o2, (rb[j] + t) * H2 * 4);
-      hh[j] = buf_load1(rhh, o2, (rb[j] + t) * H * 4);
-      hp[j] = buf_load1(rhp, o2, (rb[j] + t) * H * 4);
+      dh[j] = (b0 + j < n && vb) ? g.dh_last[(size_t)(b0 + j) * H + cb] : 0.f;
+      z[j] = buf_load1(rzr, ob, (rb[j] + t) * H2 * 4);
+      hh[j] = buf_load1(rhh, ob, (rb[j] + t) * H * 4);
+      hp[j] = buf_load1(rhp, ob, (rb[j] + t) * H * 4);
     }
     head(t, dh, z, hh, hp);
   }
@@ -436,55 +551,75 @@ __device__ __forceinline__ void gru4_bwd_loop(const Gru4Bwd& g, const Gru4BwdLds
 
   for (int t = W - 1; t >= 0; --t) {
     // ---- stage 1 ----
-    if (S1 == 1 || S1 == 3) {
-      float r[4], hp[4];
+    if (NA > 0) {
+      float r[2][4], hp[2][4];
+      if (KIND == 1) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        r[j] = buf_load1(rzr, o1r, (rb[j] + t) * H2 * 4);
-        hp[j] = buf_load1(rhp, o1, (rb[j] + t) * H * 4);
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            r[s][j] = buf_load1(rzr, oar[s], (rb[j] + t) * H2 * 4);
+            hp[s][j] = buf_load1(rhp, oa[s], (rb[j] + t) * H * 4);
+          }
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads in front of the MFMA stream
       }
-      __builtin_amdgcn_sched_barrier(0);   // keep the loads in front of the MFMA stream
-      const f32x4 acc = S1 == 1 ? strip_mix<KQ, QR>(ub, L.tail, L.dphA, lane) : strip_lds<KQ>(L.u1, L.q1, L.dphA, lane);
+      f32x4 acc[2];
+      run_strips<KQ, bwd_slot1(KQ), MA0, MA1>(u0, u1, MA1 == M_RES ? L.tail : L.la, KIND == 1 ? L.dphA : L.dpzA, lane, acc[0], acc[1]);
+      if (MB != M_NONE) {   // the head's dz / dh stores were issued a whole product ago
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float drh = acc[j];
-        const float dpr = drh * hp[j] * hs_grad4(r[j]);
-        if (vs1) {
-          L.dprA[aidx(cs1, j)] = dpr;
-          L.n2[j * H + cs1] = drh * r[j];
+        for (int j = 0; j < 4; ++j) { keep(kz[j]); keep(kh[j]); }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (s == 0 ? MA0 == M_NONE : MA1 == M_NONE) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (KIND == 1) {
+            const float drh = acc[s][j];
+            const float dpr = drh * hp[s][j] * hs_grad4(r[s][j]);
+            dsta[s][j * 4] = dpr;
+            dstn[s][j * 4] = drh * r[s][j];
+            kr[s][j] = dpr;
+            buf_store1(kr[s][j], rdg, rok[j] ? oar[s] : kBufOob, (rb[j] + t) * H3 * 4);
+          } else {
+            dstn[s][j * 4] = acc[s][j];
+          }
         }
-        if (rok[j]) buf_store1(dpr, rdg, o1r, (rb[j] + t) * H3 * 4);
       }
-    } else if (S1 == 2 || S1 == 4) {
-      const f32x4 acc = S1 == 2 ? strip_mix<KQ, QR>(ub, L.tail, L.dpzA, lane) : strip_lds<KQ>(L.u1, L.q1, L.dpzA, lane);
-      if (vs1) {
+    } else if (MB != M_NONE) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) L.n3[j * H + cs1] = acc[j];
-      }
+      for (int j = 0; j < 4; ++j) { keep(kz[j]); keep(kh[j]); }
     }
     __syncthreads();
     // ---- stage 2 (+ the element-wise head of step t-1) ----
-    if (S2 != 0) {
+    if (MB != M_NONE) {
       float z[4], hh[4], hp[4];
       const int tp = max(t - 1, 0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        z[j] = buf_load1(rzr, o2, (rb[j] + tp) * H2 * 4);
-        hh[j] = buf_load1(rhh, o2, (rb[j] + tp) * H * 4);
-        hp[j] = buf_load1(rhp, o2, (rb[j] + tp) * H * 4);
+        z[j] = buf_load1(rzr, ob, (rb[j] + tp) * H2 * 4);
+        hh[j] = buf_load1(rhh, ob, (rb[j] + tp) * H * 4);
+        hp[j] = buf_load1(rhp, ob, (rb[j] + tp) * H * 4);
       }
       __builtin_amdgcn_sched_barrier(0);
-      const f32x4 acc = S2 == 1 ? strip_mix<KQ, QR>(ub, L.tail, L.dprA, lane) : strip_lds<KQ>(L.u2, L.q2, L.dprA, lane);
+      f32x4 acc, unused;
+      run_strips<KQ, bwd_slot1(KQ), M_NONE, MB>(u0, u1, MB == M_RES ? L.tail : L.lb, L.dprA, lane, unused, acc);
       float dh[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dh[j] = vs2 ? n1[j] + L.n2[j * H + cs2] + L.n3[j * H + cs2] + acc[j] : 0.f;
+      for (int j = 0; j < 4; ++j) dh[j] = n1[j] + n2s[j * 4] + n3s[j * 4] + acc[j];
       if (t > 0) {
         head(t - 1, dh, z, hh, hp);
-      } else if (vs2) {
+      } else if (vb) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (rok[j]) g.dh0[(size_t)(b0 + j) * H + cs2] = dh[j];
+          if (b0 + j < n) g.dh0[(size_t)(b0 + j) * H + cb] = dh[j];
       }
+    }
+    if (KIND == 1 && NA > 0) {   // this step's dr stores were issued a whole product ago
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep(kr[s][j]);
     }
     __syncthreads();
   }
@@ -498,71 +633,79 @@ __global__ __launch_bounds__(G4_THREADS) void gru4_bwd_kernel(Gru4Bwd g) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G2 = cdiv(H, 64);
   const int w2 = G2 >= 3 ? min(64, H - 128) : 0, w3 = G2 >= 4 ? H - 192 : 0;
-  const int H4 = (4 * H + 3) & ~3;
-  constexpr int QR = bwd_resident_quads(KQ);
-  Gru4BwdLds L;
+  BwdLds L;
   L.dphA = smem;                    // dpre_h, A image
-  L.dpzA = L.dphA + KQ * 16;        // dpre_z
-  L.dprA = L.dpzA + KQ * 16;        // dpre_r
-  L.n2 = L.dprA + KQ * 16;          // drh * r          [4][H]
-  L.n3 = L.n2 + H4;                 // dpre_z . U_z^T   [4][H]
-  float* Lr2 = L.n3 + H4;                    // itr[:, 128:128+w2]   [KQ][w2][4]
-  float* Lh3 = Lr2 + (size_t)KQ * w2 * 4;    // ith[:, 192:H]
-  float* Lz3 = Lh3 + (size_t)KQ * w3 * 4;    // itz[:, 192:H]
-  float* Lr3 = Lz3 + (size_t)KQ * w3 * 4;    // itr[:, 192:H]
-  float* tailL = Lr3 + (size_t)KQ * w3 * 4 + (size_t)wv * (KQ - QR) * 256 + lane * 4;   // this lane's resident tail
+  L.dpzA = L.dphA + KQ * 16;        // dpre_z, A image
+  L.dprA = L.dpzA + KQ * 16;        // dpre_r, A image
+  L.n2 = L.dprA + KQ * 16;          // drh * r          (same layout)
+  L.n3 = L.n2 + KQ * 16;            // dpre_z . U_z^T
+  L.dummy = L.n3 + KQ * 16;
+  constexpr int KQP = kqp(KQ);
+  float* Lr2 = L.dummy + 16;                  // itr[:, 128:128+w2]   [w2][KQP][4]
+  float* Lh3 = Lr2 + (size_t)KQP * w2 * 4;    // ith[:, 192:H]
+  float* Lz3 = Lh3 + (size_t)KQP * w3 * 4;    // itz[:, 192:H]
+  float* Lr3 = Lz3 + (size_t)KQP * w3 * 4;    // itr[:, 192:H]
+  constexpr int QR1 = bwd_slot1(KQ);
+  float* tailL = Lr3 + (size_t)KQP * w3 * 4 + (size_t)wv * (KQ - QR1) * 256 + lane * 4;   // slot-1 tail of this lane
   L.tail = tailL;
 
-  for (int i = tid; i < 3 * KQ * 16 + 2 * H4; i += G4_THREADS) smem[i] = 0.f;
+  for (int i = tid; i < 5 * KQ * 16 + 16; i += G4_THREADS) smem[i] = 0.f;
   for (int i = tid; i < KQ * w2; i += G4_THREADS) {
     const int q = i / w2, c = i - q * w2;
-    ((float4*)Lr2)[i] = ((const float4*)g.itr)[(size_t)q * H + 128 + c];
+    ((float4*)Lr2)[c * KQP + q] = ((const float4*)g.itr)[(size_t)q * H + 128 + c];
   }
   for (int i = tid; i < KQ * w3; i += G4_THREADS) {
     const int q = i / w3, c = i - q * w3;
-    ((float4*)Lh3)[i] = ((const float4*)g.ith)[(size_t)q * H + 192 + c];
-    ((float4*)Lz3)[i] = ((const float4*)g.itz)[(size_t)q * H + 192 + c];
-    ((float4*)Lr3)[i] = ((const float4*)g.itr)[(size_t)q * H + 192 + c];
+    ((float4*)Lh3)[c * KQP + q] = ((const float4*)g.ith)[(size_t)q * H + 192 + c];
+    ((float4*)Lz3)[c * KQP + q] = ((const float4*)g.itz)[(size_t)q * H + 192 + c];
+    ((float4*)Lr3)[c * KQP + q] = ((const float4*)g.itr)[(size_t)q * H + 192 + c];
   }
 
-  // ---- roles (wave-uniform): strip j of a product covers hidden columns 64j .. 64j+63 ----
-  //   stage 1: drh strips on waves {0,1,2,6}, part_z strips on waves {3,4,5,7}; stage 2: strips on waves {6,7,0,1}.
-  //   resident: drh 0..2, part_z 0..2, stage-2 0..1;  LDS: drh 3, part_z 3, stage-2 2 and 3.
-  int s1 = 0, s1grp = 0;
-  if (wv <= 2) { s1 = 1; s1grp = wv; }
-  else if (wv <= 5) { s1 = 2; s1grp = wv - 3; }
-  else if (wv == 6) { s1 = 3; s1grp = 3; }
-  else { s1 = 4; s1grp = 3; }
-  if (s1grp >= G2) s1 = 0;
-  const int s2grp = wv >= 6 ? wv - 6 : (wv <= 1 ? wv + 2 : 99);
-  const int s2 = s2grp >= G2 ? 0 : (s2grp < 2 ? 1 : 2);
-  const bool s1res = s1 == 1 || s1 == 2;
-  L.u1 = (s1 == 3 ? Lh3 : Lz3) + (size_t)min(lane, max(w3 - 1, 0)) * 4;
-  L.q1 = w3 * 4;
-  L.u2 = s2grp == 2 ? Lr2 + (size_t)min(lane, max(w2 - 1, 0)) * 4 : Lr3 + (size_t)min(lane, max(w3 - 1, 0)) * 4;
-  L.q2 = (s2grp == 2 ? w2 : w3) * 4;
+  // ---- roles (wave-uniform) ----
+  const int kind = (wv & 1) ? 2 : 1;           // waves 0, 2: drh; waves 1, 3: part_z
+  const int ga = wv < 2 ? 0 : 2;               // first stage-1 strip
+  const int gb = wv >= 2 ? wv - 2 : wv + 2;    // stage-2 strip
+  const int ma0 = ga < G2 ? M_RES : M_NONE;
+  const int ma1 = ga + 1 < G2 ? (wv < 2 ? M_RES : M_LDS) : M_NONE;
+  const int mb = gb < G2 ? (wv >= 2 ? M_RES : M_LDS) : M_NONE;
+  L.la = (kind == 1 ? Lh3 : Lz3) + (size_t)min(lane, max(w3 - 1, 0)) * KQP * 4;
+  L.lb = gb == 2 ? Lr2 + (size_t)min(lane, max(w2 - 1, 0)) * KQP * 4 : Lr3 + (size_t)min(lane, max(w3 - 1, 0)) * KQP * 4;
 
-  float4 ub[QR];
+  float4 u0[KQ], u1[QR1];
   {
-    const int cs1 = s1grp * 64 + lane, cs2 = s2grp * 64 + lane;
-    const float4* src = s1res ? (const float4*)(s1 == 1 ? g.ith : g.itz) : (const float4*)g.itr;
-    const bool ok = s1res ? cs1 < H : (s2 == 1 && cs2 < H);
-    const int col = ok ? (s1res ? cs1 : cs2) : 0;
+    const float4* simg = (const float4*)(kind == 1 ? g.ith : g.itz);
+    const int ca = ga * 64 + lane;
+    const bool oka = ma0 == M_RES && ca < H;
+    // slot 1: second stage-1 strip (waves 0, 1) or the stage-2 strip (waves 2, 3)
+    const float4* sb = wv < 2 ? simg : (const float4*)g.itr;
+    const int cbb = wv < 2 ? (ga + 1) * 64 + lane : gb * 64 + lane;
+    const bool okb = (wv < 2 ? ma1 == M_RES : mb == M_RES) && cbb < H;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
-      float4 v = src[(size_t)q * H + col];
-      v = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < QR) ub[q] = v;
-      else *(float4*)(tailL + (q - QR) * 256) = v;
+      const float4 va = simg[(size_t)q * H + (oka ? ca : 0)];
+      float4 vb = sb[(size_t)q * H + (okb ? cbb : 0)];
+      vb = okb ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
+      u0[q] = oka ? va : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < QR1) u1[q < QR1 ? q : 0] = vb;
+      else *(float4*)(tailL + (q - QR1) * 256) = vb;
     }
   }
   __syncthreads();
 
-#define LSTUR_ROLE(A, B) \
-  if (s1 == A && s2 == B) gru4_bwd_loop<KQ, A, B>(g, L, s1grp, s2grp, lane, ub); else
-  LSTUR_ROLE(1, 2) LSTUR_ROLE(1, 0) LSTUR_ROLE(2, 0) LSTUR_ROLE(3, 1) LSTUR_ROLE(4, 1) LSTUR_ROLE(0, 1)
-  gru4_bwd_loop<KQ, 0, 0>(g, L, s1grp, s2grp, lane, ub);
+#define LSTUR_ROLE(K, A0, A1, B) \
+  if (kind == K && ma0 == A0 && ma1 == A1 && mb == B) gru4_bwd_loop<KQ, K, A0, A1, B>(g, L, ga, gb, lane, u0, u1); else
+#define LSTUR_ROLES(K)                                                                                      \
+  LSTUR_ROLE(K, M_RES, M_RES, M_LDS) LSTUR_ROLE(K, M_RES, M_RES, M_NONE) LSTUR_ROLE(K, M_RES, M_NONE, M_NONE) \
+  LSTUR_ROLE(K, M_RES, M_LDS, M_RES) LSTUR_ROLE(K, M_RES, M_NONE, M_RES) LSTUR_ROLE(K, M_NONE, M_NONE, M_RES)
+  LSTUR_ROLES(1) LSTUR_ROLES(2)
+  gru4_bwd_loop<KQ, 1, M_NONE, M_NONE, M_NONE>(g, L, ga, gb, lane, u0, u1);
+#undef LSTUR_ROLES
 #undef LSTUR_ROLE
+}
+
+static int gru4_dbg() {
+  const char* e = getenv("LSTUR_GRU4_DEBUG");
+  return e ? atoi(e) : 0;
 }
 
 // ---- launchers -------------------------------------------------------------------------------------
@@ -574,9 +717,8 @@ static void set_lds(K kern, size_t lds) {
 bool gru4_supported(int H) {
   const int KQ = gru4_kq(H);
   if (!KQ) return false;
-  const int G1 = cdiv(2 * H, 64), G2 = cdiv(H, 64);
-  const int NL = std::max(0, std::min(G2, G1 - 4));
-  return G1 <= 8 && G2 <= 4 && NL * 64 <= H && gru4_fwd_lds(H, KQ) <= G4_LDS_MAX && gru4_bwd_lds(H, KQ) <= G4_LDS_MAX;
+  const FwdPlan p(H);
+  return p.G1 <= 7 && p.G2 <= 4 && gru4_fwd_lds(H, KQ) <= G4_LDS_MAX && gru4_bwd_lds(H, KQ) <= G4_LDS_MAX;
 }
 
 void gru4_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh) {
@@ -589,7 +731,7 @@ void launch_gru4_fwd(const float* xw, const uint8_t* gmask, const float* h0, con
                      int n, int W, int H, hipStream_t s) {
   const int KQ = gru4_kq(H);
   const size_t e = (size_t)n * W * H, ie = (size_t)KQ * 4 * H;
-  Gru4Fwd a{xw, gmask, h0, img, img + 2 * ie, tape, tape + 2 * e, tape + 3 * e, tape + 4 * e, hlast, n, W, H};
+  Gru4Fwd a{xw, gmask, h0, img, img + 2 * ie, tape, tape + 2 * e, tape + 3 * e, tape + 4 * e, hlast, n, W, H, gru4_dbg()};
   const size_t lds = gru4_fwd_lds(H, KQ);
   const dim3 grid(cdiv(n, 4)), block(G4_THREADS);
 #define LSTUR_G4F(Q)                                              \
@@ -605,7 +747,8 @@ void launch_gru4_bwd(const float* dh_last, const uint8_t* gmask, float* tape, co
                      float* hprev, float* dh0, int n, int W, int H, hipStream_t s) {
   const int KQ = gru4_kq(H);
   const size_t e = (size_t)n * W * H, ie = (size_t)KQ * 4 * H;
-  Gru4Bwd a{dh_last, gmask, tape, tape + 2 * e, tape + 3 * e, img + 3 * ie, img + 4 * ie, img + 5 * ie, dgates, dh0, n, W, H};
+  Gru4Bwd a{dh_last, gmask, tape, tape + 2 * e, tape + 3 * e, img + 3 * ie, img + 4 * ie, img + 5 * ie, dgates, dh0,
+            n, W, H, gru4_dbg()};
   const size_t lds = gru4_bwd_lds(H, KQ);
   const dim3 grid(cdiv(n, 4)), block(G4_THREADS);
 #define LSTUR_G4B(Q)                                              \
