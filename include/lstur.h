@@ -46,6 +46,12 @@ enum lstur_arch {            /* user encoders of Seq2VecPaperSoftmaxId.get_user_
                                 id-less Seq2VecPaperSoftmax, paper.py:206-208); user arguments are ignored     */
 };
 
+enum lstur_head {            /* scorer + loss on top of (user_vec, doc_vec) */
+  LSTUR_HEAD_SOFTMAX = 0,    /* listwise: dot, softmax over K1 candidates, categorical_crossentropy  paper.py:446-464,658 */
+  LSTUR_HEAD_POINT_MLP = 1,  /* pointwise sibling: concat -> Dense(U,relu) -> Dense(1,sigmoid)      paper.py:223-227   */
+  LSTUR_HEAD_POINT_DOT = 2   /* pointwise sibling: sigmoid(u . d)  (Seq2VecPaperDot)                paper.py:258-262   */
+};                           /* pointwise loss: Seq2Vec.loss, task/seq2vec.py:213-216 (needs cands == 1)               */
+
 typedef struct lstur_cfg {
   int32_t max_batch;         /* largest n passed to train_step (-b)                                    */
   int32_t window;            /* W  history length (-w / window_size)                                   */
@@ -61,6 +67,9 @@ typedef struct lstur_cfg {
   float dropout;             /* -d, applied after the embedding and before the attention, paper.py:147,158 */
   uint32_t seed;             /* dropout stream seed                                                    */
   float beta1, beta2, eps;   /* Keras Adam defaults .9 / .999 / 1e-7 (paper.py:657)                    */
+  int32_t head;              /* lstur_head; 0 = the listwise model                                     */
+  float gain;                /* pointwise loss: weight of the positive term (-g / --gain)              */
+  int32_t loss_negatives;    /* pointwise loss: K = negative_samples of Seq2Vec.loss (-n)              */
 } lstur_cfg;
 
 /* Sizes (in floats unless named _bytes) the caller must allocate for a configuration. */
@@ -99,6 +108,7 @@ int lstur_query_sizes(const lstur_cfg* cfg, lstur_sizes* out);
  *   dense_w [F,U], dense_b [U]            Dense(U)          paper.py:159
  *   gru_w [U,3H], gru_u [H,3H], gru_b [3H] GRU (z|r|h)      paper.py:597-613
  *   con_w [H+Ue,U], con_b [U]             Dense after concat (arch gru only) paper.py:599
+ *   score_w1 [2U,U], score_b1 [U], score_w2 [U], score_b2 [1]   concat_dense / socre_dense (head POINT_MLP) paper.py:223-227
  * Returns offset/count in floats; LSTUR_ERR_ARG for an unknown name. */
 int lstur_param(const lstur_cfg* cfg, const char* name, size_t* offset, size_t* count);
 /* i-th parameter name in bucket order, NULL past the end. */
@@ -146,6 +156,21 @@ int lstur_predict_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_i
 /* model.evaluate_generator step (main.py:83-87): forward only, no dropout; stats as above. */
 int lstur_evaluate(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands,
                    int32_t n, float* stats, lstur_stream stream);
+
+/* Pointwise sibling (Seq2VecPaper / Seq2VecPaperDot / Seq2VecPaperId, paper.py:228-256, 356-383; contexts created
+ * with head POINT_MLP or POINT_DOT and cands == 1): one candidate and one label per sample.
+ *   user int32 [n]; hist int32 [n,W,T]; cand int32 [n,T]; labels float [n] in {0,1}
+ *   stats = 2 device floats: Seq2Vec.loss (task/seq2vec.py:213-216) and the fraction of (p > 0.5) == label;
+ *   the probabilities of the last call are readable through lstur_peek("probs") for the host-side AUC metric.
+ * lstur_predict(_ids) returns the scorer's sigmoid output for these heads; lstur_adam_step is shared. */
+int lstur_point_forward_backward(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cand,
+                                 const float* labels, int32_t n, uint32_t step, float grad_scale, float* stats,
+                                 lstur_stream stream);
+int lstur_point_forward_backward_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_ids,
+                                     const int32_t* cand_ids, const float* labels, int32_t n, uint32_t step,
+                                     float grad_scale, float* stats, lstur_stream stream);
+int lstur_point_evaluate(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cand,
+                         const float* labels, int32_t n, float* stats, lstur_stream stream);
 
 /* Measurement (bench.py): when enabled, each kernel family of the step is bracketed by HIP events on
  * the launch stream.  lstur_profile(ctx, 1) also resets the counters.  lstur_profile_read SYNCHRONISES on

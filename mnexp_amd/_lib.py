@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblstur_hip.so')
 
 ARCH = {'igru': 0, 'gru': 1, 'hgru': 2, 'nigru': 3}
+HEAD = {'softmax': 0, 'point_mlp': 1, 'point_dot': 2}
 
 
 class LsturError(RuntimeError):
@@ -21,7 +22,8 @@ class LsturError(RuntimeError):
 class Cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('max_batch', 'window', 'title_len', 'cands', 'vocab', 'word_dim',
                                          'filters', 'kernel', 'user_dim', 'n_users', 'arch')] + [
-        ('dropout', C.c_float), ('seed', C.c_uint32), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float)]
+        ('dropout', C.c_float), ('seed', C.c_uint32), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
+        ('head', C.c_int32), ('gain', C.c_float), ('loss_negatives', C.c_int32)]
 
 
 class Sizes(C.Structure):
@@ -55,6 +57,9 @@ SIGNATURES = {
     'lstur_predict': (_I, [_P, _P, _P, _P, _I, _P, _P]),
     'lstur_predict_ids': (_I, [_P, _P, _P, _P, _I, _P, _P]),
     'lstur_evaluate': (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    'lstur_point_forward_backward': (_I, [_P, _P, _P, _P, _P, _I, _U, _F, _P, _P]),
+    'lstur_point_forward_backward_ids': (_I, [_P, _P, _P, _P, _P, _I, _U, _F, _P, _P]),
+    'lstur_point_evaluate': (_I, [_P, _P, _P, _P, _P, _I, _P, _P]),
     'lstur_profile': (_I, [_P, _I]),
     'lstur_profile_read': (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_F), C.POINTER(_I)]),
     'lstur_peek': (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_Z)]),
@@ -105,11 +110,14 @@ def check(rc, what=''):
 
 
 def make_cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
-             arch='igru', dropout=0.0, seed=0, beta1=0.9, beta2=0.999, eps=1e-7):
+             arch='igru', dropout=0.0, seed=0, beta1=0.9, beta2=0.999, eps=1e-7, head='softmax', gain=1.0,
+             loss_negatives=4):
     if arch not in ARCH:
         raise LsturError('arch {!r} is not supported by the native path (have {})'.format(arch, sorted(ARCH)))
+    if head not in HEAD:
+        raise LsturError('head {!r} is not supported by the native path (have {})'.format(head, sorted(HEAD)))
     return Cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
-               ARCH[arch], dropout, seed, beta1, beta2, eps)
+               ARCH[arch], dropout, seed, beta1, beta2, eps, HEAD[head], gain, loss_negatives)
 
 
 def query_sizes(cfg):

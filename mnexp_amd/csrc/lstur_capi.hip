@@ -30,7 +30,7 @@ struct ParamSlot {
 };
 
 struct Dims {
-  int B, W, T, K1, V, D, F, k, U, Nu, arch, H, Ue, Tp, KD;
+  int B, W, T, K1, V, D, F, k, U, Nu, arch, H, Ue, Tp, KD, head;
   int nt_max;   // titles per call
   int n_cap;    // per-sample buffers
   int rows_cap; // sparse user-grad rows per adam step
@@ -71,6 +71,25 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     *why = "hgru needs an even user_dim";
     return false;
   }
+  d->head = c->head;
+  if (d->head < LSTUR_HEAD_SOFTMAX || d->head > LSTUR_HEAD_POINT_DOT) {
+    *why = "unknown head";
+    return false;
+  }
+  if (d->head != LSTUR_HEAD_SOFTMAX) {
+    if (d->K1 != 1) {
+      *why = "the pointwise heads take one candidate per sample (cands == 1)";
+      return false;
+    }
+    if (d->arch != LSTUR_ARCH_IGRU && d->arch != LSTUR_ARCH_NIGRU) {
+      *why = "the pointwise heads support arch igru and nigru";
+      return false;
+    }
+    if (!(c->gain > 0.f) || c->loss_negatives < 1) {
+      *why = "pointwise loss needs gain > 0 and loss_negatives >= 1";
+      return false;
+    }
+  }
   if (!(c->dropout >= 0.f && c->dropout < 1.f)) {
     *why = "dropout must be in [0, 1)";
     return false;
@@ -110,6 +129,12 @@ std::vector<ParamSlot> param_layout(const Dims& d, size_t* total) {
     add("con_w", (size_t)(d.H + d.Ue) * d.U);
     add("con_b", d.U);
   }
+  if (d.head == LSTUR_HEAD_POINT_MLP) {
+    add("score_w1", (size_t)2 * d.U * d.U);
+    add("score_b1", d.U);
+    add("score_w2", d.U);
+    add("score_b2", 1);
+  }
   *total = off;
   return v;
 }
@@ -122,6 +147,7 @@ struct Workspace {
   float* cat; float* dcat; float* uservec; float* duser; float* du; float* logits; float* probs; float* loss_i;
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; int32_t* first; float* gsum; int32_t* slot;
+  float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
 };
@@ -141,6 +167,9 @@ size_t max_gemm_scratch(const Dims& d) {
   upd(d.n_cap, d.U, d.H + d.Ue);
   upd(d.H + d.Ue, d.U, d.n_cap);
   upd(d.n_cap, d.H + d.Ue, d.U);
+  upd(d.n_cap, d.U, 2 * d.U);   // pointwise MLP head
+  upd(2 * d.U, d.U, d.n_cap);
+  upd(d.n_cap, 2 * d.U, d.U);
   // split-K slab bound for any smaller runtime batch: (256/tiles + 1) * tiles * 64*64 floats < 8 MiB
   return std::max(m, (size_t)8 << 20);
 }
@@ -192,6 +221,11 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->first = (int32_t*)take((size_t)d.rows_cap * 4);
   w->gsum = (float*)take((size_t)d.rows_cap * d.Ue * f4);
   w->slot = (int32_t*)take((size_t)d.Nu * 4);
+  w->scat = (float*)take(nc * 2 * d.U * f4);
+  w->spre = (float*)take(nc * d.U * f4);
+  w->sds = (float*)take(nc * f4);
+  w->sdhid = (float*)take(nc * d.U * f4);
+  w->sdcat = (float*)take(nc * 2 * d.U * f4);
   w->user_rows = (int32_t*)take(nc * 4);
   w->scores = (float*)take(nc * f4);
   w->colsum_scratch = (float*)take((size_t)kColsumSlices * std::max(std::max(3 * d.H, d.U), (int)(3 * ((d.F + kParamAlign - 1) / kParamAlign * kParamAlign) + 64)) * f4);
@@ -406,6 +440,7 @@ int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
                float grad_scale, float* stats, hipStream_t s, bool ids_form, bool backward, bool training) {
   if (!c || !user || !hist || !cands) return fail(LSTUR_ERR_ARG, "NULL argument");
   const Dims& d = c->d;
+  if (d.head != LSTUR_HEAD_SOFTMAX) return fail(LSTUR_ERR_STATE, "context was created with a pointwise head");
   if (n < 1 || n > d.B) return fail(LSTUR_ERR_ARG, "n must be in [1, max_batch]");
   int rc = stage_titles(c, hist, cands, n, d.K1, ids_form, s);
   if (rc) return rc;
@@ -420,6 +455,53 @@ int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   return check_launch(backward ? "forward_backward" : "evaluate");
 }
 
+// scorer of the pointwise heads on (uservec [n,U], doc vectors of the n candidates); fills logits/probs (+ loss,
+// + gradients wrt both inputs and the head's parameters when `backward`)
+void run_point_head(lstur_ctx* c, const float* labels, int n, float scale, bool with_loss, bool backward, hipStream_t s) {
+  const Dims& d = c->d;
+  Workspace& w = c->ws;
+  const float* dvec = w.docvec + (size_t)n * d.W * d.U;
+  float* ddvec = w.ddocvec + (size_t)n * d.W * d.U;
+  const float gain = c->cfg.gain;
+  const int K = c->cfg.loss_negatives;
+  if (d.head == LSTUR_HEAD_POINT_DOT) {
+    launch_point_dot(w.uservec, dvec, labels, w.logits, w.probs, w.loss_i, w.correct_i, backward ? w.du : nullptr,
+                     backward ? ddvec : nullptr, n, d.U, gain, K, scale, s);
+    return;
+  }
+  launch_concat2(w.uservec, d.U, dvec, d.U, w.scat, n, s);
+  launch_gemm(w.scat, 2 * d.U, 0, c->P("score_w1"), d.U, 0, w.spre, d.U, c->P("score_b1"), n, d.U, 2 * d.U, 1.f,
+              w.gemm_scratch, s);
+  launch_point_mlp_out(w.spre, c->P("score_w2"), c->P("score_b2"), labels, w.logits, w.probs,
+                       with_loss ? w.loss_i : nullptr, w.correct_i, backward ? w.sds : nullptr,
+                       backward ? w.sdhid : nullptr, n, d.U, gain, K, scale, s);
+  if (!backward) return;
+  launch_point_w2_grad(w.spre, w.sds, c->G("score_w2"), c->G("score_b2"), n, d.U, s);
+  launch_gemm(w.scat, 2 * d.U, 1, w.sdhid, d.U, 0, c->G("score_w1"), d.U, nullptr, 2 * d.U, d.U, n, 1.f, w.gemm_scratch,
+              s);
+  launch_colsum2(w.sdhid, n, d.U, d.U, c->G("score_b1"), 1.f, w.colsum_scratch, s);
+  launch_gemm(w.sdhid, d.U, 0, c->P("score_w1"), d.U, 1, w.sdcat, 2 * d.U, nullptr, n, 2 * d.U, d.U, 1.f,
+              w.gemm_scratch, s);
+  launch_split2(w.sdcat, d.U, d.U, w.du, ddvec, n, s);
+}
+
+int point_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int32_t* cand, const float* labels, int n,
+               uint32_t step, float grad_scale, float* stats, hipStream_t s, bool ids_form, bool backward,
+               bool training) {
+  if (!c || !user || !hist || !cand || !labels) return fail(LSTUR_ERR_ARG, "NULL argument");
+  const Dims& d = c->d;
+  if (d.head == LSTUR_HEAD_SOFTMAX) return fail(LSTUR_ERR_STATE, "context was created with the listwise head");
+  if (n < 1 || n > d.B) return fail(LSTUR_ERR_ARG, "n must be in [1, max_batch]");
+  int rc = stage_titles(c, hist, cand, n, 1, ids_form, s);
+  if (rc) return rc;
+  Workspace& w = c->ws;
+  PROF("forward_total", run_forward(c, user, n, 1, training, step, s));
+  run_point_head(c, labels, n, grad_scale / (float)n, true, backward, s);
+  if (stats) launch_mean2(w.loss_i, w.correct_i, n, stats, s);
+  if (backward) PROF("backward_total", run_backward(c, n, step, s));
+  return check_launch(backward ? "point_forward_backward" : "point_evaluate");
+}
+
 int predict_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int32_t* cand, int n, float* scores,
                  hipStream_t s, bool ids_form) {
   if (!c || !user || !hist || !cand || !scores) return fail(LSTUR_ERR_ARG, "NULL argument");
@@ -429,7 +511,16 @@ int predict_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const i
   int rc = stage_titles(c, hist, cand, n, 1, ids_form, s);
   if (rc) return rc;
   run_forward(c, user, n, 1, false, 0, s);
-  launch_predict_score(c->ws.uservec, c->ws.docvec + (size_t)n * d.W * d.U, scores, n, d.U, s);
+  if (d.head == LSTUR_HEAD_POINT_MLP) {   // model.predict of the pointwise model = the scorer's sigmoid output
+    Workspace& w = c->ws;
+    launch_concat2(w.uservec, d.U, w.docvec + (size_t)n * d.W * d.U, d.U, w.scat, n, s);
+    launch_gemm(w.scat, 2 * d.U, 0, c->P("score_w1"), d.U, 0, w.spre, d.U, c->P("score_b1"), n, d.U, 2 * d.U, 1.f,
+                w.gemm_scratch, s);
+    launch_point_mlp_out(w.spre, c->P("score_w2"), c->P("score_b2"), nullptr, w.logits, scores, nullptr, nullptr,
+                         nullptr, nullptr, n, d.U, 1.f, 1, 0.f, s);
+  } else {
+    launch_predict_score(c->ws.uservec, c->ws.docvec + (size_t)n * d.W * d.U, scores, n, d.U, s);
+  }
   return check_launch("predict");
 }
 
@@ -547,6 +638,22 @@ int lstur_forward_backward_ids(lstur_ctx* ctx, const int32_t* user, const int32_
 int lstur_evaluate(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands, int32_t n,
                    float* stats, lstur_stream stream) {
   return train_impl(ctx, user, hist, cands, n, 0, 1.f, stats, (hipStream_t)stream, false, false, false);
+}
+
+int lstur_point_forward_backward(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cand,
+                                 const float* labels, int32_t n, uint32_t step, float grad_scale, float* stats,
+                                 lstur_stream stream) {
+  return point_impl(ctx, user, hist, cand, labels, n, step, grad_scale, stats, (hipStream_t)stream, false, true, true);
+}
+int lstur_point_forward_backward_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_ids,
+                                     const int32_t* cand_ids, const float* labels, int32_t n, uint32_t step,
+                                     float grad_scale, float* stats, lstur_stream stream) {
+  return point_impl(ctx, user, hist_ids, cand_ids, labels, n, step, grad_scale, stats, (hipStream_t)stream, true, true,
+                    true);
+}
+int lstur_point_evaluate(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cand,
+                         const float* labels, int32_t n, float* stats, lstur_stream stream) {
+  return point_impl(ctx, user, hist, cand, labels, n, 0, 1.f, stats, (hipStream_t)stream, false, false, false);
 }
 
 int lstur_user_grad(lstur_ctx* ctx, const int32_t** rows, const float** grads, int32_t* n) {

@@ -84,6 +84,18 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
                         float drop, uint32_t key, hipStream_t s, int ldp = 0, int off_aw = 0, int off_cb = 0,
                         int off_ab = 0);
 
+// ---- pointwise head (misc.hip) --------------------------------------------------------------------
+// point_dot: s = u . d; point_mlp: s = relu(pre) . w2 + b2 (pre = [u|d] W1 + b1 computed by the caller).
+// p = sigmoid(s); loss_i = Seq2Vec.loss term (task/seq2vec.py:213-216); ok_i = ((p > .5) == label);
+// ds = dloss/ds * scale (scale = grad_scale / n).  Backward outputs may be NULL (forward only).
+void launch_point_dot(const float* u, const float* d, const float* labels, float* logits, float* probs, float* loss_i,
+                      float* ok_i, float* du, float* dd, int n, int U, float gain, int K, float scale, hipStream_t s);
+void launch_point_mlp_out(const float* pre, const float* w2, const float* b2, const float* labels, float* logits,
+                          float* probs, float* loss_i, float* ok_i, float* ds, float* dhid, int n, int U, float gain,
+                          int K, float scale, hipStream_t s);
+// dw2[j] = sum_i relu(pre[i][j]) ds[i]; db2 = sum_i ds[i]
+void launch_point_w2_grad(const float* pre, const float* ds, float* dw2, float* db2, int n, int U, hipStream_t s);
+
 // ---- gemm.hip ----------------------------------------------------------------------------------
 size_t gemm_scratch_bytes(int M, int N, int K);
 void launch_gemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, float* C, int ldc,

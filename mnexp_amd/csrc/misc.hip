@@ -528,6 +528,101 @@ void launch_predict_score(const float* u, const float* d, float* scores, int n, 
   if (n) hipLaunchKernelGGL(predict_score_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, u, d, scores, n, U);
 }
 
+// ---- pointwise head: Seq2VecPaper.score_encoder / Seq2VecPaperDot + Seq2Vec.loss -------------------
+//   loss_i = -0.5 (1+K) (y log(p + 1e-8) gain + (1-y) log(1 - p + 1e-8) / K)        task/seq2vec.py:213-216
+// One wave per sample.  ds = dloss_i/ds_i * scale.
+__device__ __forceinline__ void point_loss(float sc, float y, float gain, float K, float scale, float* prob,
+                                           float* loss, float* ok, float* ds) {
+  const float p = 1.0f / (1.0f + expf(-sc));
+  const float c = 0.5f * (1.0f + K), e = 1e-8f;
+  *prob = p;
+  *loss = -c * (y * logf(p + e) * gain + (1.0f - y) * logf(1.0f - p + e) / K);
+  *ok = ((p > 0.5f) == (y > 0.5f)) ? 1.f : 0.f;
+  const float dp = -c * (y * gain / (p + e) - (1.0f - y) / (K * (1.0f - p + e)));
+  *ds = dp * p * (1.0f - p) * scale;
+}
+__global__ __launch_bounds__(256) void point_dot_kernel(const float* __restrict__ u, const float* __restrict__ d,
+                                                        const float* __restrict__ labels, float* __restrict__ logits,
+                                                        float* __restrict__ probs, float* __restrict__ loss_i,
+                                                        float* __restrict__ ok_i, float* __restrict__ du,
+                                                        float* __restrict__ dd, int n, int U, float gain, float K,
+                                                        float scale) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= n) return;
+  float acc = 0.f;
+  for (int c = lane; c < U; c += 64) acc += u[(size_t)b * U + c] * d[(size_t)b * U + c];
+  acc = wave_sum(acc);
+  float p, l, ok, ds;
+  point_loss(acc, labels[b], gain, K, scale, &p, &l, &ok, &ds);
+  if (lane == 0) {
+    logits[b] = acc;
+    probs[b] = p;
+    loss_i[b] = l;
+    ok_i[b] = ok;
+  }
+  if (du)
+    for (int c = lane; c < U; c += 64) {
+      du[(size_t)b * U + c] = ds * d[(size_t)b * U + c];
+      dd[(size_t)b * U + c] = ds * u[(size_t)b * U + c];
+    }
+}
+void launch_point_dot(const float* u, const float* d, const float* labels, float* logits, float* probs, float* loss_i,
+                      float* ok_i, float* du, float* dd, int n, int U, float gain, int K, float scale, hipStream_t s) {
+  if (n)
+    hipLaunchKernelGGL(point_dot_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, u, d, labels, logits, probs, loss_i, ok_i,
+                       du, dd, n, U, gain, (float)K, scale);
+}
+__global__ __launch_bounds__(256) void point_mlp_out_kernel(const float* __restrict__ pre, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2,
+                                                            const float* __restrict__ labels, float* __restrict__ logits,
+                                                            float* __restrict__ probs, float* __restrict__ loss_i,
+                                                            float* __restrict__ ok_i, float* __restrict__ dsv,
+                                                            float* __restrict__ dhid, int n, int U, float gain, float K,
+                                                            float scale) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= n) return;
+  float acc = 0.f;
+  for (int c = lane; c < U; c += 64) acc += fmaxf(pre[(size_t)b * U + c], 0.f) * w2[c];
+  acc = wave_sum(acc) + b2[0];
+  float p, l, ok, ds;
+  point_loss(acc, labels ? labels[b] : 0.f, gain, K, scale, &p, &l, &ok, &ds);
+  if (lane == 0) {
+    logits[b] = acc;
+    probs[b] = p;
+    if (loss_i) {
+      loss_i[b] = l;
+      ok_i[b] = ok;
+    }
+    if (dsv) dsv[b] = ds;
+  }
+  if (dhid)
+    for (int c = lane; c < U; c += 64) dhid[(size_t)b * U + c] = pre[(size_t)b * U + c] > 0.f ? ds * w2[c] : 0.f;
+}
+void launch_point_mlp_out(const float* pre, const float* w2, const float* b2, const float* labels, float* logits,
+                          float* probs, float* loss_i, float* ok_i, float* ds, float* dhid, int n, int U, float gain,
+                          int K, float scale, hipStream_t s) {
+  if (n)
+    hipLaunchKernelGGL(point_mlp_out_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, pre, w2, b2, labels, logits, probs,
+                       loss_i, ok_i, ds, dhid, n, U, gain, (float)K, scale);
+}
+// dw2[j] = sum_i relu(pre[i][j]) ds[i] (samples in ascending order: reproducible); db2 = sum_i ds[i]
+__global__ void point_w2_grad_kernel(const float* __restrict__ pre, const float* __restrict__ ds, float* __restrict__ dw2,
+                                     float* __restrict__ db2, int n, int U) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > U) return;
+  float acc = 0.f;
+  if (j < U) {
+    for (int i = 0; i < n; ++i) acc += fmaxf(pre[(size_t)i * U + j], 0.f) * ds[i];
+    dw2[j] = acc;
+  } else {
+    for (int i = 0; i < n; ++i) acc += ds[i];
+    db2[0] = acc;
+  }
+}
+void launch_point_w2_grad(const float* pre, const float* ds, float* dw2, float* db2, int n, int U, hipStream_t s) {
+  hipLaunchKernelGGL(point_w2_grad_kernel, dim3(cdiv(U + 1, 64)), dim3(64), 0, s, pre, ds, dw2, db2, n, U);
+}
+
 __global__ __launch_bounds__(256) void mean2_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
                                                     float* __restrict__ stats) {
   __shared__ float ra[4], rb[4];

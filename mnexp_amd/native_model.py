@@ -42,30 +42,66 @@ def _orthogonal(rng, rows, cols):
     return np.ascontiguousarray(q[:rows, :cols], dtype=np.float32)
 
 
-class NativeModel:
-    metrics_names = ['loss', 'categorical_accuracy']
+class _TfAuc:
+    """``utils.auc_roc`` of the pointwise models (utils.py:88-103) = ``tf.metrics.auc(y_true, y_pred)`` with its
+    defaults: 200 thresholds, ROC curve, trapezoidal summation, confusion counts ACCUMULATED over the calls until the
+    metric variables are re-initialised (task/seq2vec.py:296-298 does that once per epoch).  Restated from the
+    published TF-1 definition; counts live on the device so a training step never synchronises."""
 
+    def __init__(self, device, num_thresholds=200):
+        k = 1e-7
+        thr = [(i + 1) * 1.0 / (num_thresholds - 1) for i in range(num_thresholds - 2)]
+        self.thr = torch.tensor([0.0 - k] + thr + [1.0 + k], dtype=torch.float32, device=device)
+        self.counts = torch.zeros(4, num_thresholds, dtype=torch.float64, device=device)   # tp, fn, tn, fp
+
+    def reset(self):
+        self.counts.zero_()
+
+    def update(self, labels, probs):
+        y = labels.reshape(-1, 1) > 0.5
+        pred = probs.reshape(-1, 1) > self.thr.reshape(1, -1)
+        self.counts[0] += (pred & y).sum(0)
+        self.counts[1] += (~pred & y).sum(0)
+        self.counts[2] += (~pred & ~y).sum(0)
+        self.counts[3] += (pred & ~y).sum(0)
+
+    def value(self):
+        tp, fn, tn, fp = self.counts.cpu().numpy()
+        eps = 1e-6
+        rec = (tp + eps) / (tp + fn + eps)
+        fpr = fp / (fp + tn + eps)
+        return float(np.sum((fpr[:-1] - fpr[1:]) * (rec[:-1] + rec[1:]) / 2.0))
+
+
+class NativeModel:
     def __init__(self, word_emb, n_users, batch_size, window, title_len, negative_samples, filters, kernel,
                  user_dim, arch='igru', dropout=0.2, lr=1e-3, seed=0, device=None, title_table=None,
-                 dist_group=None, has_user=True):
+                 dist_group=None, has_user=True, head='softmax', gain=1.0):
         if not torch.cuda.is_available():
             raise _lib.LsturError('no GPU visible: the native LSTUR model has no CPU fallback')
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
         torch.cuda.set_device(self.device)
         word_emb = np.ascontiguousarray(word_emb, dtype=np.float32)
         V, D = word_emb.shape
-        self.W, self.T, self.K1, self.B = window, title_len, negative_samples + 1, batch_size
+        self.head = head
+        self.pointwise = head != 'softmax'          # one candidate + one label per sample (SURVEY a16)
+        self.W, self.T, self.B = window, title_len, batch_size
+        self.K1 = 1 if self.pointwise else negative_samples + 1
+        self.metrics_names = ['loss', 'auc_roc'] if self.pointwise else ['loss', 'categorical_accuracy']
         self.arch = arch
         self.has_user = has_user       # False: id-less task (Seq2VecPaperSoftmax), inputs carry no user column
         self.cfg = _lib.make_cfg(batch_size, window, title_len, self.K1, V, D, filters, kernel, user_dim,
-                                 max(1, n_users), arch, dropout, seed)
+                                 max(1, n_users), arch, dropout, seed, head=head, gain=gain,
+                                 loss_negatives=max(1, negative_samples))
         self.sizes = _lib.query_sizes(self.cfg)
         self.layout = _lib.param_layout(self.cfg)
         H, Ue = self.sizes.gru_dim, self.sizes.user_emb_dim
         self.shapes = dict(conv_w=(kernel, D, filters), conv_b=(filters,), att_w=(filters,), att_b=(1,),
                            dense_w=(filters, user_dim), dense_b=(user_dim,), gru_w=(user_dim, 3 * H),
                            gru_u=(H, 3 * H), gru_b=(3 * H,), con_w=(H + Ue, user_dim), con_b=(user_dim,),
-                           user_emb=(max(1, n_users), Ue), word_emb=(V, D))
+                           user_emb=(max(1, n_users), Ue), word_emb=(V, D),
+                           score_w1=(2 * user_dim, user_dim), score_b1=(user_dim,), score_w2=(user_dim,),
+                           score_b2=(1,))
         dev = self.device
         f32 = torch.float32
         self.word_emb = torch.from_numpy(word_emb).to(dev)
@@ -96,6 +132,7 @@ class NativeModel:
         self.title_table = None
         if title_table is not None:
             self.set_title_table(title_table)
+        self.auc = _TfAuc(dev) if self.pointwise else None
         self._init_weights(np.random.RandomState(seed))
 
     # ---- construction from a task handler ----------------------------------------
@@ -148,6 +185,11 @@ class NativeModel:
         if self.arch == 'gru':
             w['con_w'] = _glorot(rng, s['con_w'], s['con_w'][0], U)
             w['con_b'] = np.zeros(U, np.float32)
+        if self.head == 'point_mlp':     # concat_dense / socre_dense (paper.py:223-227)
+            w['score_w1'] = _glorot(rng, s['score_w1'], 2 * U, U)
+            w['score_b1'] = np.zeros(U, np.float32)
+            w['score_w2'] = _glorot(rng, s['score_w2'], U, 1)
+            w['score_b2'] = np.zeros(1, np.float32)
         self.set_weights(w)
 
     def param_names(self):
@@ -197,6 +239,12 @@ class NativeModel:
         base = self.workspace.data_ptr()
         off = ptr - base
         return self.workspace[off:off + count * esz].view(dtype)
+
+    def peek_device(self, name):
+        """Device view (no copy, no sync) of an intermediate of the last call."""
+        ptr, cnt = C.c_void_p(), C.c_size_t()
+        check(lib.lstur_peek(self._ctx, name.encode(), C.byref(ptr), C.byref(cnt)), 'lstur_peek')
+        return self._peek_ptr(ptr.value, cnt.value, torch.float32)
 
     def peek(self, name):
         ptr, cnt = C.c_void_p(), C.c_size_t()
@@ -285,12 +333,23 @@ class NativeModel:
         return user, hist, cands
 
     # ---- training ---------------------------------------------------------------------
-    def _train_step(self, user, hist, cands, ids_form):
+    def _dev_f32(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.float32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.float32)).to(self.device, non_blocking=True)
+
+    def _train_step(self, user, hist, cands, ids_form, labels=None):
         n = int(user.shape[0])
-        fn = lib.lstur_forward_backward_ids if ids_form else lib.lstur_forward_backward
         s = self._stream()
-        check(fn(self._ctx, user.data_ptr(), hist.data_ptr(), cands.data_ptr(), n, self.step, 1.0 / self.world,
-                 self.stats.data_ptr(), s), 'lstur_forward_backward')
+        if self.pointwise:
+            fn = lib.lstur_point_forward_backward_ids if ids_form else lib.lstur_point_forward_backward
+            check(fn(self._ctx, user.data_ptr(), hist.data_ptr(), cands.data_ptr(), labels.data_ptr(), n, self.step,
+                     1.0 / self.world, self.stats.data_ptr(), s), 'lstur_point_forward_backward')
+            self.auc.update(labels, self.peek_device('probs')[:n])
+        else:
+            fn = lib.lstur_forward_backward_ids if ids_form else lib.lstur_forward_backward
+            check(fn(self._ctx, user.data_ptr(), hist.data_ptr(), cands.data_ptr(), n, self.step, 1.0 / self.world,
+                     self.stats.data_ptr(), s), 'lstur_forward_backward')
         self.optimizer.iterations += 1
         t = self.optimizer.iterations
         if self.world > 1 or self.force_collectives:
@@ -316,14 +375,18 @@ class NativeModel:
 
     def train_on_batch(self, X, Y=None):
         user, hist, cands = self._split_reference_x(X, self.K1)
-        self._train_step(user, hist, cands, False)
+        if self.pointwise:
+            self._train_step(user, hist, cands[:, 0].contiguous(), False, self._dev_f32(np.asarray(Y).reshape(-1)))
+        else:
+            self._train_step(user, hist, cands, False)
 
-    def train_on_ids(self, *ids):
-        """(user, hist_ids, cand_ids), or (hist_ids, cand_ids) for an id-less task."""
+    def train_on_ids(self, *ids, labels=None):
+        """(user, hist_ids, cand_ids), or (hist_ids, cand_ids) for an id-less task; pointwise: + labels."""
         if not self.has_user:
             ids = (np.zeros(len(ids[0]), dtype=np.int32),) + tuple(ids)
         user, hist_ids, cand_ids = ids
-        self._train_step(self._dev_i32(user), self._dev_i32(hist_ids), self._dev_i32(cand_ids), True)
+        lab = self._dev_f32(np.asarray(labels).reshape(-1)) if self.pointwise else None
+        self._train_step(self._dev_i32(user), self._dev_i32(hist_ids), self._dev_i32(cand_ids), True, lab)
 
     def fit_generator(self, generator, steps_per_epoch, epochs=1, initial_epoch=0, verbose=2, ids_form=False,
                       **_ignored):
@@ -334,14 +397,16 @@ class NativeModel:
             for _ in range(steps_per_epoch):
                 X, Y = next(generator)
                 if ids_form:
-                    self.train_on_ids(*X)
+                    self.train_on_ids(*X, labels=Y) if self.pointwise else self.train_on_ids(*X)
                 else:
                     self.train_on_batch(X, Y)
             loss, acc = (self.stats_acc / steps_per_epoch).tolist()
+            if self.pointwise:
+                acc = self.auc.value()       # the running tf.metrics.auc value Keras logs for the epoch
             hist.history.setdefault('loss', []).append(loss)
-            hist.history.setdefault('categorical_accuracy', []).append(acc)
+            hist.history.setdefault(self.metrics_names[1], []).append(acc)
             if verbose:
-                logging.info('Epoch %d/%d - loss: %.4f - categorical_accuracy: %.4f', epoch + 1, epochs, loss, acc)
+                logging.info('Epoch %d/%d - loss: %.4f - %s: %.4f', epoch + 1, epochs, loss, self.metrics_names[1], acc)
         return hist
 
     def evaluate_generator(self, generator, steps, verbose=0, ids_form=False, **_ignored):
@@ -353,11 +418,21 @@ class NativeModel:
                 raise NotImplementedError('evaluate on id-form batches: expand with the title table first')
             user, hist, cands = self._split_reference_x(X, self.K1)
             n = int(user.shape[0])
-            check(lib.lstur_evaluate(self._ctx, user.data_ptr(), hist.data_ptr(), cands.data_ptr(), n,
-                                     self.stats.data_ptr(), self._stream()), 'lstur_evaluate')
+            if self.pointwise:
+                labels = self._dev_f32(np.asarray(Y).reshape(-1))
+                check(lib.lstur_point_evaluate(self._ctx, user.data_ptr(), hist.data_ptr(),
+                                               cands[:, 0].contiguous().data_ptr(), labels.data_ptr(), n,
+                                               self.stats.data_ptr(), self._stream()), 'lstur_point_evaluate')
+                self.auc.update(labels, self.peek_device('probs')[:n])
+            else:
+                check(lib.lstur_evaluate(self._ctx, user.data_ptr(), hist.data_ptr(), cands.data_ptr(), n,
+                                         self.stats.data_ptr(), self._stream()), 'lstur_evaluate')
             acc += self.stats * n
             total += n
-        return (acc / max(total, 1)).tolist()
+        out = (acc / max(total, 1)).tolist()
+        if self.pointwise:
+            out[1] = self.auc.value()
+        return out
 
     # ---- inference ------------------------------------------------------------------------
     def _predict(self, user, hist, cand, ids_form):

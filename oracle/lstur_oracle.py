@@ -89,7 +89,10 @@ def orthogonal(rng, rows, cols):
     return q[:rows, :cols]
 
 
-def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.float32):
+HEADS = ("softmax", "point_mlp", "point_dot")
+
+
+def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.float32, head="softmax"):
     """Random-init parameters with the reference's initialisers
     (conv/dense/att: glorot_uniform, biases zero -- paper.py:146,159, models.py:448-449;
     user table uniform +-0.05 -- paper.py:589; GRU kernel glorot, recurrent orthogonal)."""
@@ -114,14 +117,22 @@ def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.fl
     if arch == "gru":
         p["con_w"] = glorot_uniform(rng, (H + Ue, U), H + Ue, U)
         p["con_b"] = np.zeros(U)
+    assert head in HEADS
+    if head == "point_mlp":      # concat_dense / socre_dense of Seq2VecPaper.score_encoder (paper.py:223-227)
+        p["score_w1"] = glorot_uniform(rng, (2 * U, U), 2 * U, U)
+        p["score_b1"] = np.zeros(U)
+        p["score_w2"] = glorot_uniform(rng, (U,), U, 1)
+        p["score_b2"] = np.zeros(1)
     return {n: np.ascontiguousarray(a, dtype=dtype) for n, a in p.items()}
 
 
-def dense_param_names(arch, word_trainable=False):
+def dense_param_names(arch, word_trainable=False, head="softmax"):
     """Order of the flat dense-parameter bucket (same order in the HIP library)."""
     names = ["conv_w", "conv_b", "att_w", "att_b", "dense_w", "dense_b", "gru_w", "gru_u", "gru_b"]
     if arch == "gru":
         names += ["con_w", "con_b"]
+    if head == "point_mlp":
+        names += ["score_w1", "score_b1", "score_w2", "score_b2"]
     return names
 
 
@@ -428,6 +439,105 @@ def predict(p, arch, user, hist, cand):
     u, _ = user_encoder_fwd(p, arch, user, hv, hist)
     z = np.einsum("bu,bu->b", u, dv[:, 0])
     return 1.0 / (1.0 + np.exp(-z))
+
+
+# --------------------------------------------------------------------------
+# pointwise sibling: Seq2VecPaper / Seq2VecPaperDot / Seq2VecPaperId
+# --------------------------------------------------------------------------
+def point_score_fwd(p, head, u, d):
+    """One candidate per row.  point_mlp: Seq2VecPaper.score_encoder (paper.py:223-227): concat -> Dense(U, relu)
+    -> Dense(1, sigmoid); point_dot: Seq2VecPaperDot.score_encoder (paper.py:258-262): sigmoid(u . d)."""
+    if head == "point_dot":
+        s = np.einsum("bu,bu->b", u, d)
+        cache = None
+    else:
+        cat = np.concatenate([u, d], axis=1)
+        pre = cat @ p["score_w1"] + p["score_b1"]
+        hid = np.maximum(pre, 0.0)
+        s = hid @ p["score_w2"] + p["score_b2"][0]
+        cache = (cat, pre, hid)
+    return s, 1.0 / (1.0 + np.exp(-s)), cache
+
+
+def point_score_bwd(p, head, u, d, cache, ds):
+    g = {}
+    if head == "point_dot":
+        return g, ds[:, None] * d, ds[:, None] * u
+    cat, pre, hid = cache
+    g["score_w2"] = hid.T @ ds
+    g["score_b2"] = np.array([ds.sum()], dtype=ds.dtype)
+    dhid = ds[:, None] * p["score_w2"][None, :] * (pre > 0)
+    g["score_w1"] = cat.T @ dhid
+    g["score_b1"] = dhid.sum(axis=0)
+    dcat = dhid @ p["score_w1"].T
+    U = u.shape[1]
+    return g, dcat[:, :U], dcat[:, U:]
+
+
+def weighted_bce(prob, y, gain, K):
+    """Seq2Vec.loss (seq2vec.py:213-216): -0.5 (1+K) mean(y log(p+1e-8) gain + (1-y) log(1-p+1e-8) / K).
+    Returns per-sample loss terms (their mean is the loss) and dL_i/dp_i (not yet divided by the batch)."""
+    dt = prob.dtype.type
+    c = dt(0.5 * (1 + K))
+    e = dt(1e-8)
+    li = -c * (y * np.log(prob + e) * dt(gain) + (1 - y) * np.log(1 - prob + e) / dt(K))
+    dp = -c * (y * dt(gain) / (prob + e) - (1 - y) / (dt(K) * (1 - prob + e)))
+    return li, dp
+
+
+def point_forward_backward(p, arch, head, user, hist, cand, labels, gain=1.0, K=4, drop_p=0.0, seed=0, step=0,
+                           want_grads=True):
+    """One pointwise training step (Seq2VecPaperId._build_model, paper.py:356-383).
+    user int [B]; hist int [B,W,T]; cand int [B,T]; labels {0,1} [B]."""
+    user = np.asarray(user).astype(np.int64).reshape(-1)
+    hist = np.asarray(hist).astype(np.int64)
+    cand = np.asarray(cand).astype(np.int64)
+    B, W, T = hist.shape
+    titles = np.concatenate([hist.reshape(B * W, T), cand.reshape(B, T)], axis=0)
+    keys = (dropout_key(seed, step, 0), dropout_key(seed, step, 1))
+    v, nc = news_encoder_fwd(p, titles, drop_p, keys, training=True)
+    hv, dv = split_titles(v, B, W, 1)
+    d = dv[:, 0]
+    u, uc = user_encoder_fwd(p, arch, user, hv, hist)
+    y = np.asarray(labels).astype(v.dtype).reshape(-1)
+    s, prob, cache = point_score_fwd(p, head, u, d)
+    li, dp = weighted_bce(prob, y, gain, K)
+    out = dict(loss=float(li.mean()), acc=float(((prob > 0.5) == (y > 0.5)).mean()), probs=prob, logits=s,
+               user_vec=u, doc_vec=v)
+    if not want_grads:
+        return out
+    ds = dp * prob * (1 - prob) / v.dtype.type(B)
+    gs, du, dd = point_score_bwd(p, head, u, d, cache, ds)
+    g, dhv, duser = user_encoder_bwd(p, uc, du)
+    g.update(gs)
+    dvv = np.concatenate([dhv.reshape(B * W, -1), dd], axis=0)
+    g.update(news_encoder_bwd(p, nc, dvv, False))
+    out["grads"] = g
+    out["user_rows"] = user
+    out["user_row_grads"] = duser
+    return out
+
+
+def point_predict(p, arch, head, user, hist, cand):
+    """model.predict of the pointwise model (seq2vec.py:206): the scorer's sigmoid output, [n]."""
+    user = np.asarray(user).astype(np.int64).reshape(-1)
+    hist = np.asarray(hist).astype(np.int64)
+    cand = np.asarray(cand).astype(np.int64)
+    n, W, T = hist.shape
+    titles = np.concatenate([hist.reshape(n * W, T), cand.reshape(n, T)], axis=0)
+    v, _ = news_encoder_fwd(p, titles, training=False)
+    hv, dv = split_titles(v, n, W, 1)
+    u, _ = user_encoder_fwd(p, arch, user, hv, hist)
+    return point_score_fwd(p, head, u, dv[:, 0])[1]
+
+
+def point_train_step(p, arch, head, opt, user, hist, cand, labels, gain=1.0, K=4, drop_p=0.0, seed=0, step=0):
+    out = point_forward_backward(p, arch, head, user, hist, cand, labels, gain, K, drop_p, seed, step)
+    g = out["grads"]
+    g["user_emb"] = densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"],
+                                      p["user_emb"].dtype)
+    opt.step(p, g)
+    return out
 
 
 # --------------------------------------------------------------------------

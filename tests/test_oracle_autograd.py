@@ -92,3 +92,47 @@ def test_adam_matches_keras_formula():
         v = 0.999 * v + 0.001 * g.astype(np.float64) ** 2
         w = w - lr_t * m / (np.sqrt(v) + 1e-7)
         np.testing.assert_allclose(p["w"], w, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("arch", ["igru", "nigru"])
+@pytest.mark.parametrize("head", ["point_mlp", "point_dot"])
+@pytest.mark.parametrize("drop", [0.0, 0.25])
+def test_pointwise_grads_match_autograd(arch, head, drop):
+    """the pointwise sibling (concat-MLP / dot scorer, weighted BCE of seq2vec.py:213-216)."""
+    rng = np.random.default_rng(5)
+    p = O.init_params(rng, arch=arch, dtype=np.float64, head=head, **DIMS)
+    for n in ("conv_b", "att_b", "dense_b", "gru_b", "score_b1", "score_b2"):
+        if n in p:
+            p[n] = rng.normal(0, 0.1, size=p[n].shape)
+    B, W, T = 6, 4, 7
+    user, hist, cands = make_batch(rng, B, W, T, 1, DIMS["V"], DIMS["N_u"])
+    cand = cands[:, 0]
+    labels = np.array([1, 0, 0, 1, 0, 0])
+    user[2] = user[0]
+    gain, K = 1.7, 4
+    out = O.point_forward_backward(p, arch, head, user, hist, cand, labels, gain, K, drop_p=drop, seed=9, step=1)
+    names = [n for n in p]
+    tp = TR.to_t(p, grad_names=names)
+    keep1 = keep2 = None
+    scale = 1.0
+    if drop > 0:
+        N_t = B * (W + 1)
+        keep1 = O.dropout_keep(O.dropout_key(9, 1, 0), N_t * T * DIMS["D"], drop).reshape(N_t, T, DIMS["D"])
+        keep2 = O.dropout_keep(O.dropout_key(9, 1, 1), N_t * T * DIMS["F"], drop).reshape(N_t, T, DIMS["F"])
+        scale = 1.0 / (1.0 - drop)
+    loss, s, pr = TR.point_loss(tp, arch, head, user, hist, cand, labels, gain, K, keep1, keep2, scale)
+    loss.backward()
+    assert abs(loss.item() - out["loss"]) < 1e-12
+    np.testing.assert_allclose(out["probs"], pr.detach().numpy(), rtol=1e-10, atol=1e-12)
+    g = dict(out["grads"])
+    g["user_emb"] = O.densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"], np.float64)
+    for n in names:
+        if n == "word_emb":
+            continue                                  # frozen table on this path
+        if tp[n].grad is None:
+            assert n == "user_emb" and not g[n].any()
+            continue
+        np.testing.assert_allclose(g[n], tp[n].grad.numpy(), rtol=1e-8, atol=1e-12, err_msg=n)
+    # the probabilities of predict() are the training-graph probabilities without dropout
+    out0 = O.point_forward_backward(p, arch, head, user, hist, cand, labels, gain, K, want_grads=False)
+    np.testing.assert_allclose(O.point_predict(p, arch, head, user, hist, cand), out0["probs"], rtol=1e-12)

@@ -90,3 +90,38 @@ def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0):
     q = torch.clamp(q, EPS, 1 - EPS)
     loss = -(torch.log(q[:, 0])).mean()
     return loss, z, pr
+
+
+def user_vector(p, arch, user, hist, v):
+    """user encoder on top of the doc vectors v ([B*W history rows | candidate rows])."""
+    user = torch.as_tensor(np.asarray(user), dtype=torch.long).reshape(-1)
+    hist_np = np.asarray(hist)
+    B, W, T = hist_np.shape
+    hv = v[:B * W].reshape(B, W, -1)
+    hmask = torch.as_tensor((hist_np != 0).any(-1))
+    hv = hv * hmask.unsqueeze(-1).to(hv.dtype)
+    gmask = (hv.detach() != 0).any(-1)
+    H = p["gru_u"].shape[0]
+    if arch == "igru":
+        return gru(p, hv, gmask, p["user_emb"][user])
+    assert arch == "nigru"
+    return gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
+
+
+def point_loss(p, arch, head, user, hist, cand, labels, gain, K, keep1=None, keep2=None, scale=1.0):
+    """Pointwise sibling (paper.py:223-227, 258-262, 356-383; loss seq2vec.py:213-216), autograd form."""
+    hist_np = np.asarray(hist)
+    B, W, T = hist_np.shape
+    titles = np.concatenate([hist_np.reshape(B * W, T), np.asarray(cand).reshape(B, T)], 0)
+    v = news_encoder(p, titles, keep1, keep2, scale)
+    u = user_vector(p, arch, user, hist, v)
+    d = v[B * W:]
+    if head == "point_dot":
+        s = (u * d).sum(-1)
+    else:
+        hid = torch.relu(torch.cat([u, d], 1) @ p["score_w1"] + p["score_b1"])
+        s = hid @ p["score_w2"] + p["score_b2"][0]
+    pr = torch.sigmoid(s)
+    y = torch.as_tensor(np.asarray(labels), dtype=pr.dtype).reshape(-1)
+    loss = -0.5 * (1 + K) * torch.mean(y * torch.log(pr + 1e-8) * gain + (1 - y) * torch.log(1 - pr + 1e-8) / K)
+    return loss, s, pr
