@@ -49,6 +49,9 @@ class NativeTrainFeed:
     def __init__(self, task, seed=None, rank=None, world=None):
         from . import dist
         cfg = task.config
+        if getattr(task, 'head', 'softmax') != 'softmax' or type(task).__name__.find('Days') >= 0:
+            raise NotImplementedError('--native-feed covers the Seq2VecPaperSoftmax(Id) sample stream only; use --ids '
+                                      'for {}'.format(type(task).__name__))
         self.B, self.W, self.K = cfg.batch_size, cfg.window_size, cfg.negative_samples
         rank = dist.rank() if rank is None else rank
         world = dist.world_size() if world is None else world

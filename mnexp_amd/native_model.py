@@ -142,7 +142,8 @@ class NativeModel:
         from . import utils
         if getattr(cfg, 'news_encoder', 'cnnatt') != 'cnnatt':
             raise _lib.LsturError('only the cnnatt news encoder is on the native path')
-        if getattr(cfg, 'score_model', 'dot') != 'dot':
+        head = getattr(task, 'head', 'softmax')
+        if head == 'softmax' and getattr(cfg, 'score_model', 'dot') != 'dot':
             raise _lib.LsturError('only the dot scorer is on the native path')
         if getattr(cfg, 'textual_embedding_trainable', False):
             raise _lib.LsturError('--textual-embedding-trainable is not on the native path yet')
@@ -153,15 +154,19 @@ class NativeModel:
         filters, kernel = cfg.title_filter_shape
         arch, has_user = cfg.arch, user_count > 0
         if not has_user:
-            # Seq2VecPaperSoftmax.get_user_encoder (paper.py:198-221): only its `gru` (a plain masked GRU from a zero
+            # Seq2VecPaper(Softmax).get_user_encoder (paper.py:198-221): only its `gru` (a plain masked GRU from a zero
             # state) is on the native path; it is the graph SoftmaxId calls `nigru`
             if arch != 'gru':
                 raise _lib.LsturError('id-less task: only -a gru is on the native path (got {!r})'.format(arch))
             arch = 'nigru'
+        elif head != 'softmax' and arch != 'igru':
+            # Seq2VecPaperId.get_user_encoder (paper.py:330-354): gru / iigru concatenate to 2U, vo drops the history
+            raise _lib.LsturError('pointwise task with user ids: only -a igru is on the native path (got {!r})'.format(arch))
         return cls(emb, user_count, cfg.batch_size, cfg.window_size, cfg.title_shape, cfg.negative_samples,
                    int(filters), int(kernel), cfg.user_embedding_dim, arch=arch, dropout=cfg.dropout,
                    lr=cfg.learning_rate, seed=int(getattr(cfg, 'seed', 0) or 0),
-                   title_table=task.docs.title_table, has_user=has_user)
+                   title_table=task.docs.title_table, has_user=has_user, head=head,
+                   gain=float(getattr(cfg, 'gain', 1.0)))
 
     def test_view(self):
         """The reference swaps ``model``/``test_model`` around evaluation (task/paper.py:502,524); here one

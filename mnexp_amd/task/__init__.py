@@ -1,10 +1,11 @@
 """Task registry: ``task.get(config)`` -> task handler (reference task/__init__.py:15-16,
 with the ``eval`` of the class name replaced by a lookup table)."""
-from .paper import (Seq2VecPaper, Seq2VecPaperSoftmax, Seq2VecPaperSoftmaxDays, Seq2VecPaperSoftmaxDaysId,
-                    Seq2VecPaperSoftmaxId)
+from .paper import (Seq2VecPaper, Seq2VecPaperDot, Seq2VecPaperId, Seq2VecPaperSoftmax, Seq2VecPaperSoftmaxDays,
+                    Seq2VecPaperSoftmaxDaysId, Seq2VecPaperSoftmaxId)
 from .seq2vec import Seq2Vec
 
-REGISTRY = {cls.__name__: cls for cls in (Seq2VecPaperSoftmax, Seq2VecPaperSoftmaxId, Seq2VecPaperSoftmaxDays,
+REGISTRY = {cls.__name__: cls for cls in (Seq2VecPaper, Seq2VecPaperDot, Seq2VecPaperId, Seq2VecPaperSoftmax,
+                                          Seq2VecPaperSoftmaxId, Seq2VecPaperSoftmaxDays,
                                           Seq2VecPaperSoftmaxDaysId)}
 
 

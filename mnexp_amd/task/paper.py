@@ -1,12 +1,18 @@
 """LSTUR task family (softmax ranking with user-id embedding) on the native MI355X model.
 
 Host-side mirror of /root/reference/task/paper.py:
-  ``Seq2VecPaper``          :6-255   in-memory ClickData (``_load_data`` :24-35, ``Impression`` :7-18)
+  ``Seq2VecPaper``          :6-255   in-memory ClickData (``_load_data`` :24-35, ``Impression`` :7-18); itself the
+                                     pointwise task: one candidate per sample (1 positive, then K negatives as
+                                     separate rows :38-60), concat-MLP scorer :223-227, ``Seq2Vec.loss``
+  ``Seq2VecPaperDot``       :258-262 the same with sigmoid(u . d)
+  ``Seq2VecPaperId``        :265-383 the same with the user index (= ClickData row) as first input
   ``Seq2VecPaperSoftmax``   :384-524 1+K softmax samples, lr decay + per-impression metrics ``callback`` :497-524
   ``Seq2VecPaperSoftmaxId`` :527-665 user index = ClickData row number; LSTUR-ini (``igru``) / LSTUR-con (``gru``, ``hgru``)
 Everything under ``_build_model`` is replaced by ``mnexp_amd.native_model.NativeModel`` (HIP/gfx950).
 """
 import logging
+import os
+import random
 from datetime import datetime, timedelta
 
 import numpy as np
@@ -55,16 +61,150 @@ class Seq2VecPaper(Seq2Vec):
     def save_model(self):
         pass                                          # paper.py:254-255
 
+    # ---- pointwise samples: (user?, hist_ids[W], [candidate], label) -------------------------------
+    has_user = False
+    head = 'point_mlp'                                # score_encoder, paper.py:223-227
+
+    def _users(self):
+        return ((None, d) for d in self.data)
+
+    def _row(self, user, hist, cand, label):
+        head = (user,) if self.has_user else ()
+        return head + (hist, [int(cand)], label)
+
+    def train_gen_ids(self):
+        """paper.py:38-60 / :266-288: per positive click with a non-empty history one positive row, then K rows of
+        sampled negatives; users with more than ``max_impression`` training impressions train on a random subset
+        (``random.sample``) while every click still enters the history."""
+        K = self.config.negative_samples
+        while True:
+            for user, (ih, _) in self._users():
+                if not ih:
+                    continue
+                ch = self.Window(self.docs, self.config.window_size)
+                if len(ih) > self.config.max_impression:
+                    chosen = set(random.sample(ih, self.config.max_impression))
+                else:
+                    chosen = None
+                for impression in ih:
+                    trainable = chosen is None or impression in chosen
+                    for pos in impression.pos:
+                        if ch.count and trainable:
+                            hist = ch.get_ids()
+                            yield self._row(user, hist, pos, 1)
+                            for neg in impression.negative_samples(K):
+                                yield self._row(user, hist, neg, 0)
+                        ch.push(pos)
+
+    def valid_gen_ids(self):
+        """paper.py:62-77 / :290-305."""
+        K = self.config.negative_samples
+        while True:
+            for user, (ih1, ih2) in self._users():
+                if not (ih1 and ih2):
+                    continue
+                ch = self._history_after_training(ih1)
+                for impression in ih2:
+                    for pos in impression.pos:
+                        hist = ch.get_ids()
+                        yield self._row(user, hist, pos, 1)
+                        for neg in impression.negative_samples(K):
+                            yield self._row(user, hist, neg, 0)
+                    for pos in impression.pos:
+                        ch.push(pos)
+
+    def test_gen_ids(self):
+        """paper.py:79-97 / :307-328: per valid impression all pos then all neg, history frozen before it."""
+        for user, (ih1, ih2) in self._users():
+            if not (ih1 and ih2):
+                continue
+            ch = self._history_after_training(ih1)
+            for impression in ih2:
+                hist = ch.get_ids()
+                yield ([self._row(user, hist, p, 1) for p in impression.pos] +
+                       [self._row(user, hist, n, 0) for n in impression.neg])
+                for pos in impression.pos:
+                    ch.push(pos)
+
+    def _history_after_training(self, ih1):
+        ch = self.Window(self.docs, self.config.window_size)
+        for impression in ih1:
+            for pos in impression.pos:
+                ch.push(pos)
+        return ch
+
+    # ---- batching ------------------------------------------------------------
+    def _stack_ids(self, samples):
+        cols = list(zip(*samples))
+        labels = np.stack(cols[-1])
+        hist = np.stack(cols[-3]).astype(np.int32)
+        cands = np.array(cols[-2], dtype=np.int32)
+        if self.has_user:
+            return (np.array(cols[0], dtype=np.int64), hist, cands), labels
+        return (hist, cands), labels
+
+    def _expand(self, samples):
+        ids, labels = self._stack_ids(samples)
+        hist, cands = ids[-2], ids[-1]
+        tf64 = self.docs.titles_f64
+        X = [tf64[hist]] + [tf64[cands[:, j]] for j in range(cands.shape[1])]
+        if self.has_user:
+            X = [ids[0]] + X
+        return X, labels
+
+    # ---- model -----------------------------------------------------------------
+    def _build_model(self):
+        from ..native_model import NativeModel
+        self.model = NativeModel.from_task(self, user_count=len(self.data) if self.has_user else 0)
+        self.test_model = self.model.test_view()
+
+    def callback(self, epoch):
+        """task/seq2vec.py:296-321 (the pointwise tasks do not override it): the running AUC metric is
+        re-initialised, lr *= decay, then mean per-impression AUC / nDCG@10 / nDCG@5 / MRR over the first
+        ``testing_impression`` impressions of ``self.test``; repeated after the last epoch when TestData.tsv exists."""
+        if getattr(self.model, 'auc', None) is not None:
+            self.model.auc.reset()
+        self.model.optimizer.lr = self.model.optimizer.lr * self.config.learning_rate_decay
+
+        def report():
+            rows = [(roc_auc_score(y_true, y_pred), utils.ndcg_score(y_true, y_pred, 10),
+                     utils.ndcg_score(y_true, y_pred, 5), utils.mrr_score(y_true, y_pred), np.sum(y_true),
+                     len(y_true), i)
+                    for i, (y_pred, y_true) in zip(range(self.config.testing_impression), self.test)]
+            v = [np.mean(x) for x in zip(*rows)]
+            utils.logging_evaluation(dict(auc=v[0], ndcgx=v[1], ndcgv=v[2], mrr=v[3]))
+            utils.logging_evaluation(dict(pos=v[4], size=v[5], num=v[6] * 2 + 1))
+            return dict(auc=v[0], ndcgx=v[1], ndcgv=v[2], mrr=v[3])
+
+        self.last_metrics = report()
+        if epoch == self.config.epochs - 1 and os.path.exists(self.config.testing_data_input):
+            self.is_training = False
+            self.last_metrics = report()
+
+
+class Seq2VecPaperDot(Seq2VecPaper):
+    head = 'point_dot'                                # paper.py:258-262
+
+
+class Seq2VecPaperId(Seq2VecPaper):
+    """User id = row number of ClickData.tsv (paper.py:268)."""
+    has_user = True
+
+    def _users(self):
+        from .. import dist
+        w, r = dist.world_size(), dist.rank()
+        if w == 1:
+            return enumerate(self.data)
+        return ((u, self.data[u]) for u in dist.shard_users(len(self.data), r, w))
+
 
 class Seq2VecPaperSoftmax(Seq2VecPaper):
     """Samples: (hist_ids[W], [pos, neg_1..neg_K], label=[1,0..0])."""
     has_user = False
+    head = 'softmax'
 
     def _label(self):
         return [1] + [0] * self.config.negative_samples
-
-    def _users(self):
-        return ((None, d) for d in self.data)
 
     def _sample(self, user, ch, pos, impression, label):
         cands = [pos] + [int(n) for n in impression.negative_samples(self.config.negative_samples)]
@@ -112,38 +252,6 @@ class Seq2VecPaperSoftmax(Seq2VecPaper):
                        [head + (hist, [n], 0) for n in impression.neg])
                 for pos in impression.pos:
                     ch.push(pos)
-
-    def _history_after_training(self, ih1):
-        ch = self.Window(self.docs, self.config.window_size)
-        for impression in ih1:
-            for pos in impression.pos:
-                ch.push(pos)
-        return ch
-
-    # ---- batching ------------------------------------------------------------
-    def _stack_ids(self, samples):
-        cols = list(zip(*samples))
-        labels = np.stack(cols[-1])
-        hist = np.stack(cols[-3]).astype(np.int32)
-        cands = np.array(cols[-2], dtype=np.int32)
-        if self.has_user:
-            return (np.array(cols[0], dtype=np.int64), hist, cands), labels
-        return (hist, cands), labels
-
-    def _expand(self, samples):
-        ids, labels = self._stack_ids(samples)
-        hist, cands = ids[-2], ids[-1]
-        tf64 = self.docs.titles_f64
-        X = [tf64[hist]] + [tf64[cands[:, j]] for j in range(cands.shape[1])]
-        if self.has_user:
-            X = [ids[0]] + X
-        return X, labels
-
-    # ---- model -----------------------------------------------------------------
-    def _build_model(self):
-        from ..native_model import NativeModel
-        self.model = NativeModel.from_task(self, user_count=len(self.data) if self.has_user else 0)
-        self.test_model = self.model.test_view()
 
     def callback(self, epoch):
         """paper.py:497-524: lr *= decay every epoch; mean per-impression AUC / nDCG@10 / nDCG@5 / MRR."""

@@ -196,6 +196,13 @@ def main():
         h = ref_task.get(cfg)
         for k, v in capture(h, 120, 4, seed=21, has_user=tname.endswith('Id')).items():
             out['%s_%s' % (tname, k)] = v
+    # --- pointwise sibling on the tiny set: max_impression = 3 so random.sample() picks subsets
+    for tname in ('Seq2VecPaperId', 'Seq2VecPaper'):
+        cfg = ref_config(ref_settings, tiny, task=tname, arch='igru' if tname.endswith('Id') else 'gru',
+                         max_impression=3)
+        h = ref_task.get(cfg)
+        for k, v in capture(h, 150, 4, seed=31, has_user=tname.endswith('Id')).items():
+            out['%s_%s' % (tname, k)] = v
     np.savez_compressed(os.path.join(HERE, 'data_path.npz'), **out)
 
     # --- parser known answers -------------------------------------------------

@@ -201,3 +201,53 @@ def test_time_window_variants(tname, has_user):
         same(X[u], G['%s_test%d_clicked' % (tname, i)])
         same(X[u + 1], G['%s_test%d_cand' % (tname, i)])
         same(labels, G['%s_test%d_label' % (tname, i)])
+
+
+@pytest.mark.parametrize('tname,has_user,arch', [('Seq2VecPaperId', True, 'igru'), ('Seq2VecPaper', False, 'gru')])
+def test_pointwise_sibling_data_path(tname, has_user, arch):
+    """one candidate per row (the positive, then K sampled negatives), ``random.sample`` of
+    ``max_impression`` training impressions per user (paper.py:38-97, 266-328) -- bit-exact against the reference,
+    including how both global RNG streams (``random`` and ``np.random``) are consumed."""
+    cfg = make_config(os.path.join(GOLD, 'tiny'), task=tname, arch=arch, max_impression=3)
+    h = task.get(cfg)
+    u = 1 if has_user else 0
+    np.random.seed(31)
+    random.seed(31)
+    gen = h.train_gen_ids()
+    X, Y = h._expand([next(gen) for _ in range(150)])
+    if has_user:
+        same(X[0], G[tname + '_train_user'])
+    same(X[u], G[tname + '_train_clicked'])
+    same(np.stack(X[u + 1:], axis=1), G[tname + '_train_cands'])
+    same(Y, G[tname + '_train_label'])
+    assert len(X) == u + 2 and set(np.unique(Y)) == {0, 1}
+    # the sub-sampling really happened: without the cap the same walk yields different rows
+    h_all = task.get(make_config(os.path.join(GOLD, 'tiny'), task=tname, arch=arch, max_impression=200))
+    np.random.seed(31)
+    random.seed(31)
+    gen = h_all.train_gen_ids()
+    X_all, _ = h_all._expand([next(gen) for _ in range(150)])
+    assert not np.array_equal(X_all[u], X[u])
+    np.random.seed(32)
+    random.seed(32)
+    it = h.train
+    for b in range(4):
+        X, Y = next(it)
+        if has_user:
+            same(X[0], G['%s_batch%d_user' % (tname, b)])
+        same(X[u], G['%s_batch%d_clicked' % (tname, b)])
+        same(np.stack(X[u + 1:], axis=1), G['%s_batch%d_cands' % (tname, b)])
+        same(Y, G['%s_batch%d_y' % (tname, b)])
+    same(np.random.randint(0, 1 << 30, size=4), G[tname + '_rng_after_batches'])
+    np.random.seed(33)
+    it = h.valid
+    for b in range(3):
+        X, Y = next(it)
+        same(X[u], G['%s_valid%d_clicked' % (tname, b)])
+        same(np.stack(X[u + 1:], axis=1), G['%s_valid%d_cands' % (tname, b)])
+        same(Y, G['%s_valid%d_y' % (tname, b)])
+    for i, rows in zip(range(int(G[tname + '_n_test'])), h.test_gen_ids()):
+        X, labels = h._expand(rows)
+        same(X[u], G['%s_test%d_clicked' % (tname, i)])
+        same(X[u + 1], G['%s_test%d_cand' % (tname, i)])
+        same(labels, G['%s_test%d_label' % (tname, i)])

@@ -160,3 +160,58 @@ def test_save_load_round_trip(tmp_path):
     import pickle
     arrays = pickle.load(open(paths[1], 'rb'))
     assert arrays[2].shape == (dims['F'], 1) and arrays[-1].shape == (dims['V'], dims['D'])   # Keras shapes / order
+
+
+@pytest.mark.parametrize('tname,arch,ids', [('Seq2VecPaperId', 'igru', False), ('Seq2VecPaperId', 'igru', True),
+                                            ('Seq2VecPaper', 'gru', False), ('Seq2VecPaperDot', 'gru', True)])
+def test_pointwise_cli_train_loop(tmp_path, tname, arch, ids):
+    """the pointwise sibling through the reference's train loop (fit_generator / callback of
+    task/seq2vec.py:296-321 / evaluate_generator with the auc_roc metric)."""
+    _need_gpu()
+    from mnexp_amd.main import run_training
+    cfg = _config(tmp_path, task=tname, arch=arch, epochs=2, training_step=15, validation_step=2,
+                  validation_impression=20, testing_impression=20, dropout=0.2, ids=ids, seed=1, max_impression=3,
+                  gain=1.5)
+    np.random.seed(0)
+    random.seed(0)
+    h = run_training(cfg)
+    assert h.model.pointwise and h.model.metrics_names == ['loss', 'auc_roc']
+    assert h.model.head == ('point_dot' if tname.endswith('Dot') else 'point_mlp')
+    assert 0.0 <= h.last_metrics['auc'] <= 1.0 and np.isfinite(h.last_metrics['mrr'])
+    assert abs(h.model.optimizer.lr - 1e-3 * 0.2 ** 2) < 1e-12
+    assert h.model.optimizer.iterations == 30
+    assert abs(h.model.cfg.gain - 1.5) < 1e-7 and h.model.cfg.loss_negatives == cfg.negative_samples
+
+
+def test_pointwise_training_through_the_task_tracks_oracle(tmp_path):
+    """40 steps of Seq2VecPaperId batches (pool-shuffled, 1 positive : K negatives): per-step loss follows the
+    oracle and the mean per-impression AUC of the trained scorers agrees to 0.002."""
+    _need_gpu()
+    from mnexp_amd import task as T
+    from oracle import lstur_oracle as O
+    cfg = _config(tmp_path, task='Seq2VecPaperId', arch='igru', dropout=0.2, batch_size=8, epochs=1, seed=5,
+                  max_impression=3)
+    h = T.get(cfg)
+    model = h.build_model(0)
+    tt = h.docs.title_table
+    p = {n: a.astype(np.float32) for n, a in model.get_weights().items()}
+    p['word_emb'] = model.word_emb.cpu().numpy()
+    names = O.dense_param_names('igru', head='point_mlp') + ['user_emb']
+    opt = O.Adam(p, names, lr=cfg.learning_rate)
+    np.random.seed(3)
+    random.seed(3)
+    gen = h.train_ids
+    K = cfg.negative_samples
+    losses_gpu, losses_cpu = [], []
+    for s in range(40):
+        (user, hist, cands), labels = next(gen)
+        out = O.point_train_step(p, 'igru', 'point_mlp', opt, user, tt[hist], tt[cands[:, 0]], labels, 1.0, K,
+                                 drop_p=0.2, seed=5, step=s)
+        losses_cpu.append(out['loss'])
+        model.stats_acc.zero_()
+        model.train_on_ids(user, hist, cands, labels=labels)
+        losses_gpu.append(model.stats_acc[0].item())
+    np.testing.assert_allclose(losses_gpu, losses_cpu, rtol=2e-3, atol=2e-4)
+    auc_gpu = per_impression_auc(h, lambda u, hi, c: model.predict_ids(u, hi, c.reshape(-1, 1))[:, 0], 60)
+    auc_cpu = per_impression_auc(h, lambda u, hi, c: O.point_predict(p, 'igru', 'point_mlp', u, tt[hi], tt[c]), 60)
+    assert abs(auc_gpu - auc_cpu) <= 0.002, (auc_gpu, auc_cpu)
