@@ -489,7 +489,7 @@ size_t conv_wgrad_scratch_bytes(int D, int ksize, int F) {
 
 void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
                        int ksize, int F, const int32_t* vidx, const int32_t* vcount, hipStream_t s, const int32_t* offA,
-                       const int32_t* offB, const float* zeros) {
+                       const int32_t* offB, const float* zeros, ReduceJob* defer) {
   int M = n_titles * T, Tp = T + ksize - 1, KD = ksize * D;
   WgradGeom g = wgrad_geom(D, ksize, F);
   constexpr int TK = 16;
@@ -525,6 +525,10 @@ void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scr
                        lds, s, emb, dout, part, M, T, Tp, D, KD, F, vidx, vcount);
   }
   size_t count = (size_t)KD * F;
+  if (defer) {
+    *defer = ReduceJob{part, dw, 1, (int)count, (int)count, nsplit, count, 1.0f};
+    return;
+  }
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdivz(count, 256)), dim3(256), 0, s, part, nsplit, count, dw);
 }
 

@@ -152,7 +152,8 @@ size_t gemm_scratch_bytes(int M, int N, int K) {
 }
 
 void launch_gemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, float* C, int ldc,
-                 const float* bias, int M, int N, int K, float alpha, void* scratch, hipStream_t s) {
+                 const float* bias, int M, int N, int K, float alpha, void* scratch, hipStream_t s, ReduceJob* defer) {
+  if (defer) defer->nslices = 0;
   if (M == 0 || N == 0) return;
   int ns = scratch ? gemm_splits(M, N, K) : 1;
   int kps = cdiv(cdiv(K, ns), GK) * GK;
@@ -174,6 +175,10 @@ void launch_gemm(const float* A, int lda, int ta, const float* B, int ldb, int t
   else
     LSTUR_GEMM(true, true);
 #undef LSTUR_GEMM
+  if (slab && defer && !bias) {
+    *defer = ReduceJob{(const float*)scratch, C, M, N, ldc, ns, (size_t)M * N, alpha};
+    return;
+  }
   if (slab) {
     size_t count = (size_t)M * N;
     hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)cdivz(count, 256)), dim3(256), 0, s, (const float*)scratch,

@@ -146,7 +146,7 @@ struct Workspace {
   float* dgates; float* rh; float* hprev; float* dh0; float* hlast; float* dhlast;
   float* cat; float* dcat; float* uservec; float* duser; float* du; float* logits; float* probs; float* loss_i;
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
-  void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; int32_t* first; float* gsum; int32_t* slot;
+  void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
@@ -218,6 +218,11 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->wgrad_scratch = take(conv_wgrad_scratch_bytes(d.D, d.k, d.F));
   w->gemm_scratch_bytes = max_gemm_scratch(d);
   w->gemm_scratch = take(w->gemm_scratch_bytes);
+  // weight-gradient GEMMs of the backward pass keep their split-K slabs until the step's single reduction launch
+  w->gemm_scratch_k[0] = take(std::max(gemm_scratch_bytes(d.U, 3 * d.H, (int)nW), (size_t)4 << 20));
+  w->gemm_scratch_k[1] = take(std::max(gemm_scratch_bytes(d.H, 2 * d.H, (int)nW), (size_t)4 << 20));
+  w->gemm_scratch_k[2] = take(std::max(gemm_scratch_bytes(d.H, d.H, (int)nW), (size_t)4 << 20));
+  w->gemm_scratch_k[3] = take(std::max(gemm_scratch_bytes(d.F, d.U, (int)nt), (size_t)4 << 20));
   w->first = (int32_t*)take((size_t)d.rows_cap * 4);
   w->gsum = (float*)take((size_t)d.rows_cap * d.Ue * f4);
   w->slot = (int32_t*)take((size_t)d.Nu * 4);
@@ -229,6 +234,8 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->user_rows = (int32_t*)take(nc * 4);
   w->scores = (float*)take(nc * f4);
   w->colsum_scratch = (float*)take((size_t)kColsumSlices * std::max(std::max(3 * d.H, d.U), (int)(3 * ((d.F + kParamAlign - 1) / kParamAlign * kParamAlign) + 64)) * f4);
+  for (int k = 0; k < 3; ++k)
+    w->colsum_scratch_k[k] = (float*)take((size_t)kColsumSlices * std::max(std::max(3 * d.H, d.U), (int)(3 * ((d.F + kParamAlign - 1) / kParamAlign * kParamAlign) + 64)) * f4);
   w->vidx = (int32_t*)take(nt * d.T * 4);
   w->vcount = (int32_t*)take(256);
   w->att_ds = (float*)take(nt * d.T * f4);
@@ -266,6 +273,7 @@ struct lstur_ctx {
   int32_t n_docs = 0;
   bool lazy_init_done = false;
   int last_n = 0, last_k1 = 0;
+  bool counted = false;   // stage_titles already left the per-block non-pad counts in ws.vscratch
   float* P(const char* name) const {
     for (auto& s : layout)
       if (!strcmp(s.name, name)) return buf.dense_param + s.offset;
@@ -339,7 +347,10 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, s);
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
-  launch_compact_valid(w.ids, nt * d.T, w.vidx, w.vcount, w.vscratch, s);   // non-pad tokens of this batch
+  // stable list of the non-pad tokens of this batch (+ the kernel gradient's row offsets), two launches
+  if (!c->counted) launch_compact_count(w.ids, nt * d.T, w.vscratch, s);
+  c->counted = false;
+  launch_compact_write_offsets(w.ids, nt * d.T, w.vscratch, w.vidx, w.vcount, d.T, d.Tp, d.D, d.F, w.offA, w.offB, s);
   PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
   PROF("conv_fwd", launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
                                    w.vcount, s));
@@ -348,16 +359,15 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   launch_gemm(w.pooled, d.F, 0, c->P("dense_w"), d.U, 0, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, 1.f,
               w.gemm_scratch, s);
   // user encoder (paper.py:584-633)
-  launch_hist_mask(w.ids, w.docvec, w.hmask, w.gmask, nW, d.T, d.U, s);
-  (void)hipMemcpyAsync(w.user_rows, user, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
-  launch_gather_rows(c->buf.user_emb, user, w.uvec, n, d.Ue, s);
+  launch_hist_mask(w.ids, w.docvec, w.hmask, w.gmask, nW, d.T, d.U, s, c->buf.user_emb, user, w.user_rows, w.uvec, n,
+                   d.Ue);
   launch_gemm(w.docvec, d.U, 0, c->P("gru_w"), 3 * d.H, 0, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, 1.f,
               w.gemm_scratch, s);
+  // igru / nigru: the last state IS the user vector (H == U): the recurrence writes it in place
+  const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
   PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.gru_up,
-                                 w.gru_tape, w.hlast, n, d.W, d.H, s));
-  if (d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU) {
-    (void)hipMemcpyAsync(w.uservec, w.hlast, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
-  } else {
+                                 w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s));
+  if (!direct) {
     launch_concat2(w.hlast, d.H, w.uvec, d.Ue, w.cat, n, s);
     if (d.arch == LSTUR_ARCH_GRU)
       launch_gemm(w.cat, d.H + d.Ue, 0, c->P("con_w"), d.U, 0, w.uservec, d.U, c->P("con_b"), n, d.U, d.H + d.Ue, 1.f,
@@ -369,7 +379,8 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   c->last_k1 = k1;
 }
 
-void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
+// stats (may be NULL): the batch means of loss_i / correct_i ride the pass's single reduction launch
+void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats) {
   const Dims& d = c->d;
   Workspace& w = c->ws;
   const int nW = n * d.W, nt = nW + n * d.K1;
@@ -393,32 +404,40 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s) {
   gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
   PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
                                  d.arch == LSTUR_ARCH_IGRU ? w.duser : w.dh0, n, d.W, d.H, s));
-  // GRU parameter gradients
+  // GRU parameter gradients (their split-K / column-sum partials are reduced by ONE launch at the end of the pass)
+  ReduceJob jobs[kMaxReduceJobs];
+  int nj = 0;
   launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
-              w.gemm_scratch, s);
-  launch_colsum2(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, w.colsum_scratch, s);
+              w.gemm_scratch_k[0], s, &jobs[nj++]);
+  launch_colsum2(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, w.colsum_scratch_k[0], s, &jobs[nj++]);
   launch_gemm(hprev, d.H, 1, w.dgates, 3 * d.H, 0, c->G("gru_u"), 3 * d.H, nullptr, d.H, 2 * d.H, nW, 1.f,
-              w.gemm_scratch, s);
+              w.gemm_scratch_k[1], s, &jobs[nj++]);
   launch_gemm(rh, d.H, 1, w.dgates + 2 * d.H, 3 * d.H, 0, c->G("gru_u") + 2 * d.H, 3 * d.H, nullptr, d.H, d.H, nW,
-              1.f, w.gemm_scratch, s);
+              1.f, w.gemm_scratch_k[2], s, &jobs[nj++]);
   // d(history doc vectors) = dgates . gru_w^T, masked by the history mask (paper.py:644-645)
   launch_gemm(w.dgates, 3 * d.H, 0, c->P("gru_w"), 3 * d.H, 1, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, 1.f,
               w.gemm_scratch, s);
-  launch_scale_rows_u8(w.ddocvec, w.hmask, nW, d.U, s);
+  // (the history mask needs no pass here: a padded slot is a masked GRU step, its dgates row -- hence its ddocvec
+  //  row -- is exactly 0, cf. paper.py:644-645)
   // news encoder backward (candidate rows of ddocvec were written by the scorer)
-  launch_gemm(w.pooled, d.F, 1, w.ddocvec, d.U, 0, c->G("dense_w"), d.U, nullptr, d.F, d.U, nt, 1.f, w.gemm_scratch, s);
-  launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch, s);
+  launch_gemm(w.pooled, d.F, 1, w.ddocvec, d.U, 0, c->G("dense_w"), d.U, nullptr, d.F, d.U, nt, 1.f,
+              w.gemm_scratch_k[3], s, &jobs[nj++]);
+  launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], s, &jobs[nj++]);
   launch_gemm(w.ddocvec, d.U, 0, c->P("dense_w"), d.U, 1, w.dpooled, d.F, nullptr, nt, d.F, d.U, 1.f, w.gemm_scratch, s);
   // partial sums laid out like the bucket slice conv_b .. att_b -> one reduction straight into dense_grad
   const int off_cb = 0, off_aw = (int)(c->G("att_w") - c->G("conv_b")), off_ab = (int)(c->G("att_b") - c->G("conv_b"));
   const int ldp = off_ab + 1;
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
                                          w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab));
-  launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch, s);
-  launch_token_offsets(w.vidx, w.vcount, nt * d.T, d.T, d.Tp, d.D, d.F, w.offA, w.offB, s);
+  launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch_k[2], s, &jobs[nj++]);
   PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
                                        w.vidx, w.vcount, s, w.offA, w.offB,
-                                       w.emb + (size_t)d.nt_max * d.Tp * d.D /* zero slack */));
+                                       w.emb + (size_t)d.nt_max * d.Tp * d.D /* zero slack */, &jobs[nj++]));
+  if (stats) {
+    jobs[nj++] = ReduceJob{w.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
+    jobs[nj++] = ReduceJob{w.correct_i, stats + 1, 1, 1, 1, n, 1, 1.0f / (float)n};
+  }
+  launch_multi_reduce(jobs, nj, s);
 }
 
 int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n, int k1, bool ids_form, hipStream_t s) {
@@ -427,8 +446,8 @@ int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n,
   const size_t nW = (size_t)n * d.W;
   if (ids_form) {
     if (!c->title_table) return fail(LSTUR_ERR_STATE, "no title table bound (lstur_set_title_table)");
-    launch_expand_titles(c->title_table, hist, w.ids, (int)nW, d.T, s);
-    launch_expand_titles(c->title_table, cands, w.ids + nW * d.T, n * k1, d.T, s);
+    launch_expand_count(c->title_table, hist, (int)nW, cands, n * k1, d.T, w.ids, w.vscratch, s);
+    c->counted = true;
   } else {
     (void)hipMemcpyAsync(w.ids, hist, nW * d.T * 4, hipMemcpyDeviceToDevice, s);
     (void)hipMemcpyAsync(w.ids + nW * d.T, cands, (size_t)n * k1 * d.T * 4, hipMemcpyDeviceToDevice, s);
@@ -450,8 +469,8 @@ int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   launch_score(w.uservec, w.docvec + (size_t)nW * d.U, w.logits, w.probs, w.loss_i, w.correct_i,
                backward ? w.du : nullptr, backward ? w.ddocvec + (size_t)nW * d.U : nullptr, n, d.K1, d.U,
                grad_scale / (float)n, s);
-  if (stats) launch_mean2(w.loss_i, w.correct_i, n, stats, s);
-  if (backward) PROF("backward_total", run_backward(c, n, step, s));
+  if (stats && !backward) launch_mean2(w.loss_i, w.correct_i, n, stats, s);
+  if (backward) PROF("backward_total", run_backward(c, n, step, s, stats));
   return check_launch(backward ? "forward_backward" : "evaluate");
 }
 
@@ -497,8 +516,8 @@ int point_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   Workspace& w = c->ws;
   PROF("forward_total", run_forward(c, user, n, 1, training, step, s));
   run_point_head(c, labels, n, grad_scale / (float)n, true, backward, s);
-  if (stats) launch_mean2(w.loss_i, w.correct_i, n, stats, s);
-  if (backward) PROF("backward_total", run_backward(c, n, step, s));
+  if (stats && !backward) launch_mean2(w.loss_i, w.correct_i, n, stats, s);
+  if (backward) PROF("backward_total", run_backward(c, n, step, s, stats));
   return check_launch(backward ? "point_forward_backward" : "point_evaluate");
 }
 
@@ -736,7 +755,8 @@ int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* coun
       {"conv_out", w.conv, nt * d.T * d.F}, {"att_w", w.att_wt, nt * d.T},
       {"emb", w.emb, nt * d.Tp * d.D},      {"pooled", w.pooled, nt * d.F},
       {"loss_i", w.loss_i, n},              {"user_grad", w.duser, n * d.Ue},
-      {"dconv", w.dconv, nt * d.T * d.F},   {"h_last", w.hlast, n * d.H},
+      {"dconv", w.dconv, nt * d.T * d.F},
+      {"h_last", (d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU) ? w.uservec : w.hlast, n * d.H},
       {"dgates", w.dgates, n * d.W * 3 * d.H}, {"ddoc_vec", w.ddocvec, nt * d.U},
   };
   for (auto& e : tab)

@@ -9,6 +9,23 @@
 
 namespace lstur {
 
+// ---- deferred partial-sum reductions (misc.hip) -----------------------------------------------------
+// Split-K GEMMs, two-stage column sums and the conv kernel gradient leave per-slice partial sums; instead of one
+// tiny reduction launch each (a dependent launch costs ~5 us on its own) they describe the reduction as a job and
+// ONE kernel at the end of the backward pass runs them all, in fixed slice order (bitwise reproducible):
+//   dst[r * ld + c] = alpha * sum_{s < nslices} src[s * stride + r * cols + c]
+struct ReduceJob {
+  const float* src;
+  float* dst;
+  int rows, cols, ld, nslices;
+  size_t stride;
+  float alpha;
+};
+constexpr int kMaxReduceJobs = 12;
+void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s);
+
+
+
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 __host__ __device__ static inline int ceil16(int a) { return (a + 15) & ~15; }
@@ -25,6 +42,14 @@ void launch_expand_titles(const int32_t* table, const int32_t* doc_ids, int32_t*
 // stable list of non-pad tokens: vidx[0..*count) ; scratch = compact_scratch_ints(n) int32
 size_t compact_scratch_ints(int n);
 void launch_compact_valid(const int32_t* ids, int n, int32_t* vidx, int32_t* count, int32_t* scratch, hipStream_t s);
+// the same compaction in two fused launches: block counts come from launch_expand_count (ids form, together with the
+// title expansion) or launch_compact_count; launch_compact_write_offsets then writes vidx, the count and (offA != NULL)
+// the conv kernel gradient's per-token row offsets
+void launch_expand_count(const int32_t* table, const int32_t* hist_ids, int n_hist, const int32_t* cand_ids, int n_cand,
+                         int T, int32_t* out, int32_t* block_counts, hipStream_t s);
+void launch_compact_count(const int32_t* ids, int n, int32_t* block_counts, hipStream_t s);
+void launch_compact_write_offsets(const int32_t* ids, int n, const int32_t* block_counts, int32_t* vidx, int32_t* count,
+                                  int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s);
 size_t pack_b_floats(int K, int N);
 void launch_pack_b(const float* B, int ldb, int K, int N, float* packed, hipStream_t s);
 void launch_pack_b_t(const float* Bt, int ldb, int K, int N, float* packed, hipStream_t s);
@@ -33,7 +58,7 @@ void launch_transpose(const float* in, int ld_in, int rows_in, int cols_in, floa
 void launch_colsum(const float* x, int rows, int cols, int ld, float* out, float scale, hipStream_t s);
 constexpr int kColsumSlices = 64;
 void launch_colsum2(const float* x, int rows, int cols, int ld, float* out, float scale, float* scratch,
-                    hipStream_t s);
+                    hipStream_t s, ReduceJob* defer = nullptr);
 void launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1,
                       float b2, float eps, hipStream_t s);
 // dense Adam sweep of the user table; slot[row] = index into gsum or -1
@@ -46,8 +71,10 @@ void launch_user_slot_clear(const int32_t* rows, int n, int32_t* slot, hipStream
 void launch_fill_i32(int32_t* p, int32_t v, size_t n, hipStream_t s);
 // history mask (ComputeMasking) applied to doc vectors + GRU step mask:  hv[b,w,:] *= any(ids != 0);
 // gmask[b,w] = any(hv != 0)
-void launch_hist_mask(const int32_t* hist_ids, float* hv, uint8_t* hmask, uint8_t* gmask, int nW, int T,
-                      int U, hipStream_t s);
+// + (table != NULL) the user-embedding gather of the batch in the same launch: user_rows[b] = user[b], uvec[b] = table[user[b]]
+void launch_hist_mask(const int32_t* hist_ids, float* hv, uint8_t* hmask, uint8_t* gmask, int nW, int T, int U,
+                      hipStream_t s, const float* table = nullptr, const int32_t* user = nullptr,
+                      int32_t* user_rows = nullptr, float* uvec = nullptr, int n = 0, int Ue = 0);
 void launch_scale_rows_u8(float* x, const uint8_t* mask, int rows, int cols, hipStream_t s);
 void launch_gather_rows(const float* table, const int32_t* rows, float* out, int n, int dim, hipStream_t s);
 // concat: out[b, :a_cols] = a[b], out[b, a_cols:] = bm[b]
@@ -69,7 +96,8 @@ size_t conv_wgrad_scratch_bytes(int D, int ksize, int F);
 // the F == 400 configuration stages its operands by LDS-DMA
 void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scratch, int n_titles, int T,
                        int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount, hipStream_t s,
-                       const int32_t* offA = nullptr, const int32_t* offB = nullptr, const float* zeros = nullptr);
+                       const int32_t* offA = nullptr, const int32_t* offB = nullptr, const float* zeros = nullptr,
+                       ReduceJob* defer = nullptr);
 void launch_token_offsets(const int32_t* vidx, const int32_t* vcount, int M, int T, int Tp, int D, int F, int32_t* offA,
                           int32_t* offB, hipStream_t s);
 
@@ -98,8 +126,11 @@ void launch_point_w2_grad(const float* pre, const float* ds, float* dw2, float* 
 
 // ---- gemm.hip ----------------------------------------------------------------------------------
 size_t gemm_scratch_bytes(int M, int N, int K);
+// defer != NULL (and bias == NULL): a split-K product leaves its slabs in `scratch` and fills *defer
+// (nslices == 0 when no reduction is needed); the scratch must then stay untouched until launch_multi_reduce.
 void launch_gemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, float* C, int ldc,
-                 const float* bias, int M, int N, int K, float alpha, void* scratch, hipStream_t s);
+                 const float* bias, int M, int N, int K, float alpha, void* scratch, hipStream_t s,
+                 ReduceJob* defer = nullptr);
 
 // ---- gru.hip / gru4.hip --------------------------------------------------------------------------
 // Operand images of the recurrent matrix U [H,3H]: ONE opaque buffer of gru_pack_floats(H) floats (one launch).

@@ -139,7 +139,89 @@ __global__ __launch_bounds__(256) void compact_write_kernel(const int32_t* __res
   for (int k = 0; k < 4; ++k)
     if (v[k]) vidx[pos++] = i0 + k;
 }
+// ids-form staging: expands the history and candidate doc ids through the resident title table AND counts the
+// non-pad tokens of every 1024-id block (what compact_count_kernel would do) in the same launch.
+__global__ __launch_bounds__(256) void expand_count_kernel(const int32_t* __restrict__ table,
+                                                           const int32_t* __restrict__ hist_ids, int n_hist,
+                                                           const int32_t* __restrict__ cand_ids, int n_total, int T,
+                                                           int32_t* __restrict__ out, int32_t* __restrict__ block_counts) {
+  const int n = n_total * T;
+  const int i0 = blockIdx.x * kCompactBlock + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = i0 + k;
+    if (i < n) {
+      const int title = i / T, t = i - title * T;
+      const int doc = title < n_hist ? hist_ids[title] : cand_ids[title - n_hist];
+      const int id = table[(size_t)doc * T + t];
+      out[i] = id;
+      c += id != 0;
+    }
+  }
+  int total;
+  block_exclusive_scan_256(c, &total);
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+void launch_expand_count(const int32_t* table, const int32_t* hist_ids, int n_hist, const int32_t* cand_ids, int n_cand,
+                         int T, int32_t* out, int32_t* block_counts, hipStream_t s) {
+  const int n = (n_hist + n_cand) * T;
+  if (n > 0)
+    hipLaunchKernelGGL(expand_count_kernel, dim3(cdiv(n, kCompactBlock)), dim3(256), 0, s, table, hist_ids, n_hist,
+                       cand_ids, n_hist + n_cand, T, out, block_counts);
+}
+// Second half of the compaction with the block prefix computed in place (<= a few hundred block counts, each block
+// sums its predecessors) and the conv kernel-gradient's per-token row offsets written along: offA = row of the padded
+// embedding layout, offB = row of the conv-output-shaped tensors (entries past the count are never read).
+__global__ __launch_bounds__(256) void compact_write_offsets_kernel(const int32_t* __restrict__ ids, int n,
+                                                                    const int32_t* __restrict__ block_counts,
+                                                                    int32_t* __restrict__ vidx,
+                                                                    int32_t* __restrict__ count_out, int T, int Tp, int D,
+                                                                    int F, int32_t* __restrict__ offA,
+                                                                    int32_t* __restrict__ offB) {
+  __shared__ int red[4];
+  int part = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += block_counts[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const int base = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  const int i0 = blockIdx.x * kCompactBlock + threadIdx.x * 4;
+  bool v[4];
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = i0 + k < n && ids[i0 + k] != 0;
+    c += v[k] ? 1 : 0;
+  }
+  int total;
+  int pos = base + block_exclusive_scan_256(c, &total);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (v[k]) {
+      const int m = i0 + k;
+      vidx[pos] = m;
+      if (offA) {
+        const int title = m / T, t = m - title * T;
+        offA[pos] = (title * Tp + t) * D;
+        offB[pos] = m * F;
+      }
+      ++pos;
+    }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) count_out[0] = base + total;
+}
 size_t compact_scratch_ints(int n) { return (size_t)cdiv(n, kCompactBlock); }
+void launch_compact_write_offsets(const int32_t* ids, int n, const int32_t* block_counts, int32_t* vidx, int32_t* count,
+                                  int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(compact_write_offsets_kernel, dim3(cdiv(n, kCompactBlock)), dim3(256), 0, s, ids, n, block_counts,
+                     vidx, count, T, Tp, D, F, offA, offB);
+}
+void launch_compact_count(const int32_t* ids, int n, int32_t* block_counts, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(compact_count_kernel, dim3(cdiv(n, kCompactBlock)), dim3(256), 0, s, ids, n, block_counts);
+}
 void launch_compact_valid(const int32_t* ids, int n, int32_t* vidx, int32_t* count, int32_t* scratch, hipStream_t s) {
   if (n <= 0) return;
   int nb = cdiv(n, kCompactBlock);
@@ -228,14 +310,51 @@ void launch_colsum(const float* x, int rows, int cols, int ld, float* out, float
 }
 // two-stage variant for tall inputs: scratch holds kColsumSlices x cols partial sums
 void launch_colsum2(const float* x, int rows, int cols, int ld, float* out, float scale, float* scratch,
-                    hipStream_t s) {
+                    hipStream_t s, ReduceJob* defer) {
+  if (defer) defer->nslices = 0;
   if (!cols) return;
   if (rows < 256 || !scratch) return launch_colsum(x, rows, cols, ld, out, scale, s);
   int slices = std::min(kColsumSlices, cdiv(rows, 32));
   int rps = cdiv(rows, slices);
   slices = cdiv(rows, rps);
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), slices), dim3(64, 16), 0, s, x, rows, cols, ld, scratch, 1.0f, rps);
+  if (defer) {
+    *defer = ReduceJob{scratch, out, 1, cols, cols, slices, (size_t)cols, scale};
+    return;
+  }
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), 1), dim3(64, 16), 0, s, scratch, slices, cols, cols, out, scale, slices);
+}
+
+// all deferred reductions of a step in one launch (see ReduceJob, lstur_internal.h)
+struct ReduceJobs {
+  ReduceJob job[kMaxReduceJobs];
+  int first_block[kMaxReduceJobs + 1];
+  int njobs;
+};
+__global__ __launch_bounds__(256) void multi_reduce_kernel(ReduceJobs J) {
+  int j = 0;
+  while (j + 1 < J.njobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
+  const ReduceJob& q = J.job[j];
+  const size_t count = (size_t)q.rows * q.cols;
+  const size_t i = (size_t)(blockIdx.x - J.first_block[j]) * 256 + threadIdx.x;
+  if (i >= count) return;
+  float acc = 0.f;
+  for (int s = 0; s < q.nslices; ++s) acc += q.src[(size_t)s * q.stride + i];
+  const int r = (int)(i / q.cols), c = (int)(i - (size_t)r * q.cols);
+  q.dst[(size_t)r * q.ld + c] = q.alpha * acc;
+}
+void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s) {
+  ReduceJobs J;
+  J.njobs = 0;
+  int blocks = 0;
+  for (int k = 0; k < njobs && J.njobs < kMaxReduceJobs; ++k) {
+    if (jobs[k].nslices <= 0) continue;
+    J.first_block[J.njobs] = blocks;
+    J.job[J.njobs++] = jobs[k];
+    blocks += (int)cdivz((size_t)jobs[k].rows * jobs[k].cols, 256);
+  }
+  J.first_block[J.njobs] = blocks;
+  if (blocks) hipLaunchKernelGGL(multi_reduce_kernel, dim3(blocks), dim3(256), 0, s, J);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -327,25 +446,26 @@ __global__ void first_occurrence_kernel(const int32_t* __restrict__ rows, int n,
     }
   first[i] = f;
 }
-// gsum[i,:] = sum over j (ascending) with first[j] == i of g[j,:]   (only for first occurrences)
-__global__ void combine_rows_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ first,
-                                    const float* __restrict__ g, int n, int dim, float* __restrict__ gsum,
-                                    int32_t* __restrict__ slot) {
-  int i = blockIdx.x;
-  if (first[i] != i) return;
-  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+// gsum[i,:] = sum over j >= i (ascending) with rows[j] == rows[i] of g[j,:], for the first occurrence i of each row
+__global__ __launch_bounds__(64) void combine_rows_kernel(const int32_t* __restrict__ rows, const float* __restrict__ g,
+                                                          int n, int dim, float* __restrict__ gsum,
+                                                          int32_t* __restrict__ slot) {
+  const int i = blockIdx.x, r = rows[i];
+  bool dup = false;
+  for (int j = threadIdx.x; j < i; j += 64) dup |= rows[j] == r;
+  if (__any(dup)) return;   // not the first occurrence (block = one wave)
+  for (int c = threadIdx.x; c < dim; c += 64) {
     float acc = g[(size_t)i * dim + c];
     for (int j = i + 1; j < n; ++j)
-      if (first[j] == i) acc += g[(size_t)j * dim + c];
+      if (rows[j] == r) acc += g[(size_t)j * dim + c];
     gsum[(size_t)i * dim + c] = acc;
   }
-  if (threadIdx.x == 0) slot[rows[i]] = i;
+  if (threadIdx.x == 0) slot[r] = i;
 }
 void launch_user_grad_combine(const int32_t* rows, const float* g, int n, int dim, int32_t* first, float* gsum,
                               int32_t* slot, hipStream_t s) {
-  if (!n) return;
-  hipLaunchKernelGGL(first_occurrence_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, rows, n, first);
-  hipLaunchKernelGGL(combine_rows_kernel, dim3(n), dim3(64), 0, s, rows, first, g, n, dim, gsum, slot);
+  (void)first;
+  if (n) hipLaunchKernelGGL(combine_rows_kernel, dim3(n), dim3(64), 0, s, rows, g, n, dim, gsum, slot);
 }
 __global__ void slot_clear_kernel(const int32_t* __restrict__ rows, int n, int32_t* __restrict__ slot) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,9 +486,22 @@ void launch_fill_i32(int32_t* p, int32_t v, size_t n, hipStream_t s) {
 // task/paper.py:644-645) and the user encoder's Masking() step mask (paper.py:592).  One wave per
 // history slot.
 // ---------------------------------------------------------------------------------------------
+// The trailing blocks of the same launch gather the user-embedding rows of the batch (paper.py:589-591) and keep the
+// row numbers for the sparse table update.
 __global__ __launch_bounds__(256) void hist_mask_kernel(const int32_t* __restrict__ ids, float* __restrict__ hv,
                                                         uint8_t* __restrict__ hmask, uint8_t* __restrict__ gmask,
-                                                        int nW, int T, int U) {
+                                                        int nW, int T, int U, int mask_blocks,
+                                                        const float* __restrict__ table, const int32_t* __restrict__ user,
+                                                        int32_t* __restrict__ user_rows, float* __restrict__ uvec, int n,
+                                                        int Ue) {
+  if ((int)blockIdx.x >= mask_blocks) {
+    const int b = (blockIdx.x - mask_blocks) * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (b >= n) return;
+    const int r = user[b];
+    if (l == 0) user_rows[b] = r;
+    for (int c = l; c < Ue; c += 64) uvec[(size_t)b * Ue + c] = table[(size_t)r * Ue + c];
+    return;
+  }
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   if (row >= nW) return;
@@ -389,8 +522,12 @@ __global__ __launch_bounds__(256) void hist_mask_kernel(const int32_t* __restric
   }
 }
 void launch_hist_mask(const int32_t* hist_ids, float* hv, uint8_t* hmask, uint8_t* gmask, int nW, int T, int U,
-                      hipStream_t s) {
-  if (nW) hipLaunchKernelGGL(hist_mask_kernel, dim3(cdiv(nW, 4)), dim3(256), 0, s, hist_ids, hv, hmask, gmask, nW, T, U);
+                      hipStream_t s, const float* table, const int32_t* user, int32_t* user_rows, float* uvec, int n,
+                      int Ue) {
+  const int mb = cdiv(nW, 4), ub = table ? cdiv(n, 4) : 0;
+  if (mb + ub)
+    hipLaunchKernelGGL(hist_mask_kernel, dim3(mb + ub), dim3(256), 0, s, hist_ids, hv, hmask, gmask, nW, T, U, mb, table,
+                       user, user_rows, uvec, n, Ue);
 }
 
 __global__ void scale_rows_u8_kernel(float* __restrict__ x, const uint8_t* __restrict__ mask, size_t total, int cols) {
