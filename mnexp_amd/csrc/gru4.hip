@@ -139,6 +139,13 @@ __device__ __forceinline__ float hs_grad4(float g) { return (g > 0.f && g < 1.f)
 // values alive over that stream moves the wait to a point where the store has long been acknowledged.
 __device__ __forceinline__ void keep(float& v) { asm volatile("" : "+v"(v)); }
 
+// Placement hint for the resident operand strips: ask for the value in an arch VGPR / an AGPR at this point.  MFMA
+// reads its B operand from either file; left alone the allocator parks ~85 operand registers per step in AGPRs as
+// spill slots and copies them back (v_accvgpr_read + a wait state) in front of their MFMA.
+__device__ __forceinline__ void pin_v(float4& x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
+__device__ __forceinline__ void pin_a(float4& x) { asm volatile("" : "+a"(x.x), "+a"(x.y), "+a"(x.z), "+a"(x.w)); }
+constexpr int kVgprQuads = 36;   // k-quads of the slot-0 strip kept in arch VGPRs (the rest + slot 1 live in AGPRs)
+
 // Step masks of the 4 rows of this workgroup as wave-uniform bit words (bit i = step base+i), 64 steps at a time:
 // one vector load + ballot per row and chunk instead of a byte load (and its wait) on every step.
 struct RowMasks {
@@ -429,6 +436,13 @@ __global__ __launch_bounds__(G4_THREADS) void gru4_fwd_kernel(Gru4Fwd g) {
       if (q < QR1) u1[q < QR1 ? q : 0] = vb;
       else *(float4*)(tailL + (q - QR1) * 256) = vb;
     }
+    if (KQ > 40) {
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+        if (q < kVgprQuads) pin_v(u0[q]); else pin_a(u0[q]);
+#pragma unroll
+      for (int q = 0; q < QR1; ++q) pin_a(u1[q]);
+    }
   }
   __syncthreads();
 #define LSTUR_ROLE(A, B) \
@@ -688,6 +702,13 @@ __global__ __launch_bounds__(G4_THREADS) void gru4_bwd_kernel(Gru4Bwd g) {
       u0[q] = oka ? va : make_float4(0.f, 0.f, 0.f, 0.f);
       if (q < QR1) u1[q < QR1 ? q : 0] = vb;
       else *(float4*)(tailL + (q - QR1) * 256) = vb;
+    }
+    if (KQ > 40) {
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+        if (q < kVgprQuads) pin_v(u0[q]); else pin_a(u0[q]);
+#pragma unroll
+      for (int q = 0; q < QR1; ++q) pin_a(u1[q]);
     }
   }
   __syncthreads();
