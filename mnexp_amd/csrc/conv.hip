@@ -345,10 +345,24 @@ __global__ __launch_bounds__(WK * WN * 64) void conv_wgrad_kernel(const float* _
 // stage image [A 16x192 | B 16x400]; the source address is per lane (row gather through the precomputed
 // per-token offsets), the instructions of a stage are dealt round-robin over the waves.  hipcc makes a wave
 // wait vmcnt(0) before the first ds_read that follows its own LDS-DMA, so a wave's DMA does not overlap its own
-// MFMAs -- the other 14 waves' MFMAs cover it.  (A dedicated loader wave, which keeps every compute wave free of
+// MFMAs -- the other 14 waves' MFMAs cover it (the row offsets of a stage are fetched one stage ahead, so the wave
+// spends that wait on the transfer alone).  (A dedicated loader wave, which keeps every compute wave free of
 // vmcnt waits, measured 2.5x slower: one wave cannot issue 37 gathers per stage fast enough.)
 // F == 16*CT*WN (one column block).
-template <int WK, int WN, int CT, int TK>
+// LDS-DMA issued through inline asm: invisible to hipcc's wait-count pass, which otherwise makes a wave wait
+// vmcnt(0) before the first ds_read that follows its own DMA (so a wave's transfer never overlapped its own MFMAs).
+// The wave waits for its transfers explicitly (wait_dma) before the barrier that publishes the stage.
+// (M0 carries the LDS base of the transfer, exactly as in the code hipcc emits for the builtin; the kernel has no
+//  other user of M0, hipcc only warns that it does not preserve a reserved register across the statement.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void glds16_asm(const float* src, uint32_t lds_byte_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_byte_base) : "m0");
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int WK, int WN, int CT, int TK, bool ASMDMA>
 __global__ __launch_bounds__(WK * WN * 64) void conv_wgrad_glds_kernel(
     const float* __restrict__ E, const float* __restrict__ dC, float* __restrict__ part, int KD, int F,
     const int32_t* __restrict__ offA, const int32_t* __restrict__ offB, const int32_t* __restrict__ vcount,
@@ -371,25 +385,37 @@ __global__ __launch_bounds__(WK * WN * 64) void conv_wgrad_glds_kernel(
   const int tok_end = min(count, tok_begin + tok_per_split);
   const int nstage = (tok_end > tok_begin) ? cdiv(tok_end - tok_begin, TK) : 0;
 
-  auto issue_stage = [&](int tok0, int buf) {
+  // source row of every transfer this wave issues for a stage (index loads batched, then the transfers)
+  auto stage_sources = [&](int tok0, const float** src) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int q = wv + i * NW;        // wave-uniform
+      src[i] = zeros;
       if (q < NINST) {
         const int idx = q * 64 + lane;
-        const float* src;
         if (q < A4 / 64) {                // A part: E rows (kk window of the token)
           const int r = idx / (AW / 4), x4 = idx - r * (AW / 4);
           const int tk = min(tok0 + r, count - 1);
-          src = E + (size_t)offA[tk] + kk0 + x4 * 4;
+          src[i] = E + (size_t)offA[tk] + kk0 + x4 * 4;
         } else {                          // B part: dC rows; rows past the split's range read zeros
           const int ib = idx - A4;
           const int r = ib / (BW / 4), y4 = ib - r * (BW / 4);
           const int tk = tok0 + r;
-          src = tk < tok_end ? dC + (size_t)offB[tk] + y4 * 4 : zeros;
+          if (tk < tok_end) src[i] = dC + (size_t)offB[tk] + y4 * 4;
         }
-        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(smem + buf * STAGE + q * 256),
-                                         16, 0, 0);
+      }
+    }
+  };
+  auto issue_stage = [&](const float* const* src, int buf) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int q = wv + i * NW;
+      if (q < NINST) {
+        if (ASMDMA)
+          glds16_asm(src[i], (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(smem + buf * STAGE + q * 256));
+        else
+          __builtin_amdgcn_global_load_lds(src[i], (__attribute__((address_space(3))) void*)(smem + buf * STAGE + q * 256),
+                                           16, 0, 0);
       }
     }
   };
@@ -399,11 +425,18 @@ __global__ __launch_bounds__(WK * WN * 64) void conv_wgrad_glds_kernel(
   for (int e = 0; e < 4; ++e)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[e][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (nstage > 0) issue_stage(tok_begin, 0);
+  const float* src[PER];
+  if (nstage > 0) {
+    stage_sources(tok_begin, src);
+    issue_stage(src, 0);
+  }
+  if (nstage > 1) stage_sources(tok_begin + TK, src);   // the row offsets of a stage are fetched one stage ahead
+  if (ASMDMA) wait_dma();
   __syncthreads();
   for (int st = 0; st < nstage; ++st) {
     const int buf = st & 1;
-    if (st + 1 < nstage) issue_stage(tok_begin + (st + 1) * TK, buf ^ 1);
+    if (st + 1 < nstage) issue_stage(src, buf ^ 1);
+    if (st + 2 < nstage) stage_sources(tok_begin + (st + 2) * TK, src);
     const float* as = smem + buf * STAGE + wk * 64 + i16 * 4;
     const float* bs = smem + buf * STAGE + TK * AW + wn * CT * 16 + i16;
 #pragma unroll
@@ -420,6 +453,7 @@ __global__ __launch_bounds__(WK * WN * 64) void conv_wgrad_glds_kernel(
         acc[3][ct] = mfma16(a.w, b[ct], acc[3][ct]);
       }
     }
+    if (ASMDMA) wait_dma();
     __syncthreads();   // vmcnt(0): the next stage has landed; every wave is done with this one
   }
 
@@ -501,12 +535,19 @@ void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scr
     size_t lds = 2 * TK * (64 * WK + 16 * CT * WN) * sizeof(float);
     static bool attr_set2 = false;
     if (!attr_set2) {
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<WK, WN, CT, TK>,
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<WK, WN, CT, TK, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<WK, WN, CT, TK, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set2 = true;
     }
-    hipLaunchKernelGGL((conv_wgrad_glds_kernel<WK, WN, CT, TK>), dim3(g.kblocks, nsplit, 1), dim3(WK * WN * 64), lds, s,
-                       emb, dout, part, KD, F, offA, offB, vcount, zeros);
+    static const bool asm_dma = getenv("LSTUR_WGRAD_ASMDMA") != nullptr;   // measured equal once the row offsets are prefetched
+    if (asm_dma)
+      hipLaunchKernelGGL((conv_wgrad_glds_kernel<WK, WN, CT, TK, true>), dim3(g.kblocks, nsplit, 1), dim3(WK * WN * 64),
+                         lds, s, emb, dout, part, KD, F, offA, offB, vcount, zeros);
+    else
+      hipLaunchKernelGGL((conv_wgrad_glds_kernel<WK, WN, CT, TK, false>), dim3(g.kblocks, nsplit, 1),
+                         dim3(WK * WN * 64), lds, s, emb, dout, part, KD, F, offA, offB, vcount, zeros);
   } else if (g.big) {
     constexpr int WK = 3, WN = 5, CT = 5;
     size_t lds = 2 * TK * (64 * WK + 16 * CT * WN) * sizeof(float);
