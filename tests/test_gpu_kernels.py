@@ -120,7 +120,8 @@ def test_conv_fwd_and_wgrad_at_baseline_shapes(N):
 
 
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize('M,N,K', [(3520, 200, 400), (200, 600, 3200), (37, 19, 70), (64, 64, 2048)])
+@pytest.mark.parametrize('M,N,K', [(3520, 200, 400), (200, 600, 3200), (37, 19, 70), (64, 64, 2048), (3200, 600, 200),
+                                   (100, 52, 332), (400, 200, 3520), (8, 12, 260)])
 def test_gemm_variants(ta, tb, M, N, K):
     _need_gpu()
     from mnexp_amd._lib import lib, check
