@@ -77,7 +77,7 @@ __device__ __forceinline__ void conv_rows_pass(const float* __restrict__ E, cons
       a_nxt = *(const float4*)(arow + (ch + 1) * 16);
     }
     if (active) {
-      const float* bs = smem + buf * CH + (first * 16 + c) * 16 + kq * 4;
+      const float* bs = smem + buf * CH + (first * 16 + c) * 16 + pack_b_slot(c, kq) * 4;   // conflict-free order
       // groups of G tiles: consecutive MFMAs hit different accumulators (dependent-issue latency 40
       // cycles against a 32-cycle issue interval would otherwise idle the matrix pipe)
       constexpr int G = (NT % 5 == 0) ? 5 : (NT % 4 == 0 ? 4 : (NT == 13 ? 13 : (NT == 7 ? 7 : 1)));

@@ -64,6 +64,9 @@ __device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, ui
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, (int)voff_bytes, (int)soff_bytes, 0);
 }
 
+// position (0..3) of k-quad kq inside the 16-float row of column n in a packed MFMA operand image (misc.hip: pack_b)
+__host__ __device__ __forceinline__ int pack_b_slot(int n, int kq) { return ((n >> 2) & 3) ^ ((0x9C >> (2 * kq)) & 3); }
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

@@ -236,6 +236,10 @@ void launch_compact_valid(const int32_t* ids, int n, int32_t* vidx, int32_t* cou
 // element s to MFMA s of the chunk (the k order inside a chunk is permuted identically on the
 // A side, which reads float4s along k).
 // ---------------------------------------------------------------------------------------------
+// The four k-quads of a column are stored in the order slot = ((n >> 2) & 3) ^ pi(kq), pi = (0, 3, 1, 2)
+// (pack_b_slot, lstur_device.h): a workgroup copies chunks of P verbatim into LDS, and with this order the 16 lanes
+// of every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) hit 16 different 16-byte bank slots; the natural order
+// made every such read a 2-way bank conflict (41 % of the conv kernel's LDS cycles).
 size_t pack_b_floats(int K, int N) { return (size_t)cdiv(K, 16) * ceil16(N) * 16; }
 
 template <bool TRANS>
@@ -250,7 +254,7 @@ __global__ void pack_b_kernel(const float* __restrict__ B, int ldb, int K, int N
   int k = ch * 16 + kk;
   float v = 0.f;
   if (k < K && n < N) v = TRANS ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
-  P[((size_t)ch * Np + n) * 16 + kk] = v;
+  P[((size_t)ch * Np + n) * 16 + pack_b_slot(n, kk >> 2) * 4 + (kk & 3)] = v;
 }
 void launch_pack_b(const float* B, int ldb, int K, int N, float* packed, hipStream_t s) {
   size_t total = pack_b_floats(K, N);
