@@ -118,12 +118,219 @@ __global__ __launch_bounds__(128) void att_pool_kernel(const float* __restrict__
   for (int t = threadIdx.x; t < T; t += 128) wn[t] = wn[t] * inv;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Title-resident forward and backward (T <= 32 tokens, F <= 512, F % 4 == 0): ONE workgroup per title keeps the
+// whole title -- 8 token rows per wave, 2 float4 per lane and row, dropout already applied -- in registers, so the
+// conv output is read once per pass (the streaming kernels above read it twice forward and twice backward) and a
+// pass is one launch: scores by wavefront shuffle -> T weights through LDS -> pooled row / gradient rows from the
+// registers.  Cross-wave sums go through LDS in fixed wave order (bitwise reproducible).
+// ---------------------------------------------------------------------------------------------
+constexpr int kTitleTok = 8;   // token rows per wave (4 waves)
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// rows of this wave: t = wv + 4 i.  live[i] = the row exists and is not a pad token; x = dropout(c[row]) (0 otherwise)
+__device__ __forceinline__ void title_load(const float* __restrict__ c, const int32_t* __restrict__ ids, int n, int T, int F,
+                                           int wv, int lane, uint32_t thresh, uint32_t key, float scale,
+                                           float4 (&x)[kTitleTok][2], bool (&live)[kTitleTok], bool (&nz)[kTitleTok]) {
+  const int F4 = F / 4;
+#pragma unroll
+  for (int i = 0; i < kTitleTok; ++i) {
+    const int t = wv + 4 * i;
+    const int row = n * T + min(t, T - 1);
+    live[i] = t < T && (!ids || ids[row] != 0);
+  }
+#pragma unroll
+  for (int i = 0; i < kTitleTok; ++i) {
+    const int row = n * T + min(wv + 4 * i, T - 1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int f4 = lane + 64 * h;
+      x[i][h] = (live[i] && f4 < F4) ? ((const float4*)(c + (size_t)row * F))[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kTitleTok; ++i) {
+    const int row = n * T + min(wv + 4 * i, T - 1);
+    bool any = false;
+    if (live[i]) {   // wave-uniform: pad / missing rows cost no hash work
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 v = x[i][h];
+        any |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+        x[i][h] = drop4(v, key, (uint32_t)row * (uint32_t)F + (uint32_t)(lane + 64 * h) * 4u, thresh, scale);
+      }
+    }
+    nz[i] = any;
+  }
+}
+
+__global__ __launch_bounds__(256) void att_fwd_title_kernel(const float* __restrict__ c, const int32_t* __restrict__ ids,
+                                                            const float* __restrict__ att_w,
+                                                            const float* __restrict__ att_b, float* __restrict__ a_out,
+                                                            float* __restrict__ w_out, float* __restrict__ pooled, int T,
+                                                            int F, uint32_t thresh, uint32_t key, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // e[32] | part[4][F]
+  float* eL = sm;
+  float* part = sm + 32;
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, F4 = F / 4;
+  float4 x[kTitleTok][2];
+  bool live[kTitleTok], nz[kTitleTok];
+  title_load(c, ids, n, T, F, wv, lane, thresh, key, scale, x, live, nz);
+  float4 kf[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    kf[h] = (lane + 64 * h < F4) ? ((const float4*)att_w)[lane + 64 * h] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float b = att_b[0];
+#pragma unroll
+  for (int i = 0; i < kTitleTok; ++i) {
+    const int t = wv + 4 * i;
+    float s = wave_sum(dot4(x[i][0], kf[0]) + dot4(x[i][1], kf[1]));
+    const bool m = __any(nz[i]);
+    if (t < T && lane == 0) {
+      float a = 0.f, e = 0.f;
+      if (live[i]) {
+        a = tanhf(s + b);
+        e = m ? expf(a) : 0.f;
+      }
+      a_out[(size_t)n * T + t] = a;
+      eL[t] = e;
+    }
+  }
+  __syncthreads();
+  float S = 0.f;
+  for (int t = 0; t < T; ++t) S += eL[t];
+  const float inv = 1.0f / (S + LSTUR_EPS);
+  if ((int)threadIdx.x < T) w_out[(size_t)n * T + threadIdx.x] = eL[threadIdx.x] * inv;
+  float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+  for (int i = 0; i < kTitleTok; ++i) {
+    const int t = wv + 4 * i;
+    const float wt = t < T ? eL[t] * inv : 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      acc[h].x += x[i][h].x * wt;
+      acc[h].y += x[i][h].y * wt;
+      acc[h].z += x[i][h].z * wt;
+      acc[h].w += x[i][h].w * wt;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (lane + 64 * h < F4) ((float4*)(part + wv * F))[lane + 64 * h] = acc[h];
+  __syncthreads();
+  for (int j = threadIdx.x; j < F4; j += 256) {
+    float4 r = ((float4*)part)[j];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float4 q = ((float4*)(part + k * F))[j];
+      r.x += q.x;
+      r.y += q.y;
+      r.z += q.z;
+      r.w += q.w;
+    }
+    ((float4*)(pooled + (size_t)n * F))[j] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restrict__ c, const int32_t* __restrict__ ids,
+                                                            const float* __restrict__ att_w, const float* __restrict__ a,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ dpooled, float* __restrict__ dc,
+                                                            float* __restrict__ parts, int T, int F, uint32_t thresh,
+                                                            uint32_t key, float scale, int ldp, int off_aw, int off_cb,
+                                                            int off_ab) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // dw[32] | ds[32] | red[4][2][F]
+  float* dwL = sm;
+  float* dsL = sm + 32;
+  float* red = sm + 64;
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, F4 = F / 4;
+  float4 x[kTitleTok][2];
+  bool live[kTitleTok], nz[kTitleTok];
+  float wt[kTitleTok];
+  title_load(c, ids, n, T, F, wv, lane, thresh, key, scale, x, live, nz);
+  float4 dp[2], kf[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const bool ok = lane + 64 * h < F4;
+    dp[h] = ok ? ((const float4*)(dpooled + (size_t)n * F))[lane + 64 * h] : make_float4(0.f, 0.f, 0.f, 0.f);
+    kf[h] = ok ? ((const float4*)att_w)[lane + 64 * h] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < kTitleTok; ++i) {
+    const int t = wv + 4 * i;
+    wt[i] = live[i] ? w[(size_t)n * T + t] : 0.f;     // masked rows: weight 0, they contribute nothing
+    const float s = wave_sum(dot4(x[i][0], dp[0]) + dot4(x[i][1], dp[1]));
+    if (t < T && lane == 0) dwL[t] = wt[i] != 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  float sum = 0.f;
+  for (int t = 0; t < T; ++t) sum += dwL[t] * w[(size_t)n * T + t];
+  float4 gaw[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, gcb[2] = {gaw[0], gaw[0]};
+#pragma unroll
+  for (int i = 0; i < kTitleTok; ++i) {
+    const int t = wv + 4 * i;
+    if (t >= T) continue;
+    const size_t row = (size_t)n * T + t;
+    const float av = a[row];
+    const float dst = (dwL[t] - sum) * wt[i] * (1.0f - av * av);
+    if (lane == 0) dsL[t] = dst;
+    if (!live[i]) continue;                            // pad token: its dconv row is neither read nor written
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wt[i] != 0.f) {
+        const float4 xv = x[i][h];
+        gaw[h].x += dst * xv.x;
+        gaw[h].y += dst * xv.y;
+        gaw[h].z += dst * xv.z;
+        gaw[h].w += dst * xv.w;
+        o.x = xv.x > 0.f ? (dp[h].x * wt[i] + dst * kf[h].x) * scale : 0.f;
+        o.y = xv.y > 0.f ? (dp[h].y * wt[i] + dst * kf[h].y) * scale : 0.f;
+        o.z = xv.z > 0.f ? (dp[h].z * wt[i] + dst * kf[h].z) * scale : 0.f;
+        o.w = xv.w > 0.f ? (dp[h].w * wt[i] + dst * kf[h].w) * scale : 0.f;
+        gcb[h].x += o.x;
+        gcb[h].y += o.y;
+        gcb[h].z += o.z;
+        gcb[h].w += o.w;
+      }
+      if (lane + 64 * h < F4) ((float4*)(dc + row * F))[lane + 64 * h] = o;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (lane + 64 * h < F4) {
+      ((float4*)(red + (wv * 2 + 0) * F))[lane + 64 * h] = gaw[h];
+      ((float4*)(red + (wv * 2 + 1) * F))[lane + 64 * h] = gcb[h];
+    }
+  __syncthreads();
+  float* pr = parts + (size_t)n * ldp;
+  for (int j = threadIdx.x; j < 2 * F; j += 256) {
+    const int which = j / F, f = j - which * F;
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r += red[(k * 2 + which) * F + f];
+    pr[(which ? off_cb : off_aw) + f] = r;
+  }
+  if (threadIdx.x == 0) {
+    float gab = 0.f;
+    for (int t = 0; t < T; ++t) gab += dsL[t];
+    pr[off_ab] = gab;
+  }
+}
+static bool title_path(int T, int F) { return T <= 4 * kTitleTok && F <= 512 && F % 4 == 0 && !getenv("LSTUR_ATT_STREAMING"); }
+
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
                         float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s) {
   if (!n_titles) return;
   uint32_t thresh = drop > 0.f ? dropout_thresh(drop) : 0u;
   float scale = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
   int rows = n_titles * T;
+  if (title_path(T, F)) {
+    hipLaunchKernelGGL(att_fwd_title_kernel, dim3(n_titles), dim3(256), (32 + 4 * F) * sizeof(float), s, c, ids, att_w,
+                       att_b, a, w, pooled, T, F, thresh, key, scale);
+    return;
+  }
   if (F % 4 == 0) {
     hipLaunchKernelGGL(att_score_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, c, ids, att_w, att_b, a, w, rows, F,
                        thresh, key, scale);
@@ -191,7 +398,7 @@ __global__ void att_bwd_ds_kernel(float* __restrict__ dw, const float* __restric
   }
 }
 
-int attpool_bwd_parts(int n_titles) { return n_titles < 1024 ? (n_titles > 0 ? n_titles : 1) : 1024; }
+int attpool_bwd_parts(int n_titles) { return n_titles > 0 ? n_titles : 1; }   // one partial-sum row per title
 
 // RSUB row sub-streams per block (256 threads = RSUB x 128 column slots): more loads in flight per CU for this
 // purely bandwidth-bound pass; the sub-streams' partial sums are combined through LDS in fixed order.
@@ -307,6 +514,11 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
   float scale = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
   const int rows = n_titles * T;
   const int nparts = attpool_bwd_parts(n_titles);
+  if (title_path(T, F)) {
+    hipLaunchKernelGGL(att_bwd_title_kernel, dim3(n_titles), dim3(256), (64 + 8 * F) * sizeof(float), s, c, ids, att_w, a, w,
+                       dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab);
+    return;
+  }
   if (F % 4 == 0) {
     hipLaunchKernelGGL(att_bwd_dw_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, c, w, dpooled, row_scratch, rows, T, F,
                        thresh, key, scale);

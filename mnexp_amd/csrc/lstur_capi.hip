@@ -212,7 +212,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->probs = (float*)take(nc * d.K1 * f4);
   w->loss_i = (float*)take(nc * f4);
   w->correct_i = (float*)take(nc * f4);
-  w->parts = (float*)take((size_t)1024 * (3 * ((d.F + kParamAlign - 1) / kParamAlign * kParamAlign) + 64) * f4);
+  w->parts = (float*)take(nt * (3 * ((d.F + kParamAlign - 1) / kParamAlign * kParamAlign) + 64) * f4);
   w->conv_wp = (float*)take(pack_b_floats(d.KD, d.F) * f4);
   w->gru_up = (float*)take(gru_pack_floats(d.H) * f4);
   w->wgrad_scratch = take(conv_wgrad_scratch_bytes(d.D, d.k, d.F));
