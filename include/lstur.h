@@ -127,7 +127,9 @@ int lstur_set_title_table(lstur_ctx* ctx, const int32_t* titles, int32_t n_docs)
  * per-sample user-row gradients.
  *   user  int32 [n]; hist int32 [n,W,T]; cands int32 [n,K1,T]   (token ids; 0 = pad)
  *   step  = global step counter (selects the dropout stream)
- *   stats = 2 device floats: mean categorical_crossentropy, categorical_accuracy (paper.py:655-659)
+ *   stats = 4 device floats: [0] mean categorical_crossentropy, [1] categorical_accuracy (paper.py:655-659) of
+ *           this batch; [2], [3] += the same two values (running sums the host zeroes per epoch, so that Keras'
+ *           epoch means need no extra launch per step)
  * grad_scale lets data-parallel callers pre-divide by the world size (1.0 otherwise). */
 int lstur_forward_backward(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands,
                            int32_t n, uint32_t step, float grad_scale, float* stats, lstur_stream stream);
@@ -153,14 +155,14 @@ int lstur_predict(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, cons
 int lstur_predict_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_ids, const int32_t* cand_ids,
                       int32_t n, float* scores, lstur_stream stream);
 
-/* model.evaluate_generator step (main.py:83-87): forward only, no dropout; stats as above. */
+/* model.evaluate_generator step (main.py:83-87): forward only, no dropout; writes stats[0..1] only. */
 int lstur_evaluate(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands,
                    int32_t n, float* stats, lstur_stream stream);
 
 /* Pointwise sibling (Seq2VecPaper / Seq2VecPaperDot / Seq2VecPaperId, paper.py:228-256, 356-383; contexts created
  * with head POINT_MLP or POINT_DOT and cands == 1): one candidate and one label per sample.
  *   user int32 [n]; hist int32 [n,W,T]; cand int32 [n,T]; labels float [n] in {0,1}
- *   stats = 2 device floats: Seq2Vec.loss (task/seq2vec.py:213-216) and the fraction of (p > 0.5) == label;
+ *   stats = 4 device floats (as above): Seq2Vec.loss (task/seq2vec.py:213-216) and the fraction of (p > 0.5) == label;
  *   the probabilities of the last call are readable through lstur_peek("probs") for the host-side AUC metric.
  * lstur_predict(_ids) returns the scorer's sigmoid output for these heads; lstur_adam_step is shared. */
 int lstur_point_forward_backward(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cand,

@@ -436,6 +436,8 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   if (stats) {
     jobs[nj++] = ReduceJob{w.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
     jobs[nj++] = ReduceJob{w.correct_i, stats + 1, 1, 1, 1, n, 1, 1.0f / (float)n};
+    jobs[nj++] = ReduceJob{w.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};      // running sums for the
+    jobs[nj++] = ReduceJob{w.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};   // host's epoch means
   }
   launch_multi_reduce(jobs, nj, s);
 }
@@ -697,10 +699,15 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
   if (n_rows < 0 || n_rows > d.rows_cap) return fail(LSTUR_ERR_ARG, "too many sparse rows for one adam step");
   const float lr_t = lr * (sqrtf(1.0f - powf(c.beta2, (float)t)) / (1.0f - powf(c.beta1, (float)t)));
   lazy_init(ctx, s);
-  launch_adam_flat(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v, ctx->dense_total,
-                   lr_t, c.beta1, c.beta2, c.eps, s);
+  if (d.arch == LSTUR_ARCH_NIGRU) {
+    launch_adam_flat(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v, ctx->dense_total,
+                     lr_t, c.beta1, c.beta2, c.eps, s);
+  } else {
+    launch_adam_flat_combine(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v,
+                             ctx->dense_total, lr_t, c.beta1, c.beta2, c.eps, rows, row_grads, n_rows, d.Ue,
+                             ctx->ws.gsum, ctx->ws.slot, s);
+  }
   if (d.arch != LSTUR_ARCH_NIGRU) {   // nigru: the user embedding is not part of the graph (paper.py:627-628)
-    launch_user_grad_combine(rows, row_grads, n_rows, d.Ue, ctx->ws.first, ctx->ws.gsum, ctx->ws.slot, s);
     {
       ProfScope _ps(ctx, "adam_user_table", s);
       launch_adam_table(ctx->buf.user_emb, ctx->buf.user_m, ctx->buf.user_v, ctx->ws.slot, ctx->ws.gsum, d.Nu, d.Ue,

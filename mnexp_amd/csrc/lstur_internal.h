@@ -13,15 +13,16 @@ namespace lstur {
 // Split-K GEMMs, two-stage column sums and the conv kernel gradient leave per-slice partial sums; instead of one
 // tiny reduction launch each (a dependent launch costs ~5 us on its own) they describe the reduction as a job and
 // ONE kernel at the end of the backward pass runs them all, in fixed slice order (bitwise reproducible):
-//   dst[r * ld + c] = alpha * sum_{s < nslices} src[s * stride + r * cols + c]
+//   dst[r * ld + c] = alpha * sum_{s < nslices} src[s * stride + r * cols + c]  (+ beta * dst when beta != 0)
 struct ReduceJob {
   const float* src;
   float* dst;
   int rows, cols, ld, nslices;
   size_t stride;
   float alpha;
+  float beta;
 };
-constexpr int kMaxReduceJobs = 12;
+constexpr int kMaxReduceJobs = 16;
 void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s);
 
 
@@ -61,6 +62,10 @@ void launch_colsum2(const float* x, int rows, int cols, int ld, float* out, floa
                     hipStream_t s, ReduceJob* defer = nullptr);
 void launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1,
                       float b2, float eps, hipStream_t s);
+// the same sweep + launch_user_grad_combine(rows, rg, ...) in one launch
+void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
+                              float eps, const int32_t* rows, const float* rg, int n_rows, int dim, float* gsum,
+                              int32_t* slot, hipStream_t s);
 // dense Adam sweep of the user table; slot[row] = index into gsum or -1
 void launch_adam_table(float* p, float* m, float* v, const int32_t* slot, const float* gsum, int n_rows,
                        int dim, float lr_t, float b1, float b2, float eps, hipStream_t s);

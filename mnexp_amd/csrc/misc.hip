@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void multi_reduce_kernel(ReduceJobs J) {
   float acc = 0.f;
   for (int s = 0; s < q.nslices; ++s) acc += q.src[(size_t)s * q.stride + i];
   const int r = (int)(i / q.cols), c = (int)(i - (size_t)r * q.cols);
-  q.dst[(size_t)r * q.ld + c] = q.alpha * acc;
+  float* d = q.dst + (size_t)r * q.ld + c;
+  *d = q.beta != 0.f ? q.alpha * acc + q.beta * *d : q.alpha * acc;
 }
 void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s) {
   ReduceJobs J;
@@ -382,6 +383,38 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
     m[i] = mi;
     v[i] = vi;
   }
+}
+// Adam over the dense bucket + the duplicate-row combine of the sparse user gradient (independent work) in one
+// launch: blocks [0, flat_blocks) sweep the bucket, the rest handle one sample row per wave.
+__device__ __forceinline__ void combine_row(const int32_t* __restrict__ rows, const float* __restrict__ g, int n, int dim,
+                                            float* __restrict__ gsum, int32_t* __restrict__ slot, int i, int lane);
+__global__ __launch_bounds__(256) void adam_flat_combine_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                                float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                                float lr_t, float b1, float b2, float eps,
+                                                                int flat_blocks, const int32_t* __restrict__ rows,
+                                                                const float* __restrict__ rg, int n_rows, int dim,
+                                                                float* __restrict__ gsum, int32_t* __restrict__ slot) {
+  if ((int)blockIdx.x >= flat_blocks) {
+    const int i = (blockIdx.x - flat_blocks) * 4 + (threadIdx.x >> 6);
+    if (i < n_rows) combine_row(rows, rg, n_rows, dim, gsum, slot, i, threadIdx.x & 63);
+    return;
+  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)flat_blocks * 256) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam1(pi, g[i], mi, vi, lr_t, b1, b2, eps);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
+                              float eps, const int32_t* rows, const float* rg, int n_rows, int dim, float* gsum,
+                              int32_t* slot, hipStream_t s) {
+  const int fb = (int)std::min<size_t>(cdivz(n, 256), 4096);
+  const int cb = cdiv(n_rows, 4);
+  if (fb + cb)
+    hipLaunchKernelGGL(adam_flat_combine_kernel, dim3(fb + cb), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps, fb, rows,
+                       rg, n_rows, dim, gsum, slot);
 }
 void launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                       float eps, hipStream_t s) {
@@ -450,21 +483,40 @@ __global__ void first_occurrence_kernel(const int32_t* __restrict__ rows, int n,
     }
   first[i] = f;
 }
-// gsum[i,:] = sum over j >= i (ascending) with rows[j] == rows[i] of g[j,:], for the first occurrence i of each row
+// gsum[i,:] = sum over j >= i (ascending) with rows[j] == rows[i] of g[j,:], for the first occurrence i of each row.
+// One wave per sample row; matches are found 64 rows at a time by ballot, so the usual case (no duplicate) costs
+// n/64 loads instead of n.
+__device__ __forceinline__ void combine_row(const int32_t* __restrict__ rows, const float* __restrict__ g, int n, int dim,
+                                            float* __restrict__ gsum, int32_t* __restrict__ slot, int i, int lane) {
+  const int r = rows[i];
+  bool dup = false;
+  for (int j = lane; j < i; j += 64) dup |= rows[j] == r;
+  if (__any(dup)) return;   // not the first occurrence
+  for (int c0 = 0; c0 < dim; c0 += 512) {   // 512 columns per pass
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = (c0 + lane + 64 * k < dim) ? g[(size_t)i * dim + c0 + lane + 64 * k] : 0.f;
+    for (int j0 = (i + 1) & ~63; j0 < n; j0 += 64) {
+      const int j = j0 + lane;
+      unsigned long long mask = __ballot(j > i && j < n && rows[j] == r);
+      while (mask) {   // ascending sample order
+        const int jj = j0 + __builtin_ctzll(mask);
+        mask &= mask - 1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (c0 + lane + 64 * k < dim) acc[k] += g[(size_t)jj * dim + c0 + lane + 64 * k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (c0 + lane + 64 * k < dim) gsum[(size_t)i * dim + c0 + lane + 64 * k] = acc[k];
+  }
+  if (lane == 0) slot[r] = i;
+}
 __global__ __launch_bounds__(64) void combine_rows_kernel(const int32_t* __restrict__ rows, const float* __restrict__ g,
                                                           int n, int dim, float* __restrict__ gsum,
                                                           int32_t* __restrict__ slot) {
-  const int i = blockIdx.x, r = rows[i];
-  bool dup = false;
-  for (int j = threadIdx.x; j < i; j += 64) dup |= rows[j] == r;
-  if (__any(dup)) return;   // not the first occurrence (block = one wave)
-  for (int c = threadIdx.x; c < dim; c += 64) {
-    float acc = g[(size_t)i * dim + c];
-    for (int j = i + 1; j < n; ++j)
-      if (rows[j] == r) acc += g[(size_t)j * dim + c];
-    gsum[(size_t)i * dim + c] = acc;
-  }
-  if (threadIdx.x == 0) slot[r] = i;
+  combine_row(rows, g, n, dim, gsum, slot, blockIdx.x, threadIdx.x);
 }
 void launch_user_grad_combine(const int32_t* rows, const float* g, int n, int dim, int32_t* first, float* gsum,
                               int32_t* slot, hipStream_t s) {

@@ -114,8 +114,9 @@ class NativeModel:
         self.user_v = torch.zeros(self.sizes.user_emb, dtype=f32, device=dev)
         self.workspace = torch.zeros(self.sizes.workspace_bytes + 256, dtype=torch.uint8, device=dev)
         ws_ptr = (self.workspace.data_ptr() + 255) // 256 * 256
-        self.stats = torch.zeros(2, dtype=f32, device=dev)
-        self.stats_acc = torch.zeros(2, dtype=f32, device=dev)
+        self._stats4 = torch.zeros(4, dtype=f32, device=dev)   # [loss, metric] of the last batch | running sums
+        self.stats = self._stats4[:2]
+        self.stats_acc = self._stats4[2:]
         bufs = _lib.Buffers(self.word_emb.data_ptr(), self.dense_param.data_ptr(), self.dense_grad.data_ptr(),
                             self.dense_m.data_ptr(), self.dense_v.data_ptr(), self.user_emb.data_ptr(),
                             self.user_m.data_ptr(), self.user_v.data_ptr(), ws_ptr, self.sizes.workspace_bytes)
@@ -364,7 +365,6 @@ class NativeModel:
         else:
             check(lib.lstur_adam_step(self._ctx, self.optimizer.lr, t, None, None, 0, s), 'lstur_adam_step')
         self.step += 1
-        self.stats_acc += self.stats
 
     def _allreduce_grads(self, n):
         """Data parallelism over RCCL: ONE all-reduce of the flat dense-gradient bucket (already scaled by
