@@ -139,7 +139,8 @@ def test_gemm_variants(ta, tb, M, N, K):
 
 
 @pytest.mark.parametrize('generic', [False, True], ids=['resident', 'generic'])
-@pytest.mark.parametrize('n,W,H', [(21, 12, 200), (5, 7, 40), (33, 9, 128), (6, 5, 150), (9, 4, 224)])
+@pytest.mark.parametrize('n,W,H', [(21, 12, 200), (5, 7, 40), (33, 9, 128), (6, 5, 150), (9, 4, 224), (7, 70, 40),
+                                   (3, 130, 200)])   # W > 64: the step-mask words are reloaded per 64-step chunk
 def test_gru_against_oracle(n, W, H, generic, monkeypatch):
     """Both GRU kernel families (U resident on chip for H <= 200 / the general streaming kernels)."""
     _need_gpu()

@@ -53,6 +53,8 @@ ODD = dict(V=90, D=20, F=23, k=5, U=18, N_u=9)      # F, U not multiples of 16; 
     (TINY, 5, 4, 7, 3, 0.25),
     (MID, 19, 9, 11, 5, 0.2),
     (ODD, 7, 3, 6, 2, 0.0),
+    (TINY, 4, 3, 33, 2, 0.25),     # T > 32: the streaming attention kernels (title-resident path covers T <= 32)
+    (TINY, 4, 3, 32, 2, 0.25),
 ])
 def test_forward_backward_matches_oracle(arch, dims, B, W, T, K1, drop):
     _need_gpu()
