@@ -335,18 +335,50 @@ struct ReduceJobs {
   int first_block[kMaxReduceJobs + 1];
   int njobs;
 };
+// a thread reduces 4 consecutive elements (one float4 per slice) where the job's shape allows, else one element
+__device__ __forceinline__ bool reduce_job_vec4(const ReduceJob& q) {
+  return (q.cols % 4 == 0) && (q.ld % 4 == 0) && (q.stride % 4 == 0) && ((((uintptr_t)q.src) | ((uintptr_t)q.dst)) & 15) == 0;
+}
 __global__ __launch_bounds__(256) void multi_reduce_kernel(ReduceJobs J) {
   int j = 0;
   while (j + 1 < J.njobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
   const ReduceJob& q = J.job[j];
   const size_t count = (size_t)q.rows * q.cols;
-  const size_t i = (size_t)(blockIdx.x - J.first_block[j]) * 256 + threadIdx.x;
+  const size_t t = (size_t)(blockIdx.x - J.first_block[j]) * 256 + threadIdx.x;
+  if (reduce_job_vec4(q)) {
+    const size_t i = t * 4;
+    if (i >= count) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < q.nslices; ++s) {
+      const float4 v = *(const float4*)(q.src + (size_t)s * q.stride + i);
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    }
+    const int r = (int)(i / q.cols), c = (int)(i - (size_t)r * q.cols);
+    float4* d = (float4*)(q.dst + (size_t)r * q.ld + c);
+    float4 o = make_float4(q.alpha * acc.x, q.alpha * acc.y, q.alpha * acc.z, q.alpha * acc.w);
+    if (q.beta != 0.f) {
+      const float4 p = *d;
+      o.x += q.beta * p.x;
+      o.y += q.beta * p.y;
+      o.z += q.beta * p.z;
+      o.w += q.beta * p.w;
+    }
+    *d = o;
+    return;
+  }
+  const size_t i = t;
   if (i >= count) return;
   float acc = 0.f;
   for (int s = 0; s < q.nslices; ++s) acc += q.src[(size_t)s * q.stride + i];
   const int r = (int)(i / q.cols), c = (int)(i - (size_t)r * q.cols);
   float* d = q.dst + (size_t)r * q.ld + c;
   *d = q.beta != 0.f ? q.alpha * acc + q.beta * *d : q.alpha * acc;
+}
+static bool reduce_job_vec4_host(const ReduceJob& q) {
+  return (q.cols % 4 == 0) && (q.ld % 4 == 0) && (q.stride % 4 == 0) && ((((uintptr_t)q.src) | ((uintptr_t)q.dst)) & 15) == 0;
 }
 void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s) {
   ReduceJobs J;
@@ -356,7 +388,8 @@ void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s) {
     if (jobs[k].nslices <= 0) continue;
     J.first_block[J.njobs] = blocks;
     J.job[J.njobs++] = jobs[k];
-    blocks += (int)cdivz((size_t)jobs[k].rows * jobs[k].cols, 256);
+    const size_t work = (size_t)jobs[k].rows * jobs[k].cols;
+    blocks += (int)cdivz(reduce_job_vec4_host(jobs[k]) ? work / 4 : work, 256);
   }
   J.first_block[J.njobs] = blocks;
   if (blocks) hipLaunchKernelGGL(multi_reduce_kernel, dim3(blocks), dim3(256), 0, s, J);
