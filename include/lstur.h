@@ -142,6 +142,17 @@ int lstur_forward_backward_ids(lstur_ctx* ctx, const int32_t* user, const int32_
  * (device pointers into the workspace; what a DP host all-gathers). */
 int lstur_user_grad(lstur_ctx* ctx, const int32_t** rows, const float** grads, int32_t* n);
 
+/* Data parallelism with ONE collective per step (the reference is single-device).  The caller allocates
+ * dense_grad with lstur_dp_tail_floats(cfg, world) extra floats behind the `dense` gradients.  After
+ * forward_backward (grad_scale = 1/world) every rank calls lstur_dp_stage: it writes its n (row number, gradient)
+ * pairs into slot `rank` of that tail and zeroes the other slots, so ONE all-reduce(sum) of the whole buffer both
+ * averages the dense gradients and concatenates the sparse rows of all ranks.  lstur_dp_unpack then yields rows /
+ * grads device pointers (rank order, every rank passed the same n) for lstur_adam_step(..., world * n). */
+size_t lstur_dp_tail_floats(const lstur_cfg* cfg, int32_t world);
+int lstur_dp_stage(lstur_ctx* ctx, float* tail, int32_t rank, int32_t world, lstur_stream stream);
+int lstur_dp_unpack(lstur_ctx* ctx, const float* tail, int32_t world, int32_t n, const int32_t** rows,
+                    const float** grads, lstur_stream stream);
+
 /* keras.optimizers.Adam update (paper.py:657) of the dense bucket from dense_grad, and the DENSE
  * update of the whole user table (TF-1 densifies the IndexedSlices gradient) from n_rows sparse
  * rows (duplicates are summed in ascending order).  t = 1-based Adam iteration. */

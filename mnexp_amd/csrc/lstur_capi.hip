@@ -148,6 +148,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
+  int32_t* dp_rows; float* dp_grads;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
 };
@@ -231,6 +232,8 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->sds = (float*)take(nc * f4);
   w->sdhid = (float*)take(nc * d.U * f4);
   w->sdcat = (float*)take(nc * 2 * d.U * f4);
+  w->dp_rows = (int32_t*)take((size_t)d.rows_cap * 4);
+  w->dp_grads = (float*)take((size_t)d.rows_cap * d.Ue * f4);
   w->user_rows = (int32_t*)take(nc * 4);
   w->scores = (float*)take(nc * f4);
   w->colsum_scratch = (float*)take((size_t)kColsumSlices * std::max(std::max(3 * d.H, d.U), (int)(3 * ((d.F + kParamAlign - 1) / kParamAlign * kParamAlign) + 64)) * f4);
@@ -683,6 +686,31 @@ int lstur_user_grad(lstur_ctx* ctx, const int32_t** rows, const float** grads, i
   if (grads) *grads = ctx->ws.duser;
   if (n) *n = ctx->last_n;
   return LSTUR_OK;
+}
+
+size_t lstur_dp_tail_floats(const lstur_cfg* cfg, int32_t world) {
+  Dims d;
+  std::string why;
+  if (world < 1 || !make_dims(cfg, &d, &why)) return 0;
+  return (size_t)world * d.B * (1 + d.Ue);
+}
+int lstur_dp_stage(lstur_ctx* ctx, float* tail, int32_t rank, int32_t world, lstur_stream stream) {
+  if (!ctx || !tail || world < 1 || rank < 0 || rank >= world) return fail(LSTUR_ERR_ARG, "dp stage: bad argument");
+  const Dims& d = ctx->d;
+  if ((size_t)world * d.B > (size_t)d.rows_cap) return fail(LSTUR_ERR_ARG, "dp stage: world size above 8");
+  if (d.Nu >= (1 << 24)) return fail(LSTUR_ERR_ARG, "dp stage: row numbers above 2^24 are not exact as float");
+  launch_dp_stage(ctx->ws.user_rows, ctx->ws.duser, ctx->last_n, d.B, d.Ue, tail, rank, world, (hipStream_t)stream);
+  return check_launch("dp_stage");
+}
+int lstur_dp_unpack(lstur_ctx* ctx, const float* tail, int32_t world, int32_t n, const int32_t** rows, const float** grads,
+                    lstur_stream stream) {
+  if (!ctx || !tail || !rows || !grads || world < 1 || n < 0) return fail(LSTUR_ERR_ARG, "dp unpack: bad argument");
+  const Dims& d = ctx->d;
+  if (n > d.B || (size_t)world * n > (size_t)d.rows_cap) return fail(LSTUR_ERR_ARG, "dp unpack: too many rows");
+  launch_dp_unpack(tail, n, d.B, d.Ue, world, ctx->ws.dp_rows, ctx->ws.dp_grads, (hipStream_t)stream);
+  *rows = ctx->ws.dp_rows;
+  *grads = ctx->ws.dp_grads;
+  return check_launch("dp_unpack");
 }
 
 int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, const float* row_grads, int32_t n_rows,

@@ -72,6 +72,10 @@ void launch_adam_table(float* p, float* m, float* v, const int32_t* slot, const 
 // dedupe rows -> slot map + summed grads (ascending sample order); first[i] scratch int32 [n]
 void launch_user_grad_combine(const int32_t* rows, const float* g, int n, int dim, int32_t* first,
                               float* gsum, int32_t* slot, hipStream_t s);
+// data-parallel exchange of the sparse user rows through the dense bucket's all-reduce (see misc.hip)
+void launch_dp_stage(const int32_t* rows, const float* g, int n, int B, int Ue, float* tail, int rank, int world,
+                     hipStream_t s);
+void launch_dp_unpack(const float* tail, int n, int B, int Ue, int world, int32_t* rows, float* g, hipStream_t s);
 void launch_user_slot_clear(const int32_t* rows, int n, int32_t* slot, hipStream_t s);
 void launch_fill_i32(int32_t* p, int32_t v, size_t n, hipStream_t s);
 // history mask (ComputeMasking) applied to doc vectors + GRU step mask:  hv[b,w,:] *= any(ids != 0);

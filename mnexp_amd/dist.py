@@ -3,9 +3,11 @@
 The reference is single-process; this is the build's own design:
   * users are partitioned by row number: rank r owns users r, r+N, r+2N, ... (user id = ClickData row,
     reference task/paper.py:531), every rank runs its own sample pool with the same local batch size;
-  * ONE all-reduce of the flat dense-gradient bucket per step (the library already scales by 1/N);
-  * an all-gather of the per-sample user-row gradients (rows int32[B], grads fp32[B, Ue]); every rank then
-    applies the identical dense Keras-Adam sweep to its full replica of the user table.
+  * ONE collective per step: an all-reduce of the flat gradient bucket (the library already scales by 1/N) whose
+    tail carries the per-sample user-row gradients -- every rank writes its (row, grad) pairs into its own slot and
+    zeroes the others, so the sum over ranks is the concatenation (lstur_dp_stage / lstur_dp_unpack, include/lstur.h);
+    every rank then applies the identical dense Keras-Adam sweep to its full replica of the user table.
+    (allgather_rows below is the general fallback: > 8 ranks or row numbers above 2^24.)
 The helpers take plain tensors so the same code runs on 'gloo' (CPU tests) and 'nccl' (MI355X).
 """
 import os

@@ -106,7 +106,11 @@ class NativeModel:
         f32 = torch.float32
         self.word_emb = torch.from_numpy(word_emb).to(dev)
         self.dense_param = torch.zeros(self.sizes.dense, dtype=f32, device=dev)
-        self.dense_grad = torch.zeros(self.sizes.dense, dtype=f32, device=dev)
+        # gradient bucket + room for the data-parallel exchange of the sparse user rows (up to 8 ranks): ONE all-reduce
+        # of this buffer per step averages the dense gradients and concatenates the rows (include/lstur.h: lstur_dp_*)
+        self._dp_tail = int(lib.lstur_dp_tail_floats(C.byref(self.cfg), 8))
+        self._bucket = torch.zeros(self.sizes.dense + self._dp_tail, dtype=f32, device=dev)
+        self.dense_grad = self._bucket[:self.sizes.dense]
         self.dense_m = torch.zeros(self.sizes.dense, dtype=f32, device=dev)
         self.dense_v = torch.zeros(self.sizes.dense, dtype=f32, device=dev)
         self.user_emb = torch.zeros(self.sizes.user_emb, dtype=f32, device=dev)
@@ -367,9 +371,26 @@ class NativeModel:
         self.step += 1
 
     def _allreduce_grads(self, n):
-        """Data parallelism over RCCL: ONE all-reduce of the flat dense-gradient bucket (already scaled by
-        1/world in the library) + an all-gather of the sparse user-row gradients."""
+        """Data parallelism over RCCL: ONE all-reduce per step.  The library stages this
+        rank's (row, gradient) pairs into its slot of the tail behind the dense gradients (other slots zero), so the
+        sum over ranks averages the dense bucket (already scaled by 1/world) AND concatenates the sparse rows."""
         from . import dist as D
+        world = max(1, self.world)
+        if world <= 8 and self.cfg.n_users < (1 << 24) and self.sizes.dense % 4 == 0:
+            dense = self.sizes.dense
+            used = int(lib.lstur_dp_tail_floats(C.byref(self.cfg), world))
+            tail = self._bucket[dense:dense + used]
+            rank = D.rank(self.dist_group)
+            s = self._stream()
+            check(lib.lstur_dp_stage(self._ctx, tail.data_ptr(), rank, world, s), 'lstur_dp_stage')
+            D.allreduce_bucket(self._bucket[:dense + used], self.dist_group, prescaled=True)
+            rows, grads = C.c_void_p(), C.c_void_p()
+            check(lib.lstur_dp_unpack(self._ctx, tail.data_ptr(), world, n, C.byref(rows), C.byref(grads), s),
+                  'lstur_dp_unpack')
+            Ue = self.sizes.user_emb_dim
+            return (self._peek_ptr(rows.value, world * n, torch.int32),
+                    self._peek_ptr(grads.value, world * n * Ue, torch.float32).view(world * n, Ue))
+        # general fallback: all-reduce of the bucket + all-gather of rows and gradients
         D.allreduce_bucket(self.dense_grad, self.dist_group, prescaled=True)
         rows, grads, cnt = C.c_void_p(), C.c_void_p(), C.c_int32()
         check(lib.lstur_user_grad(self._ctx, C.byref(rows), C.byref(grads), C.byref(cnt)), 'lstur_user_grad')

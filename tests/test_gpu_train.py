@@ -215,3 +215,47 @@ def test_pointwise_training_through_the_task_tracks_oracle(tmp_path):
     auc_gpu = per_impression_auc(h, lambda u, hi, c: model.predict_ids(u, hi, c.reshape(-1, 1))[:, 0], 60)
     auc_cpu = per_impression_auc(h, lambda u, hi, c: O.point_predict(p, 'igru', 'point_mlp', u, tt[hi], tt[c]), 60)
     assert abs(auc_gpu - auc_cpu) <= 0.002, (auc_gpu, auc_cpu)
+
+
+def test_single_collective_dp_with_two_emulated_ranks():
+    """The data-parallel step with world = 2 without a second GPU: two models play rank 0 / rank 1 (same weights,
+    different batches), each stages its sparse user rows into its slot of the bucket tail, the buckets are summed
+    (what the ONE all-reduce does), both unpack and apply Adam.  Result = the oracle's step on the concatenated
+    global batch, and the two replicas stay bit-identical."""
+    _need_gpu()
+    import ctypes as C
+    from conftest import make_batch
+    from mnexp_amd._lib import lib, check
+    from test_gpu_model import build, MID, rel_close
+    dims, B, W, T, K1 = MID, 12, 6, 9, 5
+    O, p, m0, rng = build('igru', dims, B, W, T, K1, 0.0)
+    _, _, m1, _ = build('igru', dims, B, W, T, K1, 0.0)
+    batches = [make_batch(rng, B, W, T, K1, dims['V'], dims['N_u']) for _ in range(2)]
+    batches[1][0][:3] = batches[0][0][:3]                     # the same users on both ranks: duplicates must sum
+    world, dense = 2, m0.sizes.dense
+    used = int(lib.lstur_dp_tail_floats(C.byref(m0.cfg), world))
+    for r, m in enumerate((m0, m1)):
+        user, hist, cands = batches[r]
+        u, h, c = m._dev_i32(user), m._dev_i32(hist), m._dev_i32(cands)
+        check(lib.lstur_forward_backward(m._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), B, 0, 1.0 / world,
+                                         m.stats.data_ptr(), m._stream()), 'fb')
+        check(lib.lstur_dp_stage(m._ctx, m._bucket[dense:].data_ptr(), r, world, m._stream()), 'stage')
+    total = m0._bucket[:dense + used] + m1._bucket[:dense + used]       # the all-reduce
+    for m in (m0, m1):
+        m._bucket[:dense + used].copy_(total)
+        rows, grads = C.c_void_p(), C.c_void_p()
+        check(lib.lstur_dp_unpack(m._ctx, m._bucket[dense:].data_ptr(), world, B, C.byref(rows), C.byref(grads),
+                                  m._stream()), 'unpack')
+        check(lib.lstur_adam_step(m._ctx, 1e-3, 1, rows.value, grads.value, world * B, m._stream()), 'adam')
+    torch.cuda.synchronize()
+    w0, w1 = m0.get_weights(), m1.get_weights()
+    for n in w0:
+        assert np.array_equal(w0[n], w1[n]), n                 # replicas bit-identical
+    pf = {n: a.astype(np.float32) for n, a in p.items()}
+    opt = O.Adam(pf, O.dense_param_names('igru') + ['user_emb'], lr=1e-3)
+    user = np.concatenate([b[0] for b in batches])
+    hist = np.concatenate([b[1] for b in batches])
+    cands = np.concatenate([b[2] for b in batches])
+    O.train_step(pf, 'igru', opt, user, hist, cands, drop_p=0.0)
+    for n in O.dense_param_names('igru') + ['user_emb']:
+        rel_close(w0[n].reshape(-1), pf[n].reshape(-1), 2e-3, n)
