@@ -70,6 +70,9 @@ typedef struct lstur_cfg {
   int32_t head;              /* lstur_head; 0 = the listwise model                                     */
   float gain;                /* pointwise loss: weight of the positive term (-g / --gain)              */
   int32_t loss_negatives;    /* pointwise loss: K = negative_samples of Seq2Vec.loss (-n)              */
+  int32_t freeze_encoder;    /* != 0: the news encoder is a loaded, non-trainable model (--enable-pretrain-encoder
+                                without --pretrain-encoder-trainable, paper.py:103-107): its backward pass is skipped,
+                                its gradients stay 0 (dropout inside it stays active in training, as in Keras)   */
 } lstur_cfg;
 
 /* Sizes (in floats unless named _bytes) the caller must allocate for a configuration. */

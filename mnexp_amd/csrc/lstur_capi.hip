@@ -417,6 +417,16 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
               w.gemm_scratch_k[1], s, &jobs[nj++]);
   launch_gemm(rh, d.H, 1, w.dgates + 2 * d.H, 3 * d.H, 0, c->G("gru_u") + 2 * d.H, 3 * d.H, nullptr, d.H, d.H, nW,
               1.f, w.gemm_scratch_k[2], s, &jobs[nj++]);
+  if (c->cfg.freeze_encoder) {   // loaded, non-trainable news encoder: nothing behind the doc vectors is trained
+    if (stats) {
+      jobs[nj++] = ReduceJob{w.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
+      jobs[nj++] = ReduceJob{w.correct_i, stats + 1, 1, 1, 1, n, 1, 1.0f / (float)n};
+      jobs[nj++] = ReduceJob{w.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
+      jobs[nj++] = ReduceJob{w.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
+    }
+    launch_multi_reduce(jobs, nj, s);
+    return;
+  }
   // d(history doc vectors) = dgates . gru_w^T, masked by the history mask (paper.py:644-645)
   launch_gemm(w.dgates, 3 * d.H, 0, c->P("gru_w"), 3 * d.H, 1, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, 1.f,
               w.gemm_scratch, s);

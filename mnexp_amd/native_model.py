@@ -76,7 +76,7 @@ class _TfAuc:
 class NativeModel:
     def __init__(self, word_emb, n_users, batch_size, window, title_len, negative_samples, filters, kernel,
                  user_dim, arch='igru', dropout=0.2, lr=1e-3, seed=0, device=None, title_table=None,
-                 dist_group=None, has_user=True, head='softmax', gain=1.0):
+                 dist_group=None, has_user=True, head='softmax', gain=1.0, freeze_encoder=False):
         if not torch.cuda.is_available():
             raise _lib.LsturError('no GPU visible: the native LSTUR model has no CPU fallback')
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
@@ -92,7 +92,8 @@ class NativeModel:
         self.has_user = has_user       # False: id-less task (Seq2VecPaperSoftmax), inputs carry no user column
         self.cfg = _lib.make_cfg(batch_size, window, title_len, self.K1, V, D, filters, kernel, user_dim,
                                  max(1, n_users), arch, dropout, seed, head=head, gain=gain,
-                                 loss_negatives=max(1, negative_samples))
+                                 loss_negatives=max(1, negative_samples), freeze_encoder=freeze_encoder)
+        self.freeze_encoder = bool(freeze_encoder)
         self.sizes = _lib.query_sizes(self.cfg)
         self.layout = _lib.param_layout(self.cfg)
         H, Ue = self.sizes.gru_dim, self.sizes.user_emb_dim
@@ -167,11 +168,16 @@ class NativeModel:
         elif head != 'softmax' and arch != 'igru':
             # Seq2VecPaperId.get_user_encoder (paper.py:330-354): gru / iigru concatenate to 2U, vo drops the history
             raise _lib.LsturError('pointwise task with user ids: only -a igru is on the native path (got {!r})'.format(arch))
-        return cls(emb, user_count, cfg.batch_size, cfg.window_size, cfg.title_shape, cfg.negative_samples,
-                   int(filters), int(kernel), cfg.user_embedding_dim, arch=arch, dropout=cfg.dropout,
-                   lr=cfg.learning_rate, seed=int(getattr(cfg, 'seed', 0) or 0),
-                   title_table=task.docs.title_table, has_user=has_user, head=head,
-                   gain=float(getattr(cfg, 'gain', 1.0)))
+        pretrained = bool(getattr(cfg, 'enable_pretrain_encoder', False))
+        model = cls(emb, user_count, cfg.batch_size, cfg.window_size, cfg.title_shape, cfg.negative_samples,
+                    int(filters), int(kernel), cfg.user_embedding_dim, arch=arch, dropout=cfg.dropout,
+                    lr=cfg.learning_rate, seed=int(getattr(cfg, 'seed', 0) or 0),
+                    title_table=task.docs.title_table, has_user=has_user, head=head,
+                    gain=float(getattr(cfg, 'gain', 1.0)),
+                    freeze_encoder=pretrained and not getattr(cfg, 'pretrain_encoder_trainable', False))
+        if pretrained:                      # paper.py:103-107
+            model.load_encoder(cfg.encoder_input)
+        return model
 
     def test_view(self):
         """The reference swaps ``model``/``test_model`` around evaluation (task/paper.py:502,524); here one
@@ -297,6 +303,42 @@ class NativeModel:
         with open(pkl_path, 'rb') as f:      # a file written by save() above
             arrays = pickle.load(f)
         self.set_weights({n: np.asarray(a).reshape(self.shapes[n]) for n, a in zip(meta['order'], arrays)})
+
+    ENCODER_ORDER = ['word_emb', 'conv_w', 'conv_b', 'att_w', 'att_b', 'dense_w', 'dense_b']
+
+    def save_encoder(self, paths):
+        """The news encoder alone, as ``utils.save_model(config.encoder_output, doc_encoder)`` would write it
+        (utils.py:73-79): pickle of ``doc_encoder.get_weights()`` -- layer order, i.e. Embedding matrix, Conv1D
+        kernel/bias, attention kernel [F,1]/bias, Dense kernel/bias."""
+        import json
+        import pickle
+        json_path, pkl_path = paths
+        w = self.get_weights()
+        w['word_emb'] = self.word_emb.cpu().numpy()
+        arrays = [w[n].reshape(-1, 1) if n == 'att_w' else w[n] for n in self.ENCODER_ORDER]
+        with open(json_path, 'w') as f:
+            json.dump(dict(format='mnexp_amd-lstur-encoder-1', order=self.ENCODER_ORDER,
+                           shapes=[list(a.shape) for a in arrays]), f)
+        with open(pkl_path, 'wb') as f:
+            pickle.dump(arrays, f, protocol=pickle.HIGHEST_PROTOCOL)
+
+    def load_encoder(self, paths):
+        """``--enable-pretrain-encoder`` (paper.py:103-107: ``utils.load_model(config.encoder_input)``): takes the 7
+        arrays of a saved cnnatt doc encoder (the list order above; the JSON side file is not interpreted)."""
+        import pickle
+        with open(paths[1], 'rb') as f:      # the user's own pre-trained encoder file
+            arrays = pickle.load(f)
+        if len(arrays) != len(self.ENCODER_ORDER):
+            raise ValueError('expected the {} weight arrays of a cnnatt doc encoder, found {}'.format(
+                len(self.ENCODER_ORDER), len(arrays)))
+        w = {}
+        for n, a in zip(self.ENCODER_ORDER, arrays):
+            a = np.asarray(a, dtype=np.float32)
+            if a.size != int(np.prod(self.shapes[n])):
+                raise ValueError('{}: saved shape {} does not fit {}'.format(n, a.shape, self.shapes[n]))
+            w[n] = a.reshape(self.shapes[n])
+        self.word_emb.copy_(torch.from_numpy(w.pop('word_emb')).to(self.device))
+        self.set_weights(w)
 
     def profile(self, enable=True):
         """Bracket each kernel family with HIP events on the launch stream (bench.py roofline figures)."""

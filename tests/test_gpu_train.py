@@ -259,3 +259,69 @@ def test_single_collective_dp_with_two_emulated_ranks():
     O.train_step(pf, 'igru', opt, user, hist, cands, drop_p=0.0)
     for n in O.dense_param_names('igru') + ['user_emb']:
         rel_close(w0[n].reshape(-1), pf[n].reshape(-1), 2e-3, n)
+
+
+def test_pretrained_frozen_news_encoder(tmp_path):
+    """--enable-pretrain-encoder (paper.py:103-107): the news encoder is loaded from the encoder files and, without
+    --pretrain-encoder-trainable, stays fixed while the user encoder trains; gradients equal the oracle's for the
+    parameters that do train."""
+    _need_gpu()
+    from conftest import make_batch
+    from mnexp_amd.native_model import NativeModel
+    from test_gpu_model import build, MID, rel_close
+    dims, B, W, T, K1 = MID, 10, 6, 9, 5
+    O, p, donor, rng = build('igru', dims, B, W, T, K1, 0.2)
+    paths = (str(tmp_path / 'encoder.json'), str(tmp_path / 'encoder.pkl'))
+    donor.save_encoder(paths)
+    import pickle
+    arrays = pickle.load(open(paths[1], 'rb'))
+    assert [a.shape for a in arrays][:4] == [(dims['V'], dims['D']), (dims['k'], dims['D'], dims['F']), (dims['F'],),
+                                              (dims['F'], 1)]                     # doc_encoder.get_weights() order
+    rng2 = np.random.default_rng(99)
+    model = NativeModel(rng2.normal(0, 0.1, (dims['V'], dims['D'])), dims['N_u'], B, W, T, K1 - 1, dims['F'], dims['k'],
+                        dims['U'], arch='igru', dropout=0.2, lr=1e-2, seed=77, freeze_encoder=True)
+    model.load_encoder(paths)
+    enc = ['conv_w', 'conv_b', 'att_w', 'att_b', 'dense_w', 'dense_b']
+    model.set_weights({n: p[n] for n in ('user_emb', 'gru_w', 'gru_u', 'gru_b')})
+    w_before = model.get_weights()
+    for n in enc:
+        assert np.array_equal(w_before[n], p[n].astype(np.float32)), n
+    assert np.array_equal(model.word_emb.cpu().numpy(), p['word_emb'].astype(np.float32))
+    user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
+    ref = O.forward_backward(p, 'igru', user, hist, cands, drop_p=0.2, seed=77, step=0)
+    X = [user.astype(np.int64), hist.astype(np.float64)] + [cands[:, j].astype(np.float64) for j in range(K1)]
+    model.train_on_batch(X, None)
+    torch.cuda.synchronize()
+    assert abs(model.stats[0].item() - ref['loss']) < 1e-4 * max(1.0, abs(ref['loss']))
+    g = model.get_grads()
+    for n in ('gru_w', 'gru_u', 'gru_b'):
+        rel_close(g[n].reshape(-1), ref['grads'][n].reshape(-1), 2e-3, n)
+    for n in enc:
+        assert not g[n].any(), n                                # no gradient behind the doc vectors
+    for _ in range(3):
+        model.train_on_batch(X, None)
+    torch.cuda.synchronize()
+    w_after = model.get_weights()
+    for n in enc:
+        assert np.array_equal(w_after[n], w_before[n]), n       # frozen
+    assert not np.array_equal(w_after['gru_w'], w_before['gru_w'])   # the user encoder learns
+
+
+def test_cli_with_pretrained_encoder(tmp_path):
+    _need_gpu()
+    from mnexp_amd.main import run_training
+    from mnexp_amd import settings
+    cfg = _config(tmp_path, arch='igru', epochs=1, training_step=8, validation_step=1, validation_impression=10,
+                  testing_impression=10, dropout=0.2, seed=1)
+    h = run_training(cfg)
+    settings.public_config.update(input_previous_model_path=str(tmp_path))
+    cfg2 = _config(tmp_path, arch='igru', epochs=1, training_step=8, validation_step=1, validation_impression=10,
+                   testing_impression=10, dropout=0.2, seed=2, enable_pretrain_encoder=True, pretrain_name='')
+    cfg2.input_previous_model_path = str(tmp_path)
+    h.model.save_encoder(cfg2.encoder_input)
+    h2 = run_training(cfg2)
+    assert h2.model.freeze_encoder
+    a, b = h.model.get_weights(), h2.model.get_weights()
+    for n in ('conv_w', 'att_w', 'dense_w', 'dense_b'):
+        assert np.array_equal(a[n], b[n]), n
+    assert not np.array_equal(a['gru_u'], b['gru_u'])
