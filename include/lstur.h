@@ -70,6 +70,9 @@ typedef struct lstur_cfg {
   int32_t head;              /* lstur_head; 0 = the listwise model                                     */
   float gain;                /* pointwise loss: weight of the positive term (-g / --gain)              */
   int32_t loss_negatives;    /* pointwise loss: K = negative_samples of Seq2Vec.loss (-n)              */
+  int32_t word_trainable;    /* != 0: --textual-embedding-trainable (paper.py:132-138): the word table receives the
+                                conv's input gradient (scatter-add over the batch's tokens, row 0 = pad id included)
+                                and a dense Keras-Adam update; needs lstur_buffers.word_grad / word_m / word_v   */
   int32_t freeze_encoder;    /* != 0: the news encoder is a loaded, non-trainable model (--enable-pretrain-encoder
                                 without --pretrain-encoder-trainable, paper.py:103-107): its backward pass is skipped,
                                 its gradients stay 0 (dropout inside it stays active in training, as in Keras)   */
@@ -87,7 +90,7 @@ typedef struct lstur_sizes {
 } lstur_sizes;
 
 typedef struct lstur_buffers {
-  float* word_emb;           /* [V, D]   frozen word table (Embedding weights, paper.py:132-138) */
+  float* word_emb;           /* [V, D]   word table (Embedding weights, paper.py:132-138); frozen unless word_trainable */
   float* dense_param;        /* [dense]  flat parameter bucket                          */
   float* dense_grad;         /* [dense]  flat gradient bucket (all-reduced by the host under DP) */
   float* dense_m;            /* [dense]  Adam first moment                              */
@@ -97,6 +100,9 @@ typedef struct lstur_buffers {
   float* user_v;             /* [n_users, Ue]                                           */
   void* workspace;           /* workspace_bytes, 256-byte aligned                       */
   size_t workspace_bytes;
+  float* word_grad;          /* [V, D]  only with cfg.word_trainable (else NULL): gradient of the word table */
+  float* word_m;             /* [V, D]  its Adam moments                                 */
+  float* word_v;
 } lstur_buffers;
 
 const char* lstur_last_error(void);

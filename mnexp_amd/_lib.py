@@ -23,7 +23,8 @@ class Cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('max_batch', 'window', 'title_len', 'cands', 'vocab', 'word_dim',
                                          'filters', 'kernel', 'user_dim', 'n_users', 'arch')] + [
         ('dropout', C.c_float), ('seed', C.c_uint32), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
-        ('head', C.c_int32), ('gain', C.c_float), ('loss_negatives', C.c_int32), ('freeze_encoder', C.c_int32)]
+        ('head', C.c_int32), ('gain', C.c_float), ('loss_negatives', C.c_int32), ('word_trainable', C.c_int32),
+        ('freeze_encoder', C.c_int32)]
 
 
 class Sizes(C.Structure):
@@ -35,7 +36,7 @@ class Sizes(C.Structure):
 class Buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('word_emb', 'dense_param', 'dense_grad', 'dense_m', 'dense_v',
                                           'user_emb', 'user_m', 'user_v', 'workspace')] + [
-        ('workspace_bytes', C.c_size_t)]
+        ('workspace_bytes', C.c_size_t), ('word_grad', C.c_void_p), ('word_m', C.c_void_p), ('word_v', C.c_void_p)]
 
 
 _P, _I, _U, _F, _Z = C.c_void_p, C.c_int32, C.c_uint32, C.c_float, C.c_size_t
@@ -114,13 +115,13 @@ def check(rc, what=''):
 
 def make_cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
              arch='igru', dropout=0.0, seed=0, beta1=0.9, beta2=0.999, eps=1e-7, head='softmax', gain=1.0,
-             loss_negatives=4, freeze_encoder=False):
+             loss_negatives=4, freeze_encoder=False, word_trainable=False):
     if arch not in ARCH:
         raise LsturError('arch {!r} is not supported by the native path (have {})'.format(arch, sorted(ARCH)))
     if head not in HEAD:
         raise LsturError('head {!r} is not supported by the native path (have {})'.format(head, sorted(HEAD)))
     return Cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
-               ARCH[arch], dropout, seed, beta1, beta2, eps, HEAD[head], gain, loss_negatives, int(bool(freeze_encoder)))
+               ARCH[arch], dropout, seed, beta1, beta2, eps, HEAD[head], gain, loss_negatives, int(bool(word_trainable)), int(bool(freeze_encoder)))
 
 
 def query_sizes(cfg):

@@ -26,12 +26,18 @@ namespace lstur {
 // One pass over K for NT column tiles [first, first+NT) of 16 output rows: the wave's share of a row block.
 // All waves of the workgroup run the chunk loop together (W staging + barriers); `active` gates the MFMAs and
 // the epilogue only.
-template <int NTW, int WAVES, int NT>
+// EPI 0: the Conv1D epilogue (+ bias, ReLU, pad-id mask).  EPI 1: the same contraction used as the conv's INPUT
+// gradient for a trainable word table (--textual-embedding-trainable): E = zero-padded conv-output gradients, the
+// weight image is the flipped kernel, and the epilogue applies the embedding dropout mask and scatter-adds row
+// (title, t) into word_grad[id(title, t)] (float atomics, like TF's unsorted_segment_sum on a GPU).
+struct EpiDrop { uint32_t thresh, key; float scale; };
+template <int NTW, int WAVES, int NT, int EPI>
 __device__ __forceinline__ void conv_rows_pass(const float* __restrict__ E, const float* __restrict__ wsrc,
                                                const float* __restrict__ bias, const int32_t* __restrict__ ids,
                                                float* __restrict__ C, const int32_t* __restrict__ vidx, float* smem,
                                                int T, int Tp, int D, int F, int Fp, int nchunk, int valid4, int tile0,
-                                               int m0, int r_end, bool active, int first, int tid, int lane) {
+                                               int m0, int r_end, bool active, int first, int tid, int lane,
+                                               EpiDrop ed) {
   constexpr int CH = NTW * 256;
   constexpr int NV4 = CH / 4;
   constexpr int PER = (NV4 + WAVES * 64 - 1) / (WAVES * 64);
@@ -114,6 +120,28 @@ __device__ __forceinline__ void conv_rows_pass(const float* __restrict__ E, cons
       rows[j] = mm;
       keep[j] = (ok && ids[mm] != 0) ? 1.f : 0.f;
     }
+    if (EPI == 1) {
+      int idr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) idr[j] = rows[j] >= 0 ? ids[rows[j]] : 0;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = (tile0 + first + nt) * 16 + c;
+        if (first + nt < NTW && col < F) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = acc[nt][j];
+            if (rows[j] < 0 || v == 0.f) continue;   // positions without a non-pad neighbour contribute exactly 0
+            if (ed.thresh) {
+              if (!keep_elem(ed.key, (uint32_t)rows[j] * (uint32_t)F + (uint32_t)col, ed.thresh)) continue;
+              v *= ed.scale;
+            }
+            atomicAdd(C + (size_t)idr[j] * F + col, v);
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       int col = (tile0 + first + nt) * 16 + c;
@@ -127,7 +155,7 @@ __device__ __forceinline__ void conv_rows_pass(const float* __restrict__ E, cons
   }
 }
 
-template <int NTW, int WAVES>
+template <int NTW, int WAVES, int EPI = 0>
 __global__ __launch_bounds__(WAVES * 64) void conv_fwd_kernel(const float* __restrict__ E,
                                                               const float* __restrict__ Wp,
                                                               const float* __restrict__ bias,
@@ -135,7 +163,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_fwd_kernel(const float* __res
                                                               float* __restrict__ C, int M, int T, int Tp, int D,
                                                               int F, int Fp, int nchunk,
                                                               const int32_t* __restrict__ vidx,
-                                                              const int32_t* __restrict__ vcount) {
+                                                              const int32_t* __restrict__ vcount, EpiDrop ed) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CH = NTW * 256;  // floats per packed chunk of this column group
   const int tid = threadIdx.x, lane = tid & 63;
@@ -154,8 +182,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv_fwd_kernel(const float* __res
   // full rounds: one 16-row tile per wave, all NTW column tiles
   for (; base < r_end && (NTW != 25 || WAVES != 8 || r_end - base > 64); base += WAVES * 16) {
     const int m0 = base + wv * 16;
-    conv_rows_pass<NTW, WAVES, NTW>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0, m0, r_end,
-                                    m0 < r_end, 0, tid, lane);
+    conv_rows_pass<NTW, WAVES, NTW, EPI>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0, m0,
+                                         r_end, m0 < r_end, 0, tid, lane, ed);
   }
   // tail of <= 4 row tiles (25-tile / 8-wave configuration): split the column tiles of each row tile over the
   // idle waves so the last round costs a fraction of a full one instead of a whole wave-round
@@ -164,16 +192,16 @@ __global__ __launch_bounds__(WAVES * 64) void conv_fwd_kernel(const float* __res
       const int rt = (r_end - base + 15) / 16;   // 1..4 row tiles left (block-uniform)
       if (rt == 1) {
         const int first = wv * 4;                // 8 waves x 4 tiles
-        conv_rows_pass<NTW, WAVES, 4>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0, base,
-                                      r_end, first < NTW, first, tid, lane);
+        conv_rows_pass<NTW, WAVES, 4, EPI>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0, base,
+                                           r_end, first < NTW, first, tid, lane, ed);
       } else if (rt == 2) {
         const int tile = wv >> 2, first = (wv & 3) * 7;   // 4 waves x 7 tiles per row tile
-        conv_rows_pass<NTW, WAVES, 7>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0,
-                                      base + tile * 16, r_end, first < NTW, first, tid, lane);
+        conv_rows_pass<NTW, WAVES, 7, EPI>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0,
+                                           base + tile * 16, r_end, first < NTW, first, tid, lane, ed);
       } else {
         const int tile = wv >> 1, first = (wv & 1) * 13;  // 2 waves x 13 tiles per row tile
-        conv_rows_pass<NTW, WAVES, 13>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0,
-                                       base + tile * 16, r_end, tile < rt && first < NTW, first, tid, lane);
+        conv_rows_pass<NTW, WAVES, 13, EPI>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0,
+                                            base + tile * 16, r_end, tile < rt && first < NTW, first, tid, lane, ed);
       }
     }
   }
@@ -190,14 +218,83 @@ void launch_conv_fwd(const float* emb, const float* w_packed, const float* bias,
     int grid = std::min(cdiv(M, WAVES * 16), 256);  // one 8-wave workgroup per CU, persistent over its rows
     hipLaunchKernelGGL((conv_fwd_kernel<NTW, WAVES>), dim3(grid, 1), dim3(WAVES * 64),
                        2 * NTW * 256 * sizeof(float), s, emb, w_packed, bias, ids, out, M, T, Tp, D, F, Fp, nchunk,
-                       vidx, vcount);
+                       vidx, vcount, EpiDrop{0u, 0u, 1.f});
   } else {
     constexpr int NTW = 4, WAVES = 4;
     int gy = cdiv(ntiles, NTW);
     int grid = std::min(cdiv(M, WAVES * 16), std::max(1, 1024 / gy));
     hipLaunchKernelGGL((conv_fwd_kernel<NTW, WAVES>), dim3(grid, gy), dim3(WAVES * 64),
                        2 * NTW * 256 * sizeof(float), s, emb, w_packed, bias, ids, out, M, T, Tp, D, F, Fp, nchunk,
-                       vidx, vcount);
+                       vidx, vcount, EpiDrop{0u, 0u, 1.f});
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Input gradient of the Conv1D for a trainable word table, on the forward kernel:
+//   dE[n,q,:] = sum_j dC[n, q - j + pl, :] . W[j]^T   =   window(dCpad)[n,q] . Wd ,   Wd[s*F + f][d] = W[k-1-s][d][f]
+// dCpad [n][T + k - 1][F] = the conv-output gradient with zero rows for pad tokens and title borders.
+// ---------------------------------------------------------------------------------------------
+__global__ void pad_dconv_kernel(const float4* __restrict__ dc, const int32_t* __restrict__ ids, float4* __restrict__ out,
+                                 uint32_t total4, int T, int Tp, int F4, int pad_l) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+    const uint32_t row = i / (uint32_t)F4, c4 = i - row * (uint32_t)F4;
+    const uint32_t n = row / (uint32_t)Tp;
+    const int t = (int)(row - n * (uint32_t)Tp) - pad_l;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < T) {
+      const uint32_t tok = n * (uint32_t)T + (uint32_t)t;
+      if (ids[tok] != 0) v = dc[(size_t)tok * F4 + c4];
+    }
+    out[i] = v;
+  }
+}
+// packed operand image (pack_b layout) of Wd [k*F, D] straight from conv_w [k, D, F]
+__global__ void pack_dgrad_w_kernel(const float* __restrict__ W, int k, int D, int F, int Np, float* __restrict__ P,
+                                    size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i % Np);
+  const size_t r = i / Np;
+  const int kk = (int)(r % 16), ch = (int)(r / 16), kr = ch * 16 + kk;   // kr = s*F + f
+  float v = 0.f;
+  if (kr < k * F && n < D) {
+    const int sgm = kr / F, f = kr - sgm * F;
+    v = W[((size_t)(k - 1 - sgm) * D + n) * F + f];
+  }
+  P[((size_t)ch * Np + n) * 16 + pack_b_slot(n, kk >> 2) * 4 + (kk & 3)] = v;
+}
+size_t conv_dgrad_scratch_floats(int n_titles, int T, int D, int ksize, int F) {
+  return (size_t)n_titles * (T + ksize - 1) * F + pack_b_floats(ksize * F, D);
+}
+void launch_conv_dgrad_scatter(const float* dconv, const float* conv_w, const int32_t* ids, float* word_grad,
+                               float* scratch, int n_titles, int T, int D, int ksize, int F, float drop, uint32_t key,
+                               hipStream_t s) {
+  const int M = n_titles * T;
+  if (M == 0) return;
+  const int Tp = T + ksize - 1, pl = (ksize - 1) / 2, pr = ksize - 1 - pl;
+  float* dcp = scratch;
+  float* wp = scratch + (size_t)n_titles * Tp * F;
+  const size_t total4 = (size_t)n_titles * Tp * (F / 4);
+  hipLaunchKernelGGL(pad_dconv_kernel, dim3((unsigned)std::min<size_t>(cdivz(total4, 256), 256 * 16)), dim3(256), 0, s,
+                     (const float4*)dconv, ids, (float4*)dcp, (uint32_t)total4, T, Tp, F / 4, pr);
+  const int Np = ceil16(D);
+  const size_t wtotal = pack_b_floats(ksize * F, D);
+  hipLaunchKernelGGL(pack_dgrad_w_kernel, dim3((unsigned)cdivz(wtotal, 256)), dim3(256), 0, s, conv_w, ksize, D, F, Np, wp,
+                     wtotal);
+  // the forward kernel with the roles of D and F exchanged: rows = all M token positions, K = k*F, N = D
+  const int KF = ksize * F, nchunk = cdiv(KF, 16), ntiles = Np / 16;
+  const EpiDrop ed{drop > 0.f ? dropout_thresh(drop) : 0u, key, drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f};
+  if (ntiles == 19) {
+    constexpr int NTW = 19, WAVES = 8;
+    const int grid = std::min(cdiv(M, WAVES * 16), 256);
+    hipLaunchKernelGGL((conv_fwd_kernel<NTW, WAVES, 1>), dim3(grid, 1), dim3(WAVES * 64), 2 * NTW * 256 * sizeof(float), s,
+                       dcp, wp, nullptr, ids, word_grad, M, T, Tp, F, D, Np, nchunk, nullptr, nullptr, ed);
+  } else {
+    constexpr int NTW = 4, WAVES = 4;
+    const int gy = cdiv(ntiles, NTW);
+    const int grid = std::min(cdiv(M, WAVES * 16), std::max(1, 1024 / gy));
+    hipLaunchKernelGGL((conv_fwd_kernel<NTW, WAVES, 1>), dim3(grid, gy), dim3(WAVES * 64), 2 * NTW * 256 * sizeof(float), s,
+                       dcp, wp, nullptr, ids, word_grad, M, T, Tp, F, D, Np, nchunk, nullptr, nullptr, ed);
   }
 }
 

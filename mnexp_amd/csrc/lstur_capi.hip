@@ -30,7 +30,7 @@ struct ParamSlot {
 };
 
 struct Dims {
-  int B, W, T, K1, V, D, F, k, U, Nu, arch, H, Ue, Tp, KD, head;
+  int B, W, T, K1, V, D, F, k, U, Nu, arch, H, Ue, Tp, KD, head, word_trainable;
   int nt_max;   // titles per call
   int n_cap;    // per-sample buffers
   int rows_cap; // sparse user-grad rows per adam step
@@ -69,6 +69,15 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
   }
   if (d->arch == LSTUR_ARCH_HGRU && (d->U % 2)) {
     *why = "hgru needs an even user_dim";
+    return false;
+  }
+  d->word_trainable = c->word_trainable != 0;
+  if (d->word_trainable && c->freeze_encoder) {
+    *why = "word_trainable and freeze_encoder exclude each other";
+    return false;
+  }
+  if (d->word_trainable && (c->filters % 4)) {
+    *why = "word_trainable needs filters % 4 == 0";
     return false;
   }
   d->head = c->head;
@@ -148,7 +157,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* dp_rows; float* dp_grads;
+  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
 };
@@ -232,6 +241,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->sds = (float*)take(nc * f4);
   w->sdhid = (float*)take(nc * d.U * f4);
   w->sdcat = (float*)take(nc * 2 * d.U * f4);
+  w->dgrad_scratch = d.word_trainable ? (float*)take(conv_dgrad_scratch_floats((int)nt, d.T, d.D, d.k, d.F) * f4) : nullptr;
   w->dp_rows = (int32_t*)take((size_t)d.rows_cap * 4);
   w->dp_grads = (float*)take((size_t)d.rows_cap * d.Ue * f4);
   w->user_rows = (int32_t*)take(nc * 4);
@@ -443,6 +453,11 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
                                          w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab));
   launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch_k[2], s, &jobs[nj++]);
+  if (d.word_trainable) {   // conv input gradient -> word-table gradient (embedding dropout mask = stream 0 of the step)
+    (void)hipMemsetAsync(c->buf.word_grad, 0, (size_t)d.V * d.D * sizeof(float), s);
+    PROF("conv_dgrad", launch_conv_dgrad_scatter(w.dconv, c->P("conv_w"), w.ids, c->buf.word_grad, w.dgrad_scratch, nt, d.T,
+                                                  d.D, d.k, d.F, drop, dropout_key(c->cfg.seed, step, 0), s));
+  }
   PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
                                        w.vidx, w.vcount, s, w.offA, w.offB,
                                        w.emb + (size_t)d.nt_max * d.Tp * d.D /* zero slack */, &jobs[nj++]));
@@ -626,6 +641,8 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
   if (!buf->word_emb || !buf->dense_param || !buf->dense_grad || !buf->dense_m || !buf->dense_v || !buf->user_emb ||
       !buf->user_m || !buf->user_v || !buf->workspace)
     return fail(LSTUR_ERR_ARG, "every buffer must be bound");
+  if (d.word_trainable && (!buf->word_grad || !buf->word_m || !buf->word_v))
+    return fail(LSTUR_ERR_ARG, "word_trainable needs word_grad / word_m / word_v");
   if (((uintptr_t)buf->workspace & 255) || ((uintptr_t)buf->word_emb & 15) || ((uintptr_t)buf->dense_param & 15) ||
       ((uintptr_t)buf->dense_grad & 15) || ((uintptr_t)buf->user_emb & 15))
     return fail(LSTUR_ERR_ARG, "buffers must be 16-byte (workspace 256-byte) aligned");
@@ -745,6 +762,9 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
                              ctx->dense_total, lr_t, c.beta1, c.beta2, c.eps, rows, row_grads, n_rows, d.Ue,
                              ctx->ws.gsum, ctx->ws.slot, s);
   }
+  if (d.word_trainable)   // dense Keras-Adam sweep of the word table (TF-1 densifies the IndexedSlices gradient)
+    launch_adam_flat(ctx->buf.word_emb, ctx->buf.word_grad, ctx->buf.word_m, ctx->buf.word_v, (size_t)d.V * d.D, lr_t,
+                     c.beta1, c.beta2, c.eps, s);
   if (d.arch != LSTUR_ARCH_NIGRU) {   // nigru: the user embedding is not part of the graph (paper.py:627-628)
     {
       ProfScope _ps(ctx, "adam_user_table", s);

@@ -107,6 +107,11 @@ void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scr
                        int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount, hipStream_t s,
                        const int32_t* offA = nullptr, const int32_t* offB = nullptr, const float* zeros = nullptr,
                        ReduceJob* defer = nullptr);
+// conv input gradient scattered into the word-table gradient (trainable word table); scratch: conv_dgrad_scratch_floats
+size_t conv_dgrad_scratch_floats(int n_titles, int T, int D, int ksize, int F);
+void launch_conv_dgrad_scatter(const float* dconv, const float* conv_w, const int32_t* ids, float* word_grad,
+                               float* scratch, int n_titles, int T, int D, int ksize, int F, float drop, uint32_t key,
+                               hipStream_t s);
 void launch_token_offsets(const int32_t* vidx, const int32_t* vcount, int M, int T, int Tp, int D, int F, int32_t* offA,
                           int32_t* offB, hipStream_t s);
 

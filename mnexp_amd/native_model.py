@@ -76,7 +76,8 @@ class _TfAuc:
 class NativeModel:
     def __init__(self, word_emb, n_users, batch_size, window, title_len, negative_samples, filters, kernel,
                  user_dim, arch='igru', dropout=0.2, lr=1e-3, seed=0, device=None, title_table=None,
-                 dist_group=None, has_user=True, head='softmax', gain=1.0, freeze_encoder=False):
+                 dist_group=None, has_user=True, head='softmax', gain=1.0, freeze_encoder=False,
+                 word_trainable=False):
         if not torch.cuda.is_available():
             raise _lib.LsturError('no GPU visible: the native LSTUR model has no CPU fallback')
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
@@ -92,8 +93,10 @@ class NativeModel:
         self.has_user = has_user       # False: id-less task (Seq2VecPaperSoftmax), inputs carry no user column
         self.cfg = _lib.make_cfg(batch_size, window, title_len, self.K1, V, D, filters, kernel, user_dim,
                                  max(1, n_users), arch, dropout, seed, head=head, gain=gain,
-                                 loss_negatives=max(1, negative_samples), freeze_encoder=freeze_encoder)
+                                 loss_negatives=max(1, negative_samples), freeze_encoder=freeze_encoder,
+                                 word_trainable=word_trainable)
         self.freeze_encoder = bool(freeze_encoder)
+        self.word_trainable = bool(word_trainable)     # --textual-embedding-trainable (paper.py:132-138)
         self.sizes = _lib.query_sizes(self.cfg)
         self.layout = _lib.param_layout(self.cfg)
         H, Ue = self.sizes.gru_dim, self.sizes.user_emb_dim
@@ -122,9 +125,16 @@ class NativeModel:
         self._stats4 = torch.zeros(4, dtype=f32, device=dev)   # [loss, metric] of the last batch | running sums
         self.stats = self._stats4[:2]
         self.stats_acc = self._stats4[2:]
+        wg = wm = wv = None
+        if self.word_trainable:
+            self.word_grad = torch.zeros(V * D, dtype=f32, device=dev)
+            self.word_m = torch.zeros(V * D, dtype=f32, device=dev)
+            self.word_v = torch.zeros(V * D, dtype=f32, device=dev)
+            wg, wm, wv = self.word_grad.data_ptr(), self.word_m.data_ptr(), self.word_v.data_ptr()
         bufs = _lib.Buffers(self.word_emb.data_ptr(), self.dense_param.data_ptr(), self.dense_grad.data_ptr(),
                             self.dense_m.data_ptr(), self.dense_v.data_ptr(), self.user_emb.data_ptr(),
-                            self.user_m.data_ptr(), self.user_v.data_ptr(), ws_ptr, self.sizes.workspace_bytes)
+                            self.user_m.data_ptr(), self.user_v.data_ptr(), ws_ptr, self.sizes.workspace_bytes,
+                            wg, wm, wv)
         self._ctx = C.c_void_p()
         check(lib.lstur_create(C.byref(self.cfg), C.byref(bufs), C.byref(self._ctx)), 'lstur_create')
         self.optimizer = _Optimizer(lr)
@@ -151,8 +161,6 @@ class NativeModel:
         head = getattr(task, 'head', 'softmax')
         if head == 'softmax' and getattr(cfg, 'score_model', 'dot') != 'dot':
             raise _lib.LsturError('only the dot scorer is on the native path')
-        if getattr(cfg, 'textual_embedding_trainable', False):
-            raise _lib.LsturError('--textual-embedding-trainable is not on the native path yet')
         emb = utils.load_textual_embedding(cfg.title_embedding_input, cfg.textual_embedding_dim)
         vmax = int(task.docs.title_table.max())
         if vmax >= emb.shape[0]:
@@ -174,7 +182,8 @@ class NativeModel:
                     lr=cfg.learning_rate, seed=int(getattr(cfg, 'seed', 0) or 0),
                     title_table=task.docs.title_table, has_user=has_user, head=head,
                     gain=float(getattr(cfg, 'gain', 1.0)),
-                    freeze_encoder=pretrained and not getattr(cfg, 'pretrain_encoder_trainable', False))
+                    freeze_encoder=pretrained and not getattr(cfg, 'pretrain_encoder_trainable', False),
+                    word_trainable=bool(getattr(cfg, 'textual_embedding_trainable', False)) and not pretrained)
         if pretrained:                      # paper.py:103-107
             model.load_encoder(cfg.encoder_input)
         return model
@@ -246,6 +255,8 @@ class NativeModel:
         rows, grads, n = C.c_void_p(), C.c_void_p(), C.c_int32()
         check(lib.lstur_user_grad(self._ctx, C.byref(rows), C.byref(grads), C.byref(n)), 'lstur_user_grad')
         Ue = self.sizes.user_emb_dim
+        if self.word_trainable:
+            g['word_emb'] = self.word_grad.view(self.shapes['word_emb']).cpu().numpy()
         g['user_rows'] = self._peek_ptr(rows.value, n.value, torch.int32).cpu().numpy()
         g['user_row_grads'] = self._peek_ptr(grads.value, n.value * Ue, torch.float32).cpu().numpy().reshape(n.value, Ue)
         return g
@@ -418,6 +429,8 @@ class NativeModel:
         sum over ranks averages the dense bucket (already scaled by 1/world) AND concatenates the sparse rows."""
         from . import dist as D
         world = max(1, self.world)
+        if self.word_trainable:          # V x D more gradient: its own all-reduce (SURVEY.md 8e: "only if trainable")
+            D.allreduce_bucket(self.word_grad, self.dist_group, prescaled=True)
         if world <= 8 and self.cfg.n_users < (1 << 24) and self.sizes.dense % 4 == 0:
             dense = self.sizes.dense
             used = int(lib.lstur_dp_tail_floats(C.byref(self.cfg), world))

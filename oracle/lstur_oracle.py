@@ -576,9 +576,10 @@ def densify_user_grad(N_u, Ue, rows, row_grads, dtype):
     return g
 
 
-def train_step(p, arch, opt, user, hist, cands, drop_p=0.0, seed=0, step=0):
-    """forward/backward + Adam over dense params and the (densified) user table."""
-    out = forward_backward(p, arch, user, hist, cands, drop_p, seed, step)
+def train_step(p, arch, opt, user, hist, cands, drop_p=0.0, seed=0, step=0, word_trainable=False):
+    """forward/backward + Adam over dense params and the (densified) user table (+ the word table when
+    --textual-embedding-trainable: `opt` must then list 'word_emb'; its IndexedSlices gradient is densified too)."""
+    out = forward_backward(p, arch, user, hist, cands, drop_p, seed, step, word_trainable=word_trainable)
     g = out["grads"]
     g["user_emb"] = densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"],
                                       p["user_emb"].dtype)

@@ -29,7 +29,7 @@ def rel_close(got, ref, tol=2e-3, name=''):
     assert err <= tol * scale + 1e-7, '{}: max err {:.3e} vs scale {:.3e}'.format(name, err, scale)
 
 
-def build(arch, dims, B, W, T, K1, drop, seed=5):
+def build(arch, dims, B, W, T, K1, drop, seed=5, **model_kw):
     from oracle import lstur_oracle as O
     from mnexp_amd.native_model import NativeModel
     rng = np.random.default_rng(seed)
@@ -37,7 +37,7 @@ def build(arch, dims, B, W, T, K1, drop, seed=5):
     for n in ('conv_b', 'att_b', 'dense_b', 'gru_b'):
         p[n] = rng.normal(0, 0.1, size=p[n].shape)
     model = NativeModel(p['word_emb'], dims['N_u'], B, W, T, K1 - 1, dims['F'], dims['k'], dims['U'], arch=arch,
-                        dropout=drop, lr=1e-3, seed=77)
+                        dropout=drop, lr=1e-3, seed=77, **model_kw)
     model.set_weights({n: p[n] for n in p if n != 'word_emb'})
     return O, p, model, rng
 
@@ -106,6 +106,65 @@ def test_three_adam_steps_track_oracle(arch):
         # after 3 Adam steps every touched weight moved by ~3e-3; the update must agree to a few %
         moved = np.abs(p32[n].astype(np.float64) - p[n]).max()
         err = np.abs(w[n].astype(np.float64) - p32[n]).max()
+        assert err <= 0.05 * moved + 2e-6, (n, err, moved)
+
+
+@pytest.mark.parametrize('dims,B,W,T,K1,drop', [
+    (TINY, 5, 4, 7, 3, 0.0),
+    (TINY, 5, 4, 7, 3, 0.25),
+    (MID, 19, 9, 11, 5, 0.2),
+    (dict(V=90, D=20, F=24, k=5, U=18, N_u=9), 7, 3, 6, 2, 0.0),   # k = 5, D = 20: ragged column tile of the flipped kernel
+    (dict(V=400, D=300, F=400, k=3, U=32, N_u=7), 3, 4, 30, 2, 0.2),   # BASELINE D / F / T: the 19-tile configuration
+])
+def test_word_table_gradient_matches_oracle(dims, B, W, T, K1, drop):
+    """--textual-embedding-trainable (paper.py:132-138, main.py:36): the conv's input gradient, through the embedding
+    dropout mask, scatter-added into the word table's gradient — the pad row 0 included (a pad token's embedding is
+    an input of its neighbours' windows even though its own conv output is masked)."""
+    _need_gpu()
+    O, p, model, rng = build('igru', dims, B, W, T, K1, drop, word_trainable=True)
+    p['word_emb'][0] = rng.normal(0, 0.1, size=dims['D'])      # a trained table's pad row is no longer zero
+    model.set_weights({'word_emb': p['word_emb']})
+    user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
+    hist[1] = 0
+    model.step = 2
+    ref = O.forward_backward(p, 'igru', user, hist, cands, drop_p=drop, seed=77, step=2, word_trainable=True)
+    from mnexp_amd._lib import lib, check
+    u, h, c = model._dev_i32(user), model._dev_i32(hist), model._dev_i32(cands)
+    check(lib.lstur_forward_backward(model._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), B, 2, 1.0,
+                                     model.stats.data_ptr(), model._stream()), 'fb')
+    torch.cuda.synchronize()
+    logits = model.peek('logits').cpu().numpy().reshape(B, K1)
+    np.testing.assert_allclose(logits, ref['logits'], rtol=1e-3, atol=1e-5)
+    g = model.get_grads()
+    for n in O.dense_param_names('igru'):
+        rel_close(g[n], ref['grads'][n], 2e-3, n)
+    gw, rw = g['word_emb'], ref['grads']['word_emb']
+    rel_close(gw, rw, 2e-3, 'word_emb')
+    assert np.abs(rw[0]).max() > 0                              # the pad row does receive gradient
+    untouched = np.setdiff1d(np.arange(dims['V']), np.concatenate([hist.reshape(-1), cands.reshape(-1)]))
+    assert not gw[untouched].any()                              # rows of absent words stay exactly 0
+
+
+def test_word_table_adam_steps_track_oracle():
+    """TF-1 Keras Adam densifies the IndexedSlices gradient of the word table: every row's moments decay each step."""
+    _need_gpu()
+    dims, B, W, T, K1 = MID, 16, 6, 9, 5
+    O, p, model, rng = build('igru', dims, B, W, T, K1, 0.2, word_trainable=True)
+    p32 = {n: a.astype(np.float32) for n, a in p.items()}
+    names = O.dense_param_names('igru') + ['user_emb', 'word_emb']
+    opt = O.Adam(p32, names, lr=1e-3)
+    for step in range(3):
+        user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
+        O.train_step(p32, 'igru', opt, user, hist, cands, drop_p=0.2, seed=77, step=step, word_trainable=True)
+        X = [user.astype(np.int64), hist.astype(np.float64)] + [cands[:, j].astype(np.float64) for j in range(K1)]
+        model.train_on_batch(X, None)
+    torch.cuda.synchronize()
+    w = model.get_weights()
+    w['word_emb'] = model.word_emb.cpu().numpy()
+    for n in names:
+        moved = np.abs(p32[n].astype(np.float64) - p[n]).max()
+        err = np.abs(w[n].astype(np.float64) - p32[n]).max()
+        assert moved > 1e-4, n
         assert err <= 0.05 * moved + 2e-6, (n, err, moved)
 
 
