@@ -52,6 +52,16 @@ enum lstur_head {            /* scorer + loss on top of (user_vec, doc_vec) */
   LSTUR_HEAD_POINT_DOT = 2   /* pointwise sibling: sigmoid(u . d)  (Seq2VecPaperDot)                paper.py:258-262   */
 };                           /* pointwise loss: Seq2Vec.loss, task/seq2vec.py:213-216 (needs cands == 1)               */
 
+enum lstur_encoder {         /* token stage of the news encoder (--news-encoder) */
+  LSTUR_ENC_CNNATT = 0,      /* Conv1D(F, k, same, relu) x (id != 0)                     paper.py:146-155 */
+  LSTUR_ENC_MHSA = 1         /* build-defined multi-head self-attention over the title tokens (BASELINE.json configs[4]);
+                                the reference has no such encoder (paper.py:119-130), parity is against
+                                oracle/lstur_oracle.py: mhsa_fwd only.  [Q|K|V] = E.qkv_w + qkv_b, per head
+                                softmax(Q K^T / sqrt(dh)) V with pad keys masked, bf16 MFMA operands / fp32
+                                accumulation; filters = heads * dh, dh in {16,32,64}, title_len <= 32; `kernel` is
+                                ignored; parameters qkv_w [D, 3F], qkv_b [3F] replace conv_w / conv_b          */
+};
+
 typedef struct lstur_cfg {
   int32_t max_batch;         /* largest n passed to train_step (-b)                                    */
   int32_t window;            /* W  history length (-w / window_size)                                   */
@@ -76,6 +86,8 @@ typedef struct lstur_cfg {
   int32_t freeze_encoder;    /* != 0: the news encoder is a loaded, non-trainable model (--enable-pretrain-encoder
                                 without --pretrain-encoder-trainable, paper.py:103-107): its backward pass is skipped,
                                 its gradients stay 0 (dropout inside it stays active in training, as in Keras)   */
+  int32_t news_encoder;      /* lstur_encoder; 0 = cnnatt                                              */
+  int32_t heads;             /* mhsa: number of attention heads (filters % heads == 0)                 */
 } lstur_cfg;
 
 /* Sizes (in floats unless named _bytes) the caller must allocate for a configuration. */
@@ -251,6 +263,15 @@ int lstur_attpool_bwd(const float* conv_out, const int32_t* ids, const float* at
                       const float* att_weight, const float* dpooled, float* dconv, float* parts,
                       float* row_scratch, int32_t n_titles, int32_t title_len, int32_t filters, float drop,
                       uint32_t key, lstur_stream stream);
+/* Token stage of the build-defined `mhsa` news encoder (LSTUR_ENC_MHSA; no reference counterpart, the specification
+ * is oracle/lstur_oracle.py: mhsa_fwd / mhsa_bwd).  qkv [N_t*T, 3F] = Q | K | V, head h = columns h*dh .. h*dh+dh-1
+ * of each third; per (title, head): P = softmax_keys(Q K^T / sqrt(dh)) with the keys of pad tokens (ids == 0) masked,
+ * out = P V.  MFMA operands are rounded to bf16, accumulation / softmax fp32.  Rows of pad tokens: `out` is not
+ * written, `dout` is not read, `dqkv` is written as 0.  title_len <= 32, filters <= 512, filters/heads in {16,32,64}. */
+int lstur_mhsa_fwd(const float* qkv, const int32_t* ids, float* out, int32_t n_titles, int32_t title_len,
+                   int32_t filters, int32_t heads, lstur_stream stream);
+int lstur_mhsa_bwd(const float* qkv, const float* dout, const int32_t* ids, float* dqkv, int32_t n_titles,
+                   int32_t title_len, int32_t filters, int32_t heads, lstur_stream stream);
 /* out[j] (+)= sum_i x[i, j]   (bias gradients, partial-sum reduction) */
 int lstur_colsum(const float* x, int32_t rows, int32_t cols, int32_t ld, float* out, float scale,
                  lstur_stream stream);

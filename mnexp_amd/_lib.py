@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'liblstur_hip.so')
 
 ARCH = {'igru': 0, 'gru': 1, 'hgru': 2, 'nigru': 3}
 HEAD = {'softmax': 0, 'point_mlp': 1, 'point_dot': 2}
+ENCODER = {'cnnatt': 0, 'mhsa': 1}     # include/lstur.h: lstur_encoder (mhsa is build-defined, no reference counterpart)
 
 
 class LsturError(RuntimeError):
@@ -24,7 +25,7 @@ class Cfg(C.Structure):
                                          'filters', 'kernel', 'user_dim', 'n_users', 'arch')] + [
         ('dropout', C.c_float), ('seed', C.c_uint32), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
         ('head', C.c_int32), ('gain', C.c_float), ('loss_negatives', C.c_int32), ('word_trainable', C.c_int32),
-        ('freeze_encoder', C.c_int32)]
+        ('freeze_encoder', C.c_int32), ('news_encoder', C.c_int32), ('heads', C.c_int32)]
 
 
 class Sizes(C.Structure):
@@ -79,6 +80,8 @@ SIGNATURES = {
     'lstur_attpool_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _P]),
     'lstur_attpool_bwd_parts': (_I, [_I]),
     'lstur_attpool_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _P]),
+    'lstur_mhsa_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'lstur_mhsa_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'lstur_colsum': (_I, [_P, _I, _I, _I, _P, _F, _P]),
     'lstur_gemm_scratch': (_Z, [_I, _I, _I]),
     'lstur_gemm_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),
@@ -115,13 +118,17 @@ def check(rc, what=''):
 
 def make_cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
              arch='igru', dropout=0.0, seed=0, beta1=0.9, beta2=0.999, eps=1e-7, head='softmax', gain=1.0,
-             loss_negatives=4, freeze_encoder=False, word_trainable=False):
+             loss_negatives=4, freeze_encoder=False, word_trainable=False, news_encoder='cnnatt', heads=0):
     if arch not in ARCH:
         raise LsturError('arch {!r} is not supported by the native path (have {})'.format(arch, sorted(ARCH)))
     if head not in HEAD:
         raise LsturError('head {!r} is not supported by the native path (have {})'.format(head, sorted(HEAD)))
+    if news_encoder not in ENCODER:
+        raise LsturError('news encoder {!r} is not supported by the native path (have {})'.format(
+            news_encoder, sorted(ENCODER)))
     return Cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
-               ARCH[arch], dropout, seed, beta1, beta2, eps, HEAD[head], gain, loss_negatives, int(bool(word_trainable)), int(bool(freeze_encoder)))
+               ARCH[arch], dropout, seed, beta1, beta2, eps, HEAD[head], gain, loss_negatives,
+               int(bool(word_trainable)), int(bool(freeze_encoder)), ENCODER[news_encoder], int(heads))
 
 
 def query_sizes(cfg):

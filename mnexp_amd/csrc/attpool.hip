@@ -29,6 +29,10 @@ __device__ __forceinline__ float4 drop4(float4 v, uint32_t key, uint32_t e, uint
   return v;
 }
 
+// does the gradient pass through this (dropped) activation?  relu: kept AND c > 0 (the conv's ReLU, cnnatt);
+// !relu: kept (a token stage without ReLU -- the mhsa encoder; an exact 0 there reads as dropped)
+__device__ __forceinline__ bool grad_gate(float x, int relu) { return relu ? x > 0.f : x != 0.f; }
+
 // ---- forward 1: per-token score.  a[row] = tanh(x.k + b), e[row] = exp(a) * any(c != 0) ------------------
 template <int VEC>
 __global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict__ c, const int32_t* __restrict__ ids,
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
                                                             const float* __restrict__ dpooled, float* __restrict__ dc,
                                                             float* __restrict__ parts, int T, int F, uint32_t thresh,
                                                             uint32_t key, float scale, int ldp, int off_aw, int off_cb,
-                                                            int off_ab) {
+                                                            int off_ab, int relu) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // dw[32] | ds[32] | red[4][2][F]
   float* dwL = sm;
   float* dsL = sm + 32;
@@ -285,10 +289,10 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
         gaw[h].y += dst * xv.y;
         gaw[h].z += dst * xv.z;
         gaw[h].w += dst * xv.w;
-        o.x = xv.x > 0.f ? (dp[h].x * wt[i] + dst * kf[h].x) * scale : 0.f;
-        o.y = xv.y > 0.f ? (dp[h].y * wt[i] + dst * kf[h].y) * scale : 0.f;
-        o.z = xv.z > 0.f ? (dp[h].z * wt[i] + dst * kf[h].z) * scale : 0.f;
-        o.w = xv.w > 0.f ? (dp[h].w * wt[i] + dst * kf[h].w) * scale : 0.f;
+        o.x = grad_gate(xv.x, relu) ? (dp[h].x * wt[i] + dst * kf[h].x) * scale : 0.f;
+        o.y = grad_gate(xv.y, relu) ? (dp[h].y * wt[i] + dst * kf[h].y) * scale : 0.f;
+        o.z = grad_gate(xv.z, relu) ? (dp[h].z * wt[i] + dst * kf[h].z) * scale : 0.f;
+        o.w = grad_gate(xv.w, relu) ? (dp[h].w * wt[i] + dst * kf[h].w) * scale : 0.f;
         gcb[h].x += o.x;
         gcb[h].y += o.y;
         gcb[h].z += o.z;
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
     const float* __restrict__ c, const int32_t* __restrict__ ids, const float* __restrict__ att_w,
     const float* __restrict__ w, const float* __restrict__ ds, const float* __restrict__ dpooled,
     float* __restrict__ dc, float* __restrict__ parts, int rows, int T, int F, uint32_t thresh, uint32_t key,
-    float scale, int ldp, int off_aw, int off_cb, int off_ab) {
+    float scale, int ldp, int off_aw, int off_cb, int off_ab, int relu) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [2][F] partials of sub-stream 1
   const int cols = VEC == 4 ? F / 4 : F;
   const int per = (rows + gridDim.x - 1) / gridDim.x;
@@ -437,10 +441,10 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
           gaw.y += dst * x.y;
           gaw.z += dst * x.z;
           gaw.w += dst * x.w;
-          o.x = x.x > 0.f ? (dp.x * wt + dst * kf.x) * scale : 0.f;
-          o.y = x.y > 0.f ? (dp.y * wt + dst * kf.y) * scale : 0.f;
-          o.z = x.z > 0.f ? (dp.z * wt + dst * kf.z) * scale : 0.f;
-          o.w = x.w > 0.f ? (dp.w * wt + dst * kf.w) * scale : 0.f;
+          o.x = grad_gate(x.x, relu) ? (dp.x * wt + dst * kf.x) * scale : 0.f;
+          o.y = grad_gate(x.y, relu) ? (dp.y * wt + dst * kf.y) * scale : 0.f;
+          o.z = grad_gate(x.z, relu) ? (dp.z * wt + dst * kf.z) * scale : 0.f;
+          o.w = grad_gate(x.w, relu) ? (dp.w * wt + dst * kf.w) * scale : 0.f;
           gcb.x += o.x;
           gcb.y += o.y;
           gcb.z += o.z;
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
           float x = c[(size_t)row * F + j];
           if (thresh) x = keep_elem(key, (uint32_t)row * (uint32_t)F + j, thresh) ? x * scale : 0.f;
           gaw += dst * x;
-          o = x > 0.f ? (dpooled[(size_t)n * F + j] * wt + dst * kf) * scale : 0.f;
+          o = grad_gate(x, relu) ? (dpooled[(size_t)n * F + j] * wt + dst * kf) * scale : 0.f;
           gcb += o;
         }
         dc[(size_t)row * F + j] = o;
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
 
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
-                        float drop, uint32_t key, hipStream_t s, int ldp, int off_aw, int off_cb, int off_ab) {
+                        float drop, uint32_t key, hipStream_t s, int ldp, int off_aw, int off_cb, int off_ab, int relu) {
   if (ldp <= 0) {   // default layout of the public entry point: datt_w[F] | dconv_b[F] | datt_b
     ldp = 2 * F + 1;
     off_aw = 0;
@@ -516,7 +520,7 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
   const int nparts = attpool_bwd_parts(n_titles);
   if (title_path(T, F)) {
     hipLaunchKernelGGL(att_bwd_title_kernel, dim3(n_titles), dim3(256), (64 + 8 * F) * sizeof(float), s, c, ids, att_w, a, w,
-                       dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab);
+                       dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu);
     return;
   }
   if (F % 4 == 0) {
@@ -524,13 +528,13 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
                        thresh, key, scale);
     hipLaunchKernelGGL(att_bwd_ds_kernel, dim3(cdiv(n_titles, 128)), dim3(128), 0, s, row_scratch, w, a, n_titles, T);
     hipLaunchKernelGGL(att_bwd_dc_kernel<4>, dim3(nparts), dim3(128 * kDcRsub), 2 * F * sizeof(float), s, c, ids, att_w, w, row_scratch, dpooled, dc,
-                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab);
+                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu);
   } else {
     hipLaunchKernelGGL(att_bwd_dw_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, s, c, w, dpooled, row_scratch, rows, T, F,
                        thresh, key, scale);
     hipLaunchKernelGGL(att_bwd_ds_kernel, dim3(cdiv(n_titles, 128)), dim3(128), 0, s, row_scratch, w, a, n_titles, T);
     hipLaunchKernelGGL(att_bwd_dc_kernel<1>, dim3(nparts), dim3(128 * kDcRsub), 2 * F * sizeof(float), s, c, ids, att_w, w, row_scratch, dpooled, dc,
-                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab);
+                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu);
   }
 }
 

@@ -30,7 +30,7 @@ struct ParamSlot {
 };
 
 struct Dims {
-  int B, W, T, K1, V, D, F, k, U, Nu, arch, H, Ue, Tp, KD, head, word_trainable;
+  int B, W, T, K1, V, D, F, k, U, Nu, arch, H, Ue, Tp, KD, head, word_trainable, enc, heads;
   int nt_max;   // titles per call
   int n_cap;    // per-sample buffers
   int rows_cap; // sparse user-grad rows per adam step
@@ -70,6 +70,23 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
   if (d->arch == LSTUR_ARCH_HGRU && (d->U % 2)) {
     *why = "hgru needs an even user_dim";
     return false;
+  }
+  d->enc = c->news_encoder;
+  d->heads = c->heads;
+  if (d->enc != LSTUR_ENC_CNNATT && d->enc != LSTUR_ENC_MHSA) {
+    *why = "unknown news_encoder";
+    return false;
+  }
+  if (d->enc == LSTUR_ENC_MHSA) {
+    d->k = 1;   // no neighbourhood: the embeddings are a plain [N_tok, D] matrix
+    if (!mhsa_supported(d->T, d->F, d->heads)) {
+      *why = "mhsa needs title_len <= 32, filters <= 512, filters % heads == 0 and filters / heads in {16, 32, 64}";
+      return false;
+    }
+    if (c->word_trainable) {
+      *why = "mhsa: a trainable word table is not on the native path";
+      return false;
+    }
   }
   d->word_trainable = c->word_trainable != 0;
   if (d->word_trainable && c->freeze_encoder) {
@@ -125,8 +142,13 @@ std::vector<ParamSlot> param_layout(const Dims& d, size_t* total) {
     v.push_back({n, off, cnt});
     off += (cnt + kParamAlign - 1) / kParamAlign * kParamAlign;
   };
-  add("conv_w", (size_t)d.KD * d.F);
-  add("conv_b", d.F);
+  if (d.enc == LSTUR_ENC_MHSA) {
+    add("qkv_w", (size_t)d.D * 3 * d.F);
+    add("qkv_b", (size_t)3 * d.F);
+  } else {
+    add("conv_w", (size_t)d.KD * d.F);
+    add("conv_b", d.F);
+  }
   add("att_w", d.F);
   add("att_b", 1);
   add("dense_w", (size_t)d.F * d.U);
@@ -157,7 +179,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch;
+  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; float* qkv; float* dqkv; void* mh_scratch; float* mh_colsum;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
 };
@@ -242,6 +264,11 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->sdhid = (float*)take(nc * d.U * f4);
   w->sdcat = (float*)take(nc * 2 * d.U * f4);
   w->dgrad_scratch = d.word_trainable ? (float*)take(conv_dgrad_scratch_floats((int)nt, d.T, d.D, d.k, d.F) * f4) : nullptr;
+  const bool mh = d.enc == LSTUR_ENC_MHSA;
+  w->qkv = mh ? (float*)take(nt * d.T * 3 * d.F * f4) : nullptr;
+  w->dqkv = mh ? (float*)take(nt * d.T * 3 * d.F * f4) : nullptr;
+  w->mh_scratch = mh ? take(std::max(gemm_scratch_bytes(d.D, 3 * d.F, (int)(nt * d.T)), (size_t)4 << 20)) : nullptr;
+  w->mh_colsum = mh ? (float*)take((size_t)kColsumSlices * 3 * d.F * f4) : nullptr;
   w->dp_rows = (int32_t*)take((size_t)d.rows_cap * 4);
   w->dp_grads = (float*)take((size_t)d.rows_cap * d.Ue * f4);
   w->user_rows = (int32_t*)take(nc * 4);
@@ -356,7 +383,8 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   const uint32_t key0 = dropout_key(c->cfg.seed, step, 0), key1 = dropout_key(c->cfg.seed, step, 1);
   lazy_init(c, s);
   // operand images of the weights used by MFMA kernels this step
-  launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, s);
+  const bool mhsa = d.enc == LSTUR_ENC_MHSA;
+  if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, s);
   launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, s);
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
@@ -365,6 +393,11 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   c->counted = false;
   launch_compact_write_offsets(w.ids, nt * d.T, w.vscratch, w.vidx, w.vcount, d.T, d.Tp, d.D, d.F, w.offA, w.offB, s);
   PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
+  if (mhsa) {   // token stage = multi-head self-attention (build-defined, include/lstur.h: LSTUR_ENC_MHSA)
+    PROF("qkv_proj", launch_gemm(w.emb, d.D, 0, c->P("qkv_w"), 3 * d.F, 0, w.qkv, 3 * d.F, c->P("qkv_b"), nt * d.T,
+                                 3 * d.F, d.D, 1.f, nullptr, s));
+    PROF("mhsa_fwd", launch_mhsa_fwd(w.qkv, w.ids, w.conv, nt, d.T, d.F, d.heads, s));
+  } else
   PROF("conv_fwd", launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
                                    w.vcount, s));
   PROF("attpool_fwd", launch_attpool_fwd(w.conv, w.ids, c->P("att_w"), c->P("att_b"), w.pooled, w.att_a, w.att_wt, nt, d.T, d.F,
@@ -448,6 +481,27 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], s, &jobs[nj++]);
   launch_gemm(w.ddocvec, d.U, 0, c->P("dense_w"), d.U, 1, w.dpooled, d.F, nullptr, nt, d.F, d.U, 1.f, w.gemm_scratch, s);
   // partial sums laid out like the bucket slice conv_b .. att_b -> one reduction straight into dense_grad
+  if (d.enc == LSTUR_ENC_MHSA) {
+    // partial sums: datt_w | datt_b like the bucket slice att_w .. att_b, the (unused) column sums of dconv behind them
+    const int off_aw = 0, off_ab = (int)(c->G("att_b") - c->G("att_w")), off_cb = off_ab + (int)kParamAlign;
+    const int ldp = off_cb + (int)((d.F + kParamAlign - 1) / kParamAlign * kParamAlign);
+    PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
+                                           w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 0));
+    launch_colsum2(w.parts, attpool_bwd_parts(nt), off_ab + 1, ldp, c->G("att_w"), 1.f, w.colsum_scratch_k[2], s,
+                   &jobs[nj++]);
+    PROF("mhsa_bwd", launch_mhsa_bwd(w.qkv, w.dconv, w.ids, w.dqkv, nt, d.T, d.F, d.heads, s));
+    PROF("qkv_wgrad", launch_gemm(w.emb, d.D, 1, w.dqkv, 3 * d.F, 0, c->G("qkv_w"), 3 * d.F, nullptr, d.D, 3 * d.F,
+                                  nt * d.T, 1.f, w.mh_scratch, s, &jobs[nj++]));
+    launch_colsum2(w.dqkv, nt * d.T, 3 * d.F, 3 * d.F, c->G("qkv_b"), 1.f, w.mh_colsum, s, &jobs[nj++]);
+    if (stats) {
+      jobs[nj++] = ReduceJob{w.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
+      jobs[nj++] = ReduceJob{w.correct_i, stats + 1, 1, 1, 1, n, 1, 1.0f / (float)n};
+      jobs[nj++] = ReduceJob{w.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
+      jobs[nj++] = ReduceJob{w.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
+    }
+    launch_multi_reduce(jobs, nj, s);
+    return;
+  }
   const int off_cb = 0, off_aw = (int)(c->G("att_w") - c->G("conv_b")), off_ab = (int)(c->G("att_b") - c->G("conv_b"));
   const int ldp = off_ab + 1;
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
@@ -884,6 +938,22 @@ int lstur_attpool_fwd(const float* conv_out, const int32_t* ids, const float* at
   launch_attpool_fwd(conv_out, ids, att_w, att_b, pooled, att_tanh, att_weight, n_titles, title_len, filters, drop, key,
                      (hipStream_t)stream);
   return check_launch("attpool_fwd");
+}
+int lstur_mhsa_fwd(const float* qkv, const int32_t* ids, float* out, int32_t n_titles, int32_t title_len,
+                   int32_t filters, int32_t heads, lstur_stream stream) {
+  if (!qkv || !ids || !out) return fail(LSTUR_ERR_ARG, "mhsa_fwd: NULL");
+  if (n_titles < 0 || !mhsa_supported(title_len, filters, heads))
+    return fail(LSTUR_ERR_ARG, "mhsa: title_len <= 32, filters <= 512, filters / heads in {16, 32, 64}");
+  launch_mhsa_fwd(qkv, ids, out, n_titles, title_len, filters, heads, (hipStream_t)stream);
+  return check_launch("mhsa_fwd");
+}
+int lstur_mhsa_bwd(const float* qkv, const float* dout, const int32_t* ids, float* dqkv, int32_t n_titles,
+                   int32_t title_len, int32_t filters, int32_t heads, lstur_stream stream) {
+  if (!qkv || !dout || !ids || !dqkv) return fail(LSTUR_ERR_ARG, "mhsa_bwd: NULL");
+  if (n_titles < 0 || !mhsa_supported(title_len, filters, heads))
+    return fail(LSTUR_ERR_ARG, "mhsa: title_len <= 32, filters <= 512, filters / heads in {16, 32, 64}");
+  launch_mhsa_bwd(qkv, dout, ids, dqkv, n_titles, title_len, filters, heads, (hipStream_t)stream);
+  return check_launch("mhsa_bwd");
 }
 int32_t lstur_attpool_bwd_parts(int32_t n_titles) { return attpool_bwd_parts(n_titles); }
 int lstur_attpool_bwd(const float* conv_out, const int32_t* ids, const float* att_w, const float* att_tanh,

@@ -124,7 +124,16 @@ int attpool_bwd_parts(int n_titles);
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
                         float drop, uint32_t key, hipStream_t s, int ldp = 0, int off_aw = 0, int off_cb = 0,
-                        int off_ab = 0);
+                        int off_ab = 0, int relu = 1);
+
+// ---- mhsa.hip (build-defined multi-head self-attention token stage; T <= 32, F/heads in {16, 32, 64}) -------
+bool mhsa_supported(int T, int F, int heads);
+// qkv [n_titles*T, 3F] = Q | K | V (head h = columns h*dh .. of each); out [n_titles*T, F] (rows of pad tokens untouched)
+void launch_mhsa_fwd(const float* qkv, const int32_t* ids, float* out, int n_titles, int T, int F, int heads,
+                     hipStream_t s);
+// dout [n_titles*T, F] (rows of pad tokens are not read) -> dqkv [n_titles*T, 3F] (rows of pad tokens = 0)
+void launch_mhsa_bwd(const float* qkv, const float* dout, const int32_t* ids, float* dqkv, int n_titles, int T, int F,
+                     int heads, hipStream_t s);
 
 // ---- pointwise head (misc.hip) --------------------------------------------------------------------
 // point_dot: s = u . d; point_mlp: s = relu(pre) . w2 + b2 (pre = [u|d] W1 + b1 computed by the caller).

@@ -77,7 +77,7 @@ class NativeModel:
     def __init__(self, word_emb, n_users, batch_size, window, title_len, negative_samples, filters, kernel,
                  user_dim, arch='igru', dropout=0.2, lr=1e-3, seed=0, device=None, title_table=None,
                  dist_group=None, has_user=True, head='softmax', gain=1.0, freeze_encoder=False,
-                 word_trainable=False):
+                 word_trainable=False, news_encoder='cnnatt', heads=0):
         if not torch.cuda.is_available():
             raise _lib.LsturError('no GPU visible: the native LSTUR model has no CPU fallback')
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
@@ -94,13 +94,15 @@ class NativeModel:
         self.cfg = _lib.make_cfg(batch_size, window, title_len, self.K1, V, D, filters, kernel, user_dim,
                                  max(1, n_users), arch, dropout, seed, head=head, gain=gain,
                                  loss_negatives=max(1, negative_samples), freeze_encoder=freeze_encoder,
-                                 word_trainable=word_trainable)
+                                 word_trainable=word_trainable, news_encoder=news_encoder, heads=heads)
+        self.news_encoder = news_encoder     # 'mhsa': build-defined multi-head self-attention token stage (heads x F/heads)
         self.freeze_encoder = bool(freeze_encoder)
         self.word_trainable = bool(word_trainable)     # --textual-embedding-trainable (paper.py:132-138)
         self.sizes = _lib.query_sizes(self.cfg)
         self.layout = _lib.param_layout(self.cfg)
         H, Ue = self.sizes.gru_dim, self.sizes.user_emb_dim
-        self.shapes = dict(conv_w=(kernel, D, filters), conv_b=(filters,), att_w=(filters,), att_b=(1,),
+        self.shapes = dict(conv_w=(kernel, D, filters), conv_b=(filters,), qkv_w=(D, 3 * filters), qkv_b=(3 * filters,),
+                           att_w=(filters,), att_b=(1,),
                            dense_w=(filters, user_dim), dense_b=(user_dim,), gru_w=(user_dim, 3 * H),
                            gru_u=(H, 3 * H), gru_b=(3 * H,), con_w=(H + Ue, user_dim), con_b=(user_dim,),
                            user_emb=(max(1, n_users), Ue), word_emb=(V, D),
@@ -156,8 +158,11 @@ class NativeModel:
     def from_task(cls, task, user_count):
         cfg = task.config
         from . import utils
-        if getattr(cfg, 'news_encoder', 'cnnatt') != 'cnnatt':
-            raise _lib.LsturError('only the cnnatt news encoder is on the native path')
+        enc = getattr(cfg, 'news_encoder', 'cnnatt')
+        if enc not in ('cnnatt', 'mhsa'):
+            # the reference's gruatt / lstmatt / bigruatt / bilstmatt (paper.py:119-130) are out of scope; `mhsa` is the
+            # build-defined multi-head self-attention encoder of BASELINE.json configs[4] (--title-filter-shape F heads)
+            raise _lib.LsturError('news encoder {!r} is not on the native path (have cnnatt, mhsa)'.format(enc))
         head = getattr(task, 'head', 'softmax')
         if head == 'softmax' and getattr(cfg, 'score_model', 'dot') != 'dot':
             raise _lib.LsturError('only the dot scorer is on the native path')
@@ -183,7 +188,8 @@ class NativeModel:
                     title_table=task.docs.title_table, has_user=has_user, head=head,
                     gain=float(getattr(cfg, 'gain', 1.0)),
                     freeze_encoder=pretrained and not getattr(cfg, 'pretrain_encoder_trainable', False),
-                    word_trainable=bool(getattr(cfg, 'textual_embedding_trainable', False)) and not pretrained)
+                    word_trainable=bool(getattr(cfg, 'textual_embedding_trainable', False)) and not pretrained,
+                    news_encoder=enc, heads=int(kernel) if enc == 'mhsa' else 0)
         if pretrained:                      # paper.py:103-107
             model.load_encoder(cfg.encoder_input)
         return model
@@ -201,12 +207,17 @@ class NativeModel:
         k, D, F = s['conv_w']
         U = s['dense_w'][1]
         H = s['gru_u'][0]
-        w = dict(conv_w=_glorot(rng, s['conv_w'], k * D, k * F), conv_b=np.zeros(F, np.float32),
-                 att_w=_glorot(rng, s['att_w'], F, 1), att_b=np.zeros(1, np.float32),
+        w = dict(att_w=_glorot(rng, s['att_w'], F, 1), att_b=np.zeros(1, np.float32),
                  dense_w=_glorot(rng, s['dense_w'], F, U), dense_b=np.zeros(U, np.float32),
                  gru_w=_glorot(rng, s['gru_w'], U, 3 * H), gru_u=_orthogonal(rng, H, 3 * H),
                  gru_b=np.zeros(3 * H, np.float32),
                  user_emb=rng.uniform(-0.05, 0.05, size=s['user_emb']).astype(np.float32))
+        if self.news_encoder == 'mhsa':    # three glorot_uniform [D, F] projections side by side, zero bias
+            w['qkv_w'] = np.concatenate([_glorot(rng, (D, F), D, F) for _ in range(3)], axis=1)
+            w['qkv_b'] = np.zeros(3 * F, np.float32)
+        else:
+            w['conv_w'] = _glorot(rng, s['conv_w'], k * D, k * F)
+            w['conv_b'] = np.zeros(F, np.float32)
         if self.arch == 'gru':
             w['con_w'] = _glorot(rng, s['con_w'], s['con_w'][0], U)
             w['con_b'] = np.zeros(U, np.float32)
@@ -283,7 +294,8 @@ class NativeModel:
         """Names in the order ``keras.Model.get_weights()`` lists them for the reference graph: trainable
         weights layer by layer (doc_encoder: Conv1D kernel/bias, attention kernel/bias, Dense kernel/bias;
         user_encoder: user Embedding, GRU kernel/recurrent/bias[, concat Dense]), then the frozen word table."""
-        names = ['conv_w', 'conv_b', 'att_w', 'att_b', 'dense_w', 'dense_b', 'user_emb', 'gru_w', 'gru_u', 'gru_b']
+        tok = ['qkv_w', 'qkv_b'] if self.news_encoder == 'mhsa' else ['conv_w', 'conv_b']
+        names = tok + ['att_w', 'att_b', 'dense_w', 'dense_b', 'user_emb', 'gru_w', 'gru_u', 'gru_b']
         if self.arch == 'gru':
             names += ['con_w', 'con_b']
         return names + ['word_emb']

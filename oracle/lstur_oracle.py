@@ -92,7 +92,8 @@ def orthogonal(rng, rows, cols):
 HEADS = ("softmax", "point_mlp", "point_dot")
 
 
-def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.float32, head="softmax"):
+def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.float32, head="softmax",
+                encoder="cnnatt", heads=1):
     """Random-init parameters with the reference's initialisers
     (conv/dense/att: glorot_uniform, biases zero -- paper.py:146,159, models.py:448-449;
     user table uniform +-0.05 -- paper.py:589; GRU kernel glorot, recurrent orthogonal)."""
@@ -104,8 +105,13 @@ def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.fl
         word_emb = rng.normal(0.0, 0.1, size=(V, D))
         word_emb[0] = 0.0
     p["word_emb"] = word_emb
-    p["conv_w"] = glorot_uniform(rng, (k, D, F), k * D, k * F)
-    p["conv_b"] = np.zeros(F)
+    if encoder == "mhsa":        # build-defined encoder (no reference counterpart)
+        assert F % heads == 0
+        p["qkv_w"] = np.concatenate([glorot_uniform(rng, (D, F), D, F) for _ in range(3)], axis=1)   # Wq | Wk | Wv
+        p["qkv_b"] = np.zeros(3 * F)
+    else:
+        p["conv_w"] = glorot_uniform(rng, (k, D, F), k * D, k * F)
+        p["conv_b"] = np.zeros(F)
     p["att_w"] = glorot_uniform(rng, (F,), F, 1)
     p["att_b"] = np.zeros(1)
     p["dense_w"] = glorot_uniform(rng, (F, U), F, U)
@@ -123,12 +129,16 @@ def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.fl
         p["score_b1"] = np.zeros(U)
         p["score_w2"] = glorot_uniform(rng, (U,), U, 1)
         p["score_b2"] = np.zeros(1)
-    return {n: np.ascontiguousarray(a, dtype=dtype) for n, a in p.items()}
+    p = {n: np.ascontiguousarray(a, dtype=dtype) for n, a in p.items()}
+    if encoder == "mhsa":
+        p["mhsa_heads"] = np.int64(heads)       # structural, not a weight
+    return p
 
 
-def dense_param_names(arch, word_trainable=False, head="softmax"):
+def dense_param_names(arch, word_trainable=False, head="softmax", encoder="cnnatt"):
     """Order of the flat dense-parameter bucket (same order in the HIP library)."""
-    names = ["conv_w", "conv_b", "att_w", "att_b", "dense_w", "dense_b", "gru_w", "gru_u", "gru_b"]
+    names = ["qkv_w", "qkv_b"] if encoder == "mhsa" else ["conv_w", "conv_b"]
+    names += ["att_w", "att_b", "dense_w", "dense_b", "gru_w", "gru_u", "gru_b"]
     if arch == "gru":
         names += ["con_w", "con_b"]
     if head == "point_mlp":
@@ -150,30 +160,111 @@ def _im2col(Epad, T, k):
     return win.reshape(n * T, k * D)
 
 
+# --------------------------------------------------------------------------
+# build-defined news encoder `mhsa` (BASELINE.json configs[4]; SURVEY.md section 8 row a17: the reference has NO
+# multi-head self-attention news encoder, so this spec is ours and its parity is against this restatement only):
+#   E = Dropout(Embedding(ids));  [Q|K|V] = E . qkv_w + qkv_b   (heads x dh = F columns each)
+#   per head: S = Q K^T / sqrt(dh), keys of pad tokens masked, P = softmax_keys(S) (all keys masked -> P = 0)
+#   O = P V, heads concatenated, rows of pad tokens zeroed (like paper.py:150-155)
+#   then the cnnatt tail unchanged: Masking -> Dropout -> additive attention pool -> Dense(U)
+# The HIP path feeds the two attention products (and their gradients) to bf16 MFMA: `bf16_round` marks every
+# operand it rounds (accumulation fp32 there, fp64/fp32 here); MHSA_EMULATE_BF16 = False gives the exact math.
+# --------------------------------------------------------------------------
+MHSA_EMULATE_BF16 = True
+MHSA_PROJ_BF16 = False    # the projection products E.W (and E^T.dQKV) also take bf16 operands
+
+
+def bf16_round(x):
+    """Round to nearest-even bfloat16 (restated in csrc/mhsa.hip: f2bf); returns x's dtype."""
+    x = np.asarray(x)
+    if not MHSA_EMULATE_BF16:
+        return x
+    f = np.ascontiguousarray(x, dtype=np.float32)
+    u = f.view(np.uint32)
+    with np.errstate(over="ignore"):
+        r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32).astype(x.dtype)
+
+
+def _proj_round(x):
+    return bf16_round(x) if MHSA_PROJ_BF16 else x
+
+
+def mhsa_fwd(p, E, ids):
+    """E [N,T,D] (after dropout), ids [N,T] -> c [N,T,F] and the cache of the backward pass."""
+    N, T, D = E.shape
+    F = p["qkv_w"].shape[1] // 3
+    h = int(p["mhsa_heads"])
+    dh = F // h
+    dt = E.dtype
+    Er = _proj_round(E.reshape(N * T, D))
+    qkv = (Er @ _proj_round(p["qkv_w"]) + p["qkv_b"]).reshape(N, T, 3, h, dh)
+    Q, K, V = (bf16_round(qkv[:, :, i]) for i in range(3))
+    scale = dt.type(1.0 / np.sqrt(dh))
+    km = (ids != 0)
+    S = np.einsum("nqhd,nkhd->nhqk", Q, K) * scale
+    S = np.where(km[:, None, None, :], S, -np.inf)
+    m = S.max(axis=-1, keepdims=True)
+    m = np.where(np.isfinite(m), m, 0.0)
+    Pe = np.exp(S - m) * km[:, None, None, :]
+    l = Pe.sum(axis=-1, keepdims=True)
+    P = np.where(l > 0, Pe / np.where(l > 0, l, 1.0), 0.0).astype(dt)
+    Pb = bf16_round(P)
+    O = np.einsum("nhqk,nkhd->nqhd", Pb, V).reshape(N, T, F)
+    c = O * km[..., None]
+    return c, dict(Er=Er, Q=Q, K=K, V=V, P=P, Pb=Pb, scale=scale, km=km)
+
+
+def mhsa_bwd(p, mc, dc, want_dE=False):
+    """dc [N,T,F] (zero on pad rows) -> (qkv_w grad, qkv_b grad, dE or None)."""
+    Q, K, V, P, Pb = mc["Q"], mc["K"], mc["V"], mc["P"], mc["Pb"]
+    N, T, h, dh = Q.shape
+    dO = bf16_round(dc * mc["km"][..., None]).reshape(N, T, h, dh)
+    dV = np.einsum("nhqk,nqhd->nkhd", Pb, dO)
+    dP = np.einsum("nqhd,nkhd->nhqk", dO, V)
+    delta = (P * dP).sum(axis=-1, keepdims=True)
+    dS = bf16_round(P * (dP - delta) * mc["scale"])
+    dQ = np.einsum("nhqk,nkhd->nqhd", dS, K)
+    dK = np.einsum("nhqk,nqhd->nkhd", dS, Q)
+    dqkv = np.stack([dQ, dK, dV], axis=2).reshape(N * T, 3 * h * dh)
+    gb = dqkv.sum(axis=0)
+    dqr = _proj_round(dqkv)
+    gw = mc["Er"].T @ dqr
+    dE = (dqr @ _proj_round(p["qkv_w"]).T).reshape(N, T, -1) if want_dE else None
+    return gw, gb, dE
+
+
 def news_encoder_fwd(p, titles, drop_p=0.0, keys=(0, 0), training=True, chunk=4096):
     """titles int [N_t,T] -> doc vectors [N_t,U]; returns (v, cache)."""
-    dt = p["conv_w"].dtype
+    mhsa = "qkv_w" in p
+    dt = p["att_w"].dtype
     ids = np.asarray(titles).astype(np.int64)
     N, T = ids.shape
-    k, D, F = p["conv_w"].shape
-    pl = (k - 1) // 2
-    pr = k - 1 - pl
-    Wm = p["conv_w"].reshape(k * D, F)
+    F = p["att_w"].shape[0]
     use_drop = training and drop_p > 0.0
     scale = dt.type(1.0 / (1.0 - drop_p)) if use_drop else dt.type(1.0)
-
-    c = np.empty((N, T, F), dtype=dt)
-    for s in range(0, N, chunk):
-        e = min(N, s + chunk)
-        E = p["word_emb"][ids[s:e]].astype(dt)  # gather, pad id 0 is gathered too
+    mcache = None
+    if mhsa:
+        E = p["word_emb"][ids].astype(dt)
         if use_drop:
-            keep = dropout_keep(keys[0], (e - s) * T * D, drop_p, start=s * T * D).reshape(e - s, T, D)
-            E = E * keep * scale
-        Epad = np.zeros((e - s, T + k - 1, D), dtype=dt)
-        Epad[:, pl:pl + T] = E
-        cc = _im2col(Epad, T, k) @ Wm + p["conv_b"]
-        c[s:e] = np.maximum(cc, 0).reshape(e - s, T, F)
-    c *= (ids != 0)[..., None]                      # paper.py:150-155
+            E = E * dropout_keep(keys[0], N * T * E.shape[-1], drop_p).reshape(E.shape) * scale
+        c, mcache = mhsa_fwd(p, E, ids)
+    else:
+        k, D, _ = p["conv_w"].shape
+        pl = (k - 1) // 2
+        Wm = p["conv_w"].reshape(k * D, F)
+        c = np.empty((N, T, F), dtype=dt)
+        for s in range(0, N, chunk):
+            e = min(N, s + chunk)
+            E = p["word_emb"][ids[s:e]].astype(dt)  # gather, pad id 0 is gathered too
+            if use_drop:
+                keep = dropout_keep(keys[0], (e - s) * T * D, drop_p, start=s * T * D).reshape(e - s, T, D)
+                E = E * keep * scale
+            Epad = np.zeros((e - s, T + k - 1, D), dtype=dt)
+            Epad[:, pl:pl + T] = E
+            cc = _im2col(Epad, T, k) @ Wm + p["conv_b"]
+            c[s:e] = np.maximum(cc, 0).reshape(e - s, T, F)
+        c *= (ids != 0)[..., None]                      # paper.py:150-155
     tmask = np.any(c != 0, axis=-1)                 # keras Masking(0.) paper.py:157
     if use_drop:
         keep2 = dropout_keep(keys[1], N * T * F, drop_p).reshape(N, T, F)
@@ -188,17 +279,15 @@ def news_encoder_fwd(p, titles, drop_p=0.0, keys=(0, 0), training=True, chunk=40
     pooled = np.einsum("ntf,nt->nf", x, w)
     v = pooled @ p["dense_w"] + p["dense_b"]        # paper.py:159
     cache = dict(ids=ids, c=c, tmask=tmask, keep2=keep2, x=x, a=a, w=w, pooled=pooled,
-                 scale=scale, drop_p=drop_p if use_drop else 0.0, keys=keys)
+                 scale=scale, drop_p=drop_p if use_drop else 0.0, keys=keys, mhsa=mcache)
     return v, cache
 
 
 def news_encoder_bwd(p, cache, dv, word_trainable=False, chunk=4096):
-    """dv [N_t,U] -> grads dict for conv/att/dense (+ word_emb when trainable)."""
-    dt = p["conv_w"].dtype
+    """dv [N_t,U] -> grads dict for conv (or qkv) /att/dense (+ word_emb when trainable)."""
+    dt = p["att_w"].dtype
     ids, c, x, a, w = cache["ids"], cache["c"], cache["x"], cache["a"], cache["w"]
     N, T = ids.shape
-    k, D, F = p["conv_w"].shape
-    pl = (k - 1) // 2
     g = {}
     g["dense_w"] = cache["pooled"].T @ dv
     g["dense_b"] = dv.sum(axis=0)
@@ -212,10 +301,22 @@ def news_encoder_bwd(p, cache, dv, word_trainable=False, chunk=4096):
     g["att_b"] = np.array([ds.sum()], dtype=dt)
     if cache["keep2"] is not None:
         dx = dx * cache["keep2"] * cache["scale"]
+    use_drop = cache["drop_p"] > 0.0
+    if cache["mhsa"] is not None:                   # no ReLU behind the self-attention: only the pad-row mask
+        dc = dx * (ids != 0)[..., None]
+        g["qkv_w"], g["qkv_b"], dE = mhsa_bwd(p, cache["mhsa"], dc, want_dE=word_trainable)
+        if word_trainable:
+            if use_drop:
+                dE = dE * dropout_keep(cache["keys"][0], dE.size, cache["drop_p"]).reshape(dE.shape) * cache["scale"]
+            g_word = np.zeros_like(p["word_emb"])
+            np.add.at(g_word, ids.reshape(-1), dE.reshape(N * T, -1))
+            g["word_emb"] = g_word
+        return g
+    k, D, F = p["conv_w"].shape
+    pl = (k - 1) // 2
     dc = dx * (c > 0)                               # ReLU' ; pad-masked / masked rows have c == 0
     g["conv_b"] = dc.sum(axis=(0, 1))
     gW = np.zeros((k * D, F), dtype=dt)
-    use_drop = cache["drop_p"] > 0.0
     if word_trainable:
         g_word = np.zeros_like(p["word_emb"])
         Wm = p["conv_w"].reshape(k * D, F)

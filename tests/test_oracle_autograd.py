@@ -47,6 +47,49 @@ def test_grads_match_autograd(arch, drop):
         np.testing.assert_allclose(g[n], ref, rtol=1e-8, atol=1e-12, err_msg=n)
 
 
+@pytest.mark.parametrize("drop", [0.0, 0.25])
+def test_mhsa_grads_match_autograd(drop, monkeypatch):
+    """The build-defined multi-head self-attention news encoder (no reference counterpart: SURVEY.md section 8 row
+    a17): the oracle's hand-derived backward, bf16 emulation off, against torch autograd in fp64."""
+    monkeypatch.setattr(O, "MHSA_EMULATE_BF16", False)
+    rng = np.random.default_rng(4)
+    dims = dict(V=60, D=12, F=32, k=1, U=8, N_u=11)
+    p = O.init_params(rng, arch="igru", dtype=np.float64, encoder="mhsa", heads=2, **dims)
+    for n in ("qkv_b", "att_b", "dense_b", "gru_b"):
+        p[n] = rng.normal(0, 0.1, size=p[n].shape)
+    B, W, T, K1 = 5, 4, 7, 3
+    user, hist, cands = make_batch(rng, B, W, T, K1, dims["V"], dims["N_u"])
+    hist[2] = 0
+    out = O.forward_backward(p, "igru", user, hist, cands, drop_p=drop, seed=7, step=2, word_trainable=True)
+    names = [n for n in p if n != "mhsa_heads"]
+    tp = TR.to_t({n: p[n] for n in names}, grad_names=names)
+    tp["mhsa_heads"] = 2
+    keep1 = keep2 = None
+    scale = 1.0
+    if drop > 0:
+        N_t = B * (W + K1)
+        keep1 = O.dropout_keep(O.dropout_key(7, 2, 0), N_t * T * dims["D"], drop).reshape(N_t, T, dims["D"])
+        keep2 = O.dropout_keep(O.dropout_key(7, 2, 1), N_t * T * dims["F"], drop).reshape(N_t, T, dims["F"])
+        scale = 1.0 / (1.0 - drop)
+    loss, z, pr = TR.model_loss(tp, "igru", user, hist, cands, keep1, keep2, scale)
+    loss.backward()
+    assert abs(loss.item() - out["loss"]) < 1e-12
+    np.testing.assert_allclose(out["logits"], z.detach().numpy(), rtol=1e-10, atol=1e-12)
+    g = dict(out["grads"])
+    g["user_emb"] = O.densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"], np.float64)
+    for n in names:
+        np.testing.assert_allclose(g[n], tp[n].grad.numpy(), rtol=1e-8, atol=1e-12, err_msg=n)
+
+
+def test_bf16_round_is_round_to_nearest_even():
+    x = np.array([1.0, 1.00390625, 1.01171875, -2.5, 3.1415927, 1e-30, 0.0], dtype=np.float32)
+    got = O.bf16_round(x)
+    ref = torch.tensor(x).to(torch.bfloat16).to(torch.float32).numpy()
+    np.testing.assert_array_equal(got, ref)
+    r = np.random.default_rng(0).normal(size=4096).astype(np.float32)
+    np.testing.assert_array_equal(O.bf16_round(r), torch.tensor(r).to(torch.bfloat16).to(torch.float32).numpy())
+
+
 def test_all_masked_history_returns_initial_state():
     rng = np.random.default_rng(0)
     p = O.init_params(rng, arch="igru", dtype=np.float64, **DIMS)

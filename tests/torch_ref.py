@@ -25,14 +25,25 @@ def to_t(p, dtype=torch.float64, grad_names=()):
 def news_encoder(p, titles, keep1=None, keep2=None, scale=1.0):
     ids = torch.as_tensor(np.asarray(titles), dtype=torch.long)
     N, T = ids.shape
-    k, D, Fo = p["conv_w"].shape
     E = p["word_emb"][ids]                                  # [N,T,D]
     if keep1 is not None:
         E = E * torch.as_tensor(keep1, dtype=E.dtype) * scale
-    pl = (k - 1) // 2
-    x = F.pad(E.transpose(1, 2), (pl, k - 1 - pl))           # [N,D,T+k-1]
-    w = p["conv_w"].permute(2, 1, 0)                        # [F,D,k]
-    c = F.relu(F.conv1d(x, w, p["conv_b"])).transpose(1, 2)  # [N,T,F]
+    if "qkv_w" in p:                                        # build-defined mhsa encoder (exact math, no bf16 rounding)
+        h = int(p["mhsa_heads"])
+        qkv = (E @ p["qkv_w"] + p["qkv_b"]).reshape(N, T, 3, h, -1).permute(2, 0, 3, 1, 4)   # [3,N,h,T,dh]
+        km = (ids != 0)
+        bias = torch.zeros(N, 1, 1, T, dtype=E.dtype).masked_fill(~km[:, None, None, :], float("-inf"))
+        S = qkv[0] @ qkv[1].transpose(-1, -2) / np.sqrt(qkv.shape[-1]) + bias
+        allm = ~km.any(-1)
+        S = torch.where(allm[:, None, None, None], torch.zeros_like(S), S)   # no NaN from an all-pad title
+        P = torch.softmax(S, dim=-1) * km[:, None, None, :].to(E.dtype)
+        c = (P @ qkv[2]).permute(0, 2, 1, 3).reshape(N, T, -1)
+    else:
+        k, D, Fo = p["conv_w"].shape
+        pl = (k - 1) // 2
+        x = F.pad(E.transpose(1, 2), (pl, k - 1 - pl))           # [N,D,T+k-1]
+        w = p["conv_w"].permute(2, 1, 0)                        # [F,D,k]
+        c = F.relu(F.conv1d(x, w, p["conv_b"])).transpose(1, 2)  # [N,T,F]
     c = c * (ids != 0).unsqueeze(-1).to(c.dtype)
     tmask = (c.detach() != 0).any(dim=-1)
     c = c * tmask.unsqueeze(-1).to(c.dtype)
