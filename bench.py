@@ -28,7 +28,14 @@ WORKLOADS = {
     # BASELINE.json configs[3]
     'lstur_ini_b512_1Musers': dict(arch='igru', B=512, W=50, T=30, K1=5, D=300, F=400, k=3, U=200, V=100000,
                                    N_u=1000000, N_d=200000),
+    # BASELINE.json configs[4]: the build-defined multi-head self-attention news encoder (16 heads x 16; the reference has
+    # no such encoder) at the config-2 and config-4 shapes
+    'mhsa_b64': dict(arch='igru', B=64, W=50, T=30, K1=5, D=300, F=256, k=1, U=200, V=50000, N_u=50000, N_d=20000,
+                     encoder='mhsa', heads=16),
+    'mhsa_b512_1Musers': dict(arch='igru', B=512, W=50, T=30, K1=5, D=300, F=256, k=1, U=200, V=100000, N_u=1000000,
+                              N_d=200000, encoder='mhsa', heads=16),
 }
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy ceiling)
 
@@ -74,9 +81,10 @@ def cpu_baseline(wl, titles, word, batches, budget_s=20.0):
     cores for a bounded number of full training steps of the SAME workload in fp32."""
     from oracle import lstur_oracle as O
     rng = np.random.default_rng(0)
+    enc = wl.get('encoder', 'cnnatt')
     p = O.init_params(rng, V=wl['V'], D=wl['D'], F=wl['F'], k=wl['k'], U=wl['U'], N_u=wl['N_u'], arch=wl['arch'],
-                      word_emb=word, dtype=np.float32)
-    opt = O.Adam(p, O.dense_param_names(wl['arch']) + ['user_emb'], lr=1e-3)
+                      word_emb=word, dtype=np.float32, encoder=enc, heads=wl.get('heads', 1))
+    opt = O.Adam(p, O.dense_param_names(wl['arch'], encoder=enc) + ['user_emb'], lr=1e-3)
     try:
         import threadpoolctl
         threads = max(i['num_threads'] for i in threadpoolctl.threadpool_info() if i.get('user_api') == 'blas')
@@ -128,7 +136,7 @@ def main():
     _, _, batches = synth_inputs(wl, rng, 32)                            # per-rank sample stream
     model = NativeModel(word, wl['N_u'], wl['B'], wl['W'], wl['T'], wl['K1'] - 1, wl['F'], wl['k'], wl['U'],
                         arch=wl['arch'], dropout=args.dropout, lr=1e-3, seed=7, device='cuda:%d' % local,
-                        title_table=titles)
+                        title_table=titles, news_encoder=wl.get('encoder', 'cnnatt'), heads=wl.get('heads', 0))
     model.force_collectives = args.force_dp
     dev = [(model._dev_i32(u), model._dev_i32(h), model._dev_i32(c)) for u, h, c in batches]
     torch.cuda.synchronize()
@@ -172,7 +180,17 @@ def main():
         roofline_gather = None
         pmc = pmc_traffic(args.workload)
         traffic = (lambda k: pmc['kernels'][k]['traffic_bytes'] if pmc and k in pmc['kernels'] else None)
-        if prof:
+        mhsa = wl.get('encoder') == 'mhsa'
+        if prof and mhsa:
+            # token stage = Q|K|V projection GEMMs over ALL tokens (pads included) + the attention kernels
+            dom = max(('qkv_proj', 'qkv_wgrad'), key=lambda k: kern[k]['avg_us'])
+            flop = 2.0 * n_tok * wl['D'] * 3 * wl['F']
+            peak = PEAK_BF16_MFMA_TFLOPS if model.mhsa_proj_dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
+            ach = flop / (kern[dom]['avg_us'] * 1e-6) / 1e12
+            roofline = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s',
+                            frac=round(ach / peak, 4), traffic=traffic(dom), avg_us=round(kern[dom]['avg_us'], 1),
+                            flop_per_launch=flop, operand_dtype=model.mhsa_proj_dtype)
+        if prof and not mhsa:
             dom = max(('conv_fwd', 'conv_wgrad'), key=lambda k: kern[k]['avg_us'])
             ach = conv_flop / (kern[dom]['avg_us'] * 1e-6) / 1e12
             roofline = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
@@ -180,6 +198,7 @@ def main():
                             avg_us=round(kern[dom]['avg_us'], 1), flop_per_launch=conv_flop,
                             non_pad_token_fraction=round(real_tok / n_tok, 4),
                             effective_algorithmic=round(conv_flop_full / (kern[dom]['avg_us'] * 1e-6) / 1e12, 2))
+        if prof:
             gb = gather_bytes / (kern['gather']['avg_us'] * 1e-6) / 1e9
             roofline_gather = dict(kernel='gather', bound='hbm', achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                                    frac=round(gb / PEAK_HBM_GBS, 4), traffic=traffic('gather'),
@@ -188,11 +207,12 @@ def main():
             'metric': 'training impressions/sec', 'value': round(world * wl['B'] * args.steps / el, 1),
             'unit': 'impressions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * el / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'bf16' if wl.get('encoder') == 'mhsa' else 'f32', 'data': 'synthetic',
             'config': {'workload': args.workload, 'arch': wl['arch'], 'batch_per_gpu': wl['B'],
                        'global_batch': wl['B'] * world, 'hist_len': wl['W'], 'title_len': wl['T'],
                        'candidates': wl['K1'], 'word_dim': wl['D'], 'filters': wl['F'], 'user_dim': wl['U'],
                        'n_users': wl['N_u'], 'n_docs': wl['N_d'], 'vocab': wl['V'], 'dropout': args.dropout,
+                       'news_encoder': wl.get('encoder', 'cnnatt'), 'heads': wl.get('heads', 0),
                        'parallelism': 'dp%d' % world, 'optimizer': 'keras-adam (dense user-table sweep)'},
             'roofline': roofline, 'roofline_gather': roofline_gather,
             'kernels_us': {k: round(v['avg_us'], 1) for k, v in sorted(kern.items())},

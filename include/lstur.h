@@ -272,6 +272,16 @@ int lstur_mhsa_fwd(const float* qkv, const int32_t* ids, float* out, int32_t n_t
                    int32_t filters, int32_t heads, lstur_stream stream);
 int lstur_mhsa_bwd(const float* qkv, const float* dout, const int32_t* ids, float* dqkv, int32_t n_titles,
                    int32_t title_len, int32_t filters, int32_t heads, lstur_stream stream);
+/* Projections of the mhsa encoder on bf16 MFMA (operands rounded to nearest-even bf16, fp32 accumulation):
+ *   lstur_proj_fwd_bf16  : out bf16 [M, N] = E[M, K] . W[K, N] + bias[N]   (E, W, bias fp32; bias may be NULL)
+ *   lstur_proj_wgrad_bf16: dw fp32 [D + 1, N] = [E | 1]^T . dout           (E fp32 [K, D], dout bf16 [K, N]; row D of dw
+ *                          = column sums of dout = the bias gradient); scratch: lstur_proj_wgrad_scratch(D, N, K) bytes.
+ * N % 8 == 0; K % 4 == 0 (forward); D % 4 == 0 and D <= 316 (gradient). */
+int lstur_proj_fwd_bf16(const float* E, const float* W, const float* bias, uint16_t* out, int32_t M, int32_t N, int32_t K,
+                        lstur_stream stream);
+size_t lstur_proj_wgrad_scratch(int32_t D, int32_t N, int32_t K);
+int lstur_proj_wgrad_bf16(const float* E, const uint16_t* dout, float* dw, void* scratch, int32_t D, int32_t N, int32_t K,
+                          lstur_stream stream);
 /* out[j] (+)= sum_i x[i, j]   (bias gradients, partial-sum reduction) */
 int lstur_colsum(const float* x, int32_t rows, int32_t cols, int32_t ld, float* out, float scale,
                  lstur_stream stream);

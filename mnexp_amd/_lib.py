@@ -82,6 +82,9 @@ SIGNATURES = {
     'lstur_attpool_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U, _P]),
     'lstur_mhsa_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'lstur_mhsa_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'lstur_proj_fwd_bf16': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'lstur_proj_wgrad_scratch': (_Z, [_I, _I, _I]),
+    'lstur_proj_wgrad_bf16': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'lstur_colsum': (_I, [_P, _I, _I, _I, _P, _F, _P]),
     'lstur_gemm_scratch': (_Z, [_I, _I, _I]),
     'lstur_gemm_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),

@@ -87,6 +87,10 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
       *why = "mhsa: a trainable word table is not on the native path";
       return false;
     }
+    if (d->D > 316) {
+      *why = "mhsa: word_dim must be <= 316 (one 320-row tile holds the projection's weight + bias gradient)";
+      return false;
+    }
   }
   d->word_trainable = c->word_trainable != 0;
   if (d->word_trainable && c->freeze_encoder) {
@@ -179,7 +183,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; float* qkv; float* dqkv; void* mh_scratch; float* mh_colsum;
+  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
 };
@@ -265,10 +269,9 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->sdcat = (float*)take(nc * 2 * d.U * f4);
   w->dgrad_scratch = d.word_trainable ? (float*)take(conv_dgrad_scratch_floats((int)nt, d.T, d.D, d.k, d.F) * f4) : nullptr;
   const bool mh = d.enc == LSTUR_ENC_MHSA;
-  w->qkv = mh ? (float*)take(nt * d.T * 3 * d.F * f4) : nullptr;
-  w->dqkv = mh ? (float*)take(nt * d.T * 3 * d.F * f4) : nullptr;
-  w->mh_scratch = mh ? take(std::max(gemm_scratch_bytes(d.D, 3 * d.F, (int)(nt * d.T)), (size_t)4 << 20)) : nullptr;
-  w->mh_colsum = mh ? (float*)take((size_t)kColsumSlices * 3 * d.F * f4) : nullptr;
+  w->qkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;     // bf16 Q | K | V rows
+  w->dqkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;
+  w->mh_scratch = mh ? take(proj_wgrad_scratch_bytes(d.D, 3 * d.F, (int)(nt * d.T))) : nullptr;
   w->dp_rows = (int32_t*)take((size_t)d.rows_cap * 4);
   w->dp_grads = (float*)take((size_t)d.rows_cap * d.Ue * f4);
   w->user_rows = (int32_t*)take(nc * 4);
@@ -394,9 +397,8 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   launch_compact_write_offsets(w.ids, nt * d.T, w.vscratch, w.vidx, w.vcount, d.T, d.Tp, d.D, d.F, w.offA, w.offB, s);
   PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
   if (mhsa) {   // token stage = multi-head self-attention (build-defined, include/lstur.h: LSTUR_ENC_MHSA)
-    PROF("qkv_proj", launch_gemm(w.emb, d.D, 0, c->P("qkv_w"), 3 * d.F, 0, w.qkv, 3 * d.F, c->P("qkv_b"), nt * d.T,
-                                 3 * d.F, d.D, 1.f, nullptr, s));
-    PROF("mhsa_fwd", launch_mhsa_fwd(w.qkv, w.ids, w.conv, nt, d.T, d.F, d.heads, s));
+    PROF("qkv_proj", launch_proj_fwd_bf16(w.emb, c->P("qkv_w"), c->P("qkv_b"), w.qkv, nt * d.T, 3 * d.F, d.D, s));
+    PROF("mhsa_fwd", launch_mhsa_fwd_bf16(w.qkv, w.ids, w.conv, nt, d.T, d.F, d.heads, s));
   } else
   PROF("conv_fwd", launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
                                    w.vcount, s));
@@ -489,10 +491,11 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
                                            w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 0));
     launch_colsum2(w.parts, attpool_bwd_parts(nt), off_ab + 1, ldp, c->G("att_w"), 1.f, w.colsum_scratch_k[2], s,
                    &jobs[nj++]);
-    PROF("mhsa_bwd", launch_mhsa_bwd(w.qkv, w.dconv, w.ids, w.dqkv, nt, d.T, d.F, d.heads, s));
-    PROF("qkv_wgrad", launch_gemm(w.emb, d.D, 1, w.dqkv, 3 * d.F, 0, c->G("qkv_w"), 3 * d.F, nullptr, d.D, 3 * d.F,
-                                  nt * d.T, 1.f, w.mh_scratch, s, &jobs[nj++]));
-    launch_colsum2(w.dqkv, nt * d.T, 3 * d.F, 3 * d.F, c->G("qkv_b"), 1.f, w.mh_colsum, s, &jobs[nj++]);
+    PROF("mhsa_bwd", launch_mhsa_bwd_bf16(w.qkv, w.dconv, w.ids, w.dqkv, nt, d.T, d.F, d.heads, s));
+    // weight AND bias gradient in one product: the bucket keeps qkv_b right behind qkv_w (D * 3F is a multiple of the
+    // slot alignment), so row D of [E | 1]^T . dQKV lands on it
+    PROF("qkv_wgrad", launch_proj_wgrad_bf16(w.emb, w.dqkv, c->G("qkv_w"), w.mh_scratch, d.D, 3 * d.F, nt * d.T, s,
+                                             &jobs[nj++]));
     if (stats) {
       jobs[nj++] = ReduceJob{w.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
       jobs[nj++] = ReduceJob{w.correct_i, stats + 1, 1, 1, 1, n, 1, 1.0f / (float)n};
@@ -705,6 +708,10 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
   c->d = d;
   c->buf = *buf;
   c->layout = param_layout(d, &c->dense_total);
+  if (d.enc == LSTUR_ENC_MHSA && c->G("qkv_b") != c->G("qkv_w") + (size_t)d.D * 3 * d.F) {
+    delete c;
+    return fail(LSTUR_ERR_ARG, "mhsa: qkv_b must follow qkv_w in the bucket");
+  }
   carve(d, buf->workspace, &c->ws);
   if (c->ws.bytes > buf->workspace_bytes) {
     delete c;
@@ -954,6 +961,24 @@ int lstur_mhsa_bwd(const float* qkv, const float* dout, const int32_t* ids, floa
     return fail(LSTUR_ERR_ARG, "mhsa: title_len <= 32, filters <= 512, filters / heads in {16, 32, 64}");
   launch_mhsa_bwd(qkv, dout, ids, dqkv, n_titles, title_len, filters, heads, (hipStream_t)stream);
   return check_launch("mhsa_bwd");
+}
+int lstur_proj_fwd_bf16(const float* E, const float* W, const float* bias, uint16_t* out, int32_t M, int32_t N, int32_t K,
+                        lstur_stream stream) {
+  if (!E || !W || !out) return fail(LSTUR_ERR_ARG, "proj_fwd_bf16: NULL");
+  if (M < 0 || N < 8 || (N % 8) || K < 4 || (K % 4)) return fail(LSTUR_ERR_ARG, "proj_fwd_bf16: N % 8 == 0, K % 4 == 0");
+  launch_proj_fwd_bf16(E, W, bias, out, M, N, K, (hipStream_t)stream);
+  return check_launch("proj_fwd_bf16");
+}
+size_t lstur_proj_wgrad_scratch(int32_t D, int32_t N, int32_t K) { return proj_wgrad_scratch_bytes(D, N, K); }
+int lstur_proj_wgrad_bf16(const float* E, const uint16_t* dout, float* dw, void* scratch, int32_t D, int32_t N, int32_t K,
+                          lstur_stream stream) {
+  if (!E || !dout || !dw || !scratch) return fail(LSTUR_ERR_ARG, "proj_wgrad_bf16: NULL");
+  if (D < 4 || (D % 4) || D > 316 || N < 8 || (N % 8) || K < 1)
+    return fail(LSTUR_ERR_ARG, "proj_wgrad_bf16: D % 4 == 0, D <= 316, N % 8 == 0");
+  ReduceJob job;
+  launch_proj_wgrad_bf16(E, dout, dw, scratch, D, N, K, (hipStream_t)stream, &job);
+  launch_multi_reduce(&job, 1, (hipStream_t)stream);
+  return check_launch("proj_wgrad_bf16");
 }
 int32_t lstur_attpool_bwd_parts(int32_t n_titles) { return attpool_bwd_parts(n_titles); }
 int lstur_attpool_bwd(const float* conv_out, const int32_t* ids, const float* att_w, const float* att_tanh,

@@ -135,6 +135,22 @@ void launch_mhsa_fwd(const float* qkv, const int32_t* ids, float* out, int n_tit
 void launch_mhsa_bwd(const float* qkv, const float* dout, const int32_t* ids, float* dqkv, int n_titles, int T, int F,
                      int heads, hipStream_t s);
 
+// the same two kernels on bf16 Q|K|V / dQ|dK|dV rows (the form the step uses: gemm_bf16.hip writes / reads them)
+void launch_mhsa_fwd_bf16(const unsigned short* qkv, const int32_t* ids, float* out, int n_titles, int T, int F,
+                          int heads, hipStream_t s);
+void launch_mhsa_bwd_bf16(const unsigned short* qkv, const float* dout, const int32_t* ids, unsigned short* dqkv,
+                          int n_titles, int T, int F, int heads, hipStream_t s);
+
+// ---- gemm_bf16.hip (projections of the mhsa encoder: bf16 MFMA operands, fp32 accumulation) ------------------
+bool proj_bf16_supported(int D, int N);
+// out bf16 [M, N] = E[M, K] . W[K, N] + bias
+void launch_proj_fwd_bf16(const float* E, const float* W, const float* bias, unsigned short* out, int M, int N, int K,
+                          hipStream_t s);
+size_t proj_wgrad_scratch_bytes(int D, int N, int K);
+// dW [D + 1, N] = [E | 1]^T . dqkv (row D = bias gradient; dW and db contiguous in the bucket), K = tokens
+void launch_proj_wgrad_bf16(const float* E, const unsigned short* dqkv, float* dW, void* scratch, int D, int N, int K,
+                            hipStream_t s, ReduceJob* defer);
+
 // ---- pointwise head (misc.hip) --------------------------------------------------------------------
 // point_dot: s = u . d; point_mlp: s = relu(pre) . w2 + b2 (pre = [u|d] W1 + b1 computed by the caller).
 // p = sigmoid(s); loss_i = Seq2Vec.loss term (task/seq2vec.py:213-216); ok_i = ((p > .5) == label);

@@ -25,23 +25,33 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ unsigned short f2bf(float f) {   // restated in oracle/lstur_oracle.py: bf16_round
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+// round-to-nearest-even to bf16 (v_cvt_pk_bf16_f32); restated in oracle/lstur_oracle.py: bf16_round
+__device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ f32x16 mfma32(u16x8 a, u16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// 8 consecutive fp32 -> bf16 fragment (zeros when !ok)
+// 8 consecutive fp32 -> bf16 fragment (zeros when !ok).  The load itself is unconditional -- callers pass an
+// in-bounds address either way -- and the predicate is a select: a guarded load compiles to a branch plus a
+// s_waitcnt per load, which serialises the loads of a tile.
 __device__ __forceinline__ u16x8 ld8(const float* __restrict__ p, bool ok) {
-  u16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (ok) {
-    const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
-    r[0] = f2bf(a.x); r[1] = f2bf(a.y); r[2] = f2bf(a.z); r[3] = f2bf(a.w);
-    r[4] = f2bf(b.x); r[5] = f2bf(b.y); r[6] = f2bf(b.z); r[7] = f2bf(b.w);
-  }
-  return r;
+  const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+  u16x8 r;
+  r[0] = f2bf(a.x); r[1] = f2bf(a.y); r[2] = f2bf(a.z); r[3] = f2bf(a.w);
+  r[4] = f2bf(b.x); r[5] = f2bf(b.y); r[6] = f2bf(b.z); r[7] = f2bf(b.w);
+  const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return ok ? r : z;
+}
+__device__ __forceinline__ u16x8 ld8(const unsigned short* __restrict__ p, bool ok) {   // already bf16
+  const u16x8 r = *(const u16x8*)p;
+  const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return ok ? r : z;
+}
+// one element through a buffer descriptor (offset in elements; kBufOob drops the store: no branch, no s_waitcnt)
+__device__ __forceinline__ void bst1(__amdgpu_buffer_rsrc_t r, uint32_t off, float v, const float*) {
+  buf_store1(v, r, off == kBufOob ? kBufOob : off * 4u, 0);
+}
+__device__ __forceinline__ void bst1(__amdgpu_buffer_rsrc_t r, uint32_t off, float v, const unsigned short*) {
+  __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(v), r, (int)(off == kBufOob ? kBufOob : off * 2u), 0, 0);
 }
 // accumulator register r of lane half hh <-> tile row
 __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
@@ -51,8 +61,8 @@ __device__ __forceinline__ int perm_row(int s, int hh, int j) { return 16 * s + 
 constexpr int kMhsaWaves = 4;
 
 // S^T = K Q^T (scaled, pad keys masked) -> p[16] = softmax over keys, fp32.  kmask: bit t = token t is not a pad.
-template <int DH>
-__device__ __forceinline__ void mhsa_probs(const float* __restrict__ rowp, bool rowok, int F, int hc, int hh,
+template <int DH, typename QT>
+__device__ __forceinline__ void mhsa_probs(const QT* __restrict__ rowp, bool rowok, int F, int hc, int hh,
                                            uint32_t kmask, float scale, float (&p)[16]) {
   f32x16 acc;
 #pragma unroll
@@ -84,20 +94,20 @@ __device__ __forceinline__ void mhsa_probs(const float* __restrict__ rowp, bool 
 }
 
 // rows [0,32) x DH columns of one operand (fp32 in HBM) -> bf16 LDS tile [32][DH + 2]
-template <int DH>
-__device__ __forceinline__ void stage_tile(const float* __restrict__ base, int ld, int T, uint32_t rowmask, int lane,
+template <int DH, typename QT>
+__device__ __forceinline__ void stage_tile(const QT* __restrict__ base, int ld, int T, uint32_t rowmask, int lane,
                                            unsigned short (*tile)[DH + 2]) {
   constexpr int CH = DH / 8;
   for (int i = lane; i < 32 * CH; i += 64) {
     const int row = i / CH, ch = i - row * CH;
-    const u16x8 v = ld8(base + (size_t)row * ld + ch * 8, row < T && ((rowmask >> row) & 1u));
+    const u16x8 v = ld8(base + (size_t)min(row, T - 1) * ld + ch * 8, row < T && ((rowmask >> row) & 1u));
 #pragma unroll
     for (int j = 0; j < 8; ++j) tile[row][ch * 8 + j] = v[j];
   }
 }
 
-template <int DH>
-__global__ __launch_bounds__(kMhsaWaves * 64) void mhsa_fwd_kernel(const float* __restrict__ qkv,
+template <int DH, typename QT>
+__global__ __launch_bounds__(kMhsaWaves * 64) void mhsa_fwd_kernel(const QT* __restrict__ qkv,
                                                                   const int32_t* __restrict__ ids,
                                                                   float* __restrict__ out, int T, int F, int heads,
                                                                   float scale) {
@@ -107,17 +117,18 @@ __global__ __launch_bounds__(kMhsaWaves * 64) void mhsa_fwd_kernel(const float* 
   const int r32 = lane & 31, hh = lane >> 5, F3 = 3 * F;
   const bool rowok = r32 < T;
   const uint32_t kmask = (uint32_t)__ballot(rowok && ids[(size_t)n * T + min(r32, T - 1)] != 0);
-  const float* tile0 = qkv + (size_t)n * T * F3;
-  const float* rowp = tile0 + (size_t)min(r32, T - 1) * F3;
+  const QT* tile0 = qkv + (size_t)n * T * F3;
+  const QT* rowp = tile0 + (size_t)min(r32, T - 1) * F3;
   unsigned short (*vt)[DH + 2] = vt_all[wv];
+  const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(out + (size_t)n * T * F, (uint32_t)T * (uint32_t)F * 4u);
   for (int h0 = 0; h0 < heads; h0 += kMhsaWaves) {
     const int h = h0 + wv;
     const bool act = h < heads;
     const int hc = act ? h : 0;
     float p[16];
-    mhsa_probs<DH>(rowp, rowok, F, hc, hh, kmask, scale, p);
+    mhsa_probs<DH, QT>(rowp, rowok, F, hc, hh, kmask, scale, p);
     __syncthreads();                                   // the previous head's reads of vt are done
-    stage_tile<DH>(tile0 + 2 * F + hc * DH, F3, T, 0xFFFFFFFFu, lane, vt);
+    stage_tile<DH, QT>(tile0 + 2 * F + hc * DH, F3, T, 0xFFFFFFFFu, lane, vt);
     __syncthreads();
     u16x8 a[2];
 #pragma unroll
@@ -137,22 +148,21 @@ __global__ __launch_bounds__(kMhsaWaves * 64) void mhsa_fwd_kernel(const float* 
         for (int j = 0; j < 8; ++j) b[j] = c < DH ? vt[perm_row(s, hh, j)][c] : (unsigned short)0;
         o = mfma32(a[s], b, o);
       }
-      if (act && c < DH) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int q = acc_row(r, hh);
-          if ((kmask >> q) & 1u) out[((size_t)n * T + q) * F + h * DH + c] = o[r];   // pad rows: neither read nor written
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int q = acc_row(r, hh);
+        const bool ok = act && c < DH && ((kmask >> q) & 1u);                // pad rows: neither read nor written
+        bst1(rs_out, ok ? (uint32_t)q * (uint32_t)F + (uint32_t)(h * DH + c) : kBufOob, o[r], (const float*)nullptr);
       }
     }
   }
 }
 
-template <int DH>
-__global__ __launch_bounds__(kMhsaWaves * 64) void mhsa_bwd_kernel(const float* __restrict__ qkv,
+template <int DH, typename QT>
+__global__ __launch_bounds__(kMhsaWaves * 64) void mhsa_bwd_kernel(const QT* __restrict__ qkv,
                                                                   const float* __restrict__ dout,
                                                                   const int32_t* __restrict__ ids,
-                                                                  float* __restrict__ dqkv, int T, int F, int heads,
+                                                                  QT* __restrict__ dqkv, int T, int F, int heads,
                                                                   float scale) {
   constexpr int NC = (DH + 31) / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
@@ -167,17 +177,19 @@ __global__ __launch_bounds__(kMhsaWaves * 64) void mhsa_bwd_kernel(const float* 
   const int r32 = lane & 31, hh = lane >> 5, F3 = 3 * F;
   const bool rowok = r32 < T;
   const uint32_t kmask = (uint32_t)__ballot(rowok && ids[(size_t)n * T + min(r32, T - 1)] != 0);
-  const float* tile0 = qkv + (size_t)n * T * F3;
-  const float* rowp = tile0 + (size_t)min(r32, T - 1) * F3;
+  const QT* tile0 = qkv + (size_t)n * T * F3;
+  const QT* rowp = tile0 + (size_t)min(r32, T - 1) * F3;
   const float* dtile = dout + (size_t)n * T * F;
   const float* drow = dtile + (size_t)min(r32, T - 1) * F;
   const bool qok = (kmask >> r32) & 1u;               // rows of pad tokens in `dout` were never written
+  const __amdgpu_buffer_rsrc_t rs_dq =
+      make_rsrc(dqkv + (size_t)n * T * F3, (uint32_t)T * (uint32_t)F3 * (uint32_t)sizeof(QT));
   for (int h0 = 0; h0 < heads; h0 += kMhsaWaves) {
     const int h = h0 + wv;
     const bool act = h < heads;
     const int hc = act ? h : 0;
     float p[16];
-    mhsa_probs<DH>(rowp, rowok, F, hc, hh, kmask, scale, p);
+    mhsa_probs<DH, QT>(rowp, rowok, F, hc, hh, kmask, scale, p);
     // dP^T[key][query] = sum_c V[key][c] dO[query][c]
     f32x16 dp;
 #pragma unroll
@@ -196,9 +208,9 @@ __global__ __launch_bounds__(kMhsaWaves * 64) void mhsa_bwd_kernel(const float* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) ds[r] = p[r] * (dp[r] - delta) * scale;
     __syncthreads();                                   // the previous head's LDS reads are done
-    stage_tile<DH>(tile0 + hc * DH, F3, T, 0xFFFFFFFFu, lane, qt);
-    stage_tile<DH>(tile0 + F + hc * DH, F3, T, 0xFFFFFFFFu, lane, kt);
-    stage_tile<DH>(dtile + hc * DH, F, T, kmask, lane, gt);
+    stage_tile<DH, QT>(tile0 + hc * DH, F3, T, 0xFFFFFFFFu, lane, qt);
+    stage_tile<DH, QT>(tile0 + F + hc * DH, F3, T, 0xFFFFFFFFu, lane, kt);
+    stage_tile<DH, float>(dtile + hc * DH, F, T, kmask, lane, gt);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       xp[acc_row(r, hh)][r32] = f2bf(p[r]);
@@ -232,17 +244,14 @@ __global__ __launch_bounds__(kMhsaWaves * 64) void mhsa_bwd_kernel(const float* 
         gk = mfma32(as, bq, gk);       // dK[key][c] = sum_q dS^T[key][q] Q[q][c]
         gq = mfma32(ad[s], bk, gq);    // dQ[q][c]   = sum_key dS^T[key][q] K[key][c]
       }
-      if (act && c < DH) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = acc_row(r, hh);
-          if (row < T) {               // rows of pad tokens come out as exact zeros (the weight-gradient GEMM reads them)
-            float* dst = dqkv + ((size_t)n * T + row) * F3 + h * DH + c;
-            dst[0] = gq[r];
-            dst[F] = gk[r];
-            dst[2 * F] = gv[r];
-          }
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hh);
+        // rows of pad tokens come out as exact zeros (the weight-gradient GEMM reads them); rows >= T do not exist
+        const uint32_t off = (act && c < DH && row < T) ? (uint32_t)row * (uint32_t)F3 + (uint32_t)(h * DH + c) : kBufOob;
+        bst1(rs_dq, off, gq[r], (const QT*)nullptr);
+        bst1(rs_dq, off == kBufOob ? kBufOob : off + F, gk[r], (const QT*)nullptr);
+        bst1(rs_dq, off == kBufOob ? kBufOob : off + 2 * F, gv[r], (const QT*)nullptr);
       }
     }
   }
@@ -256,31 +265,57 @@ bool mhsa_supported(int T, int F, int heads) {
 
 static size_t mhsa_bwd_lds(int dh) { return (size_t)kMhsaWaves * (3 * 32 * (dh + 2) + 2 * 32 * 40) * sizeof(unsigned short); }
 
-void launch_mhsa_fwd(const float* qkv, const int32_t* ids, float* out, int n_titles, int T, int F, int heads,
-                     hipStream_t s) {
+template <typename QT>
+static void mhsa_fwd_t(const QT* qkv, const int32_t* ids, float* out, int n_titles, int T, int F, int heads, hipStream_t s) {
   if (!n_titles) return;
   const int dh = F / heads;
   const float scale = 1.0f / sqrtf((float)dh);
-#define LSTUR_MHSA_F(DH) \
-  hipLaunchKernelGGL((mhsa_fwd_kernel<DH>), dim3(n_titles), dim3(kMhsaWaves * 64), 0, s, qkv, ids, out, T, F, heads, scale)
+#define LSTUR_MHSA_F(DH)                                                                                         \
+  hipLaunchKernelGGL((mhsa_fwd_kernel<DH, QT>), dim3(n_titles), dim3(kMhsaWaves * 64), 0, s, qkv, ids, out, T, F, heads, \
+                     scale)
   if (dh == 16) LSTUR_MHSA_F(16);
   else if (dh == 32) LSTUR_MHSA_F(32);
   else LSTUR_MHSA_F(64);
 #undef LSTUR_MHSA_F
 }
+void launch_mhsa_fwd(const float* qkv, const int32_t* ids, float* out, int n_titles, int T, int F, int heads,
+                     hipStream_t s) {
+  mhsa_fwd_t<float>(qkv, ids, out, n_titles, T, F, heads, s);
+}
+void launch_mhsa_fwd_bf16(const unsigned short* qkv, const int32_t* ids, float* out, int n_titles, int T, int F,
+                          int heads, hipStream_t s) {
+  mhsa_fwd_t<unsigned short>(qkv, ids, out, n_titles, T, F, heads, s);
+}
 
-void launch_mhsa_bwd(const float* qkv, const float* dout, const int32_t* ids, float* dqkv, int n_titles, int T, int F,
-                     int heads, hipStream_t s) {
+template <typename QT>
+static void mhsa_bwd_t(const QT* qkv, const float* dout, const int32_t* ids, QT* dqkv, int n_titles, int T, int F,
+                       int heads, hipStream_t s) {
   if (!n_titles) return;
   const int dh = F / heads;
   const float scale = 1.0f / sqrtf((float)dh);
-#define LSTUR_MHSA_B(DH)                                                                                            \
-  hipLaunchKernelGGL((mhsa_bwd_kernel<DH>), dim3(n_titles), dim3(kMhsaWaves * 64), mhsa_bwd_lds(DH), s, qkv, dout, \
-                     ids, dqkv, T, F, heads, scale)
+#define LSTUR_MHSA_B(DH)                                                                                               \
+  do {                                                                                                                 \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {   /* dh = 64 needs 70 KB of LDS (4 waves x 5 tiles) */                                            \
+      (void)hipFuncSetAttribute((const void*)mhsa_bwd_kernel<DH, QT>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                (int)mhsa_bwd_lds(DH));                                                                \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((mhsa_bwd_kernel<DH, QT>), dim3(n_titles), dim3(kMhsaWaves * 64), mhsa_bwd_lds(DH), s, qkv, dout, \
+                       ids, dqkv, T, F, heads, scale);                                                                 \
+  } while (0)
   if (dh == 16) LSTUR_MHSA_B(16);
   else if (dh == 32) LSTUR_MHSA_B(32);
   else LSTUR_MHSA_B(64);
 #undef LSTUR_MHSA_B
+}
+void launch_mhsa_bwd(const float* qkv, const float* dout, const int32_t* ids, float* dqkv, int n_titles, int T, int F,
+                     int heads, hipStream_t s) {
+  mhsa_bwd_t<float>(qkv, dout, ids, dqkv, n_titles, T, F, heads, s);
+}
+void launch_mhsa_bwd_bf16(const unsigned short* qkv, const float* dout, const int32_t* ids, unsigned short* dqkv,
+                          int n_titles, int T, int F, int heads, hipStream_t s) {
+  mhsa_bwd_t<unsigned short>(qkv, dout, ids, dqkv, n_titles, T, F, heads, s);
 }
 
 }  // namespace lstur

@@ -96,6 +96,7 @@ class NativeModel:
                                  loss_negatives=max(1, negative_samples), freeze_encoder=freeze_encoder,
                                  word_trainable=word_trainable, news_encoder=news_encoder, heads=heads)
         self.news_encoder = news_encoder     # 'mhsa': build-defined multi-head self-attention token stage (heads x F/heads)
+        self.mhsa_proj_dtype = 'bf16'        # operand type of the mhsa Q|K|V projection GEMMs (attention products: bf16)
         self.freeze_encoder = bool(freeze_encoder)
         self.word_trainable = bool(word_trainable)     # --textual-embedding-trainable (paper.py:132-138)
         self.sizes = _lib.query_sizes(self.cfg)

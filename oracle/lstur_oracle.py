@@ -171,7 +171,7 @@ def _im2col(Epad, T, k):
 # operand it rounds (accumulation fp32 there, fp64/fp32 here); MHSA_EMULATE_BF16 = False gives the exact math.
 # --------------------------------------------------------------------------
 MHSA_EMULATE_BF16 = True
-MHSA_PROJ_BF16 = False    # the projection products E.W (and E^T.dQKV) also take bf16 operands
+MHSA_PROJ_BF16 = True     # the projection products E.W (and E^T.dQKV) also take bf16 operands
 
 
 def bf16_round(x):
@@ -227,8 +227,8 @@ def mhsa_bwd(p, mc, dc, want_dE=False):
     dQ = np.einsum("nhqk,nkhd->nqhd", dS, K)
     dK = np.einsum("nhqk,nqhd->nkhd", dS, Q)
     dqkv = np.stack([dQ, dK, dV], axis=2).reshape(N * T, 3 * h * dh)
-    gb = dqkv.sum(axis=0)
-    dqr = _proj_round(dqkv)
+    dqr = _proj_round(dqkv)             # the HIP path stores dQ|dK|dV rows as bf16; the bias gradient sums those
+    gb = dqr.sum(axis=0)
     gw = mc["Er"].T @ dqr
     dE = (dqr @ _proj_round(p["qkv_w"]).T).reshape(N, T, -1) if want_dE else None
     return gw, gb, dE

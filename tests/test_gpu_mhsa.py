@@ -64,9 +64,11 @@ def test_mhsa_kernels_match_oracle(T, F, heads):
     km = ids != 0
     # the oracle's stage on the same Q|K|V: bypass its projection by handing it E = qkv through an identity matrix
     p = dict(qkv_w=np.eye(3 * F, dtype=np.float64), qkv_b=np.zeros(3 * F), mhsa_heads=np.int64(heads))
-    c, mc = O.mhsa_fwd(p, qkv.astype(np.float64).reshape(N, T, 3 * F), ids.astype(np.int64))
-    dc = dout.reshape(N, T, F).astype(np.float64) * km[..., None]
-    _, _, dE = O.mhsa_bwd(p, mc, dc, want_dE=True)  # dE = dqkv . I
+    import unittest.mock as mock
+    with mock.patch.object(O, 'MHSA_PROJ_BF16', False):     # this entry point takes and returns fp32 rows
+        c, mc = O.mhsa_fwd(p, qkv.astype(np.float64).reshape(N, T, 3 * F), ids.astype(np.int64))
+        dc = dout.reshape(N, T, F).astype(np.float64) * km[..., None]
+        _, _, dE = O.mhsa_bwd(p, mc, dc, want_dE=True)  # dE = dqkv . I
     q_d, i_d, do_d = dev(qkv), dev(ids), dev(np.where(km.reshape(-1, 1), dout, np.float32(np.nan)))   # pad rows of dout: never read
     out = torch.full((N * T, F), 7.0, dtype=torch.float32, device='cuda')
     dq = torch.full((N * T, 3 * F), 7.0, dtype=torch.float32, device='cuda')
