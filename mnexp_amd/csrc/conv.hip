@@ -37,7 +37,7 @@ __device__ __forceinline__ void conv_rows_pass(const float* __restrict__ E, cons
                                                float* __restrict__ C, const int32_t* __restrict__ vidx, float* smem,
                                                int T, int Tp, int D, int F, int Fp, int nchunk, int valid4, int tile0,
                                                int m0, int r_end, bool active, int first, int tid, int lane,
-                                               EpiDrop ed) {
+                                               EpiDrop ed, __amdgpu_buffer_rsrc_t rsC) {
   constexpr int CH = NTW * 256;
   constexpr int NV4 = CH / 4;
   constexpr int PER = (NV4 + WAVES * 64 - 1) / (WAVES * 64);
@@ -65,9 +65,18 @@ __device__ __forceinline__ void conv_rows_pass(const float* __restrict__ E, cons
   int n = mr / T, t = mr - n * T;
   const float* arow = E + ((size_t)n * Tp + t) * D + kq * 4;
 
+  // the accumulators start from the bias (EPI 0), so the epilogue has no loads: a load between its stores makes the
+  // compiler drain every outstanding store first (loads and stores share vmcnt on gfx9)
   f32x4 acc[NT];
 #pragma unroll
-  for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NT; ++i) {
+    float bv = 0.f;
+    if (EPI == 0) {
+      const int col = (tile0 + first + i) * 16 + c;
+      bv = bias[(first + i < NTW && col < F) ? col : 0];
+    }
+    acc[i] = (f32x4){bv, bv, bv, bv};
+  }
 
   __syncthreads();  // previous row block's LDS reads are done
   load_w(0);
@@ -107,7 +116,7 @@ __device__ __forceinline__ void conv_rows_pass(const float* __restrict__ E, cons
     __syncthreads();
   }
 
-  // epilogue: + bias, ReLU, * (id != 0)   (paper.py:146, 150-155)
+  // epilogue: (+ bias: already in the accumulators), ReLU, * (id != 0)   (paper.py:146, 150-155)
   if (active) {
     const int rq = lane >> 4;
     float keep[4];
@@ -116,8 +125,8 @@ __device__ __forceinline__ void conv_rows_pass(const float* __restrict__ E, cons
     for (int j = 0; j < 4; ++j) {
       int rr = m0 + rq * 4 + j;
       bool ok = rr < r_end;
-      int mm = ok ? (vidx ? vidx[rr] : rr) : -1;
-      rows[j] = mm;
+      int mm = vidx ? vidx[ok ? rr : r_end - 1] : (ok ? rr : r_end - 1);   // unconditional loads, predicate by select
+      rows[j] = ok ? mm : -1;
       keep[j] = (ok && ids[mm] != 0) ? 1.f : 0.f;
     }
     if (EPI == 1) {
@@ -142,15 +151,16 @@ __device__ __forceinline__ void conv_rows_pass(const float* __restrict__ E, cons
       }
       return;
     }
+    // branch-free stores through a buffer descriptor: rows of the tail and columns past F get the out-of-range offset
+    // (a guarded store is a branch + s_waitcnt each: 100 serialised round trips per wave and row block)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      int col = (tile0 + first + nt) * 16 + c;
-      if (first + nt < NTW && col < F) {
-        float bv = bias[col];
+      const int col = (tile0 + first + nt) * 16 + c;
+      const bool cok = first + nt < NTW && col < F;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (rows[j] >= 0) C[(size_t)rows[j] * F + col] = fmaxf(acc[nt][j] + bv, 0.f) * keep[j];
-      }
+      for (int j = 0; j < 4; ++j)
+        buf_store1(fmaxf(acc[nt][j], 0.f) * keep[j], rsC,
+                   (cok && rows[j] >= 0) ? ((uint32_t)rows[j] * (uint32_t)F + (uint32_t)col) * 4u : kBufOob, 0);
     }
   }
 }
@@ -177,13 +187,14 @@ __global__ __launch_bounds__(WAVES * 64) void conv_fwd_kernel(const float* __res
   const int r_end = min(count, r_begin + per);
   const float* wsrc = Wp + (size_t)tile0 * 256;  // + ch * Fp * 16
   const int valid4 = min(CH / 4, (Fp / 16 - tile0) * 64);  // last column group may be partial
+  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(C, EPI == 0 ? (uint32_t)((size_t)M * F * 4) : 0u);   // EPI 0: out [M, F]
 
   int base = r_begin;
   // full rounds: one 16-row tile per wave, all NTW column tiles
   for (; base < r_end && (NTW != 25 || WAVES != 8 || r_end - base > 64); base += WAVES * 16) {
     const int m0 = base + wv * 16;
     conv_rows_pass<NTW, WAVES, NTW, EPI>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0, m0,
-                                         r_end, m0 < r_end, 0, tid, lane, ed);
+                                         r_end, m0 < r_end, 0, tid, lane, ed, rsC);
   }
   // tail of <= 4 row tiles (25-tile / 8-wave configuration): split the column tiles of each row tile over the
   // idle waves so the last round costs a fraction of a full one instead of a whole wave-round
@@ -193,15 +204,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv_fwd_kernel(const float* __res
       if (rt == 1) {
         const int first = wv * 4;                // 8 waves x 4 tiles
         conv_rows_pass<NTW, WAVES, 4, EPI>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0, base,
-                                           r_end, first < NTW, first, tid, lane, ed);
+                                           r_end, first < NTW, first, tid, lane, ed, rsC);
       } else if (rt == 2) {
         const int tile = wv >> 2, first = (wv & 3) * 7;   // 4 waves x 7 tiles per row tile
         conv_rows_pass<NTW, WAVES, 7, EPI>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0,
-                                           base + tile * 16, r_end, first < NTW, first, tid, lane, ed);
+                                           base + tile * 16, r_end, first < NTW, first, tid, lane, ed, rsC);
       } else {
         const int tile = wv >> 1, first = (wv & 1) * 13;  // 2 waves x 13 tiles per row tile
         conv_rows_pass<NTW, WAVES, 13, EPI>(E, wsrc, bias, ids, C, vidx, smem, T, Tp, D, F, Fp, nchunk, valid4, tile0,
-                                            base + tile * 16, r_end, tile < rt && first < NTW, first, tid, lane, ed);
+                                            base + tile * 16, r_end, tile < rt && first < NTW, first, tid, lane, ed, rsC);
       }
     }
   }

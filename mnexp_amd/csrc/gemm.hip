@@ -11,51 +11,45 @@ namespace lstur {
 
 constexpr int GT = 64, GK = 32, GLD = 80;  // tile, k-step, LDS row stride (80 % 32 == 16: conflict-free b32 reads)
 
-// four consecutive elements base[i0 .. i0+3] with element-level bounds (count valid from i0)
-__device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int valid, bool vec) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (vec && valid >= 4) return *(const float4*)p;
-  if (valid > 0) v.x = p[0];
-  if (valid > 1) v.y = p[1];
-  if (valid > 2) v.z = p[2];
-  if (valid > 3) v.w = p[3];
-  return v;
-}
-
 // One 64 x 32 operand tile = 512 float4, two per thread.  KMAJOR: the operand is stored with k contiguous
 // (A[m][k] or B[n][k]) and is transposed on its way into the k-major LDS image; otherwise (A[k][m] / B[k][n])
 // the image is a straight copy.
+// Loads go through a buffer descriptor covering exactly the operand (reads past its end return 0) and carry NO
+// guards: a guarded load compiles to a branch plus a s_waitcnt per load, which turned the prefetch of a tile into four
+// serialised round trips.  The k-tail (k >= kend: the next slab's rows, or the next row's head) is zeroed by selects
+// when the tile is written to LDS; rows / columns past M / N hold in-range garbage that only reaches outputs which
+// are never stored.
 template <bool KMAJOR>
-__device__ __forceinline__ void tile_load(const float* __restrict__ P, int ld, int x0, int xmax, int k0, int kend,
-                                          bool vec, int tid, float4 (&r)[2]) {
+__device__ __forceinline__ void tile_load(__amdgpu_buffer_rsrc_t rs, int ld, int x0, int k0, int tid, float4 (&r)[2]) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int idx = tid + q * 256;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t off;
     if (KMAJOR) {
       const int x = idx >> 3, kg = (idx & 7) * 4;
-      if (x0 + x < xmax) v = load4_guard(P + (size_t)(x0 + x) * ld + k0 + kg, kend - (k0 + kg), vec);
+      off = ((uint32_t)(x0 + x) * (uint32_t)ld + (uint32_t)(k0 + kg)) * 4u;
     } else {
       const int k = idx >> 4, xg = (idx & 15) * 4;
-      if (k0 + k < kend) v = load4_guard(P + (size_t)(k0 + k) * ld + x0 + xg, xmax - (x0 + xg), vec);
+      off = ((uint32_t)(k0 + k) * (uint32_t)ld + (uint32_t)(x0 + xg)) * 4u;
     }
-    r[q] = v;
+    r[q] = buf_load4(rs, off, 0);
   }
 }
 template <bool KMAJOR>
-__device__ __forceinline__ void tile_store(float (*S)[GLD], int tid, const float4 (&r)[2]) {
+__device__ __forceinline__ void tile_store(float (*S)[GLD], int tid, const float4 (&r)[2], int k0, int kend) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int idx = tid + q * 256;
     if (KMAJOR) {
-      const int x = idx >> 3, kg = (idx & 7) * 4;
-      S[kg + 0][x] = r[q].x;
-      S[kg + 1][x] = r[q].y;
-      S[kg + 2][x] = r[q].z;
-      S[kg + 3][x] = r[q].w;
+      const int x = idx >> 3, kg = (idx & 7) * 4, kv = kend - (k0 + kg);   // valid k from kg on
+      S[kg + 0][x] = kv > 0 ? r[q].x : 0.f;
+      S[kg + 1][x] = kv > 1 ? r[q].y : 0.f;
+      S[kg + 2][x] = kv > 2 ? r[q].z : 0.f;
+      S[kg + 3][x] = kv > 3 ? r[q].w : 0.f;
     } else {
       const int k = idx >> 4, xg = (idx & 15) * 4;
-      *(float4*)&S[k][xg] = r[q];
+      const bool ok = k0 + k < kend;
+      *(float4*)&S[k][xg] = ok ? r[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }
@@ -64,7 +58,7 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int lda,
                                                    const float* __restrict__ B, int ldb, float* __restrict__ C,
                                                    int ldc, const float* __restrict__ bias, int M, int N, int K,
-                                                   float alpha, int k_per_split, bool vecA, bool vecB,
+                                                   float alpha, int k_per_split, uint32_t bytesA, uint32_t bytesB,
                                                    bool to_slab) {
   __shared__ __attribute__((aligned(16))) float As[GK][GLD];
   __shared__ __attribute__((aligned(16))) float Bs[GK][GLD];
@@ -82,15 +76,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 
   // register-staged pipeline: the next tile's global loads are in flight while this tile's MFMAs run
   float4 ra[2], rb[2];
-  tile_load<!TA>(A, lda, m0, M, kbeg, kend, vecA, tid, ra);
-  tile_load<TB>(B, ldb, n0, N, kbeg, kend, vecB, tid, rb);
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, bytesA), rsB = make_rsrc(B, bytesB);
+  tile_load<!TA>(rsA, lda, m0, kbeg, tid, ra);
+  tile_load<TB>(rsB, ldb, n0, kbeg, tid, rb);
   for (int k0 = kbeg; k0 < kend; k0 += GK) {
-    tile_store<!TA>(As, tid, ra);
-    tile_store<TB>(Bs, tid, rb);
+    tile_store<!TA>(As, tid, ra, k0, kend);
+    tile_store<TB>(Bs, tid, rb, k0, kend);
     __syncthreads();
     if (k0 + GK < kend) {
-      tile_load<!TA>(A, lda, m0, M, k0 + GK, kend, vecA, tid, ra);
-      tile_load<TB>(B, ldb, n0, N, k0 + GK, kend, vecB, tid, rb);
+      tile_load<!TA>(rsA, lda, m0, k0 + GK, tid, ra);
+      tile_load<TB>(rsB, ldb, n0, k0 + GK, tid, rb);
     }
 #pragma unroll
     for (int s = 0; s < GK / 4; ++s) {
@@ -106,23 +101,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     __syncthreads();
   }
 
+  // branch-free epilogue: rows >= M fall outside the descriptor (it ends behind row M - 1), columns >= N get the
+  // out-of-range offset
   float* dst = C;
   int ld = ldc;
   if (to_slab) {
     dst = C + (size_t)blockIdx.z * M * N;
     ld = N;
   }
+  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(dst, (uint32_t)(((size_t)(M - 1) * ld + N) * 4));
+  const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias, (!to_slab && bias) ? (uint32_t)N * 4u : 0u);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int n = n0 + wc * 32 + j * 16 + r16;
-      if (n >= N) continue;
-      float bv = (!to_slab && bias) ? bias[n] : 0.f;
+      const int n = n0 + wc * 32 + j * 16 + r16;
+      const float bv = buf_load1(rsBias, (uint32_t)n * 4u, 0);     // no bias / n >= N: 0
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        int m = m0 + wr * 32 + i * 16 + kq * 4 + q;
-        if (m < M) dst[(size_t)m * ld + n] = to_slab ? acc[i][j][q] : alpha * acc[i][j][q] + bv;
+        const int m = m0 + wr * 32 + i * 16 + kq * 4 + q;
+        const float v = to_slab ? acc[i][j][q] : alpha * acc[i][j][q] + bv;
+        buf_store1(v, rsC, n < N ? ((uint32_t)m * (uint32_t)ld + (uint32_t)n) * 4u : kBufOob, 0);
       }
     }
 }
@@ -159,13 +158,14 @@ void launch_gemm(const float* A, int lda, int ta, const float* B, int ldb, int t
   int kps = cdiv(cdiv(K, ns), GK) * GK;
   ns = std::max(1, cdiv(K, kps));
   bool slab = ns > 1;
-  bool vecA = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
-  bool vecB = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
+  // operand extents in bytes (descriptor ranges): op(A) is M x K, op(B) is K x N
+  const uint32_t bytesA = (uint32_t)((ta ? (size_t)(K - 1) * lda + M : (size_t)(M - 1) * lda + K) * 4);
+  const uint32_t bytesB = (uint32_t)((tb ? (size_t)(N - 1) * ldb + K : (size_t)(K - 1) * ldb + N) * 4);
   dim3 grid(cdiv(N, GT), cdiv(M, GT), ns), block(256);
   float* dst = slab ? (float*)scratch : C;
 #define LSTUR_GEMM(TA, TB)                                                                                       \
   hipLaunchKernelGGL((gemm_kernel<TA, TB>), grid, block, 0, s, A, lda, B, ldb, dst, ldc, bias, M, N, K, alpha, kps, \
-                     vecA, vecB, slab)
+                     bytesA, bytesB, slab)
   if (!ta && !tb)
     LSTUR_GEMM(false, false);
   else if (!ta && tb)
