@@ -84,6 +84,36 @@ def test_cli_train_loop(tmp_path, arch, ids):
     assert h.model.optimizer.iterations == 30
 
 
+def test_cli_train_loop_mhsa_encoder(tmp_path):
+    """`--news-encoder mhsa --title-filter-shape F heads`: the build-defined multi-head self-attention encoder
+    (BASELINE.json configs[4]; no reference counterpart) through the same task / CLI loop."""
+    _need_gpu()
+    from mnexp_amd.main import run_training
+    cfg = _config(tmp_path, news_encoder='mhsa', title_filter_shape=(32, 2), epochs=2, training_step=15,
+                  validation_step=2, validation_impression=20, testing_impression=20, dropout=0.2, ids=True, seed=1)
+    np.random.seed(0)
+    h = run_training(cfg)
+    assert h.model.news_encoder == 'mhsa' and 'qkv_w' in h.model.param_names()
+    assert 0.0 <= h.last_metrics['auc'] <= 1.0 and np.isfinite(h.last_metrics['mrr'])
+    assert h.model.optimizer.iterations == 30
+    with pytest.raises(Exception, match='not on the native path'):
+        run_training(_config(tmp_path, news_encoder='gruatt', epochs=1))
+
+
+def test_cli_train_loop_trainable_word_table(tmp_path):
+    """--textual-embedding-trainable (main.py:36, paper.py:132-138): the word table moves, its pad row included."""
+    _need_gpu()
+    from mnexp_amd.main import run_training
+    cfg = _config(tmp_path, textual_embedding_trainable=True, epochs=1, training_step=10, validation_step=1,
+                  validation_impression=10, testing_impression=10, dropout=0.2, ids=True, seed=1)
+    np.random.seed(0)
+    h = run_training(cfg)
+    from mnexp_amd import utils
+    emb0 = utils.load_textual_embedding(cfg.title_embedding_input, cfg.textual_embedding_dim)
+    moved = np.abs(h.model.word_emb.cpu().numpy() - emb0)
+    assert h.model.word_trainable and moved.max() > 1e-3 and moved[0].max() > 0
+
+
 def test_idless_softmax_task(tmp_path):
     """Seq2VecPaperSoftmax (no user id, paper.py:384-524) with its `gru` user encoder."""
     _need_gpu()
