@@ -240,6 +240,15 @@ int lstur_conv1d_relu_mask_fwd(const float* emb_padded, const float* w_packed, c
                                const int32_t* ids, float* out, int32_t n_titles, int32_t title_len,
                                int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx,
                                const int32_t* vcount, lstur_stream stream);
+/* The same Conv1D forward as an fp32-GRADE contraction on the bf16 matrix cores ("bf16x3": both operands split into
+ * three bf16 parts, six products accumulated in fp32; error ~2^-23 of |a||b| per product, the level of an fp32 FMA
+ * chain in another order -- not a reduced-precision kernel).  This is the kernel the training step uses (filters <= 448);
+ * w3 = lstur_conv3_pack_w(conv_w [k*D, F]) holds lstur_conv3_w3_elems() bf16 elements.  Same arguments otherwise. */
+size_t lstur_conv3_w3_elems(int32_t dim, int32_t ksize, int32_t filters);
+int lstur_conv3_pack_w(const float* w, int32_t dim, int32_t ksize, int32_t filters, uint16_t* w3, lstur_stream stream);
+int lstur_conv3_relu_mask_fwd(const float* emb_padded, const uint16_t* w3, const float* bias, const int32_t* ids, float* out,
+                              int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters,
+                              const int32_t* vidx, const int32_t* vcount, lstur_stream stream);
 /* Conv1D kernel gradient: dW[k*D,F] = im2col(emb)^T . dOut ; scratch >= lstur_conv1d_wgrad_scratch() bytes. */
 size_t lstur_conv1d_wgrad_scratch(int32_t dim, int32_t ksize, int32_t filters);
 int lstur_conv1d_wgrad(const float* emb_padded, const float* dout, float* dw, void* scratch,

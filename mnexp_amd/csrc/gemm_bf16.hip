@@ -11,51 +11,10 @@
 // Two LDS buffers, register-staged prefetch of the next k-tile under the MFMAs of the current one, one barrier per
 // k-tile.  The weight gradient is split along the tokens into slabs reduced in fixed order by the step's single
 // multi_reduce launch (bitwise reproducible); its extra row of ones yields the bias gradient in the same pass.
-#include "lstur_device.h"
+#include "bf16_mfma.h"
 #include "lstur_internal.h"
 
 namespace lstur {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ unsigned short f2bf_rne(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u16x4 cvt4(float4 v) {   // 2 x v_cvt_pk_bf16_f32 (round-to-nearest-even, = f2bf_rne)
-  const f32x4v f = {v.x, v.y, v.z, v.w};
-  return __builtin_bit_cast(u16x4, __builtin_convertvector(f, bf16x4));
-}
-__device__ __forceinline__ f32x16 mfma32b(u16x8 a, u16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-// MFMA fragment (index x0 + (lane & 31), 8 consecutive k from k0 + 8 * (lane >> 5)) out of a row-major [k][x] bf16
-// tile: two transposed reads of a 4 x 16 block per 16-lane group.  EXEC must be full.
-__device__ __forceinline__ u16x8 tr_frag(const unsigned short* tile, int stride, int k0, int x0, int lane) {
-  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const unsigned short* a = tile + (k0 + 8 * (g >> 1) + q) * stride + x0 + 16 * (g & 1) + 4 * p;
-  typedef __attribute__((address_space(3))) s16x4 lds4;
-  const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)a);
-  const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(a + 4 * stride));
-  u16x8 r;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    r[j] = (unsigned short)v0[j];
-    r[4 + j] = (unsigned short)v1[j];
-  }
-  return r;
-}
-
-// row stride (elements) of a [k][X] tile: bytes = 64 (mod 128) -> the 4 k-rows of a transposed read start 16 banks
-// apart (64 banks of 4 bytes): conflict-free
-__host__ __device__ constexpr int tr_stride(int X) { return ((X * 2 - 64 + 127) / 128 * 128 + 64) / 2; }
 
 // A_KM = false: A is [M][K] (k contiguous), fp32.   A_KM = true: A is [K][M] fp32, and ONES_ROW appends the row
 // m == M of ones (bias gradient).  B is [K][N], fp32 (TB = float) or bf16 (TB = unsigned short).

@@ -183,7 +183,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
+  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; unsigned short* conv_w3; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
 };
@@ -269,6 +269,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->sdcat = (float*)take(nc * 2 * d.U * f4);
   w->dgrad_scratch = d.word_trainable ? (float*)take(conv_dgrad_scratch_floats((int)nt, d.T, d.D, d.k, d.F) * f4) : nullptr;
   const bool mh = d.enc == LSTUR_ENC_MHSA;
+  w->conv_w3 = (!mh && conv3_supported(d.D, d.k, d.F)) ? (unsigned short*)take(conv3_w3_elems(d.D, d.k, d.F) * 2) : nullptr;
   w->qkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;     // bf16 Q | K | V rows
   w->dqkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;
   w->mh_scratch = mh ? take(proj_wgrad_scratch_bytes(d.D, 3 * d.F, (int)(nt * d.T))) : nullptr;
@@ -387,7 +388,12 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   lazy_init(c, s);
   // operand images of the weights used by MFMA kernels this step
   const bool mhsa = d.enc == LSTUR_ENC_MHSA;
-  if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, s);
+  // conv forward: fp32-grade bf16x3 contraction on the bf16 matrix cores (conv3.hip) unless LSTUR_CONV_F32 asks for the
+  // exact-fp32 MFMA kernel of conv.hip
+  static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr;
+  const bool use3 = !mhsa && w.conv_w3 && !conv_f32;
+  if (use3) launch_conv3_pack_w(c->P("conv_w"), d.KD, d.F, w.conv_w3, s);
+  else if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, s);
   launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, s);
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
@@ -399,9 +405,13 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   if (mhsa) {   // token stage = multi-head self-attention (build-defined, include/lstur.h: LSTUR_ENC_MHSA)
     PROF("qkv_proj", launch_proj_fwd_bf16(w.emb, c->P("qkv_w"), c->P("qkv_b"), w.qkv, nt * d.T, 3 * d.F, d.D, s));
     PROF("mhsa_fwd", launch_mhsa_fwd_bf16(w.qkv, w.ids, w.conv, nt, d.T, d.F, d.heads, s));
-  } else
-  PROF("conv_fwd", launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
-                                   w.vcount, s));
+  } else if (use3) {
+    PROF("conv_fwd", launch_conv3_fwd(w.emb, w.conv_w3, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
+                                      w.vcount, s));
+  } else {
+    PROF("conv_fwd", launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
+                                     w.vcount, s));
+  }
   PROF("attpool_fwd", launch_attpool_fwd(w.conv, w.ids, c->P("att_w"), c->P("att_b"), w.pooled, w.att_a, w.att_wt, nt, d.T, d.F,
                                          drop, key1, s));
   launch_gemm(w.pooled, d.F, 0, c->P("dense_w"), d.U, 0, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, 1.f,
@@ -945,6 +955,24 @@ int lstur_attpool_fwd(const float* conv_out, const int32_t* ids, const float* at
   launch_attpool_fwd(conv_out, ids, att_w, att_b, pooled, att_tanh, att_weight, n_titles, title_len, filters, drop, key,
                      (hipStream_t)stream);
   return check_launch("attpool_fwd");
+}
+size_t lstur_conv3_w3_elems(int32_t dim, int32_t ksize, int32_t filters) {
+  return conv3_supported(dim, ksize, filters) ? conv3_w3_elems(dim, ksize, filters) : 0;
+}
+int lstur_conv3_pack_w(const float* w, int32_t dim, int32_t ksize, int32_t filters, uint16_t* w3, lstur_stream stream) {
+  if (!w || !w3) return fail(LSTUR_ERR_ARG, "conv3_pack_w: NULL");
+  if (!conv3_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
+  launch_conv3_pack_w(w, ksize * dim, filters, w3, (hipStream_t)stream);
+  return check_launch("conv3_pack_w");
+}
+int lstur_conv3_relu_mask_fwd(const float* emb_padded, const uint16_t* w3, const float* bias, const int32_t* ids, float* out,
+                              int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters,
+                              const int32_t* vidx, const int32_t* vcount, lstur_stream stream) {
+  if (!emb_padded || !w3 || !bias || !ids || !out) return fail(LSTUR_ERR_ARG, "conv3_fwd: NULL");
+  if (!conv3_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
+  if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "conv3_fwd: vidx and vcount go together");
+  launch_conv3_fwd(emb_padded, w3, bias, ids, out, n_titles, title_len, dim, ksize, filters, vidx, vcount, (hipStream_t)stream);
+  return check_launch("conv3_fwd");
 }
 int lstur_mhsa_fwd(const float* qkv, const int32_t* ids, float* out, int32_t n_titles, int32_t title_len,
                    int32_t filters, int32_t heads, lstur_stream stream) {

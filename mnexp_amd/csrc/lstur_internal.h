@@ -115,6 +115,14 @@ void launch_conv_dgrad_scatter(const float* dconv, const float* conv_w, const in
 void launch_token_offsets(const int32_t* vidx, const int32_t* vcount, int M, int T, int Tp, int D, int F, int32_t* offA,
                           int32_t* offB, hipStream_t s);
 
+// ---- conv3.hip: the same Conv1D as an fp32-grade "bf16x3" contraction on the bf16 matrix cores (F <= 448) --------
+bool conv3_supported(int D, int ksize, int F);
+size_t conv3_w3_elems(int D, int ksize, int F);                 // bf16 elements of the split weight image
+void launch_conv3_pack_w(const float* W, int K, int F, unsigned short* W3, hipStream_t s);   // W [K = k*D, F]
+void launch_conv3_fwd(const float* emb, const unsigned short* W3, const float* bias, const int32_t* ids, float* out,
+                      int n_titles, int T, int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount,
+                      hipStream_t s);
+
 // ---- attpool.hip -------------------------------------------------------------------------------
 // ids (nullable): rows with id == 0 are taken as zero without reading c / writing dc
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,

@@ -211,3 +211,55 @@ def test_full_step_at_baseline_shapes_small_batch():
     for n in O.dense_param_names('igru'):
         rel_close(g[n], ref['grads'][n], 2e-3, n)
     rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
+
+
+@pytest.mark.parametrize('N,D,T,F,k', [(130, 300, 30, 400, 3), (3, 300, 30, 400, 3), (9, 12, 7, 16, 3), (7, 20, 6, 24, 5),
+                                       (11, 48, 11, 448, 1), (5, 16, 8, 230, 3)])
+def test_conv3_bf16x3_forward_is_fp32_grade(N, D, T, F, k):
+    """conv3.hip: the Conv1D forward as six bf16 MFMA products of 3-way split operands.  Held to the SAME bound as the
+    exact-fp32 MFMA kernel (2e-5 of the output scale against fp64) and to 4e-6 against that kernel directly."""
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    rng = np.random.default_rng(N * 7 + F)
+    Tp = T + k - 1
+    pl = (k - 1) // 2
+    E = rng.normal(0, 0.3, size=(N, T, D)).astype(np.float32)
+    ids = rng.integers(0, 50, size=(N, T)).astype(np.int32)
+    ids[:, max(1, T - 4):] = 0
+    Wc = rng.normal(0, 0.05, size=(k, D, F)).astype(np.float32)
+    b = rng.normal(0, 0.1, size=F).astype(np.float32)
+    Ep = np.zeros((N, Tp, D), np.float32)
+    Ep[:, pl:pl + T] = E
+    Epd = torch.zeros(N * Tp * D + 256, dtype=torch.float32, device='cuda')
+    Epd[:N * Tp * D] = dev(Ep).view(-1)
+    Wd = dev(Wc.reshape(k * D, F))
+    w3 = torch.zeros(lib.lstur_conv3_w3_elems(D, k, F), dtype=torch.int16, device='cuda')
+    check(lib.lstur_conv3_pack_w(Wd.data_ptr(), D, k, F, w3.data_ptr(), stream()))
+    b_d, ids_d = dev(b), dev(ids)
+    out = torch.full((N * T, F), -7.0, dtype=torch.float32, device='cuda')
+    check(lib.lstur_conv3_relu_mask_fwd(Epd.data_ptr(), w3.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(), out.data_ptr(),
+                                        N, T, D, k, F, None, None, stream()))
+    x = torch.nn.functional.pad(dev(E).double().transpose(1, 2), (pl, k - 1 - pl))
+    ref = torch.relu(torch.nn.functional.conv1d(x, dev(Wc).double().permute(2, 1, 0), dev(b).double()))
+    ref = ref.transpose(1, 2) * (dev(ids) != 0).unsqueeze(-1)
+    scale = max(1.0, ref.abs().max().item())
+    err = (out.view(N, T, F).double() - ref).abs().max().item()
+    assert err < 2e-5 * scale, err
+    assert (out.view(N, T, F)[dev(ids) == 0] == 0).all()
+    # against the exact-fp32 MFMA kernel
+    Wp = pack_b(Wd)
+    out32 = torch.empty(N * T, F, dtype=torch.float32, device='cuda')
+    check(lib.lstur_conv1d_relu_mask_fwd(Epd.data_ptr(), Wp.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(),
+                                         out32.data_ptr(), N, T, D, k, F, None, None, stream()))
+    assert (out - out32).abs().max().item() < 4e-6 * scale
+    # over the compacted list of non-pad tokens: same rows bit-identical, pad rows untouched
+    vidx = torch.full((N * T,), -1, dtype=torch.int32, device='cuda')
+    vcount = torch.zeros(1, dtype=torch.int32, device='cuda')
+    vs = torch.zeros(max(1, lib.lstur_valid_tokens_scratch(N * T) // 4), dtype=torch.int32, device='cuda')
+    check(lib.lstur_valid_tokens(ids_d.data_ptr(), N * T, vidx.data_ptr(), vcount.data_ptr(), vs.data_ptr(), stream()))
+    out2 = torch.full((N * T, F), -7.0, dtype=torch.float32, device='cuda')
+    check(lib.lstur_conv3_relu_mask_fwd(Epd.data_ptr(), w3.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(), out2.data_ptr(),
+                                        N, T, D, k, F, vidx.data_ptr(), vcount.data_ptr(), stream()))
+    valid = dev(ids.reshape(-1) != 0)
+    assert torch.equal(out2[valid], out[valid])
+    assert (out2[~valid] == -7.0).all()
