@@ -249,6 +249,11 @@ int lstur_conv3_pack_w(const float* w, int32_t dim, int32_t ksize, int32_t filte
 int lstur_conv3_relu_mask_fwd(const float* emb_padded, const uint16_t* w3, const float* bias, const int32_t* ids, float* out,
                               int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters,
                               const int32_t* vidx, const int32_t* vcount, lstur_stream stream);
+/* ... and the kernel gradient in the same scheme (what the training step uses); scratch: lstur_conv3_wgrad_scratch bytes. */
+size_t lstur_conv3_wgrad_scratch(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters);
+int lstur_conv3_wgrad(const float* emb_padded, const float* dout, float* dw, void* scratch, int32_t n_titles,
+                      int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx,
+                      const int32_t* vcount, lstur_stream stream);
 /* Conv1D kernel gradient: dW[k*D,F] = im2col(emb)^T . dOut ; scratch >= lstur_conv1d_wgrad_scratch() bytes. */
 size_t lstur_conv1d_wgrad_scratch(int32_t dim, int32_t ksize, int32_t filters);
 int lstur_conv1d_wgrad(const float* emb_padded, const float* dout, float* dw, void* scratch,

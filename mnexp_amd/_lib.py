@@ -75,6 +75,8 @@ SIGNATURES = {
     'lstur_conv3_w3_elems': (_Z, [_I, _I, _I]),
     'lstur_conv3_pack_w': (_I, [_P, _I, _I, _I, _P, _P]),
     'lstur_conv3_relu_mask_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'lstur_conv3_wgrad_scratch': (_Z, [_I, _I, _I, _I, _I]),
+    'lstur_conv3_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'lstur_conv1d_wgrad_scratch': (_Z, [_I, _I, _I]),
     'lstur_conv1d_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'lstur_pack_b_floats': (_Z, [_I, _I]),

@@ -115,13 +115,19 @@ __global__ __launch_bounds__(C3_THREADS) void conv3_fwd_kernel(const float* __re
       if (b_loff[i] >= 0) *(float4*)(st + b_loff[i]) = rb[i];
   };
 
+  // Software pipeline: global loads two k-steps ahead; the split + LDS store of step it + 1 is issued in step it before
+  // that step's MFMAs with no barrier in between (its VALU work overlaps the matrix pipe); one barrier per step.
   const int nit = Kp / C3_BK;
   load(0);
+  store(0);
+  if (nit > 1) load(C3_BK);
+  __syncthreads();
   for (int it = 0; it < nit; ++it) {
     const int buf = it & 1;
-    store(buf);
-    __syncthreads();
-    if (it + 1 < nit) load((it + 1) * C3_BK);
+    if (it + 1 < nit) {
+      store(buf ^ 1);
+      if (it + 2 < nit) load((it + 2) * C3_BK);
+    }
     const unsigned short* st = smem + buf * C3_STAGE;
     const unsigned short* ap = st + (32 * wm + (lane & 31)) * C3_SA + 8 * (lane >> 5);
     const u16x8 ah = *(const u16x8*)ap, am = *(const u16x8*)(ap + C3_A_IMG), al = *(const u16x8*)(ap + 2 * C3_A_IMG);
@@ -143,6 +149,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv3_fwd_kernel(const float* __re
         acc[j] = c;
       }
     }
+    __syncthreads();
   }
 
   // epilogue: + bias, ReLU, x (id != 0); rows scattered to the token's place, branch-free through a buffer descriptor
@@ -184,6 +191,235 @@ void launch_conv3_fwd(const float* emb, const unsigned short* W3, const float* b
   const uint32_t e_bytes = (uint32_t)std::min(((size_t)n_titles * Tp * D + kEmbSlack) * 4, (size_t)0xFFFFFFFFu);
   hipLaunchKernelGGL(conv3_fwd_kernel, dim3(cdiv(M, C3_BM)), dim3(C3_THREADS), C3_LDS, s, emb, e_bytes, W3, bias, ids, out,
                      vidx, vcount, M, T, Tp, D, F, conv3_kp(K), conv3_np(F));
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Kernel gradient dW[k*D, F] = im2col(E)^T . dC over the (compacted) tokens, same bf16x3 scheme.
+// The contraction index is the token, and BOTH operands lie token-major in HBM (the window of a token is 900
+// contiguous floats of the padded layout, its conv-output gradient a row of 400): both LDS tiles are row-major
+// [token][x] images read with transposed LDS reads.  Workgroup = 6 waves, tile 192 (k*D) x 224 (F): wave w owns
+// row tile w and 7 column tiles (112 accumulator registers); 16 tokens per step, 42 MFMAs per wave and barrier.
+// Tokens are cut into slabs (one per workgroup row); slabs are reduced in fixed order by the step's multi_reduce.
+// ---------------------------------------------------------------------------------------------
+constexpr int W3_TM = 6, W3_TN = 7, W3_BK = 16, W3_THREADS = W3_TM * 64;
+constexpr int W3_BMR = W3_TM * 32, W3_BNC = W3_TN * 32;                       // 192 x 224
+constexpr int W3_SA = tr_stride(W3_BMR), W3_SB = tr_stride(W3_BNC);          // 224 / 288 elements
+constexpr int W3_A_IMG = W3_BK * W3_SA, W3_B_IMG = W3_BK * W3_SB;
+constexpr int W3_STAGE = 3 * W3_A_IMG + 3 * W3_B_IMG;
+constexpr size_t W3_LDS = 2 * W3_STAGE * sizeof(unsigned short);
+constexpr int W3_APC = W3_BK * (W3_BMR / 4) / W3_THREADS;                     // 2 float4 per thread and step
+constexpr int W3_BPC = (W3_BK * (W3_BNC / 4) + W3_THREADS - 1) / W3_THREADS;  // 3
+static_assert(W3_BK * (W3_BMR / 4) % W3_THREADS == 0, "A pieces divide evenly");
+
+static int conv3_wgrad_mblocks(int K) { return cdiv(cdiv(K, 32), W3_TM); }
+static int conv3_wgrad_nblocks(int F) { return cdiv(cdiv(F, 32), W3_TN); }
+// slabs: about one workgroup per CU (or whole multiples), at least 512 tokens each
+static int conv3_wgrad_slabs(int M, int K, int F) {
+  const int per = conv3_wgrad_mblocks(K) * conv3_wgrad_nblocks(F);
+  const int rounds = std::max(1, cdiv(M, 120000));                 // ~105 600 tokens at B = 64 -> one round
+  // whole multiples of 8 slabs: each XCD (32 CUs) then gets the same number of workgroups (<= 32 per round)
+  const int want = rounds * 256 / per / 8 * 8;
+  return std::max(1, std::min(std::max(8, want), std::max(1, M / 512)));
+}
+size_t conv3_wgrad_scratch_bytes(int n_titles, int T, int D, int ksize, int F) {
+  return (size_t)conv3_wgrad_slabs(n_titles * T, ksize * D, F) * ksize * D * F * sizeof(float);
+}
+
+template <bool HAS_OFF>
+__global__ __launch_bounds__(W3_THREADS) void conv3_wgrad_kernel(const float* __restrict__ E, uint32_t e_bytes,
+                                                                 const float* __restrict__ G, uint32_t g_bytes,
+                                                                 float* __restrict__ slabs,
+                                                                 const int32_t* __restrict__ vidx,
+                                                                 const int32_t* __restrict__ vcount, int M, int T, int Tp,
+                                                                 int D, int F, int K, int mblocks, int nblocks, int nslabs,
+                                                                 const int32_t* __restrict__ offA,
+                                                                 const int32_t* __restrict__ offB) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int count = vcount ? vcount[0] : M;
+  // block -> (slab, m-block, n-block); the blocks of one slab are adjacent (they re-read the same tokens from L2)
+  // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the blocks of one slab get
+  // ids 8 apart: they run on ONE XCD at about the same time and share the slab's tokens through its L2
+  const int per = mblocks * nblocks;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int slab = (seq / per) * 8 + xcd, rem = seq - (seq / per) * per, mb = rem / nblocks, nb = rem - mb * nblocks;
+  if (slab >= nslabs) return;
+  const int per_slab = (count + nslabs - 1) / nslabs, tpad = (per_slab + W3_BK - 1) / W3_BK * W3_BK;
+  const int t_begin = slab * tpad, t_end = min(count, t_begin + tpad);
+  const int kd0 = mb * W3_BMR, f0 = nb * W3_BNC;
+  const __amdgpu_buffer_rsrc_t rsE = make_rsrc(E, e_bytes), rsG = make_rsrc(G, g_bytes);
+
+  f32x16 acc[W3_TN];
+#pragma unroll
+  for (int j = 0; j < W3_TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // loader roles: A piece p -> (token row, 4 kd); B piece p -> (token row, 4 f)
+  int a_kr[W3_APC], a_sg[W3_APC], b_kr[W3_BPC], b_sg[W3_BPC];
+#pragma unroll
+  for (int p = 0; p < W3_APC; ++p) {
+    const int idx = tid + p * W3_THREADS;
+    a_kr[p] = idx / (W3_BMR / 4);
+    a_sg[p] = idx - a_kr[p] * (W3_BMR / 4);
+  }
+#pragma unroll
+  for (int p = 0; p < W3_BPC; ++p) {
+    const int idx = tid + p * W3_THREADS;
+    b_kr[p] = idx / (W3_BNC / 4);
+    b_sg[p] = idx - b_kr[p] * (W3_BNC / 4);      // b_kr >= 16: not a piece of the tile
+  }
+  // Row offsets of a step's pieces come in two halves so that no wait sits between the prefetch loads: `fetch_rows`
+  // only issues the index loads (clamped, branch-free), `make_offsets` turns them into byte offsets one step later.
+  // A token past the slab's end contributes 0 through the out-of-range offset of G.
+  uint32_t a_off[W3_APC], b_off[W3_BPC];
+  int a_raw[W3_APC], b_raw[W3_BPC];
+  auto fetch_rows = [&](int t0) {
+#pragma unroll
+    for (int p = 0; p < W3_APC; ++p) {
+      const int tok = min(t0 + a_kr[p], count - 1);
+      a_raw[p] = HAS_OFF ? offA[tok] : (vidx ? vidx[tok] : tok);
+    }
+#pragma unroll
+    for (int p = 0; p < W3_BPC; ++p) {
+      const int tok = min(t0 + b_kr[p], count - 1);
+      b_raw[p] = HAS_OFF ? offB[tok] : (vidx ? vidx[tok] : tok);
+    }
+  };
+  auto make_offsets = [&](int t0) {
+#pragma unroll
+    for (int p = 0; p < W3_APC; ++p) {
+      uint32_t row = (uint32_t)a_raw[p];              // HAS_OFF: float offset of the token's window (misc.hip)
+      if (!HAS_OFF) {
+        const int title = a_raw[p] / T, t = a_raw[p] - title * T;
+        row = (uint32_t)(title * Tp + t) * (uint32_t)D;
+      }
+      a_off[p] = (row + (uint32_t)(kd0 + a_sg[p] * 4)) * 4u;
+    }
+#pragma unroll
+    for (int p = 0; p < W3_BPC; ++p) {
+      const bool ok = b_kr[p] < W3_BK && t0 + b_kr[p] < t_end;
+      const uint32_t row = HAS_OFF ? (uint32_t)b_raw[p] : (uint32_t)b_raw[p] * (uint32_t)F;
+      b_off[p] = ok ? (row + (uint32_t)(f0 + b_sg[p] * 4)) * 4u : kBufOob;
+    }
+  };
+  float4 ra[W3_APC], rb[W3_BPC];
+  auto load = [&]() {
+#pragma unroll
+    for (int p = 0; p < W3_APC; ++p) ra[p] = buf_load4(rsE, a_off[p], 0);
+#pragma unroll
+    for (int p = 0; p < W3_BPC; ++p) rb[p] = buf_load4(rsG, b_off[p], 0);
+  };
+  auto store = [&](int buf) {
+    unsigned short* st = smem + buf * W3_STAGE;
+#pragma unroll
+    for (int p = 0; p < W3_APC; ++p) {
+      u16x4 h, m, l;
+      split3(ra[p], h, m, l);
+      unsigned short* d = st + a_kr[p] * W3_SA + a_sg[p] * 4;
+      *(u16x4*)d = h;
+      *(u16x4*)(d + W3_A_IMG) = m;
+      *(u16x4*)(d + 2 * W3_A_IMG) = l;
+    }
+#pragma unroll
+    for (int p = 0; p < W3_BPC; ++p) {
+      if (b_kr[p] < W3_BK) {
+        u16x4 h, m, l;
+        split3(rb[p], h, m, l);
+        unsigned short* d = st + 3 * W3_A_IMG + b_kr[p] * W3_SB + b_sg[p] * 4;
+        *(u16x4*)d = h;
+        *(u16x4*)(d + W3_B_IMG) = m;
+        *(u16x4*)(d + 2 * W3_B_IMG) = l;
+      }
+    }
+  };
+
+  // Software pipeline: global loads run two steps ahead (their row offsets three), the split + LDS store of step
+  // it + 1 is issued in step it BEFORE that step's MFMAs and with no barrier between them, so its VALU work overlaps the
+  // matrix pipe; one barrier per step.
+  const int nit = t_end > t_begin ? (t_end - t_begin + W3_BK - 1) / W3_BK : 0;
+  if (nit > 0) {
+    fetch_rows(t_begin);
+    make_offsets(t_begin);
+    load();                                          // step 0
+    fetch_rows(t_begin + W3_BK);
+    store(0);
+    make_offsets(t_begin + W3_BK);
+    load();                                          // step 1
+    fetch_rows(t_begin + 2 * W3_BK);
+    __syncthreads();
+  }
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nit) {
+      store(buf ^ 1);                                // step it + 1 (its loads were issued a step ago)
+      make_offsets(t_begin + (it + 2) * W3_BK);      // from the rows fetched a step ago
+      load();                                        // step it + 2
+      fetch_rows(t_begin + (it + 3) * W3_BK);        // consumed in the next step
+    }
+    const unsigned short* st = smem + buf * W3_STAGE;
+    const unsigned short* bp = st + 3 * W3_A_IMG;
+    const u16x8 ah = tr_frag(st, W3_SA, 0, wv * 32, lane);
+    const u16x8 am = tr_frag(st + W3_A_IMG, W3_SA, 0, wv * 32, lane);
+    const u16x8 al = tr_frag(st + 2 * W3_A_IMG, W3_SA, 0, wv * 32, lane);
+#pragma unroll
+    for (int j = 0; j < W3_TN; ++j) {
+      const u16x8 bh = tr_frag(bp, W3_SB, 0, j * 32, lane);
+      const u16x8 bm = tr_frag(bp + W3_B_IMG, W3_SB, 0, j * 32, lane);
+      const u16x8 bl = tr_frag(bp + 2 * W3_B_IMG, W3_SB, 0, j * 32, lane);
+      f32x16 c = acc[j];
+      c = mfma32b(al, bh, c);
+      c = mfma32b(ah, bl, c);
+      c = mfma32b(am, bm, c);
+      c = mfma32b(am, bh, c);
+      c = mfma32b(ah, bm, c);
+      c = mfma32b(ah, bh, c);
+      acc[j] = c;
+    }
+    __syncthreads();
+  }
+
+  // slab [K, F] of this token range (zeros when the range is empty: the reduction reads every slab)
+  const int hh = lane >> 5, c32 = lane & 31;
+  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(slabs + (size_t)slab * K * F, (uint32_t)((size_t)K * F * 4));
+#pragma unroll
+  for (int j = 0; j < W3_TN; ++j) {
+    const int f = f0 + j * 32 + c32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kd = kd0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      buf_store1(acc[j][r], rsC, (f < F && kd < K) ? ((uint32_t)kd * (uint32_t)F + (uint32_t)f) * 4u : kBufOob, 0);
+    }
+  }
+}
+
+// dw [k*D, F] through *defer (slabs in `scratch`, conv3_wgrad_scratch_bytes); dout rows of pad tokens are not read
+void launch_conv3_wgrad(const float* emb, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
+                        int ksize, int F, const int32_t* vidx, const int32_t* vcount, hipStream_t s, ReduceJob* defer,
+                        const int32_t* offA, const int32_t* offB) {
+  const int M = n_titles * T, Tp = T + ksize - 1, K = ksize * D;
+  if (M == 0) {
+    defer->nslices = 0;
+    return;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv3_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS);
+    (void)hipFuncSetAttribute((const void*)conv3_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS);
+    attr_set = true;
+  }
+  const int mblocks = conv3_wgrad_mblocks(K), nblocks = conv3_wgrad_nblocks(F), ns = conv3_wgrad_slabs(M, K, F);
+  const uint32_t e_bytes = (uint32_t)std::min(((size_t)n_titles * Tp * D + kEmbSlack) * 4, (size_t)0xFFFFFFFFu);
+  const uint32_t g_bytes = (uint32_t)std::min((size_t)M * F * 4, (size_t)0xFFFFFFFFu);
+  const dim3 grid(cdiv(ns, 8) * 8 * mblocks * nblocks);
+  if (offA && offB)
+    hipLaunchKernelGGL(conv3_wgrad_kernel<true>, grid, dim3(W3_THREADS), W3_LDS, s, emb, e_bytes, dout, g_bytes,
+                       (float*)scratch, vidx, vcount, M, T, Tp, D, F, K, mblocks, nblocks, ns, offA, offB);
+  else
+    hipLaunchKernelGGL(conv3_wgrad_kernel<false>, grid, dim3(W3_THREADS), W3_LDS, s, emb, e_bytes, dout, g_bytes,
+                       (float*)scratch, vidx, vcount, M, T, Tp, D, F, K, mblocks, nblocks, ns, offA, offB);
+  *defer = ReduceJob{(const float*)scratch, dw, K, F, F, ns, (size_t)K * F, 1.0f};
 }
 
 }  // namespace lstur

@@ -251,7 +251,8 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->parts = (float*)take(nt * (3 * ((d.F + kParamAlign - 1) / kParamAlign * kParamAlign) + 64) * f4);
   w->conv_wp = (float*)take(pack_b_floats(d.KD, d.F) * f4);
   w->gru_up = (float*)take(gru_pack_floats(d.H) * f4);
-  w->wgrad_scratch = take(conv_wgrad_scratch_bytes(d.D, d.k, d.F));
+  w->wgrad_scratch = take(std::max(conv_wgrad_scratch_bytes(d.D, d.k, d.F),
+                                   conv3_supported(d.D, d.k, d.F) ? conv3_wgrad_scratch_bytes((int)nt, d.T, d.D, d.k, d.F) : 0));
   w->gemm_scratch_bytes = max_gemm_scratch(d);
   w->gemm_scratch = take(w->gemm_scratch_bytes);
   // weight-gradient GEMMs of the backward pass keep their split-K slabs until the step's single reduction launch
@@ -525,6 +526,11 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     PROF("conv_dgrad", launch_conv_dgrad_scatter(w.dconv, c->P("conv_w"), w.ids, c->buf.word_grad, w.dgrad_scratch, nt, d.T,
                                                   d.D, d.k, d.F, drop, dropout_key(c->cfg.seed, step, 0), s));
   }
+  static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr;
+  if (w.conv_w3 && !conv_f32)   // fp32-grade bf16x3 contraction (conv3.hip), like the forward
+    PROF("conv_wgrad", launch_conv3_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vidx,
+                                          w.vcount, s, &jobs[nj++], w.offA, w.offB));
+  else
   PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
                                        w.vidx, w.vcount, s, w.offA, w.offB,
                                        w.emb + (size_t)d.nt_max * d.Tp * d.D /* zero slack */, &jobs[nj++]));
@@ -973,6 +979,21 @@ int lstur_conv3_relu_mask_fwd(const float* emb_padded, const uint16_t* w3, const
   if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "conv3_fwd: vidx and vcount go together");
   launch_conv3_fwd(emb_padded, w3, bias, ids, out, n_titles, title_len, dim, ksize, filters, vidx, vcount, (hipStream_t)stream);
   return check_launch("conv3_fwd");
+}
+size_t lstur_conv3_wgrad_scratch(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters) {
+  return conv3_supported(dim, ksize, filters) ? conv3_wgrad_scratch_bytes(n_titles, title_len, dim, ksize, filters) : 0;
+}
+int lstur_conv3_wgrad(const float* emb_padded, const float* dout, float* dw, void* scratch, int32_t n_titles,
+                      int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx,
+                      const int32_t* vcount, lstur_stream stream) {
+  if (!emb_padded || !dout || !dw || !scratch) return fail(LSTUR_ERR_ARG, "conv3_wgrad: NULL");
+  if (!conv3_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
+  if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "conv3_wgrad: vidx and vcount go together");
+  ReduceJob job;
+  launch_conv3_wgrad(emb_padded, dout, dw, scratch, n_titles, title_len, dim, ksize, filters, vidx, vcount,
+                     (hipStream_t)stream, &job);
+  if (job.nslices > 0) launch_multi_reduce(&job, 1, (hipStream_t)stream);
+  return check_launch("conv3_wgrad");
 }
 int lstur_mhsa_fwd(const float* qkv, const int32_t* ids, float* out, int32_t n_titles, int32_t title_len,
                    int32_t filters, int32_t heads, lstur_stream stream) {

@@ -119,6 +119,11 @@ void launch_token_offsets(const int32_t* vidx, const int32_t* vcount, int M, int
 bool conv3_supported(int D, int ksize, int F);
 size_t conv3_w3_elems(int D, int ksize, int F);                 // bf16 elements of the split weight image
 void launch_conv3_pack_w(const float* W, int K, int F, unsigned short* W3, hipStream_t s);   // W [K = k*D, F]
+// kernel gradient, same scheme; dw through *defer (token slabs in `scratch`: conv3_wgrad_scratch_bytes)
+size_t conv3_wgrad_scratch_bytes(int n_titles, int T, int D, int ksize, int F);
+void launch_conv3_wgrad(const float* emb, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
+                        int ksize, int F, const int32_t* vidx, const int32_t* vcount, hipStream_t s, ReduceJob* defer,
+                        const int32_t* offA = nullptr, const int32_t* offB = nullptr);   // per-token row offsets (optional)
 void launch_conv3_fwd(const float* emb, const unsigned short* W3, const float* bias, const int32_t* ids, float* out,
                       int n_titles, int T, int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount,
                       hipStream_t s);

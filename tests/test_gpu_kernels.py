@@ -263,3 +263,22 @@ def test_conv3_bf16x3_forward_is_fp32_grade(N, D, T, F, k):
     valid = dev(ids.reshape(-1) != 0)
     assert torch.equal(out2[valid], out[valid])
     assert (out2[~valid] == -7.0).all()
+    # ---- kernel gradient, same scheme: against fp64, against the exact-fp32 kernel, and over the compacted list
+    dC = rng.normal(size=(N * T, F)).astype(np.float32)
+    dC_d = dev(dC)
+    Ep_d = dev(Ep)
+    cols = torch.stack([Ep_d[:, j:j + T] for j in range(k)], dim=2).reshape(N * T, k * D).double()
+    ref_dw = cols.t() @ dC_d.double()
+    dw = torch.full((k * D, F), 3.0, dtype=torch.float32, device='cuda')
+    scr = torch.empty(lib.lstur_conv3_wgrad_scratch(N, T, D, k, F), dtype=torch.uint8, device='cuda')
+    check(lib.lstur_conv3_wgrad(Epd.data_ptr(), dC_d.data_ptr(), dw.data_ptr(), scr.data_ptr(), N, T, D, k, F, None, None,
+                                stream()))
+    wscale = ref_dw.abs().max().item()
+    assert (dw.double() - ref_dw).abs().max().item() < 2e-5 * wscale
+    dC_m = dC_d * valid.unsqueeze(-1)
+    ref2 = cols.t() @ dC_m.double()
+    dC_g = torch.where(valid.unsqueeze(-1), dC_d, torch.full_like(dC_d, float('nan')))   # pad rows must not be read
+    dw2 = torch.full((k * D, F), 3.0, dtype=torch.float32, device='cuda')
+    check(lib.lstur_conv3_wgrad(Epd.data_ptr(), dC_g.data_ptr(), dw2.data_ptr(), scr.data_ptr(), N, T, D, k, F,
+                                vidx.data_ptr(), vcount.data_ptr(), stream()))
+    assert (dw2.double() - ref2).abs().max().item() < 2e-5 * wscale
