@@ -198,13 +198,13 @@ void launch_conv3_fwd(const float* emb, const unsigned short* W3, const float* b
 // Kernel gradient dW[k*D, F] = im2col(E)^T . dC over the (compacted) tokens, same bf16x3 scheme.
 // The contraction index is the token, and BOTH operands lie token-major in HBM (the window of a token is 900
 // contiguous floats of the padded layout, its conv-output gradient a row of 400): both LDS tiles are row-major
-// [token][x] images read with transposed LDS reads.  Workgroup = 6 waves, tile 192 (k*D) x 224 (F): wave w owns
+// [token][x] images read with transposed LDS reads.  Workgroup = 8 waves, tile 256 (k*D) x 224 (F): wave w owns
 // row tile w and 7 column tiles (112 accumulator registers); 16 tokens per step, 42 MFMAs per wave and barrier.
 // Tokens are cut into slabs (one per workgroup row); slabs are reduced in fixed order by the step's multi_reduce.
 // ---------------------------------------------------------------------------------------------
-constexpr int W3_TM = 6, W3_TN = 7, W3_BK = 16, W3_THREADS = W3_TM * 64;
-constexpr int W3_BMR = W3_TM * 32, W3_BNC = W3_TN * 32;                       // 192 x 224
-constexpr int W3_SA = tr_stride(W3_BMR), W3_SB = tr_stride(W3_BNC);          // 224 / 288 elements
+constexpr int W3_TM = 8, W3_TN = 7, W3_BK = 16, W3_THREADS = W3_TM * 64;
+constexpr int W3_BMR = W3_TM * 32, W3_BNC = W3_TN * 32;                       // 256 x 224
+constexpr int W3_SA = tr_stride(W3_BMR), W3_SB = tr_stride(W3_BNC);          // 288 / 224 elements
 constexpr int W3_A_IMG = W3_BK * W3_SA, W3_B_IMG = W3_BK * W3_SB;
 constexpr int W3_STAGE = 3 * W3_A_IMG + 3 * W3_B_IMG;
 constexpr size_t W3_LDS = 2 * W3_STAGE * sizeof(unsigned short);
