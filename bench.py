@@ -193,11 +193,19 @@ def main():
         if prof and not mhsa:
             dom = max(('conv_fwd', 'conv_wgrad'), key=lambda k: kern[k]['avg_us'])
             ach = conv_flop / (kern[dom]['avg_us'] * 1e-6) / 1e12
-            roofline = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic(dom),
+            bf16x3 = model.conv_scheme == 'bf16x3'
+            # bf16x3 (conv3.hip): every fp32-grade product is SIX bf16 MFMA products, so the kernel's roofline is the
+            # dense bf16 matrix peak / 6; the exact-fp32 MFMA kernels (LSTUR_CONV_F32=1) are priced against the fp32 peak
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if bf16x3 else PEAK_F32_MFMA_TFLOPS
+            roofline = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s',
+                            frac=round(ach / peak, 4), traffic=traffic(dom),
                             avg_us=round(kern[dom]['avg_us'], 1), flop_per_launch=conv_flop,
                             non_pad_token_fraction=round(real_tok / n_tok, 4),
-                            effective_algorithmic=round(conv_flop_full / (kern[dom]['avg_us'] * 1e-6) / 1e12, 2))
+                            effective_algorithmic=round(conv_flop_full / (kern[dom]['avg_us'] * 1e-6) / 1e12, 2),
+                            scheme=('bf16x3: 3-way bf16 split of both fp32 operands, 6 MFMA products, fp32 accumulate '
+                                    '(fp32-grade; peak = 2500 TFLOP/s dense bf16 / 6)') if bf16x3 else 'fp32 MFMA 16x16x4',
+                            mfma_executed_tflops=round(ach * (6.0 if bf16x3 else 1.0), 1),
+                            frac_vs_fp32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 4))
         if prof:
             gb = gather_bytes / (kern['gather']['avg_us'] * 1e-6) / 1e9
             roofline_gather = dict(kernel='gather', bound='hbm', achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit='GB/s',
@@ -208,6 +216,7 @@ def main():
             'unit': 'impressions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * el / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16' if wl.get('encoder') == 'mhsa' else 'f32', 'data': 'synthetic',
+            'conv_scheme': model.conv_scheme,
             'config': {'workload': args.workload, 'arch': wl['arch'], 'batch_per_gpu': wl['B'],
                        'global_batch': wl['B'] * world, 'hist_len': wl['W'], 'title_len': wl['T'],
                        'candidates': wl['K1'], 'word_dim': wl['D'], 'filters': wl['F'], 'user_dim': wl['U'],

@@ -8,6 +8,7 @@ memory, the stream and (under data parallelism) RCCL collectives; all arithmetic
 runs in the library.  There is no CPU path.
 """
 import ctypes as C
+import os
 import logging
 
 import numpy as np
@@ -96,6 +97,10 @@ class NativeModel:
                                  loss_negatives=max(1, negative_samples), freeze_encoder=freeze_encoder,
                                  word_trainable=word_trainable, news_encoder=news_encoder, heads=heads)
         self.news_encoder = news_encoder     # 'mhsa': build-defined multi-head self-attention token stage (heads x F/heads)
+        # how the Conv1D contractions run: 'bf16x3' = fp32-grade 3-way split on the bf16 matrix cores (conv3.hip, filters
+        # <= 448), 'f32' = exact-fp32 MFMA (conv.hip; forced by LSTUR_CONV_F32=1)
+        self.conv_scheme = ('bf16x3' if filters <= 448 and not os.environ.get('LSTUR_CONV_F32') else 'f32') \
+            if news_encoder == 'cnnatt' else 'n/a'
         self.mhsa_proj_dtype = 'bf16'        # operand type of the mhsa Q|K|V projection GEMMs (attention products: bf16)
         self.freeze_encoder = bool(freeze_encoder)
         self.word_trainable = bool(word_trainable)     # --textual-embedding-trainable (paper.py:132-138)
