@@ -11,31 +11,50 @@ namespace lstur {
 // One 16-byte access per lane on both sides: a table row (D*4 B, 1200 B at D=300) is read by
 // D/4 consecutive lanes, so every wave instruction covers whole 64-B segments of a row.
 // ---------------------------------------------------------------------------------------------
+// Four independent float4 per thread and pass, branch-free (pad rows are a select on an unconditional, clamped
+// load): the four id loads, then the four row loads are in flight together, and the dropout hash of one piece
+// overlaps the loads of the others -- a guarded load per grid-stride step left ONE dependent id -> row chain in flight
+// per thread.
 template <bool DROP>
 __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ table,
                                                      const int32_t* __restrict__ ids,
                                                      float4* __restrict__ out, uint32_t total4, int T, int Tp,
                                                      int D4, int pad_l, uint32_t thresh, uint32_t key,
                                                      float scale) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
-    uint32_t row = i / (uint32_t)D4;
-    uint32_t c4 = i - row * (uint32_t)D4;
-    uint32_t n = row / (uint32_t)Tp;
-    int t = (int)(row - n * (uint32_t)Tp) - pad_l;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t >= 0 && t < T) {
-      uint32_t tok = n * (uint32_t)T + (uint32_t)t;
-      int id = ids[tok];
-      v = table[(size_t)id * D4 + c4];
-      if (DROP) {
-        uint32_t e = (tok * (uint32_t)D4 + c4) * 4u;
-        v.x = keep_elem(key, e + 0u, thresh) ? v.x * scale : 0.f;
-        v.y = keep_elem(key, e + 1u, thresh) ? v.y * scale : 0.f;
-        v.z = keep_elem(key, e + 2u, thresh) ? v.z * scale : 0.f;
-        v.w = keep_elem(key, e + 3u, thresh) ? v.w * scale : 0.f;
-      }
+  constexpr int U = 4;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < total4; i0 += U * stride) {
+    uint32_t c4[U], tok[U];
+    bool inr[U], real[U];
+    int id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = min(i0 + u * stride, total4 - 1u);
+      inr[u] = i0 + u * stride < total4;
+      const uint32_t row = i / (uint32_t)D4;
+      c4[u] = i - row * (uint32_t)D4;
+      const uint32_t n = row / (uint32_t)Tp;
+      const int t = (int)(row - n * (uint32_t)Tp) - pad_l;
+      real[u] = t >= 0 && t < T;
+      tok[u] = n * (uint32_t)T + (uint32_t)min(max(t, 0), T - 1);
+      id[u] = ids[tok[u]];
     }
-    out[i] = v;
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = table[(size_t)id[u] * D4 + c4[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float4 w = v[u];
+      if (DROP) {
+        const uint32_t e = (tok[u] * (uint32_t)D4 + c4[u]) * 4u;
+        w.x = keep_elem(key, e + 0u, thresh) ? w.x * scale : 0.f;
+        w.y = keep_elem(key, e + 1u, thresh) ? w.y * scale : 0.f;
+        w.z = keep_elem(key, e + 2u, thresh) ? w.z * scale : 0.f;
+        w.w = keep_elem(key, e + 3u, thresh) ? w.w * scale : 0.f;
+      }
+      if (!real[u]) w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (inr[u]) out[i0 + u * stride] = w;
+    }
   }
 }
 
@@ -44,7 +63,7 @@ void launch_gather(const float* table, const int32_t* ids, float* out, int n_tit
   int Tp = T + pad_l + pad_r, D4 = D / 4;
   size_t total4 = (size_t)n_titles * Tp * D4;
   if (total4 == 0) return;
-  int blocks = (int)std::min<size_t>(cdivz(total4, 256), 256 * 16);
+  int blocks = (int)std::min<size_t>(cdivz(total4, 256 * 4), 256 * 16);
   if (drop > 0.f)
     hipLaunchKernelGGL(gather_kernel<true>, dim3(blocks), dim3(256), 0, s, (const float4*)table, ids,
                        (float4*)out, (uint32_t)total4, T, Tp, D4, pad_l, dropout_thresh(drop), key,
