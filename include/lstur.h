@@ -42,9 +42,20 @@ enum lstur_arch {            /* user encoders of Seq2VecPaperSoftmaxId.get_user_
   LSTUR_ARCH_IGRU = 0,       /* LSTUR-ini: GRU(U)(x, initial_state=user_vec)            paper.py:612-613 */
   LSTUR_ARCH_GRU = 1,        /* LSTUR-con: Dense(U)(concat[GRU(U)(x), user_vec])        paper.py:596-599 */
   LSTUR_ARCH_HGRU = 2,       /* LSTUR-con: concat[GRU(U/2)(x), Embedding(N_u, U/2)]     paper.py:603-607 */
-  LSTUR_ARCH_NIGRU = 3       /* no user id: GRU(U)(x) from a zero state (paper.py:627-628 `nigru`; `gru` of the
+  LSTUR_ARCH_NIGRU = 3,      /* no user id: GRU(U)(x) from a zero state (paper.py:627-628 `nigru`; `gru` of the
                                 id-less Seq2VecPaperSoftmax, paper.py:206-208); user arguments are ignored     */
+  LSTUR_ARCH_NGRU = 4,       /* LSTUR-con, plain concat[GRU(U)(x), user_vec]: a 2U-wide user vector (paper.py:600-602);
+                                needs score_model ddot or dnn                                                  */
+  LSTUR_ARCH_DGRU = 5        /* ngru with Dropout(0.5, noise_shape=(None,1)) on the user embedding: a sample's whole
+                                embedding is dropped with p = 0.5 in training (paper.py:608-611; the masking of
+                                the LSTUR paper); dropout stream 2 of the step                                 */
 };
+
+enum lstur_score_model {     /* Seq2VecPaperSoftmax._score_model (--score-model), paper.py:443-458; listwise head only */
+  LSTUR_SCORE_DOT = 0,       /* dot([u, d])                                                                     */
+  LSTUR_SCORE_DDOT = 1,      /* dot([tanh(Dense(U)(u)), tanh(Dense(U)(d))]); parameters sdu_w/sdu_b/sdd_w/sdd_b */
+  LSTUR_SCORE_DNN = 2        /* Dense(1)(relu(Dense(U)(concat[u, d]))); parameters sn1_w/sn1_b/sn2_w/sn2_b      */
+};                           /* test model (lstur_predict): sigmoid(score_model([u, d])), paper.py:661-665      */
 
 enum lstur_head {            /* scorer + loss on top of (user_vec, doc_vec) */
   LSTUR_HEAD_SOFTMAX = 0,    /* listwise: dot, softmax over K1 candidates, categorical_crossentropy  paper.py:446-464,658 */
@@ -88,6 +99,7 @@ typedef struct lstur_cfg {
                                 its gradients stay 0 (dropout inside it stays active in training, as in Keras)   */
   int32_t news_encoder;      /* lstur_encoder; 0 = cnnatt                                              */
   int32_t heads;             /* mhsa: number of attention heads (filters % heads == 0)                 */
+  int32_t score_model;       /* lstur_score_model; 0 = dot                                              */
 } lstur_cfg;
 
 /* Sizes (in floats unless named _bytes) the caller must allocate for a configuration. */

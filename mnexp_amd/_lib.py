@@ -11,7 +11,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblstur_hip.so')
 
-ARCH = {'igru': 0, 'gru': 1, 'hgru': 2, 'nigru': 3}
+ARCH = {'igru': 0, 'gru': 1, 'hgru': 2, 'nigru': 3, 'ngru': 4, 'dgru': 5}
+SCORE = {'dot': 0, 'ddot': 1, 'dnn': 2}     # --score-model (paper.py:443-458)
 HEAD = {'softmax': 0, 'point_mlp': 1, 'point_dot': 2}
 ENCODER = {'cnnatt': 0, 'mhsa': 1}     # include/lstur.h: lstur_encoder (mhsa is build-defined, no reference counterpart)
 
@@ -25,7 +26,7 @@ class Cfg(C.Structure):
                                          'filters', 'kernel', 'user_dim', 'n_users', 'arch')] + [
         ('dropout', C.c_float), ('seed', C.c_uint32), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
         ('head', C.c_int32), ('gain', C.c_float), ('loss_negatives', C.c_int32), ('word_trainable', C.c_int32),
-        ('freeze_encoder', C.c_int32), ('news_encoder', C.c_int32), ('heads', C.c_int32)]
+        ('freeze_encoder', C.c_int32), ('news_encoder', C.c_int32), ('heads', C.c_int32), ('score_model', C.c_int32)]
 
 
 class Sizes(C.Structure):
@@ -126,17 +127,21 @@ def check(rc, what=''):
 
 def make_cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
              arch='igru', dropout=0.0, seed=0, beta1=0.9, beta2=0.999, eps=1e-7, head='softmax', gain=1.0,
-             loss_negatives=4, freeze_encoder=False, word_trainable=False, news_encoder='cnnatt', heads=0):
+             loss_negatives=4, freeze_encoder=False, word_trainable=False, news_encoder='cnnatt', heads=0,
+             score_model='dot'):
     if arch not in ARCH:
         raise LsturError('arch {!r} is not supported by the native path (have {})'.format(arch, sorted(ARCH)))
     if head not in HEAD:
         raise LsturError('head {!r} is not supported by the native path (have {})'.format(head, sorted(HEAD)))
+    if score_model not in SCORE:
+        raise LsturError('score model {!r} is not supported by the native path (have {})'.format(score_model, sorted(SCORE)))
     if news_encoder not in ENCODER:
         raise LsturError('news encoder {!r} is not supported by the native path (have {})'.format(
             news_encoder, sorted(ENCODER)))
     return Cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
                ARCH[arch], dropout, seed, beta1, beta2, eps, HEAD[head], gain, loss_negatives,
-               int(bool(word_trainable)), int(bool(freeze_encoder)), ENCODER[news_encoder], int(heads))
+               int(bool(word_trainable)), int(bool(freeze_encoder)), ENCODER[news_encoder], int(heads),
+               SCORE[score_model])
 
 
 def query_sizes(cfg):

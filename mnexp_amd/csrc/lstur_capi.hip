@@ -30,7 +30,7 @@ struct ParamSlot {
 };
 
 struct Dims {
-  int B, W, T, K1, V, D, F, k, U, Nu, arch, H, Ue, Tp, KD, head, word_trainable, enc, heads;
+  int B, W, T, K1, V, D, F, k, U, Nu, arch, H, Ue, Tp, KD, head, word_trainable, enc, heads, Uu, score;
   int nt_max;   // titles per call
   int n_cap;    // per-sample buffers
   int rows_cap; // sparse user-grad rows per adam step
@@ -63,7 +63,7 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     *why = "filters must be <= 1024";
     return false;
   }
-  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_NIGRU) {
+  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_DGRU) {
     *why = "unknown arch";
     return false;
   }
@@ -126,6 +126,20 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
   }
   d->H = d->arch == LSTUR_ARCH_HGRU ? d->U / 2 : d->U;
   d->Ue = d->arch == LSTUR_ARCH_HGRU ? d->U / 2 : d->U;
+  d->Uu = (d->arch == LSTUR_ARCH_NGRU || d->arch == LSTUR_ARCH_DGRU) ? 2 * d->U : d->U;   // width of the user vector
+  d->score = c->score_model;
+  if (d->score < LSTUR_SCORE_DOT || d->score > LSTUR_SCORE_DNN) {
+    *why = "unknown score_model";
+    return false;
+  }
+  if (d->score != LSTUR_SCORE_DOT && d->head != LSTUR_HEAD_SOFTMAX) {
+    *why = "score_model ddot / dnn belong to the listwise head";
+    return false;
+  }
+  if (d->score == LSTUR_SCORE_DOT && d->Uu != d->U) {
+    *why = "ngru / dgru user vectors are 2U wide: they need score_model ddot or dnn (paper.py:600-602)";
+    return false;
+  }
   if (d->H > 256) {
     *why = "GRU width must be <= 256";
     return false;
@@ -164,6 +178,17 @@ std::vector<ParamSlot> param_layout(const Dims& d, size_t* total) {
     add("con_w", (size_t)(d.H + d.Ue) * d.U);
     add("con_b", d.U);
   }
+  if (d.score == LSTUR_SCORE_DDOT) {
+    add("sdu_w", (size_t)d.Uu * d.U);
+    add("sdu_b", d.U);
+    add("sdd_w", (size_t)d.U * d.U);
+    add("sdd_b", d.U);
+  } else if (d.score == LSTUR_SCORE_DNN) {
+    add("sn1_w", (size_t)(d.Uu + d.U) * d.U);
+    add("sn1_b", d.U);
+    add("sn2_w", d.U);
+    add("sn2_b", 1);
+  }
   if (d.head == LSTUR_HEAD_POINT_MLP) {
     add("score_w1", (size_t)2 * d.U * d.U);
     add("score_b1", d.U);
@@ -183,7 +208,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; unsigned short* conv_w3; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
+  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; unsigned short* conv_w3; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
 };
@@ -203,6 +228,16 @@ size_t max_gemm_scratch(const Dims& d) {
   upd(d.n_cap, d.U, d.H + d.Ue);
   upd(d.H + d.Ue, d.U, d.n_cap);
   upd(d.n_cap, d.H + d.Ue, d.U);
+  if (d.score != LSTUR_SCORE_DOT) {   // listwise ddot / dnn score models
+    const int rows = d.n_cap * d.K1, wc = d.Uu + d.U;
+    upd(rows, d.U, wc);
+    upd(wc, d.U, rows);
+    upd(rows, wc, d.U);
+    upd(d.n_cap, d.U, d.Uu);
+    upd(d.Uu, d.U, d.n_cap);
+    upd(d.n_cap, d.Uu, d.U);
+    upd(d.U, d.U, rows);
+  }
   upd(d.n_cap, d.U, 2 * d.U);   // pointwise MLP head
   upd(2 * d.U, d.U, d.n_cap);
   upd(d.n_cap, 2 * d.U, d.U);
@@ -241,9 +276,9 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->dhlast = (float*)take(nc * d.H * f4);
   w->cat = (float*)take(nc * (d.H + d.Ue) * f4);
   w->dcat = (float*)take(nc * (d.H + d.Ue) * f4);
-  w->uservec = (float*)take(nc * d.U * f4);
+  w->uservec = (float*)take(nc * d.Uu * f4);
   w->duser = (float*)take(nc * d.Ue * f4);
-  w->du = (float*)take(nc * d.U * f4);
+  w->du = (float*)take(nc * d.Uu * f4);
   w->logits = (float*)take(nc * d.K1 * f4);
   w->probs = (float*)take(nc * d.K1 * f4);
   w->loss_i = (float*)take(nc * f4);
@@ -269,6 +304,15 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->sdhid = (float*)take(nc * d.U * f4);
   w->sdcat = (float*)take(nc * 2 * d.U * f4);
   w->dgrad_scratch = d.word_trainable ? (float*)take(conv_dgrad_scratch_floats((int)nt, d.T, d.D, d.k, d.F) * f4) : nullptr;
+  const bool lw = d.score != LSTUR_SCORE_DOT;   // scratch of the listwise ddot / dnn score models
+  const size_t lrows = nc * d.K1;
+  w->lw_a = lw ? (float*)take(lrows * (d.Uu + d.U) * f4) : nullptr;
+  w->lw_b = lw ? (float*)take(lrows * (d.Uu + d.U) * f4) : nullptr;
+  w->lw_c = lw ? (float*)take(lrows * d.U * f4) : nullptr;
+  w->lw_d = lw ? (float*)take(lrows * d.U * f4) : nullptr;
+  w->lw_s = lw ? (float*)take(lrows * f4) : nullptr;
+  w->lw_ds = lw ? (float*)take(lrows * f4) : nullptr;
+  w->lw_ones = lw ? (float*)take(nc * f4) : nullptr;
   const bool mh = d.enc == LSTUR_ENC_MHSA;
   w->conv_w3 = (!mh && conv3_supported(d.D, d.k, d.F)) ? (unsigned short*)take(conv3_w3_elems(d.D, d.k, d.F) * 2) : nullptr;
   w->qkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;     // bf16 Q | K | V rows
@@ -420,6 +464,8 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   // user encoder (paper.py:584-633)
   launch_hist_mask(w.ids, w.docvec, w.hmask, w.gmask, nW, d.T, d.U, s, c->buf.user_emb, user, w.user_rows, w.uvec, n,
                    d.Ue);
+  if (d.arch == LSTUR_ARCH_DGRU && training)   // Dropout(0.5, noise_shape=(None, 1)) on the user embedding, paper.py:610
+    launch_drop_rows(w.uvec, n, d.Ue, 0.5f, dropout_key(c->cfg.seed, step, 2), s);
   launch_gemm(w.docvec, d.U, 0, c->P("gru_w"), 3 * d.H, 0, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, 1.f,
               w.gemm_scratch, s);
   // igru / nigru: the last state IS the user vector (H == U): the recurrence writes it in place
@@ -431,8 +477,8 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     if (d.arch == LSTUR_ARCH_GRU)
       launch_gemm(w.cat, d.H + d.Ue, 0, c->P("con_w"), d.U, 0, w.uservec, d.U, c->P("con_b"), n, d.U, d.H + d.Ue, 1.f,
                   w.gemm_scratch, s);
-    else
-      (void)hipMemcpyAsync(w.uservec, w.cat, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
+    else   // hgru (U/2 + U/2), ngru / dgru (U + U): the concatenation is the user vector
+      (void)hipMemcpyAsync(w.uservec, w.cat, (size_t)n * d.Uu * 4, hipMemcpyDeviceToDevice, s);
   }
   c->last_n = n;
   c->last_k1 = k1;
@@ -455,8 +501,10 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
                 w.gemm_scratch, s);
     launch_split2(w.dcat, d.H, d.Ue, w.dhlast, w.duser, n, s);
     dhl = w.dhlast;
-  } else if (d.arch == LSTUR_ARCH_HGRU) {
+  } else if (d.arch == LSTUR_ARCH_HGRU || d.arch == LSTUR_ARCH_NGRU || d.arch == LSTUR_ARCH_DGRU) {
     launch_split2(w.du, d.H, d.Ue, w.dhlast, w.duser, n, s);
+    if (d.arch == LSTUR_ARCH_DGRU)   // the same per-sample mask and scale as the forward
+      launch_drop_rows(w.duser, n, d.Ue, 0.5f, dropout_key(c->cfg.seed, step, 2), s);
     dhl = w.dhlast;
   }
   float *hprev = w.hprev, *rh = w.rh;   // fast path: both already sit row-major in the tape (no copies)
@@ -558,6 +606,67 @@ int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n,
   return LSTUR_OK;
 }
 
+// Listwise score model on (uservec [n, Uu], candidate doc vectors [n*k1, U]) (paper.py:443-464).
+//   scores != NULL: test model, sigmoid(score) for k1 == 1 (paper.py:661-665)
+//   else: logits / probs / loss (+ `backward`: du, d(candidate doc vectors) and the score model's parameter gradients)
+void run_listwise_score(lstur_ctx* c, int n, int k1, float inv_n, bool backward, float* scores, hipStream_t s) {
+  const Dims& d = c->d;
+  Workspace& w = c->ws;
+  const int nW = n * d.W, rows = n * k1;
+  const float* dvec = w.docvec + (size_t)nW * d.U;
+  float* ddvec = w.ddocvec + (size_t)nW * d.U;
+  if (d.score == LSTUR_SCORE_DOT) {
+    if (scores) launch_predict_score(w.uservec, dvec, scores, n, d.U, s);
+    else
+      launch_score(w.uservec, dvec, w.logits, w.probs, w.loss_i, w.correct_i, backward ? w.du : nullptr,
+                   backward ? ddvec : nullptr, n, k1, d.U, inv_n, s);
+    return;
+  }
+  if (d.score == LSTUR_SCORE_DDOT) {   // tanh-Dense on both sides, then dot (paper.py:452-455)
+    float *uh = w.lw_c, *dh = w.lw_a, *duh = w.lw_d, *ddh = w.lw_b;   // [n,U], [rows,U], [n,U], [rows,U]
+    launch_gemm(w.uservec, d.Uu, 0, c->P("sdu_w"), d.U, 0, uh, d.U, c->P("sdu_b"), n, d.U, d.Uu, 1.f, w.gemm_scratch, s);
+    launch_tanh_inplace(uh, (size_t)n * d.U, s);
+    launch_gemm(dvec, d.U, 0, c->P("sdd_w"), d.U, 0, dh, d.U, c->P("sdd_b"), rows, d.U, d.U, 1.f, w.gemm_scratch, s);
+    launch_tanh_inplace(dh, (size_t)rows * d.U, s);
+    if (scores) {
+      launch_predict_score(uh, dh, scores, n, d.U, s);
+      return;
+    }
+    launch_score(uh, dh, w.logits, w.probs, w.loss_i, w.correct_i, backward ? duh : nullptr, backward ? ddh : nullptr, n,
+                 k1, d.U, inv_n, s);
+    if (!backward) return;
+    launch_tanh_bwd(duh, uh, (size_t)n * d.U, s);
+    launch_tanh_bwd(ddh, dh, (size_t)rows * d.U, s);
+    launch_gemm(w.uservec, d.Uu, 1, duh, d.U, 0, c->G("sdu_w"), d.U, nullptr, d.Uu, d.U, n, 1.f, w.gemm_scratch, s);
+    launch_colsum2(duh, n, d.U, d.U, c->G("sdu_b"), 1.f, w.colsum_scratch, s);
+    launch_gemm(dvec, d.U, 1, ddh, d.U, 0, c->G("sdd_w"), d.U, nullptr, d.U, d.U, rows, 1.f, w.gemm_scratch, s);
+    launch_colsum2(ddh, rows, d.U, d.U, c->G("sdd_b"), 1.f, w.colsum_scratch, s);
+    launch_gemm(duh, d.U, 0, c->P("sdu_w"), d.U, 1, w.du, d.Uu, nullptr, n, d.Uu, d.U, 1.f, w.gemm_scratch, s);
+    launch_gemm(ddh, d.U, 0, c->P("sdd_w"), d.U, 1, ddvec, d.U, nullptr, rows, d.U, d.U, 1.f, w.gemm_scratch, s);
+    return;
+  }
+  // dnn: concat -> Dense(U, relu) -> Dense(1) per candidate (paper.py:448-451)
+  const int wc = d.Uu + d.U;
+  float *cat = w.lw_a, *dcat = w.lw_b, *pre = w.lw_c, *dhid = w.lw_d;
+  launch_concat_rep(w.uservec, d.Uu, k1, dvec, d.U, cat, rows, s);
+  launch_gemm(cat, wc, 0, c->P("sn1_w"), d.U, 0, pre, d.U, c->P("sn1_b"), rows, d.U, wc, 1.f, w.gemm_scratch, s);
+  // raw score = relu(pre) . sn2_w + sn2_b (lw_s); the kernel's sigmoid output is the test model's score
+  launch_point_mlp_out(pre, c->P("sn2_w"), c->P("sn2_b"), nullptr, w.lw_s, scores ? scores : w.lw_ds, nullptr, nullptr,
+                       nullptr, nullptr, rows, d.U, 1.f, 1, 0.f, s);
+  if (scores) return;
+  // softmax + categorical cross-entropy over the k1 scores of a sample: the dot scorer's kernel with u = 1, U = 1
+  launch_fill_f32(w.lw_ones, 1.0f, n, s);
+  launch_score(w.lw_ones, w.lw_s, w.logits, w.probs, w.loss_i, w.correct_i, backward ? w.sds : nullptr,
+               backward ? w.lw_ds : nullptr, n, k1, 1, inv_n, s);
+  if (!backward) return;
+  launch_point_w2_grad(pre, w.lw_ds, c->G("sn2_w"), c->G("sn2_b"), rows, d.U, s);
+  launch_mlp_dhid(pre, w.lw_ds, c->P("sn2_w"), dhid, rows, d.U, s);
+  launch_gemm(cat, wc, 1, dhid, d.U, 0, c->G("sn1_w"), d.U, nullptr, wc, d.U, rows, 1.f, w.gemm_scratch, s);
+  launch_colsum2(dhid, rows, d.U, d.U, c->G("sn1_b"), 1.f, w.colsum_scratch, s);
+  launch_gemm(dhid, d.U, 0, c->P("sn1_w"), d.U, 1, dcat, wc, nullptr, rows, wc, d.U, 1.f, w.gemm_scratch, s);
+  launch_split_sum(dcat, d.Uu, d.U, k1, w.du, ddvec, n, s);
+}
+
 int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int32_t* cands, int n, uint32_t step,
                float grad_scale, float* stats, hipStream_t s, bool ids_form, bool backward, bool training) {
   if (!c || !user || !hist || !cands) return fail(LSTUR_ERR_ARG, "NULL argument");
@@ -568,10 +677,7 @@ int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   if (rc) return rc;
   Workspace& w = c->ws;
   PROF("forward_total", run_forward(c, user, n, d.K1, training, step, s));
-  const int nW = n * d.W;
-  launch_score(w.uservec, w.docvec + (size_t)nW * d.U, w.logits, w.probs, w.loss_i, w.correct_i,
-               backward ? w.du : nullptr, backward ? w.ddocvec + (size_t)nW * d.U : nullptr, n, d.K1, d.U,
-               grad_scale / (float)n, s);
+  run_listwise_score(c, n, d.K1, grad_scale / (float)n, backward, nullptr, s);
   if (stats && !backward) launch_mean2(w.loss_i, w.correct_i, n, stats, s);
   if (backward) PROF("backward_total", run_backward(c, n, step, s, stats));
   return check_launch(backward ? "forward_backward" : "evaluate");
@@ -641,7 +747,7 @@ int predict_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const i
     launch_point_mlp_out(w.spre, c->P("score_w2"), c->P("score_b2"), nullptr, w.logits, scores, nullptr, nullptr,
                          nullptr, nullptr, n, d.U, 1.f, 1, 0.f, s);
   } else {
-    launch_predict_score(c->ws.uservec, c->ws.docvec + (size_t)n * d.W * d.U, scores, n, d.U, s);
+    run_listwise_score(c, n, 1, 0.f, false, scores, s);
   }
   return check_launch("predict");
 }

@@ -89,6 +89,14 @@ void launch_gather_rows(const float* table, const int32_t* rows, float* out, int
 // concat: out[b, :a_cols] = a[b], out[b, a_cols:] = bm[b]
 void launch_concat2(const float* a, int a_cols, const float* bm, int b_cols, float* out, int n, hipStream_t s);
 void launch_split2(const float* in, int a_cols, int b_cols, float* a, float* bm, int n, hipStream_t s);
+// listwise score models ddot / dnn (paper.py:448-455) and the dgru whole-row dropout (paper.py:610)
+void launch_tanh_inplace(float* x, size_t n, hipStream_t s);
+void launch_tanh_bwd(float* g, const float* y, size_t n, hipStream_t s);
+void launch_concat_rep(const float* u, int uc, int K1, const float* d, int dc, float* out, int rows, hipStream_t s);
+void launch_mlp_dhid(const float* pre, const float* ds, const float* w2, float* dhid, int rows, int U, hipStream_t s);
+void launch_split_sum(const float* dcat, int uc, int dc, int K1, float* du, float* dd, int n, hipStream_t s);
+void launch_fill_f32(float* p, float v, size_t n, hipStream_t s);
+void launch_drop_rows(float* x, int n, int dim, float p, uint32_t key, hipStream_t s);
 void launch_score(const float* u, const float* d, float* logits, float* probs, float* loss_i, float* correct_i,
                   float* du, float* dd, int n, int K1, int U, float inv_n, hipStream_t s);
 void launch_predict_score(const float* u, const float* d, float* scores, int n, int U, hipStream_t s);

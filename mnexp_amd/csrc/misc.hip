@@ -711,6 +711,85 @@ void launch_concat2(const float* a, int a_cols, const float* bm, int b_cols, flo
   int total = n * (a_cols + b_cols);
   if (total) hipLaunchKernelGGL(concat2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, a, a_cols, bm, b_cols, out, n);
 }
+// ---- listwise score models ddot / dnn (Seq2VecPaperSoftmax._score_model, task/paper.py:448-455) -----------------
+__global__ void tanh_inplace_kernel(float* __restrict__ x, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = tanhf(x[i]);
+}
+void launch_tanh_inplace(float* x, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)cdivz(n, 256)), dim3(256), 0, s, x, n);
+}
+// g *= 1 - y^2   (y = tanh output)
+__global__ void tanh_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) g[i] *= 1.0f - y[i] * y[i];
+}
+void launch_tanh_bwd(float* g, const float* y, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(tanh_bwd_kernel, dim3((unsigned)cdivz(n, 256)), dim3(256), 0, s, g, y, n);
+}
+// out[b*K1 + j] = [u[b] | d[b*K1 + j]]   (keras concatenate of the user vector with every candidate, paper.py:449)
+__global__ void concat_rep_kernel(const float* __restrict__ u, int uc, int K1, const float* __restrict__ d, int dc,
+                                  float* __restrict__ out, int rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, w = uc + dc;
+  if (i >= rows * w) return;
+  const int r = i / w, c = i - r * w;
+  out[i] = c < uc ? u[(size_t)(r / K1) * uc + c] : d[(size_t)r * dc + (c - uc)];
+}
+void launch_concat_rep(const float* u, int uc, int K1, const float* d, int dc, float* out, int rows, hipStream_t s) {
+  const int total = rows * (uc + dc);
+  if (total) hipLaunchKernelGGL(concat_rep_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, u, uc, K1, d, dc, out, rows);
+}
+// dhid[r][i] = ds[r] * w2[i] * (pre[r][i] > 0)     (Dense(1) on a ReLU hidden layer)
+__global__ void mlp_dhid_kernel(const float* __restrict__ pre, const float* __restrict__ ds, const float* __restrict__ w2,
+                                float* __restrict__ dhid, int rows, int U) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * U) return;
+  const int r = i / U, c = i - r * U;
+  dhid[i] = pre[i] > 0.f ? ds[r] * w2[c] : 0.f;
+}
+void launch_mlp_dhid(const float* pre, const float* ds, const float* w2, float* dhid, int rows, int U, hipStream_t s) {
+  if (rows * U) hipLaunchKernelGGL(mlp_dhid_kernel, dim3(cdiv(rows * U, 256)), dim3(256), 0, s, pre, ds, w2, dhid, rows, U);
+}
+// dcat [n*K1, uc + dc] -> du[b] = sum_j dcat[b*K1 + j][:uc] (fixed order), dd[b*K1 + j] = dcat[..][uc:]
+__global__ void split_sum_kernel(const float* __restrict__ dcat, int uc, int dc, int K1, float* __restrict__ du,
+                                 float* __restrict__ dd, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, w = uc + dc;
+  if (i < n * uc) {
+    const int b = i / uc, c = i - b * uc;
+    float acc = 0.f;
+    for (int j = 0; j < K1; ++j) acc += dcat[(size_t)(b * K1 + j) * w + c];
+    du[i] = acc;
+  }
+  if (i < n * K1 * dc) {
+    const int r = i / dc, c = i - r * dc;
+    dd[i] = dcat[(size_t)r * w + uc + c];
+  }
+}
+void launch_split_sum(const float* dcat, int uc, int dc, int K1, float* du, float* dd, int n, hipStream_t s) {
+  const int total = std::max(n * uc, n * K1 * dc);
+  if (total) hipLaunchKernelGGL(split_sum_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, dcat, uc, dc, K1, du, dd, n);
+}
+__global__ void fill_f32_kernel(float* __restrict__ p, float v, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+void launch_fill_f32(float* p, float v, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)cdivz(n, 256)), dim3(256), 0, s, p, v, n);
+}
+// whole-row inverted dropout (keras Dropout(p, noise_shape=(None, 1)), the `dgru` user embedding, paper.py:610):
+// row b is kept iff keep_elem(key, b), kept rows are scaled by 1 / (1 - p)
+__global__ void drop_rows_kernel(float* __restrict__ x, int n, int dim, uint32_t key, uint32_t thresh, float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * dim) return;
+  const int b = i / dim;
+  x[i] = keep_elem(key, (uint32_t)b, thresh) ? x[i] * scale : 0.f;
+}
+void launch_drop_rows(float* x, int n, int dim, float p, uint32_t key, hipStream_t s) {
+  if (n * dim && p > 0.f)
+    hipLaunchKernelGGL(drop_rows_kernel, dim3(cdiv(n * dim, 256)), dim3(256), 0, s, x, n, dim, key, dropout_thresh(p),
+                       1.0f / (1.0f - p));
+}
+
 __global__ void split2_kernel(const float* __restrict__ in, int ac, int bc, float* __restrict__ a,
                               float* __restrict__ b, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -78,7 +78,7 @@ class NativeModel:
     def __init__(self, word_emb, n_users, batch_size, window, title_len, negative_samples, filters, kernel,
                  user_dim, arch='igru', dropout=0.2, lr=1e-3, seed=0, device=None, title_table=None,
                  dist_group=None, has_user=True, head='softmax', gain=1.0, freeze_encoder=False,
-                 word_trainable=False, news_encoder='cnnatt', heads=0):
+                 word_trainable=False, news_encoder='cnnatt', heads=0, score_model='dot'):
         if not torch.cuda.is_available():
             raise _lib.LsturError('no GPU visible: the native LSTUR model has no CPU fallback')
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
@@ -95,7 +95,9 @@ class NativeModel:
         self.cfg = _lib.make_cfg(batch_size, window, title_len, self.K1, V, D, filters, kernel, user_dim,
                                  max(1, n_users), arch, dropout, seed, head=head, gain=gain,
                                  loss_negatives=max(1, negative_samples), freeze_encoder=freeze_encoder,
-                                 word_trainable=word_trainable, news_encoder=news_encoder, heads=heads)
+                                 word_trainable=word_trainable, news_encoder=news_encoder, heads=heads,
+                                 score_model=score_model)
+        self.score_model = score_model       # listwise --score-model dot | ddot | dnn (paper.py:443-458)
         self.news_encoder = news_encoder     # 'mhsa': build-defined multi-head self-attention token stage (heads x F/heads)
         # how the Conv1D contractions run: 'bf16x3' = fp32-grade 3-way split on the bf16 matrix cores (conv3.hip, filters
         # <= 448), 'f32' = exact-fp32 MFMA (conv.hip; forced by LSTUR_CONV_F32=1)
@@ -114,6 +116,9 @@ class NativeModel:
                            user_emb=(max(1, n_users), Ue), word_emb=(V, D),
                            score_w1=(2 * user_dim, user_dim), score_b1=(user_dim,), score_w2=(user_dim,),
                            score_b2=(1,))
+        Uu = 2 * user_dim if arch in ('ngru', 'dgru') else user_dim      # width of the user vector
+        self.shapes.update(sdu_w=(Uu, user_dim), sdu_b=(user_dim,), sdd_w=(user_dim, user_dim), sdd_b=(user_dim,),
+                           sn1_w=(Uu + user_dim, user_dim), sn1_b=(user_dim,), sn2_w=(user_dim,), sn2_b=(1,))
         dev = self.device
         f32 = torch.float32
         self.word_emb = torch.from_numpy(word_emb).to(dev)
@@ -170,8 +175,7 @@ class NativeModel:
             # build-defined multi-head self-attention encoder of BASELINE.json configs[4] (--title-filter-shape F heads)
             raise _lib.LsturError('news encoder {!r} is not on the native path (have cnnatt, mhsa)'.format(enc))
         head = getattr(task, 'head', 'softmax')
-        if head == 'softmax' and getattr(cfg, 'score_model', 'dot') != 'dot':
-            raise _lib.LsturError('only the dot scorer is on the native path')
+        score_model = getattr(cfg, 'score_model', 'dot') if head == 'softmax' else 'dot'
         emb = utils.load_textual_embedding(cfg.title_embedding_input, cfg.textual_embedding_dim)
         vmax = int(task.docs.title_table.max())
         if vmax >= emb.shape[0]:
@@ -195,7 +199,7 @@ class NativeModel:
                     gain=float(getattr(cfg, 'gain', 1.0)),
                     freeze_encoder=pretrained and not getattr(cfg, 'pretrain_encoder_trainable', False),
                     word_trainable=bool(getattr(cfg, 'textual_embedding_trainable', False)) and not pretrained,
-                    news_encoder=enc, heads=int(kernel) if enc == 'mhsa' else 0)
+                    news_encoder=enc, heads=int(kernel) if enc == 'mhsa' else 0, score_model=score_model)
         if pretrained:                      # paper.py:103-107
             model.load_encoder(cfg.encoder_input)
         return model
@@ -227,6 +231,16 @@ class NativeModel:
         if self.arch == 'gru':
             w['con_w'] = _glorot(rng, s['con_w'], s['con_w'][0], U)
             w['con_b'] = np.zeros(U, np.float32)
+        if self.score_model == 'ddot':   # Dense(U, tanh) on both sides (paper.py:452-454)
+            w['sdu_w'] = _glorot(rng, s['sdu_w'], s['sdu_w'][0], U)
+            w['sdu_b'] = np.zeros(U, np.float32)
+            w['sdd_w'] = _glorot(rng, s['sdd_w'], U, U)
+            w['sdd_b'] = np.zeros(U, np.float32)
+        elif self.score_model == 'dnn':  # Dense(U, relu) -> Dense(1) on the concatenation (paper.py:448-451)
+            w['sn1_w'] = _glorot(rng, s['sn1_w'], s['sn1_w'][0], U)
+            w['sn1_b'] = np.zeros(U, np.float32)
+            w['sn2_w'] = _glorot(rng, s['sn2_w'], U, 1)
+            w['sn2_b'] = np.zeros(1, np.float32)
         if self.head == 'point_mlp':     # concat_dense / socre_dense (paper.py:223-227)
             w['score_w1'] = _glorot(rng, s['score_w1'], 2 * U, U)
             w['score_b1'] = np.zeros(U, np.float32)
@@ -304,6 +318,10 @@ class NativeModel:
         names = tok + ['att_w', 'att_b', 'dense_w', 'dense_b', 'user_emb', 'gru_w', 'gru_u', 'gru_b']
         if self.arch == 'gru':
             names += ['con_w', 'con_b']
+        if self.score_model == 'ddot':
+            names += ['sdu_w', 'sdu_b', 'sdd_w', 'sdd_b']
+        elif self.score_model == 'dnn':
+            names += ['sn1_w', 'sn1_b', 'sn2_w', 'sn2_b']
         return names + ['word_emb']
 
     def save(self, paths):
@@ -314,7 +332,7 @@ class NativeModel:
         json_path, pkl_path = paths
         w = self.get_weights()
         w['word_emb'] = self.word_emb.cpu().numpy()
-        arrays = [w[n].reshape(-1, 1) if n == 'att_w' else w[n] for n in self.keras_weight_order()]
+        arrays = [w[n].reshape(-1, 1) if n in ('att_w', 'sn2_w') else w[n] for n in self.keras_weight_order()]
         with open(json_path, 'w') as f:
             json.dump(dict(format='mnexp_amd-lstur-1', arch=self.arch, order=self.keras_weight_order(),
                            shapes=[list(a.shape) for a in arrays]), f)

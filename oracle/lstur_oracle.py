@@ -38,7 +38,8 @@ import numpy as np
 
 EPS = 1e-7  # keras.backend.epsilon()
 
-ARCHS = ("igru", "gru", "hgru", "nigru")
+ARCHS = ("igru", "gru", "hgru", "nigru", "ngru", "dgru")
+SCORE_MODELS = ("dot", "ddot", "dnn")      # Seq2VecPaperSoftmax._score_model, paper.py:443-458
 
 
 # --------------------------------------------------------------------------
@@ -93,7 +94,7 @@ HEADS = ("softmax", "point_mlp", "point_dot")
 
 
 def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.float32, head="softmax",
-                encoder="cnnatt", heads=1):
+                encoder="cnnatt", heads=1, score_model="dot"):
     """Random-init parameters with the reference's initialisers
     (conv/dense/att: glorot_uniform, biases zero -- paper.py:146,159, models.py:448-449;
     user table uniform +-0.05 -- paper.py:589; GRU kernel glorot, recurrent orthogonal)."""
@@ -123,7 +124,19 @@ def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.fl
     if arch == "gru":
         p["con_w"] = glorot_uniform(rng, (H + Ue, U), H + Ue, U)
         p["con_b"] = np.zeros(U)
-    assert head in HEADS
+    assert head in HEADS and score_model in SCORE_MODELS
+    Uu = 2 * U if arch in ("ngru", "dgru") else U      # width of the user vector (paper.py:600-602, 608-611)
+    assert score_model != "dot" or Uu == U, "ngru / dgru user vectors are 2U wide: not dot-compatible"
+    if score_model == "ddot":    # tanh-Dense on both sides, then dot (paper.py:452-455)
+        p["sdu_w"] = glorot_uniform(rng, (Uu, U), Uu, U)
+        p["sdu_b"] = np.zeros(U)
+        p["sdd_w"] = glorot_uniform(rng, (U, U), U, U)
+        p["sdd_b"] = np.zeros(U)
+    elif score_model == "dnn":   # concat -> Dense(U, relu) -> Dense(1) (paper.py:448-451)
+        p["sn1_w"] = glorot_uniform(rng, (Uu + U, U), Uu + U, U)
+        p["sn1_b"] = np.zeros(U)
+        p["sn2_w"] = glorot_uniform(rng, (U,), U, 1)
+        p["sn2_b"] = np.zeros(1)
     if head == "point_mlp":      # concat_dense / socre_dense of Seq2VecPaper.score_encoder (paper.py:223-227)
         p["score_w1"] = glorot_uniform(rng, (2 * U, U), 2 * U, U)
         p["score_b1"] = np.zeros(U)
@@ -135,7 +148,7 @@ def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.fl
     return p
 
 
-def dense_param_names(arch, word_trainable=False, head="softmax", encoder="cnnatt"):
+def dense_param_names(arch, word_trainable=False, head="softmax", encoder="cnnatt", score_model="dot"):
     """Order of the flat dense-parameter bucket (same order in the HIP library)."""
     names = ["qkv_w", "qkv_b"] if encoder == "mhsa" else ["conv_w", "conv_b"]
     names += ["att_w", "att_b", "dense_w", "dense_b", "gru_w", "gru_u", "gru_b"]
@@ -143,6 +156,10 @@ def dense_param_names(arch, word_trainable=False, head="softmax", encoder="cnnat
         names += ["con_w", "con_b"]
     if head == "point_mlp":
         names += ["score_w1", "score_b1", "score_w2", "score_b2"]
+    if score_model == "ddot":
+        names += ["sdu_w", "sdu_b", "sdd_w", "sdd_b"]
+    elif score_model == "dnn":
+        names += ["sn1_w", "sn1_b", "sn2_w", "sn2_b"]
     return names
 
 
@@ -425,8 +442,9 @@ def split_titles(v, B, W, K1):
     return hv, dv
 
 
-def user_encoder_fwd(p, arch, user, hv, hist_ids):
-    """paper.py:584-633 for arch in igru|gru|hgru; hv [B,W,U] raw doc vectors of the history."""
+def user_encoder_fwd(p, arch, user, hv, hist_ids, uvec_keep=None):
+    """paper.py:584-633 for arch in igru|gru|hgru|nigru|ngru|dgru; hv [B,W,U] raw doc vectors of the history.
+    uvec_keep (dgru, training): bool [B], the whole-vector Dropout(0.5, noise_shape=(None, 1)) of paper.py:610."""
     hmask = np.any(hist_ids != 0, axis=-1)           # models.ComputeMasking, paper.py:644
     hvm = hv * hmask[..., None]                      # paper.py:645
     gmask = np.any(hvm != 0, axis=-1)                # Masking() paper.py:592
@@ -442,13 +460,15 @@ def user_encoder_fwd(p, arch, user, hv, hist_ids):
         extra = None
     else:
         h, gc = gru_fwd(p, hvm, gmask, np.zeros((len(user), H), dtype=hv.dtype))
+        if arch == "dgru" and uvec_keep is not None:
+            uvec = uvec * uvec_keep[:, None] * hv.dtype.type(2.0)
         cat = np.concatenate([h, uvec], axis=1)
         if arch == "gru":
             u = cat @ p["con_w"] + p["con_b"]
-        else:  # hgru
+        else:  # hgru (H = Ue = U/2), ngru / dgru (H = Ue = U: a 2U-wide user vector)
             u = cat
         extra = cat
-    return u, dict(gc=gc, hmask=hmask, user=user, cat=extra, arch=arch)
+    return u, dict(gc=gc, hmask=hmask, user=user, cat=extra, arch=arch, uvec_keep=uvec_keep)
 
 
 def user_encoder_bwd(p, cache, du):
@@ -470,6 +490,8 @@ def user_encoder_bwd(p, cache, du):
             dcat = du
         gg, dx, _ = gru_bwd(p, gc, np.ascontiguousarray(dcat[:, :H]))
         duser = dcat[:, H:]
+        if arch == "dgru" and cache["uvec_keep"] is not None:
+            duser = duser * cache["uvec_keep"][:, None] * du.dtype.type(2.0)
     g.update(gg)
     dhv = dx * cache["hmask"][..., None]
     return g, dhv, duser
@@ -494,6 +516,55 @@ def softmax_ce(z):
     return loss, pr, dz
 
 
+def score_model_of(p):
+    return "ddot" if "sdu_w" in p else ("dnn" if "sn1_w" in p else "dot")
+
+
+def listwise_score_fwd(p, u, dv):
+    """score_model applied to every candidate (paper.py:443-464): u [B,Uu], dv [B,K1,U] -> z [B,K1]."""
+    sm = score_model_of(p)
+    if sm == "dot":
+        return np.einsum("bu,bju->bj", u, dv), None
+    if sm == "ddot":
+        uh = np.tanh(u @ p["sdu_w"] + p["sdu_b"])
+        dh = np.tanh(dv @ p["sdd_w"] + p["sdd_b"])
+        return np.einsum("bu,bju->bj", uh, dh), (uh, dh)
+    B, K1, U = dv.shape
+    cat = np.concatenate([np.repeat(u[:, None, :], K1, axis=1), dv], axis=2).reshape(B * K1, -1)
+    pre = cat @ p["sn1_w"] + p["sn1_b"]
+    hid = np.maximum(pre, 0.0)
+    z = (hid @ p["sn2_w"] + p["sn2_b"][0]).reshape(B, K1)
+    return z, (cat, pre, hid)
+
+
+def listwise_score_bwd(p, u, dv, cache, dz):
+    """dz [B,K1] -> (du [B,Uu], ddv [B,K1,U], grads of the score model's own parameters)."""
+    sm = score_model_of(p)
+    g = {}
+    if sm == "dot":
+        return np.einsum("bj,bju->bu", dz, dv), dz[..., None] * u[:, None, :], g
+    B, K1, U = dv.shape
+    if sm == "ddot":
+        uh, dh = cache
+        duh = np.einsum("bj,bju->bu", dz, dh) * (1.0 - uh * uh)
+        ddh = (dz[..., None] * uh[:, None, :]) * (1.0 - dh * dh)
+        g["sdu_w"] = u.T @ duh
+        g["sdu_b"] = duh.sum(axis=0)
+        g["sdd_w"] = dv.reshape(B * K1, U).T @ ddh.reshape(B * K1, U)
+        g["sdd_b"] = ddh.sum(axis=(0, 1))
+        return duh @ p["sdu_w"].T, ddh @ p["sdd_w"].T, g
+    cat, pre, hid = cache
+    ds = dz.reshape(B * K1)
+    g["sn2_w"] = hid.T @ ds
+    g["sn2_b"] = np.array([ds.sum()], dtype=u.dtype)
+    dhid = ds[:, None] * p["sn2_w"][None, :] * (pre > 0)
+    g["sn1_w"] = cat.T @ dhid
+    g["sn1_b"] = dhid.sum(axis=0)
+    dcat = (dhid @ p["sn1_w"].T).reshape(B, K1, -1)
+    Uu = u.shape[1]
+    return dcat[:, :, :Uu].sum(axis=1), dcat[:, :, Uu:], g
+
+
 def forward_backward(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0, word_trainable=False,
                      want_grads=True):
     """One training step's loss + gradients.
@@ -508,17 +579,18 @@ def forward_backward(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0, wor
     keys = (dropout_key(seed, step, 0), dropout_key(seed, step, 1))
     v, nc = news_encoder_fwd(p, titles, drop_p, keys, training=True)
     hv, dv = split_titles(v, B, W, K1)
-    u, uc = user_encoder_fwd(p, arch, user, hv, hist)
-    z = np.einsum("bu,bju->bj", u, dv)
+    keep_u = dropout_keep(dropout_key(seed, step, 2), B, 0.5) if arch == "dgru" else None   # paper.py:610, training
+    u, uc = user_encoder_fwd(p, arch, user, hv, hist, keep_u)
+    z, sc = listwise_score_fwd(p, u, dv)
     loss_i, pr, dz = softmax_ce(z)
     out = dict(loss=float(loss_i.mean()), acc=float((pr.argmax(axis=1) == 0).mean()),
                probs=pr, logits=z, user_vec=u, doc_vec=v)
     if not want_grads:
         return out
     dz = dz / v.dtype.type(B)
-    du = np.einsum("bj,bju->bu", dz, dv)
-    ddv = dz[..., None] * u[:, None, :]
+    du, ddv, gs = listwise_score_bwd(p, u, dv, sc, dz)
     g, dhv, duser = user_encoder_bwd(p, uc, du)
+    g.update(gs)
     dvv = np.concatenate([dhv.reshape(B * W, -1), ddv.reshape(B * K1, -1)], axis=0)
     g.update(news_encoder_bwd(p, nc, dvv, word_trainable))
     out["grads"] = g
@@ -538,8 +610,8 @@ def predict(p, arch, user, hist, cand):
     v, _ = news_encoder_fwd(p, titles, training=False)
     hv, dv = split_titles(v, n, W, 1)
     u, _ = user_encoder_fwd(p, arch, user, hv, hist)
-    z = np.einsum("bu,bu->b", u, dv[:, 0])
-    return 1.0 / (1.0 + np.exp(-z))
+    z, _ = listwise_score_fwd(p, u, dv)              # sigmoid(score_model([u, d])), paper.py:661-665
+    return 1.0 / (1.0 + np.exp(-z[:, 0]))
 
 
 # --------------------------------------------------------------------------

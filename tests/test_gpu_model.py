@@ -168,6 +168,73 @@ def test_word_table_adam_steps_track_oracle():
         assert err <= 0.05 * moved + 2e-6, (n, err, moved)
 
 
+@pytest.mark.parametrize('arch,score_model', [('igru', 'ddot'), ('igru', 'dnn'), ('gru', 'ddot'), ('hgru', 'dnn'),
+                                              ('ngru', 'ddot'), ('ngru', 'dnn'), ('dgru', 'ddot'), ('dgru', 'dnn')])
+def test_score_models_and_wide_user_vectors_match_oracle(arch, score_model):
+    """--score-model ddot | dnn (paper.py:448-455), and -a ngru | dgru (paper.py:600-602, 608-611: 2U-wide user vectors;
+    dgru drops a sample's whole user embedding with p = 0.5 in training): logits, every gradient, three Adam steps and
+    the test model sigmoid(score_model([u, d]))."""
+    _need_gpu()
+    from oracle import lstur_oracle as O
+    from mnexp_amd.native_model import NativeModel
+    dims, B, W, T, K1, drop = MID, 19, 6, 9, 5, 0.2
+    rng = np.random.default_rng(21)
+    p = O.init_params(rng, arch=arch, dtype=np.float64, score_model=score_model, **dims)
+    for n in p:
+        if n.endswith('_b'):
+            p[n] = rng.normal(0, 0.1, size=p[n].shape)
+    model = NativeModel(p['word_emb'], dims['N_u'], B, W, T, K1 - 1, dims['F'], dims['k'], dims['U'], arch=arch,
+                        dropout=drop, lr=1e-3, seed=77, score_model=score_model)
+    model.set_weights({n: p[n] for n in p if n != 'word_emb'})
+    names = O.dense_param_names(arch, score_model=score_model)
+    assert set(names) | {'user_emb'} == set(model.param_names())
+    user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
+    user[1] = user[0]
+    hist[2] = 0
+    model.step = 3
+    ref = O.forward_backward(p, arch, user, hist, cands, drop_p=drop, seed=77, step=3)
+    from mnexp_amd._lib import lib, check
+    u, h, c = model._dev_i32(user), model._dev_i32(hist), model._dev_i32(cands)
+    check(lib.lstur_forward_backward(model._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), B, 3, 1.0,
+                                     model.stats.data_ptr(), model._stream()), 'fb')
+    torch.cuda.synchronize()
+    loss, acc = model.stats.tolist()
+    logits = model.peek('logits').cpu().numpy().reshape(B, K1)
+    np.testing.assert_allclose(logits, ref['logits'], rtol=1e-3, atol=1e-5)
+    assert abs(loss - ref['loss']) <= 1e-4 * max(1.0, abs(ref['loss'])) and abs(acc - ref['acc']) < 1e-6
+    g = model.get_grads()
+    for n in names:
+        rel_close(g[n], ref['grads'][n], 2e-3, n)
+    rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
+    if arch == 'dgru':       # dropped samples: exactly no gradient for their user row
+        keep = O.dropout_keep(O.dropout_key(77, 3, 2), B, 0.5)
+        assert 0 < keep.sum() < B and not g['user_row_grads'][~keep].any()
+    # three Adam steps
+    p32 = {n: a.astype(np.float32) for n, a in p.items()}
+    opt = O.Adam(p32, names + ['user_emb'], lr=1e-3)
+    model.step = 0
+    for step in range(3):
+        user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
+        O.train_step(p32, arch, opt, user, hist, cands, drop_p=drop, seed=77, step=step)
+        X = [user.astype(np.int64), hist.astype(np.float64)] + [cands[:, j].astype(np.float64) for j in range(K1)]
+        model.train_on_batch(X, None)
+    torch.cuda.synchronize()
+    w = model.get_weights()
+    for n in names + ['user_emb']:
+        if n == 'sn2_b':     # softmax is shift-invariant: this gradient is identically 0, Adam only normalises rounding noise
+            continue
+        moved = np.abs(p32[n].astype(np.float64) - p[n]).max()
+        err = np.abs(w[n].astype(np.float64) - p32[n]).max()
+        assert err <= 0.05 * moved + 2e-6, (n, err, moved)
+    # test model
+    n = 23
+    user, hist, cands = make_batch(rng, n, W, T, 1, dims['V'], dims['N_u'])
+    got = model.predict([user.astype(np.int64), hist.astype(np.float64), cands[:, 0].astype(np.float64)])
+    pw = {k: np.asarray(v, dtype=np.float64) for k, v in w.items()}
+    pw['word_emb'] = p['word_emb']
+    np.testing.assert_allclose(got[:, 0], O.predict(pw, arch, user, hist, cands[:, 0]), rtol=1e-3, atol=1e-6)
+
+
 def test_predict_and_evaluate_match_oracle():
     _need_gpu()
     dims, B, W, T, K1 = MID, 16, 6, 9, 5

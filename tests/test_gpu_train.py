@@ -100,6 +100,22 @@ def test_cli_train_loop_mhsa_encoder(tmp_path):
         run_training(_config(tmp_path, news_encoder='gruatt', epochs=1))
 
 
+@pytest.mark.parametrize('arch,score_model', [('dgru', 'dnn'), ('ngru', 'ddot'), ('igru', 'ddot')])
+def test_cli_train_loop_score_models(tmp_path, arch, score_model):
+    """`--score-model ddot | dnn` and the LSTUR-con user encoders that need them (`-a ngru | dgru`, paper.py:600-611)."""
+    _need_gpu()
+    from mnexp_amd.main import run_training
+    cfg = _config(tmp_path, arch=arch, score_model=score_model, epochs=2, training_step=15, validation_step=2,
+                  validation_impression=20, testing_impression=20, dropout=0.2, ids=True, seed=1)
+    np.random.seed(0)
+    h = run_training(cfg)
+    assert h.model.score_model == score_model and h.model.arch == arch
+    assert 0.0 <= h.last_metrics['auc'] <= 1.0 and np.isfinite(h.last_metrics['mrr'])
+    assert h.model.optimizer.iterations == 30
+    with pytest.raises(Exception, match='2U wide'):
+        run_training(_config(tmp_path, arch='ngru', score_model='dot', epochs=1))
+
+
 def test_cli_train_loop_trainable_word_table(tmp_path):
     """--textual-embedding-trainable (main.py:36, paper.py:132-138): the word table moves, its pad row included."""
     _need_gpu()

@@ -47,6 +47,40 @@ def test_grads_match_autograd(arch, drop):
         np.testing.assert_allclose(g[n], ref, rtol=1e-8, atol=1e-12, err_msg=n)
 
 
+@pytest.mark.parametrize("arch,score_model", [("igru", "ddot"), ("igru", "dnn"), ("gru", "ddot"), ("ngru", "dnn"),
+                                              ("ngru", "ddot"), ("dgru", "dnn"), ("dgru", "ddot"), ("hgru", "dnn")])
+def test_score_models_and_wide_user_vectors_match_autograd(arch, score_model):
+    """`--score-model ddot | dnn` (paper.py:448-455) and the 2U-wide user vectors of `-a ngru | dgru`
+    (paper.py:600-602, 608-611; dgru drops the whole user embedding of a sample with p = 0.5)."""
+    rng = np.random.default_rng(11)
+    p = O.init_params(rng, arch=arch, dtype=np.float64, score_model=score_model, **DIMS)
+    for n in p:
+        if n.endswith("_b"):
+            p[n] = rng.normal(0, 0.1, size=p[n].shape)
+    B, W, T, K1 = 6, 4, 7, 3
+    user, hist, cands = make_batch(rng, B, W, T, K1, DIMS["V"], DIMS["N_u"])
+    user[1] = user[0]
+    out = O.forward_backward(p, arch, user, hist, cands, drop_p=0.0, seed=7, step=2)
+    names = [n for n in p if n != "word_emb"]
+    tp = TR.to_t(p, grad_names=names)
+    keep_u = O.dropout_keep(O.dropout_key(7, 2, 2), B, 0.5) if arch == "dgru" else None
+    if arch == "dgru":
+        assert 0 < keep_u.sum() < B
+    loss, z, pr = TR.model_loss(tp, arch, user, hist, cands, keep_u=keep_u)
+    loss.backward()
+    assert abs(loss.item() - out["loss"]) < 1e-12
+    np.testing.assert_allclose(out["logits"], z.detach().numpy(), rtol=1e-10, atol=1e-12)
+    g = dict(out["grads"])
+    g["user_emb"] = O.densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"], np.float64)
+    assert set(O.dense_param_names(arch, score_model=score_model)) <= set(g)
+    for n in names:
+        np.testing.assert_allclose(g[n], tp[n].grad.numpy(), rtol=1e-8, atol=1e-12, err_msg=n)
+    # test model: sigmoid(score_model([u, d])) without dropout
+    pr1 = O.predict(p, arch, user, hist, cands[:, 1])
+    _, z1, _ = TR.model_loss(tp, arch, user, hist, cands[:, 1:2])
+    np.testing.assert_allclose(pr1, torch.sigmoid(z1[:, 0]).detach().numpy(), rtol=1e-10)
+
+
 @pytest.mark.parametrize("drop", [0.0, 0.25])
 def test_mhsa_grads_match_autograd(drop, monkeypatch):
     """The build-defined multi-head self-attention news encoder (no reference counterpart: SURVEY.md section 8 row

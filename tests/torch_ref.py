@@ -72,7 +72,7 @@ def gru(p, x, mask, h0):
     return h
 
 
-def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0):
+def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0, keep_u=None):
     user = torch.as_tensor(np.asarray(user), dtype=torch.long).reshape(-1)
     hist_np = np.asarray(hist)
     B, W, T = hist_np.shape
@@ -92,10 +92,18 @@ def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0):
         u = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
     else:
         h = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
+        if arch == "dgru" and keep_u is not None:       # Dropout(0.5, noise_shape=(None, 1)), paper.py:610
+            uvec = uvec * torch.as_tensor(keep_u, dtype=uvec.dtype).unsqueeze(-1) * 2.0
         u = torch.cat([h, uvec], dim=1)
         if arch == "gru":
             u = u @ p["con_w"] + p["con_b"]
-    z = (u.unsqueeze(1) * dv).sum(-1)
+    if "sdu_w" in p:                                    # ddot (paper.py:452-455)
+        z = (torch.tanh(u @ p["sdu_w"] + p["sdu_b"]).unsqueeze(1) * torch.tanh(dv @ p["sdd_w"] + p["sdd_b"])).sum(-1)
+    elif "sn1_w" in p:                                  # dnn (paper.py:448-451)
+        cat = torch.cat([u.unsqueeze(1).expand(-1, K1, -1), dv], dim=-1)
+        z = torch.relu(cat @ p["sn1_w"] + p["sn1_b"]) @ p["sn2_w"] + p["sn2_b"]
+    else:
+        z = (u.unsqueeze(1) * dv).sum(-1)
     pr = torch.softmax(z, dim=-1)
     q = pr / pr.sum(-1, keepdim=True)
     q = torch.clamp(q, EPS, 1 - EPS)
