@@ -17,10 +17,27 @@
 
 namespace lstur {
 
-constexpr int C3_BM = 128, C3_BK = 16, C3_SA = 24, C3_SB = 480, C3_NTW = 7, C3_THREADS = 512;
-constexpr int C3_A_IMG = C3_BM * C3_SA, C3_B_IMG = C3_BK * C3_SB;          // elements per split part
-constexpr int C3_STAGE = 3 * C3_A_IMG + 3 * C3_B_IMG;                      // elements per pipeline stage
-constexpr size_t C3_LDS = 2 * C3_STAGE * sizeof(unsigned short) + 2 * C3_BM * sizeof(int32_t);
+constexpr int C3_BK = 16, C3_SA = 24;   // k-step; A image row stride (48-byte rows: conflict-free ds_read_b128)
+
+// One kernel, two shapes.  <4, 2, 7> (512 threads): 128 token rows x all column tiles (7 + up to 7) -- the bulk.
+// <1, 2, 1> (128 threads): 32 rows x 64 columns -- the REMAINDER.  Row tiles of 128 are coarse: 514 of them on 256
+// CUs (one resident workgroup per CU, 127 KB of LDS) take three rounds for 2.008 rounds of work.  So the bulk launch
+// only takes whole rounds of 256 tiles (plus a last partial round of >= 64 tiles), and the rows behind them go to the
+// small shape, whose many light workgroups (7 column groups per 32 rows) spread over all CUs.
+__host__ __device__ constexpr int c3_rows(int RW) { return 32 * RW; }
+__host__ __device__ constexpr int c3_sb(int CW, int NTW) { return tr_stride(CW * NTW * 32); }
+__host__ __device__ constexpr int c3_stage(int RW, int CW, int NTW) {
+  return 3 * c3_rows(RW) * C3_SA + 3 * C3_BK * c3_sb(CW, NTW);
+}
+__host__ __device__ constexpr size_t c3_lds(int RW, int CW, int NTW) {
+  return 2 * c3_stage(RW, CW, NTW) * sizeof(unsigned short) + 2 * c3_rows(RW) * sizeof(int32_t);
+}
+// rows [0, bulk_rows) belong to the bulk shape, [bulk_rows, count) to the remainder shape
+__host__ __device__ inline int c3_bulk_rows(int count) {
+  const int tiles = (count + 127) / 128, part = tiles % 256;
+  const int bulk_tiles = part < 64 ? tiles - part : tiles;
+  return min(count, bulk_tiles * 128);
+}
 
 bool conv3_supported(int D, int ksize, int F) { return D % 4 == 0 && F >= 1 && F <= 448; }
 static int conv3_kp(int K) { return cdiv(K, C3_BK) * C3_BK; }
@@ -45,73 +62,92 @@ void launch_conv3_pack_w(const float* W, int K, int F, unsigned short* W3, hipSt
   hipLaunchKernelGGL(conv3_pack_w_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, W, K, F, Kp, Np, W3);
 }
 
-__global__ __launch_bounds__(C3_THREADS) void conv3_fwd_kernel(const float* __restrict__ E, uint32_t e_bytes,
+template <int RW, int CW, int NTW, bool REMAINDER>
+__global__ __launch_bounds__(RW* CW * 64) void conv3_fwd_kernel(const float* __restrict__ E, uint32_t e_bytes,
                                                                const unsigned short* __restrict__ W3,
                                                                const float* __restrict__ bias,
                                                                const int32_t* __restrict__ ids, float* __restrict__ C,
                                                                const int32_t* __restrict__ vidx,
                                                                const int32_t* __restrict__ vcount, int M, int T, int Tp, int D,
                                                                int F, int Kp, int Np) {
+  constexpr int BM = c3_rows(RW), NTH = RW * CW * 64, SB = c3_sb(CW, NTW), BCOLS = CW * NTW * 32;
+  constexpr int A_IMG = BM * C3_SA, B_IMG = C3_BK * SB, STAGE = c3_stage(RW, CW, NTW);
+  constexpr int A_PER = (BM * 4 + NTH - 1) / NTH;                    // float4 per thread of the BM x 16 A tile
+  constexpr int B_CH = 3 * C3_BK * (BCOLS / 8), B_PER = (B_CH + NTH - 1) / NTH;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  int32_t* rowm = (int32_t*)(smem + 2 * C3_STAGE);        // output row of each of the 128 tile rows (-1: none)
-  float* rowkeep = (float*)(rowm + C3_BM);                // 1 / 0: id != 0
+  int32_t* rowm = (int32_t*)(smem + 2 * STAGE);           // output row of each tile row (-1: none)
+  float* rowkeep = (float*)(rowm + BM);                   // 1 / 0: id != 0
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int count = vcount ? vcount[0] : M;
-  const int m0 = blockIdx.x * C3_BM;
-  if (m0 >= count) return;
+  const int bulk = c3_bulk_rows(count);
+  const int m0 = REMAINDER ? bulk + blockIdx.x * BM : blockIdx.x * BM;
+  const int m_end = REMAINDER ? count : bulk;
+  if (m0 >= m_end) return;
   const int NT = Np / 32;                                  // column tiles of 32
-  const int wm = wv >> 1, wn = wv & 1;
-  const int nt_lo = wn * C3_NTW, my_nt = max(0, min(C3_NTW, NT - nt_lo));
+  const int col0 = blockIdx.y * BCOLS;                     // first column of this workgroup
+  const int wm = wv / CW, wn = wv - wm * CW;
+  const int nt_lo = col0 / 32 + wn * NTW, my_nt = max(0, min(NTW, NT - nt_lo));
 
-  // A loader role: thread -> (row, 4 k) of the 128 x 16 tile; the row's window offset in E is fixed for the kernel
-  const int arow = tid >> 2, aseg = tid & 3;
-  uint32_t a_off;
-  {
-    const int i = min(m0 + arow, count - 1);
+  // A loader role: piece -> (row, 4 k) of the BM x 16 tile; the row's window offset in E is fixed for the kernel
+  uint32_t a_off[A_PER];
+  int a_lds[A_PER];
+#pragma unroll
+  for (int p = 0; p < A_PER; ++p) {
+    const int idx = tid + p * NTH, arow = idx >> 2, aseg = idx & 3;
+    const bool use = (BM * 4) % NTH == 0 || idx < BM * 4;
+    const int i = min(m0 + min(arow, BM - 1), count - 1);
     const int m = vidx ? vidx[i] : i;
     const int title = m / T, t = m - title * T;
-    a_off = ((uint32_t)(title * Tp + t) * (uint32_t)D + (uint32_t)aseg * 4u) * 4u;
-    if (aseg == 0) {
-      rowm[arow] = (m0 + arow < count) ? m : -1;
+    a_off[p] = use ? ((uint32_t)(title * Tp + t) * (uint32_t)D + (uint32_t)aseg * 4u) * 4u : kBufOob;
+    a_lds[p] = use ? arow * C3_SA + aseg * 4 : -1;
+    if (use && aseg == 0) {
+      rowm[arow] = (m0 + arow < m_end) ? m : -1;
       rowkeep[arow] = ids[m] != 0 ? 1.f : 0.f;
     }
   }
-  // B loader role: up to 6 pieces of 16 bytes (8 columns) of the 3 x [16][Np] weight tile
-  const int C8 = Np / 8, b_total = 3 * C3_BK * C8;
-  uint32_t b_goff[6];
-  int b_loff[6];
+  // B loader role: pieces of 16 bytes (8 columns) of the 3 x [16][BCOLS] window of the weight parts
+  uint32_t b_goff[B_PER];
+  int b_loff[B_PER];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int idx = tid + i * C3_THREADS;
+  for (int i = 0; i < B_PER; ++i) {
+    const int idx = tid + i * NTH;
+    constexpr int C8 = BCOLS / 8;
     const int img = idx / (C3_BK * C8), rem = idx - img * (C3_BK * C8), krow = rem / C8, ch = rem - krow * C8;
-    b_goff[i] = idx < b_total ? (((uint32_t)img * (uint32_t)Kp + (uint32_t)krow) * (uint32_t)Np + (uint32_t)ch * 8u) * 2u : kBufOob;
-    b_loff[i] = idx < b_total ? 3 * C3_A_IMG + img * C3_B_IMG + krow * C3_SB + ch * 8 : -1;
+    const bool use = idx < B_CH && col0 + ch * 8 < Np;
+    b_goff[i] = use ? (((uint32_t)img * (uint32_t)Kp + (uint32_t)krow) * (uint32_t)Np + (uint32_t)(col0 + ch * 8)) * 2u : kBufOob;
+    b_loff[i] = use ? 3 * A_IMG + img * B_IMG + krow * SB + ch * 8 : -1;
   }
   const __amdgpu_buffer_rsrc_t rsE = make_rsrc(E, e_bytes);
   const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W3, (uint32_t)((size_t)3 * Kp * Np * 2));
 
-  f32x16 acc[C3_NTW];
+  f32x16 acc[NTW];
 #pragma unroll
-  for (int j = 0; j < C3_NTW; ++j)
+  for (int j = 0; j < NTW; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  float4 ra;
-  float4 rb[6];
+  float4 ra[A_PER];
+  float4 rb[B_PER];
   auto load = [&](int k0) {
-    ra = buf_load4(rsE, a_off, (uint32_t)k0 * 4u);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) rb[i] = buf_load4(rsW, b_goff[i], (uint32_t)k0 * (uint32_t)Np * 2u);
+    for (int p = 0; p < A_PER; ++p) ra[p] = buf_load4(rsE, a_off[p], (uint32_t)k0 * 4u);
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) rb[i] = buf_load4(rsW, b_goff[i], (uint32_t)k0 * (uint32_t)Np * 2u);
   };
   auto store = [&](int buf) {
-    unsigned short* st = smem + buf * C3_STAGE;
-    u16x4 h, m, l;
-    split3(ra, h, m, l);
-    *(u16x4*)(st + arow * C3_SA + aseg * 4) = h;
-    *(u16x4*)(st + C3_A_IMG + arow * C3_SA + aseg * 4) = m;
-    *(u16x4*)(st + 2 * C3_A_IMG + arow * C3_SA + aseg * 4) = l;
+    unsigned short* st = smem + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int p = 0; p < A_PER; ++p) {
+      if (a_lds[p] >= 0) {
+        u16x4 h, m, l;
+        split3(ra[p], h, m, l);
+        *(u16x4*)(st + a_lds[p]) = h;
+        *(u16x4*)(st + A_IMG + a_lds[p]) = m;
+        *(u16x4*)(st + 2 * A_IMG + a_lds[p]) = l;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
       if (b_loff[i] >= 0) *(float4*)(st + b_loff[i]) = rb[i];
   };
 
@@ -128,17 +164,17 @@ __global__ __launch_bounds__(C3_THREADS) void conv3_fwd_kernel(const float* __re
       store(buf ^ 1);
       if (it + 2 < nit) load((it + 2) * C3_BK);
     }
-    const unsigned short* st = smem + buf * C3_STAGE;
+    const unsigned short* st = smem + buf * STAGE;
     const unsigned short* ap = st + (32 * wm + (lane & 31)) * C3_SA + 8 * (lane >> 5);
-    const u16x8 ah = *(const u16x8*)ap, am = *(const u16x8*)(ap + C3_A_IMG), al = *(const u16x8*)(ap + 2 * C3_A_IMG);
-    const unsigned short* bp = st + 3 * C3_A_IMG;
+    const u16x8 ah = *(const u16x8*)ap, am = *(const u16x8*)(ap + A_IMG), al = *(const u16x8*)(ap + 2 * A_IMG);
+    const unsigned short* bp = st + 3 * A_IMG;
 #pragma unroll
-    for (int j = 0; j < C3_NTW; ++j) {
+    for (int j = 0; j < NTW; ++j) {
       if (j < my_nt) {                                   // wave-uniform: EXEC stays full for the transposed reads
-        const int x0 = (nt_lo + j) * 32;
-        const u16x8 bh = tr_frag(bp, C3_SB, 0, x0, lane);
-        const u16x8 bm = tr_frag(bp + C3_B_IMG, C3_SB, 0, x0, lane);
-        const u16x8 bl = tr_frag(bp + 2 * C3_B_IMG, C3_SB, 0, x0, lane);
+        const int x0 = (wn * NTW + j) * 32;              // column inside this workgroup's window
+        const u16x8 bh = tr_frag(bp, SB, 0, x0, lane);
+        const u16x8 bm = tr_frag(bp + B_IMG, SB, 0, x0, lane);
+        const u16x8 bl = tr_frag(bp + 2 * B_IMG, SB, 0, x0, lane);
         f32x16 c = acc[j];
         c = mfma32b(al, bh, c);                          // small terms first
         c = mfma32b(ah, bl, c);
@@ -165,7 +201,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv3_fwd_kernel(const float* __re
     okeep[r] = rowkeep[lr];
   }
 #pragma unroll
-  for (int j = 0; j < C3_NTW; ++j) {
+  for (int j = 0; j < NTW; ++j) {
     const int col = (nt_lo + j) * 32 + c32;
     const bool cok = j < my_nt && col < F;
     const float bv = buf_load1(rsBias, cok ? (uint32_t)col * 4u : kBufOob, 0);
@@ -181,16 +217,22 @@ void launch_conv3_fwd(const float* emb, const unsigned short* W3, const float* b
                       hipStream_t s) {
   const int M = n_titles * T;
   if (M == 0) return;
-  const int Tp = T + ksize - 1, K = ksize * D;
+  const int Tp = T + ksize - 1, K = ksize * D, Np = conv3_np(F);
+  auto bulk = conv3_fwd_kernel<4, 2, 7, false>;
+  auto rest = conv3_fwd_kernel<1, 2, 1, true>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv3_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS);
+    (void)hipFuncSetAttribute((const void*)bulk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c3_lds(4, 2, 7));
     attr_set = true;
   }
   // the padded embedding layout + its zero slack (kEmbSlack floats): the k-tail of the last window reads into it
   const uint32_t e_bytes = (uint32_t)std::min(((size_t)n_titles * Tp * D + kEmbSlack) * 4, (size_t)0xFFFFFFFFu);
-  hipLaunchKernelGGL(conv3_fwd_kernel, dim3(cdiv(M, C3_BM)), dim3(C3_THREADS), C3_LDS, s, emb, e_bytes, W3, bias, ids, out,
-                     vidx, vcount, M, T, Tp, D, F, conv3_kp(K), conv3_np(F));
+  hipLaunchKernelGGL(bulk, dim3(cdiv(M, 128)), dim3(512), c3_lds(4, 2, 7), s, emb, e_bytes, W3, bias, ids, out, vidx, vcount,
+                     M, T, Tp, D, F, conv3_kp(K), Np);
+  // remainder: fewer than 64 tiles of 128 rows (the device decides from the token count), 64 columns per workgroup
+  const int rest_rows = std::min(M, 64 * 128);
+  hipLaunchKernelGGL(rest, dim3(cdiv(rest_rows, 32), cdiv(Np, 64)), dim3(128), c3_lds(1, 2, 1), s, emb, e_bytes, W3, bias, ids,
+                     out, vidx, vcount, M, T, Tp, D, F, conv3_kp(K), Np);
 }
 
 
