@@ -144,13 +144,16 @@ __device__ __forceinline__ void title_load(const float* __restrict__ c, const in
     const int row = n * T + min(t, T - 1);
     live[i] = t < T && (!ids || ids[row] != 0);
   }
+  // all 16 row pieces in flight at once: buffer loads with the out-of-range offset for pad / missing rows and columns
+  // past F (a guarded load is a branch + s_waitcnt each, i.e. 16 serialised round trips)
+  const __amdgpu_buffer_rsrc_t rsc = make_rsrc(c + (size_t)n * T * F, (uint32_t)T * (uint32_t)F * 4u);
 #pragma unroll
   for (int i = 0; i < kTitleTok; ++i) {
-    const int row = n * T + min(wv + 4 * i, T - 1);
+    const int t = min(wv + 4 * i, T - 1);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int f4 = lane + 64 * h;
-      x[i][h] = (live[i] && f4 < F4) ? ((const float4*)(c + (size_t)row * F))[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      x[i][h] = buf_load4(rsc, (live[i] && f4 < F4) ? ((uint32_t)t * (uint32_t)F + (uint32_t)f4 * 4u) * 4u : kBufOob, 0);
     }
   }
 #pragma unroll
@@ -182,9 +185,9 @@ __global__ __launch_bounds__(256) void att_fwd_title_kernel(const float* __restr
   bool live[kTitleTok], nz[kTitleTok];
   title_load(c, ids, n, T, F, wv, lane, thresh, key, scale, x, live, nz);
   float4 kf[2];
+  const __amdgpu_buffer_rsrc_t rs_aw = make_rsrc(att_w, (uint32_t)F * 4u);
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-    kf[h] = (lane + 64 * h < F4) ? ((const float4*)att_w)[lane + 64 * h] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int h = 0; h < 2; ++h) kf[h] = buf_load4(rs_aw, (uint32_t)(lane + 64 * h) * 16u, 0);   // past F: zeros
   const float b = att_b[0];
 #pragma unroll
   for (int i = 0; i < kTitleTok; ++i) {
@@ -254,29 +257,35 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
   float wt[kTitleTok];
   title_load(c, ids, n, T, F, wv, lane, thresh, key, scale, x, live, nz);
   float4 dp[2], kf[2];
+  const __amdgpu_buffer_rsrc_t rs_aw = make_rsrc(att_w, (uint32_t)F * 4u);
+  const __amdgpu_buffer_rsrc_t rs_dp = make_rsrc(dpooled + (size_t)n * F, (uint32_t)F * 4u);
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(w + (size_t)n * T, (uint32_t)T * 4u);
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(a + (size_t)n * T, (uint32_t)T * 4u);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const bool ok = lane + 64 * h < F4;
-    dp[h] = ok ? ((const float4*)(dpooled + (size_t)n * F))[lane + 64 * h] : make_float4(0.f, 0.f, 0.f, 0.f);
-    kf[h] = ok ? ((const float4*)att_w)[lane + 64 * h] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int h = 0; h < 2; ++h) {   // columns past F read zeros (descriptor range)
+    dp[h] = buf_load4(rs_dp, (uint32_t)(lane + 64 * h) * 16u, 0);
+    kf[h] = buf_load4(rs_aw, (uint32_t)(lane + 64 * h) * 16u, 0);
   }
+  float av_[kTitleTok];
 #pragma unroll
   for (int i = 0; i < kTitleTok; ++i) {
     const int t = wv + 4 * i;
-    wt[i] = live[i] ? w[(size_t)n * T + t] : 0.f;     // masked rows: weight 0, they contribute nothing
+    wt[i] = buf_load1(rs_w, live[i] ? (uint32_t)t * 4u : kBufOob, 0);   // masked rows: weight 0, they contribute nothing
+    av_[i] = buf_load1(rs_a, (uint32_t)t * 4u, 0);                        // t >= T: 0
     const float s = wave_sum(dot4(x[i][0], dp[0]) + dot4(x[i][1], dp[1]));
     if (t < T && lane == 0) dwL[t] = wt[i] != 0.f ? s : 0.f;
   }
   __syncthreads();
   float sum = 0.f;
   for (int t = 0; t < T; ++t) sum += dwL[t] * w[(size_t)n * T + t];
+  const __amdgpu_buffer_rsrc_t rs_dc = make_rsrc(dc + (size_t)n * T * F, (uint32_t)T * (uint32_t)F * 4u);
   float4 gaw[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, gcb[2] = {gaw[0], gaw[0]};
 #pragma unroll
   for (int i = 0; i < kTitleTok; ++i) {
     const int t = wv + 4 * i;
     if (t >= T) continue;
     const size_t row = (size_t)n * T + t;
-    const float av = a[row];
+    const float av = av_[i];
     const float dst = (dwL[t] - sum) * wt[i] * (1.0f - av * av);
     if (lane == 0) dsL[t] = dst;
     if (!live[i]) continue;                            // pad token: its dconv row is neither read nor written
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
         gcb[h].z += o.z;
         gcb[h].w += o.w;
       }
-      if (lane + 64 * h < F4) ((float4*)(dc + row * F))[lane + 64 * h] = o;
+      buf_store4(o, rs_dc, (lane + 64 * h < F4) ? ((uint32_t)t * (uint32_t)F + (uint32_t)(lane + 64 * h) * 4u) * 4u : kBufOob, 0);
     }
   }
 #pragma unroll

@@ -54,6 +54,10 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t v
   return *(float4*)&v;
 }
 
+__device__ __forceinline__ void buf_store4(float4 v, __amdgpu_buffer_rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes) {
+  __builtin_amdgcn_raw_buffer_store_b128(*(u32x4*)&v, r, (int)voff_bytes, (int)soff_bytes, 0);
+}
+
 // one dword per lane through a buffer descriptor: lanes whose offset is past the descriptor's range (e.g.
 // kBufOob) load 0 and store nothing, so column guards need no exec-mask branches and no address VGPRs
 constexpr uint32_t kBufOob = 0x80000000u;
