@@ -10,8 +10,11 @@
 namespace lstur {
 
 constexpr int GT = 64, GK = 32, GLD = 80;  // tile, k-step, LDS row stride (80 % 32 == 16: conflict-free b32 reads)
+constexpr int GQ = GT * GK / 4 / 256;       // float4 per thread and operand tile
+constexpr int GKF = GK / 4;                 // float4 per k-row of a k-contiguous operand
 
-// One 64 x 32 operand tile = 512 float4, two per thread.  KMAJOR: the operand is stored with k contiguous
+// One 64 x GK operand tile, GQ float4 per thread (GK = 64 was tried: the transposing LDS stores of the k-contiguous
+// operand double per step and the forward shapes lose 40 %).  KMAJOR: the operand is stored with k contiguous
 // (A[m][k] or B[n][k]) and is transposed on its way into the k-major LDS image; otherwise (A[k][m] / B[k][n])
 // the image is a straight copy.
 // Loads go through a buffer descriptor covering exactly the operand (reads past its end return 0) and carry NO
@@ -20,13 +23,13 @@ constexpr int GT = 64, GK = 32, GLD = 80;  // tile, k-step, LDS row stride (80 %
 // when the tile is written to LDS; rows / columns past M / N hold in-range garbage that only reaches outputs which
 // are never stored.
 template <bool KMAJOR>
-__device__ __forceinline__ void tile_load(__amdgpu_buffer_rsrc_t rs, int ld, int x0, int k0, int tid, float4 (&r)[2]) {
+__device__ __forceinline__ void tile_load(__amdgpu_buffer_rsrc_t rs, int ld, int x0, int k0, int tid, float4 (&r)[GQ]) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < GQ; ++q) {
     const int idx = tid + q * 256;
     uint32_t off;
     if (KMAJOR) {
-      const int x = idx >> 3, kg = (idx & 7) * 4;
+      const int x = idx / GKF, kg = (idx % GKF) * 4;
       off = ((uint32_t)(x0 + x) * (uint32_t)ld + (uint32_t)(k0 + kg)) * 4u;
     } else {
       const int k = idx >> 4, xg = (idx & 15) * 4;
@@ -36,12 +39,12 @@ __device__ __forceinline__ void tile_load(__amdgpu_buffer_rsrc_t rs, int ld, int
   }
 }
 template <bool KMAJOR>
-__device__ __forceinline__ void tile_store(float (*S)[GLD], int tid, const float4 (&r)[2], int k0, int kend) {
+__device__ __forceinline__ void tile_store(float (*S)[GLD], int tid, const float4 (&r)[GQ], int k0, int kend) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < GQ; ++q) {
     const int idx = tid + q * 256;
     if (KMAJOR) {
-      const int x = idx >> 3, kg = (idx & 7) * 4, kv = kend - (k0 + kg);   // valid k from kg on
+      const int x = idx / GKF, kg = (idx % GKF) * 4, kv = kend - (k0 + kg);   // valid k from kg on
       S[kg + 0][x] = kv > 0 ? r[q].x : 0.f;
       S[kg + 1][x] = kv > 1 ? r[q].y : 0.f;
       S[kg + 2][x] = kv > 2 ? r[q].z : 0.f;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // register-staged pipeline: the next tile's global loads are in flight while this tile's MFMAs run
-  float4 ra[2], rb[2];
+  float4 ra[GQ], rb[GQ];
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, bytesA), rsB = make_rsrc(B, bytesB);
   tile_load<!TA>(rsA, lda, m0, kbeg, tid, ra);
   tile_load<TB>(rsB, ldb, n0, kbeg, tid, rb);
