@@ -20,11 +20,13 @@
 namespace lstur {
 
 __device__ __forceinline__ float4 drop4(float4 v, uint32_t key, uint32_t e, uint32_t thresh, float scale) {
-  if (thresh) {
-    v.x = keep_elem(key, e + 0u, thresh) ? v.x * scale : 0.f;
-    v.y = keep_elem(key, e + 1u, thresh) ? v.y * scale : 0.f;
-    v.z = keep_elem(key, e + 2u, thresh) ? v.z * scale : 0.f;
-    v.w = keep_elem(key, e + 3u, thresh) ? v.w * scale : 0.f;
+  if (thresh) {          // e is a multiple of 4: two hashes decide the four elements
+    bool k[4];
+    keep_quad(key, e, thresh, k);
+    v.x = k[0] ? v.x * scale : 0.f;
+    v.y = k[1] ? v.y * scale : 0.f;
+    v.z = k[2] ? v.z * scale : 0.f;
+    v.w = k[3] ? v.w * scale : 0.f;
   }
   return v;
 }

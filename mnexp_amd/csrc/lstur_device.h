@@ -22,10 +22,22 @@ __host__ __device__ __forceinline__ uint32_t dropout_key(uint32_t seed, uint32_t
   uint32_t k = fmix32(seed + 0x9E3779B9u * (stream + 1u));
   return fmix32(k ^ (step * 0x7FEB352Du + 0x165667B1u));
 }
-__host__ __device__ __forceinline__ uint32_t dropout_thresh(float p) { return (uint32_t)(p * 16777216.0f); }
+// One hash decides a PAIR of elements (its two 16-bit halves against a 16-bit threshold): the masks are pure VALU work
+// on the gather / attention kernels' critical path, and a hash per element made those kernels ALU-bound.
+__host__ __device__ __forceinline__ uint32_t dropout_thresh(float p) { return (uint32_t)(p * 65536.0f); }
+__device__ __forceinline__ uint32_t pair_hash(uint32_t key, uint32_t pair) { return fmix32(pair * 0x9E3779B1u + key); }
 // keep element idx?  (thresh == 0 keeps everything)
 __device__ __forceinline__ bool keep_elem(uint32_t key, uint32_t idx, uint32_t thresh) {
-  return (fmix32(idx * 0x9E3779B1u + key) >> 8) >= thresh;
+  const uint32_t h = pair_hash(key, idx >> 1);
+  return ((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thresh;
+}
+// the four decisions of elements e .. e+3 (e a multiple of 4) from two hashes
+__device__ __forceinline__ void keep_quad(uint32_t key, uint32_t e, uint32_t thresh, bool (&k)[4]) {
+  const uint32_t h0 = pair_hash(key, e >> 1), h1 = pair_hash(key, (e >> 1) + 1u);
+  k[0] = (h0 & 0xFFFFu) >= thresh;
+  k[1] = (h0 >> 16) >= thresh;
+  k[2] = (h1 & 0xFFFFu) >= thresh;
+  k[3] = (h1 >> 16) >= thresh;
 }
 
 // ---- wave (64 lanes) reductions ---------------------------------------------------------------

@@ -47,10 +47,12 @@ __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ 
       float4 w = v[u];
       if (DROP) {
         const uint32_t e = (tok[u] * (uint32_t)D4 + c4[u]) * 4u;
-        w.x = keep_elem(key, e + 0u, thresh) ? w.x * scale : 0.f;
-        w.y = keep_elem(key, e + 1u, thresh) ? w.y * scale : 0.f;
-        w.z = keep_elem(key, e + 2u, thresh) ? w.z * scale : 0.f;
-        w.w = keep_elem(key, e + 3u, thresh) ? w.w * scale : 0.f;
+        bool k[4];
+        keep_quad(key, e, thresh, k);
+        w.x = k[0] ? w.x * scale : 0.f;
+        w.y = k[1] ? w.y * scale : 0.f;
+        w.z = k[2] ? w.z * scale : 0.f;
+        w.w = k[3] ? w.w * scale : 0.f;
       }
       if (!real[u]) w = make_float4(0.f, 0.f, 0.f, 0.f);
       if (inr[u]) out[i0 + u * stride] = w;

@@ -65,14 +65,15 @@ def dropout_key(seed: int, step: int, stream: int) -> int:
 
 
 def dropout_keep(key: int, n: int, p: float, start: int = 0):
-    """keep[i] for element indices start..start+n-1:  (hash >> 8) >= floor(p * 2^24)."""
+    """keep[i] for element indices start..start+n-1: one hash per PAIR of elements, its low / high 16 bits against
+    floor(p * 2^16)  (csrc/lstur_device.h: keep_elem / keep_quad)."""
     if p <= 0.0:
         return np.ones(n, dtype=bool)
     with np.errstate(over="ignore"):
         idx = np.arange(start, start + n, dtype=np.uint64).astype(np.uint32)
-        h = _fmix32(idx * np.uint32(0x9E3779B1) + np.uint32(key))
-    thresh = np.uint32(int(p * 16777216.0))
-    return (h >> np.uint32(8)) >= thresh
+        h = _fmix32((idx >> np.uint32(1)) * np.uint32(0x9E3779B1) + np.uint32(key))
+    field = np.where(idx & np.uint32(1), h >> np.uint32(16), h & np.uint32(0xFFFF))
+    return field >= np.uint32(int(p * 65536.0))
 
 
 # --------------------------------------------------------------------------

@@ -148,10 +148,12 @@ def test_dropout_hash_scalar_restatement():
     k = fmix(k ^ ((step * 0x7FEB352D + 0x165667B1) & 0xFFFFFFFF))
     assert k == O.dropout_key(seed, step, stream)
     keep = O.dropout_keep(k, 1000, 0.2, start=5)
-    thr = int(0.2 * 16777216.0)
+    thr = int(0.2 * 65536.0)
     for i in range(1000):
-        h = fmix(((i + 5) * 0x9E3779B1 + k) & 0xFFFFFFFF)
-        assert keep[i] == ((h >> 8) >= thr)
+        e = i + 5
+        h = fmix(((e >> 1) * 0x9E3779B1 + k) & 0xFFFFFFFF)        # one hash per pair of elements
+        assert keep[i] == (((h >> 16) if e & 1 else (h & 0xFFFF)) >= thr)
+    assert abs(O.dropout_keep(k, 200000, 0.2).mean() - 0.8) < 3e-3
 
 
 def test_adam_matches_keras_formula():
