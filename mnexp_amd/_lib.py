@@ -109,6 +109,13 @@ def _load():
         raise LsturError(
             'liblstur_hip.so is not built ({}): the LSTUR path is HIP-only and has no CPU fallback. '
             'Run `make -C mnexp_amd/csrc` (hipcc, gfx950).'.format(LIB_PATH))
+    # PyTorch-ROCm bundles its own HIP runtime; if this library is loaded first it binds the system one and the two
+    # runtimes then disagree about the devices (hipGetDeviceCount fails in whichever came second).  Loading torch
+    # first makes both share torch's copy.  (The plain-C example links the system runtime and needs no torch.)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
