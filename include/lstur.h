@@ -46,10 +46,14 @@ enum lstur_arch {            /* user encoders of Seq2VecPaperSoftmaxId.get_user_
                                 id-less Seq2VecPaperSoftmax, paper.py:206-208); user arguments are ignored     */
   LSTUR_ARCH_NGRU = 4,       /* LSTUR-con, plain concat[GRU(U)(x), user_vec]: a 2U-wide user vector (paper.py:600-602);
                                 needs score_model ddot or dnn                                                  */
-  LSTUR_ARCH_DGRU = 5        /* ngru with Dropout(0.5, noise_shape=(None,1)) on the user embedding: a sample's whole
+  LSTUR_ARCH_DGRU = 5,       /* ngru with Dropout(0.5, noise_shape=(None,1)) on the user embedding: a sample's whole
                                 embedding is dropped with p = 0.5 in training (paper.py:608-611; the masking of
                                 the LSTUR paper); dropout stream 2 of the step                                 */
-};
+  LSTUR_ARCH_PGRU = 6,       /* GRU(U)(x) + user_vec                                      paper.py:624-626       */
+  LSTUR_ARCH_VO = 7,         /* the user embedding alone; the history is not used         paper.py:622-623       */
+  LSTUR_ARCH_NIAVG = 8       /* no user id: sum_w x_w / (sum_w mask_w + 1e-7), models.GlobalAveragePoolingMaskSupport
+                                (models.py:433-435)                                       paper.py:629-630       */
+};                           /* vo / niavg have no GRU: gru_w / gru_u / gru_b stay in the bucket with zero gradients */
 
 enum lstur_score_model {     /* Seq2VecPaperSoftmax._score_model (--score-model), paper.py:443-458; listwise head only */
   LSTUR_SCORE_DOT = 0,       /* dot([u, d])                                                                     */

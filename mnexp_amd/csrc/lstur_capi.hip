@@ -63,7 +63,7 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     *why = "filters must be <= 1024";
     return false;
   }
-  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_DGRU) {
+  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_NIAVG) {
     *why = "unknown arch";
     return false;
   }
@@ -468,17 +468,25 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     launch_drop_rows(w.uvec, n, d.Ue, 0.5f, dropout_key(c->cfg.seed, step, 2), s);
   launch_gemm(w.docvec, d.U, 0, c->P("gru_w"), 3 * d.H, 0, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, 1.f,
               w.gemm_scratch, s);
+  if (d.arch == LSTUR_ARCH_VO) {          // the user embedding alone (paper.py:622-623)
+    (void)hipMemcpyAsync(w.uservec, w.uvec, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
+  } else if (d.arch == LSTUR_ARCH_NIAVG) {   // masked mean of the history vectors (paper.py:629-630)
+    launch_masked_mean(w.docvec, w.gmask, w.uservec, nullptr, nullptr, n, d.W, d.U, s);
+  } else {
   // igru / nigru: the last state IS the user vector (H == U): the recurrence writes it in place
   const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
   PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.gru_up,
                                  w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s));
-  if (!direct) {
+  if (d.arch == LSTUR_ARCH_PGRU) {        // GRU(U)(x) + user_vec (paper.py:624-626)
+    launch_add2(w.hlast, w.uvec, w.uservec, (size_t)n * d.U, s);
+  } else if (!direct) {
     launch_concat2(w.hlast, d.H, w.uvec, d.Ue, w.cat, n, s);
     if (d.arch == LSTUR_ARCH_GRU)
       launch_gemm(w.cat, d.H + d.Ue, 0, c->P("con_w"), d.U, 0, w.uservec, d.U, c->P("con_b"), n, d.U, d.H + d.Ue, 1.f,
                   w.gemm_scratch, s);
     else   // hgru (U/2 + U/2), ngru / dgru (U + U): the concatenation is the user vector
       (void)hipMemcpyAsync(w.uservec, w.cat, (size_t)n * d.Uu * 4, hipMemcpyDeviceToDevice, s);
+  }
   }
   c->last_n = n;
   c->last_k1 = k1;
@@ -506,14 +514,18 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     if (d.arch == LSTUR_ARCH_DGRU)   // the same per-sample mask and scale as the forward
       launch_drop_rows(w.duser, n, d.Ue, 0.5f, dropout_key(c->cfg.seed, step, 2), s);
     dhl = w.dhlast;
+  } else if (d.arch == LSTUR_ARCH_PGRU || d.arch == LSTUR_ARCH_VO) {   // u = h + user_vec / u = user_vec
+    (void)hipMemcpyAsync(w.duser, w.du, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
   }
+  const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG;
+  ReduceJob jobs[kMaxReduceJobs];
+  int nj = 0;
+  if (has_gru) {
   float *hprev = w.hprev, *rh = w.rh;   // fast path: both already sit row-major in the tape (no copies)
   gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
   PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
                                  d.arch == LSTUR_ARCH_IGRU ? w.duser : w.dh0, n, d.W, d.H, s));
   // GRU parameter gradients (their split-K / column-sum partials are reduced by ONE launch at the end of the pass)
-  ReduceJob jobs[kMaxReduceJobs];
-  int nj = 0;
   launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
               w.gemm_scratch_k[0], s, &jobs[nj++]);
   launch_colsum2(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, w.colsum_scratch_k[0], s, &jobs[nj++]);
@@ -521,6 +533,9 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
               w.gemm_scratch_k[1], s, &jobs[nj++]);
   launch_gemm(rh, d.H, 1, w.dgates + 2 * d.H, 3 * d.H, 0, c->G("gru_u") + 2 * d.H, 3 * d.H, nullptr, d.H, d.H, nW,
               1.f, w.gemm_scratch_k[2], s, &jobs[nj++]);
+  } else {   // vo / niavg: no GRU in the graph -- its bucket slots get an exact zero gradient
+    (void)hipMemsetAsync(c->G("gru_w"), 0, (size_t)(c->G("gru_b") + 3 * d.H - c->G("gru_w")) * sizeof(float), s);
+  }
   if (c->cfg.freeze_encoder) {   // loaded, non-trainable news encoder: nothing behind the doc vectors is trained
     if (stats) {
       jobs[nj++] = ReduceJob{w.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
@@ -532,8 +547,13 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     return;
   }
   // d(history doc vectors) = dgates . gru_w^T, masked by the history mask (paper.py:644-645)
-  launch_gemm(w.dgates, 3 * d.H, 0, c->P("gru_w"), 3 * d.H, 1, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, 1.f,
-              w.gemm_scratch, s);
+  if (has_gru)
+    launch_gemm(w.dgates, 3 * d.H, 0, c->P("gru_w"), 3 * d.H, 1, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, 1.f,
+                w.gemm_scratch, s);
+  else if (d.arch == LSTUR_ARCH_NIAVG)   // dx[b,w] = mask[b,w] * du[b] / (count_b + eps)
+    launch_masked_mean(nullptr, w.gmask, nullptr, w.du, w.ddocvec, n, d.W, d.U, s);
+  else                                   // vo: the history never reaches the loss
+    (void)hipMemsetAsync(w.ddocvec, 0, (size_t)nW * d.U * sizeof(float), s);
   // (the history mask needs no pass here: a padded slot is a masked GRU step, its dgates row -- hence its ddocvec
   //  row -- is exactly 0, cf. paper.py:644-645)
   // news encoder backward (candidate rows of ddocvec were written by the scorer)
@@ -937,7 +957,8 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
   if (n_rows < 0 || n_rows > d.rows_cap) return fail(LSTUR_ERR_ARG, "too many sparse rows for one adam step");
   const float lr_t = lr * (sqrtf(1.0f - powf(c.beta2, (float)t)) / (1.0f - powf(c.beta1, (float)t)));
   lazy_init(ctx, s);
-  if (d.arch == LSTUR_ARCH_NIGRU) {
+  const bool no_user = d.arch == LSTUR_ARCH_NIGRU || d.arch == LSTUR_ARCH_NIAVG;
+  if (no_user) {
     launch_adam_flat(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v, ctx->dense_total,
                      lr_t, c.beta1, c.beta2, c.eps, s);
   } else {
@@ -948,7 +969,7 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
   if (d.word_trainable)   // dense Keras-Adam sweep of the word table (TF-1 densifies the IndexedSlices gradient)
     launch_adam_flat(ctx->buf.word_emb, ctx->buf.word_grad, ctx->buf.word_m, ctx->buf.word_v, (size_t)d.V * d.D, lr_t,
                      c.beta1, c.beta2, c.eps, s);
-  if (d.arch != LSTUR_ARCH_NIGRU) {   // nigru: the user embedding is not part of the graph (paper.py:627-628)
+  if (!no_user) {   // nigru / niavg: the user embedding is not part of the graph (paper.py:627-630)
     {
       ProfScope _ps(ctx, "adam_user_table", s);
       launch_adam_table(ctx->buf.user_emb, ctx->buf.user_m, ctx->buf.user_v, ctx->ws.slot, ctx->ws.gsum, d.Nu, d.Ue,

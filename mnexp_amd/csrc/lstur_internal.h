@@ -96,6 +96,10 @@ void launch_concat_rep(const float* u, int uc, int K1, const float* d, int dc, f
 void launch_mlp_dhid(const float* pre, const float* ds, const float* w2, float* dhid, int rows, int U, hipStream_t s);
 void launch_split_sum(const float* dcat, int uc, int dc, int K1, float* du, float* dd, int n, hipStream_t s);
 void launch_fill_f32(float* p, float v, size_t n, hipStream_t s);
+// niavg: masked mean over the history (forward: du == NULL; backward: writes dx)
+void launch_masked_mean(const float* x, const uint8_t* mask, float* u, const float* du, float* dx, int n, int W, int U,
+                        hipStream_t s);
+void launch_add2(const float* a, const float* b, float* out, size_t n, hipStream_t s);
 void launch_drop_rows(float* x, int n, int dim, float p, uint32_t key, hipStream_t s);
 void launch_score(const float* u, const float* d, float* logits, float* probs, float* loss_i, float* correct_i,
                   float* du, float* dd, int n, int K1, int U, float inv_n, hipStream_t s);

@@ -771,6 +771,37 @@ void launch_split_sum(const float* dcat, int uc, int dc, int K1, float* du, floa
   const int total = std::max(n * uc, n * K1 * dc);
   if (total) hipLaunchKernelGGL(split_sum_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, dcat, uc, dc, K1, du, dd, n);
 }
+// niavg user encoder (models.GlobalAveragePoolingMaskSupport, models.py:433-435): u[b] = sum_w x[b,w] / (cnt_b + eps);
+// backward (du != NULL): dx[b,w] = mask[b,w] * du[b] / (cnt_b + eps).  x rows of masked steps are already zero.
+__global__ void masked_mean_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, float* __restrict__ u,
+                                   const float* __restrict__ du, float* __restrict__ dx, int n, int W, int U) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * U) return;
+  const int b = i / U, c = i - b * U;
+  float cnt = 0.f;
+  for (int w = 0; w < W; ++w) cnt += mask[b * W + w] ? 1.f : 0.f;
+  const float inv = 1.0f / (cnt + LSTUR_EPS);
+  if (!du) {
+    float acc = 0.f;
+    for (int w = 0; w < W; ++w) acc += x[((size_t)b * W + w) * U + c];
+    u[i] = acc * inv;
+  } else {
+    const float g = du[i] * inv;
+    for (int w = 0; w < W; ++w) dx[((size_t)b * W + w) * U + c] = mask[b * W + w] ? g : 0.f;
+  }
+}
+void launch_masked_mean(const float* x, const uint8_t* mask, float* u, const float* du, float* dx, int n, int W, int U,
+                        hipStream_t s) {
+  if (n * U) hipLaunchKernelGGL(masked_mean_kernel, dim3(cdiv(n * U, 256)), dim3(256), 0, s, x, mask, u, du, dx, n, W, U);
+}
+// out = a + b
+__global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+void launch_add2(const float* a, const float* b, float* out, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(add2_kernel, dim3((unsigned)cdivz(n, 256)), dim3(256), 0, s, a, b, out, n);
+}
 __global__ void fill_f32_kernel(float* __restrict__ p, float v, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

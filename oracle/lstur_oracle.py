@@ -38,7 +38,7 @@ import numpy as np
 
 EPS = 1e-7  # keras.backend.epsilon()
 
-ARCHS = ("igru", "gru", "hgru", "nigru", "ngru", "dgru")
+ARCHS = ("igru", "gru", "hgru", "nigru", "ngru", "dgru", "pgru", "vo", "niavg")
 SCORE_MODELS = ("dot", "ddot", "dnn")      # Seq2VecPaperSoftmax._score_model, paper.py:443-458
 
 
@@ -459,6 +459,16 @@ def user_encoder_fwd(p, arch, user, hv, hist_ids, uvec_keep=None):
         h, gc = gru_fwd(p, hvm, gmask, np.zeros((len(user), H), dtype=hv.dtype))
         u = h
         extra = None
+    elif arch == "pgru":                            # paper.py:624-626: GRU(U)(x) + user_vec
+        h, gc = gru_fwd(p, hvm, gmask, np.zeros((len(user), H), dtype=hv.dtype))
+        u = h + uvec
+        extra = None
+    elif arch == "vo":                              # paper.py:622-623: the user embedding alone, the history is unused
+        u, gc, extra = uvec, None, None
+    elif arch == "niavg":                           # paper.py:629-630 + models.py:433-435: masked mean, no user id
+        cnt = gmask.sum(axis=1, keepdims=True).astype(hv.dtype)
+        u = hvm.sum(axis=1) / (cnt + hv.dtype.type(EPS))
+        gc, extra = (gmask, cnt), None
     else:
         h, gc = gru_fwd(p, hvm, gmask, np.zeros((len(user), H), dtype=hv.dtype))
         if arch == "dgru" and uvec_keep is not None:
@@ -482,6 +492,18 @@ def user_encoder_bwd(p, cache, du):
     elif arch == "nigru":
         gg, dx, _ = gru_bwd(p, gc, du)
         duser = np.zeros_like(du)
+    elif arch == "pgru":
+        gg, dx, _ = gru_bwd(p, gc, du)
+        duser = du
+    elif arch in ("vo", "niavg"):                   # no GRU in the graph: its parameters get no gradient
+        gg = {n: np.zeros_like(p[n]) for n in ("gru_w", "gru_u", "gru_b")}
+        if arch == "vo":
+            dx = np.zeros(cache["hmask"].shape + (du.shape[1],), dtype=du.dtype)
+            duser = du
+        else:
+            gmask, cnt = gc
+            dx = gmask[..., None] * (du / (cnt + du.dtype.type(EPS)))[:, None, :]
+            duser = np.zeros_like(du)
     else:
         if arch == "gru":
             g["con_w"] = cache["cat"].T @ du

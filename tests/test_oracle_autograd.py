@@ -47,6 +47,30 @@ def test_grads_match_autograd(arch, drop):
         np.testing.assert_allclose(g[n], ref, rtol=1e-8, atol=1e-12, err_msg=n)
 
 
+@pytest.mark.parametrize("arch", ["pgru", "vo", "niavg"])
+def test_minor_user_encoders_match_autograd(arch):
+    """`-a pgru | vo | niavg` (paper.py:622-630): GRU + user vector, the user vector alone, masked mean of the history."""
+    rng = np.random.default_rng(5)
+    p = O.init_params(rng, arch=arch, dtype=np.float64, **DIMS)
+    for n in ("conv_b", "att_b", "dense_b", "gru_b"):
+        p[n] = rng.normal(0, 0.1, size=p[n].shape)
+    B, W, T, K1 = 5, 4, 7, 3
+    user, hist, cands = make_batch(rng, B, W, T, K1, DIMS["V"], DIMS["N_u"])
+    user[1] = user[0]
+    hist[2] = 0
+    out = O.forward_backward(p, arch, user, hist, cands, drop_p=0.0)
+    names = [n for n in p if n != "word_emb"]
+    tp = TR.to_t(p, grad_names=names)
+    loss, z, pr = TR.model_loss(tp, arch, user, hist, cands)
+    loss.backward()
+    assert abs(loss.item() - out["loss"]) < 1e-12
+    g = dict(out["grads"])
+    g["user_emb"] = O.densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"], np.float64)
+    for n in names:
+        ref = tp[n].grad.numpy() if tp[n].grad is not None else np.zeros_like(p[n])
+        np.testing.assert_allclose(g[n], ref, rtol=1e-8, atol=1e-12, err_msg=n)
+
+
 @pytest.mark.parametrize("arch,score_model", [("igru", "ddot"), ("igru", "dnn"), ("gru", "ddot"), ("ngru", "dnn"),
                                               ("ngru", "ddot"), ("dgru", "dnn"), ("dgru", "ddot"), ("hgru", "dnn")])
 def test_score_models_and_wide_user_vectors_match_autograd(arch, score_model):

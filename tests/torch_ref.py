@@ -90,6 +90,12 @@ def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0, ke
         u = gru(p, hv, gmask, uvec)
     elif arch == "nigru":
         u = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
+    elif arch == "pgru":
+        u = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype)) + uvec
+    elif arch == "vo":
+        u = uvec
+    elif arch == "niavg":
+        u = hv.sum(1) / (gmask.to(hv.dtype).sum(1, keepdim=True) + EPS)
     else:
         h = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
         if arch == "dgru" and keep_u is not None:       # Dropout(0.5, noise_shape=(None, 1)), paper.py:610
