@@ -239,6 +239,40 @@ def test_score_models_and_wide_user_vectors_match_oracle(arch, score_model):
     np.testing.assert_allclose(got[:, 0], O.predict(pw, arch, user, hist, cands[:, 0]), rtol=1e-3, atol=1e-6)
 
 
+def test_all_pad_batch_and_short_batch():
+    """Edge cases of the compacted token list: a batch whose every title is padding (count = 0: no conv work at all,
+    exact-zero encoder gradients) and a batch shorter than max_batch."""
+    _need_gpu()
+    O, p, model, rng = build('igru', MID, 16, 6, 9, 5, 0.2)
+    from mnexp_amd._lib import lib, check
+    B, W, T, K1 = 16, 6, 9, 5
+    user = rng.integers(0, MID['N_u'], size=B).astype(np.int32)
+    hist = np.zeros((B, W, T), np.int32)
+    cands = np.zeros((B, K1, T), np.int32)
+    ref = O.forward_backward(p, 'igru', user, hist, cands, drop_p=0.2, seed=77, step=0)
+    u, h, c = model._dev_i32(user), model._dev_i32(hist), model._dev_i32(cands)
+    check(lib.lstur_forward_backward(model._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), B, 0, 1.0,
+                                     model.stats.data_ptr(), model._stream()), 'fb')
+    torch.cuda.synchronize()
+    loss, _ = model.stats.tolist()
+    assert abs(loss - ref['loss']) < 1e-5 and np.isfinite(loss)
+    g = model.get_grads()
+    for n in ('conv_w', 'conv_b', 'att_w'):
+        assert not g[n].any() and not ref['grads'][n].any(), n
+    rel_close(g['dense_b'], ref['grads']['dense_b'], 2e-3, 'dense_b')
+    # n < max_batch
+    n = 5
+    user, hist, cands = make_batch(rng, n, W, T, K1, MID['V'], MID['N_u'])
+    ref = O.forward_backward(p, 'igru', user, hist, cands, drop_p=0.2, seed=77, step=1)
+    u, h, c = model._dev_i32(user), model._dev_i32(hist), model._dev_i32(cands)
+    check(lib.lstur_forward_backward(model._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), n, 1, 1.0,
+                                     model.stats.data_ptr(), model._stream()), 'fb')
+    torch.cuda.synchronize()
+    g = model.get_grads()
+    for nm in O.dense_param_names('igru'):
+        rel_close(g[nm], ref['grads'][nm], 2e-3, nm)
+
+
 def test_predict_and_evaluate_match_oracle():
     _need_gpu()
     dims, B, W, T, K1 = MID, 16, 6, 9, 5
