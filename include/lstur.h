@@ -51,8 +51,10 @@ enum lstur_arch {            /* user encoders of Seq2VecPaperSoftmaxId.get_user_
                                 the LSTUR paper); dropout stream 2 of the step                                 */
   LSTUR_ARCH_PGRU = 6,       /* GRU(U)(x) + user_vec                                      paper.py:624-626       */
   LSTUR_ARCH_VO = 7,         /* the user embedding alone; the history is not used         paper.py:622-623       */
-  LSTUR_ARCH_NIAVG = 8       /* no user id: sum_w x_w / (sum_w mask_w + 1e-7), models.GlobalAveragePoolingMaskSupport
-                                (models.py:433-435)                                       paper.py:629-630       */
+  LSTUR_ARCH_NIAVG = 8,      /* no user id: sum_w x_w / (sum_w mask_w + 1e-7), models.GlobalAveragePoolingMaskSupport
+                                (models.py:433-435)            paper.py:629-630; id-less `avg`, paper.py:213-215 */
+  LSTUR_ARCH_NIATT = 9       /* no user id: SimpleAttentionMaskSupport over the history vectors (models.py:474-489);
+                                the id-less tasks' `att`, paper.py:207-209; parameters uatt_w [U], uatt_b [1]   */
 };                           /* vo / niavg have no GRU: gru_w / gru_u / gru_b stay in the bucket with zero gradients */
 
 enum lstur_score_model {     /* Seq2VecPaperSoftmax._score_model (--score-model), paper.py:443-458; listwise head only */

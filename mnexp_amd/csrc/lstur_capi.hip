@@ -63,7 +63,7 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     *why = "filters must be <= 1024";
     return false;
   }
-  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_NIAVG) {
+  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_NIATT) {
     *why = "unknown arch";
     return false;
   }
@@ -111,8 +111,9 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
       *why = "the pointwise heads take one candidate per sample (cands == 1)";
       return false;
     }
-    if (d->arch != LSTUR_ARCH_IGRU && d->arch != LSTUR_ARCH_NIGRU) {
-      *why = "the pointwise heads support arch igru and nigru";
+    if (d->arch != LSTUR_ARCH_IGRU && d->arch != LSTUR_ARCH_NIGRU && d->arch != LSTUR_ARCH_NIAVG &&
+        d->arch != LSTUR_ARCH_NIATT) {
+      *why = "the pointwise heads support arch igru, nigru, niavg and niatt";
       return false;
     }
     if (!(c->gain > 0.f) || c->loss_negatives < 1) {
@@ -178,6 +179,10 @@ std::vector<ParamSlot> param_layout(const Dims& d, size_t* total) {
     add("con_w", (size_t)(d.H + d.Ue) * d.U);
     add("con_b", d.U);
   }
+  if (d.arch == LSTUR_ARCH_NIATT) {
+    add("uatt_w", d.U);
+    add("uatt_b", 1);
+  }
   if (d.score == LSTUR_SCORE_DDOT) {
     add("sdu_w", (size_t)d.Uu * d.U);
     add("sdu_b", d.U);
@@ -208,7 +213,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; unsigned short* conv_w3; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
+  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; unsigned short* conv_w3; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
 };
@@ -313,6 +318,11 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->lw_s = lw ? (float*)take(lrows * f4) : nullptr;
   w->lw_ds = lw ? (float*)take(lrows * f4) : nullptr;
   w->lw_ones = lw ? (float*)take(nc * f4) : nullptr;
+  const bool ua = d.arch == LSTUR_ARCH_NIATT;   // attention over the history: saved tanh / weights, gradient partials
+  w->ua_a = ua ? (float*)take(nW * f4) : nullptr;
+  w->ua_w = ua ? (float*)take(nW * f4) : nullptr;
+  w->ua_parts = ua ? (float*)take(nc * (size_t)(2 * d.U + 1) * f4) : nullptr;
+  w->ua_ds = ua ? (float*)take(nW * f4) : nullptr;
   const bool mh = d.enc == LSTUR_ENC_MHSA;
   w->conv_w3 = (!mh && conv3_supported(d.D, d.k, d.F)) ? (unsigned short*)take(conv3_w3_elems(d.D, d.k, d.F) * 2) : nullptr;
   w->qkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;     // bf16 Q | K | V rows
@@ -472,6 +482,9 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     (void)hipMemcpyAsync(w.uservec, w.uvec, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
   } else if (d.arch == LSTUR_ARCH_NIAVG) {   // masked mean of the history vectors (paper.py:629-630)
     launch_masked_mean(w.docvec, w.gmask, w.uservec, nullptr, nullptr, n, d.W, d.U, s);
+  } else if (d.arch == LSTUR_ARCH_NIATT) {   // additive attention over the history vectors (paper.py:207-209): the title
+    // kernels with "tokens" = history slots, "filters" = U, no dropout; Masking = any(x != 0), like the title path
+    launch_attpool_fwd(w.docvec, nullptr, c->P("uatt_w"), c->P("uatt_b"), w.uservec, w.ua_a, w.ua_w, n, d.W, d.U, 0.f, 0u, s);
   } else {
   // igru / nigru: the last state IS the user vector (H == U): the recurrence writes it in place
   const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
@@ -517,7 +530,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   } else if (d.arch == LSTUR_ARCH_PGRU || d.arch == LSTUR_ARCH_VO) {   // u = h + user_vec / u = user_vec
     (void)hipMemcpyAsync(w.duser, w.du, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
   }
-  const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG;
+  const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
   ReduceJob jobs[kMaxReduceJobs];
   int nj = 0;
   if (has_gru) {
@@ -552,6 +565,14 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
                 w.gemm_scratch, s);
   else if (d.arch == LSTUR_ARCH_NIAVG)   // dx[b,w] = mask[b,w] * du[b] / (count_b + eps)
     launch_masked_mean(nullptr, w.gmask, nullptr, w.du, w.ddocvec, n, d.W, d.U, s);
+  else if (d.arch == LSTUR_ARCH_NIATT) {   // backward of the attention over the history (no ReLU behind it: relu = 0)
+    launch_attpool_bwd(w.docvec, nullptr, c->P("uatt_w"), w.ua_a, w.ua_w, w.du, w.ddocvec, w.ua_parts, w.ua_ds, n, d.W, d.U,
+                       0.f, 0u, s, 0, 0, 0, 0, 0);
+    // partial sums per row: datt_w[U] | (column sums of dx: unused)[U] | datt_b
+    const int np_ = attpool_bwd_parts(n);
+    launch_colsum2(w.ua_parts, np_, d.U, 2 * d.U + 1, c->G("uatt_w"), 1.f, w.colsum_scratch, s);
+    launch_colsum2(w.ua_parts + 2 * d.U, np_, 1, 2 * d.U + 1, c->G("uatt_b"), 1.f, w.colsum_scratch, s);
+  }
   else                                   // vo: the history never reaches the loss
     (void)hipMemsetAsync(w.ddocvec, 0, (size_t)nW * d.U * sizeof(float), s);
   // (the history mask needs no pass here: a padded slot is a masked GRU step, its dgates row -- hence its ddocvec
@@ -957,7 +978,7 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
   if (n_rows < 0 || n_rows > d.rows_cap) return fail(LSTUR_ERR_ARG, "too many sparse rows for one adam step");
   const float lr_t = lr * (sqrtf(1.0f - powf(c.beta2, (float)t)) / (1.0f - powf(c.beta1, (float)t)));
   lazy_init(ctx, s);
-  const bool no_user = d.arch == LSTUR_ARCH_NIGRU || d.arch == LSTUR_ARCH_NIAVG;
+  const bool no_user = d.arch == LSTUR_ARCH_NIGRU || d.arch == LSTUR_ARCH_NIAVG || d.arch == LSTUR_ARCH_NIATT;
   if (no_user) {
     launch_adam_flat(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v, ctx->dense_total,
                      lr_t, c.beta1, c.beta2, c.eps, s);

@@ -118,7 +118,8 @@ class NativeModel:
                            score_b2=(1,))
         Uu = 2 * user_dim if arch in ('ngru', 'dgru') else user_dim      # width of the user vector
         self.shapes.update(sdu_w=(Uu, user_dim), sdu_b=(user_dim,), sdd_w=(user_dim, user_dim), sdd_b=(user_dim,),
-                           sn1_w=(Uu + user_dim, user_dim), sn1_b=(user_dim,), sn2_w=(user_dim,), sn2_b=(1,))
+                           sn1_w=(Uu + user_dim, user_dim), sn1_b=(user_dim,), sn2_w=(user_dim,), sn2_b=(1,),
+                           uatt_w=(user_dim,), uatt_b=(1,))
         dev = self.device
         f32 = torch.float32
         self.word_emb = torch.from_numpy(word_emb).to(dev)
@@ -185,9 +186,10 @@ class NativeModel:
         if not has_user:
             # Seq2VecPaper(Softmax).get_user_encoder (paper.py:198-221): only its `gru` (a plain masked GRU from a zero
             # state) is on the native path; it is the graph SoftmaxId calls `nigru`
-            if arch != 'gru':
-                raise _lib.LsturError('id-less task: only -a gru is on the native path (got {!r})'.format(arch))
-            arch = 'nigru'
+            idless = {'gru': 'nigru', 'avg': 'niavg', 'att': 'niatt'}    # paper.py:206-215
+            if arch not in idless:
+                raise _lib.LsturError('id-less task: -a gru | avg | att (got {!r})'.format(arch))
+            arch = idless[arch]
         elif head != 'softmax' and arch != 'igru':
             # Seq2VecPaperId.get_user_encoder (paper.py:330-354): gru / iigru concatenate to 2U, vo drops the history
             raise _lib.LsturError('pointwise task with user ids: only -a igru is on the native path (got {!r})'.format(arch))
@@ -231,6 +233,9 @@ class NativeModel:
         if self.arch == 'gru':
             w['con_w'] = _glorot(rng, s['con_w'], s['con_w'][0], U)
             w['con_b'] = np.zeros(U, np.float32)
+        if self.arch == 'niatt':         # SimpleAttentionMaskSupport over the history (paper.py:207-209, models.py:448-449)
+            w['uatt_w'] = _glorot(rng, s['uatt_w'], U, 1)
+            w['uatt_b'] = np.zeros(1, np.float32)
         if self.score_model == 'ddot':   # Dense(U, tanh) on both sides (paper.py:452-454)
             w['sdu_w'] = _glorot(rng, s['sdu_w'], s['sdu_w'][0], U)
             w['sdu_b'] = np.zeros(U, np.float32)
@@ -318,6 +323,8 @@ class NativeModel:
         names = tok + ['att_w', 'att_b', 'dense_w', 'dense_b', 'user_emb', 'gru_w', 'gru_u', 'gru_b']
         if self.arch == 'gru':
             names += ['con_w', 'con_b']
+        if self.arch == 'niatt':
+            names += ['uatt_w', 'uatt_b']
         if self.score_model == 'ddot':
             names += ['sdu_w', 'sdu_b', 'sdd_w', 'sdd_b']
         elif self.score_model == 'dnn':
@@ -332,7 +339,7 @@ class NativeModel:
         json_path, pkl_path = paths
         w = self.get_weights()
         w['word_emb'] = self.word_emb.cpu().numpy()
-        arrays = [w[n].reshape(-1, 1) if n in ('att_w', 'sn2_w') else w[n] for n in self.keras_weight_order()]
+        arrays = [w[n].reshape(-1, 1) if n in ('att_w', 'sn2_w', 'uatt_w') else w[n] for n in self.keras_weight_order()]
         with open(json_path, 'w') as f:
             json.dump(dict(format='mnexp_amd-lstur-1', arch=self.arch, order=self.keras_weight_order(),
                            shapes=[list(a.shape) for a in arrays]), f)

@@ -38,7 +38,7 @@ import numpy as np
 
 EPS = 1e-7  # keras.backend.epsilon()
 
-ARCHS = ("igru", "gru", "hgru", "nigru", "ngru", "dgru", "pgru", "vo", "niavg")
+ARCHS = ("igru", "gru", "hgru", "nigru", "ngru", "dgru", "pgru", "vo", "niavg", "niatt")
 SCORE_MODELS = ("dot", "ddot", "dnn")      # Seq2VecPaperSoftmax._score_model, paper.py:443-458
 
 
@@ -125,6 +125,9 @@ def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.fl
     if arch == "gru":
         p["con_w"] = glorot_uniform(rng, (H + Ue, U), H + Ue, U)
         p["con_b"] = np.zeros(U)
+    if arch == "niatt":          # SimpleAttentionMaskSupport over the history (id-less `att`, paper.py:207-209)
+        p["uatt_w"] = glorot_uniform(rng, (U,), U, 1)
+        p["uatt_b"] = np.zeros(1)
     assert head in HEADS and score_model in SCORE_MODELS
     Uu = 2 * U if arch in ("ngru", "dgru") else U      # width of the user vector (paper.py:600-602, 608-611)
     assert score_model != "dot" or Uu == U, "ngru / dgru user vectors are 2U wide: not dot-compatible"
@@ -155,6 +158,8 @@ def dense_param_names(arch, word_trainable=False, head="softmax", encoder="cnnat
     names += ["att_w", "att_b", "dense_w", "dense_b", "gru_w", "gru_u", "gru_b"]
     if arch == "gru":
         names += ["con_w", "con_b"]
+    if arch == "niatt":
+        names += ["uatt_w", "uatt_b"]
     if head == "point_mlp":
         names += ["score_w1", "score_b1", "score_w2", "score_b2"]
     if score_model == "ddot":
@@ -469,6 +474,12 @@ def user_encoder_fwd(p, arch, user, hv, hist_ids, uvec_keep=None):
         cnt = gmask.sum(axis=1, keepdims=True).astype(hv.dtype)
         u = hvm.sum(axis=1) / (cnt + hv.dtype.type(EPS))
         gc, extra = (gmask, cnt), None
+    elif arch == "niatt":                           # paper.py:207-209 + models.py:474-489: additive attention, no user id
+        a = np.tanh(hvm @ p["uatt_w"] + p["uatt_b"][0])
+        e_ = np.exp(a) * gmask
+        wgt = e_ / (e_.sum(axis=1, keepdims=True) + hv.dtype.type(EPS))
+        u = np.einsum("bwu,bw->bu", hvm, wgt)
+        gc, extra = (hvm, a, wgt), None
     else:
         h, gc = gru_fwd(p, hvm, gmask, np.zeros((len(user), H), dtype=hv.dtype))
         if arch == "dgru" and uvec_keep is not None:
@@ -495,9 +506,18 @@ def user_encoder_bwd(p, cache, du):
     elif arch == "pgru":
         gg, dx, _ = gru_bwd(p, gc, du)
         duser = du
-    elif arch in ("vo", "niavg"):                   # no GRU in the graph: its parameters get no gradient
+    elif arch in ("vo", "niavg", "niatt"):          # no GRU in the graph: its parameters get no gradient
         gg = {n: np.zeros_like(p[n]) for n in ("gru_w", "gru_u", "gru_b")}
-        if arch == "vo":
+        if arch == "niatt":
+            x, a, wgt = gc
+            dw = np.einsum("bu,bwu->bw", du, x)
+            da = (dw - (dw * wgt).sum(axis=1, keepdims=True)) * wgt
+            ds = da * (1.0 - a * a)
+            dx = du[:, None, :] * wgt[..., None] + ds[..., None] * p["uatt_w"][None, None, :]
+            gg["uatt_w"] = np.einsum("bw,bwu->u", ds, x)
+            gg["uatt_b"] = np.array([ds.sum()], dtype=du.dtype)
+            duser = np.zeros_like(du)
+        elif arch == "vo":
             dx = np.zeros(cache["hmask"].shape + (du.shape[1],), dtype=du.dtype)
             duser = du
         else:

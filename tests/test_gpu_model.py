@@ -170,7 +170,8 @@ def test_word_table_adam_steps_track_oracle():
 
 @pytest.mark.parametrize('arch,score_model', [('igru', 'ddot'), ('igru', 'dnn'), ('gru', 'ddot'), ('hgru', 'dnn'),
                                               ('ngru', 'ddot'), ('ngru', 'dnn'), ('dgru', 'ddot'), ('dgru', 'dnn'),
-                                              ('pgru', 'dot'), ('vo', 'dot'), ('niavg', 'dot'), ('pgru', 'ddot')])
+                                              ('pgru', 'dot'), ('vo', 'dot'), ('niavg', 'dot'), ('pgru', 'ddot'),
+                                              ('niatt', 'dot'), ('niatt', 'dnn')])
 def test_score_models_and_wide_user_vectors_match_oracle(arch, score_model):
     """--score-model ddot | dnn (paper.py:448-455), and -a ngru | dgru (paper.py:600-602, 608-611: 2U-wide user vectors;
     dgru drops a sample's whole user embedding with p = 0.5 in training): logits, every gradient, three Adam steps and
@@ -206,9 +207,9 @@ def test_score_models_and_wide_user_vectors_match_oracle(arch, score_model):
     g = model.get_grads()
     for n in names:
         rel_close(g[n], ref['grads'][n], 2e-3, n)
-    if arch != 'niavg':      # niavg has no user embedding in its graph (paper.py:629-630)
+    if arch not in ('niavg', 'niatt'):      # no user embedding in these graphs (paper.py:629-630, 207-209)
         rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
-    if arch in ('vo', 'niavg'):
+    if arch in ('vo', 'niavg', 'niatt'):
         assert not g['gru_w'].any() and not g['gru_u'].any() and not g['gru_b'].any()     # no GRU in these graphs
     if arch == 'dgru':       # dropped samples: exactly no gradient for their user row
         keep = O.dropout_keep(O.dropout_key(77, 3, 2), B, 0.5)

@@ -102,7 +102,7 @@ def test_head_argument_checks():
     from mnexp_amd import _lib
     from mnexp_amd.native_model import NativeModel
     emb = np.zeros((20, 8), np.float32)
-    with pytest.raises(_lib.LsturError, match='igru and nigru'):
+    with pytest.raises(_lib.LsturError, match='the pointwise heads support arch'):
         NativeModel(emb, 5, 4, 3, 5, 4, 8, 3, 6, arch='gru', head='point_mlp')
     m = NativeModel(emb, 5, 4, 3, 5, 4, 8, 3, 6, arch='igru', head='point_dot')
     z = torch.zeros(64, dtype=torch.int32, device='cuda')

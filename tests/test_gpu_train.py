@@ -139,8 +139,14 @@ def test_idless_softmax_task(tmp_path):
     np.random.seed(0)
     h = run_training(cfg)
     assert h.model.arch == 'nigru' and 0.0 <= h.last_metrics['auc'] <= 1.0
-    cfg = _config(tmp_path, task='Seq2VecPaperSoftmax', arch='att', epochs=1)
-    with pytest.raises(Exception, match='only -a gru'):
+    for arch, native in (('att', 'niatt'), ('avg', 'niavg')):        # paper.py:207-215
+        cfg = _config(tmp_path, task='Seq2VecPaperSoftmax', arch=arch, epochs=1, training_step=10, validation_step=1,
+                      validation_impression=10, testing_impression=10, dropout=0.2, seed=1)
+        np.random.seed(0)
+        h = run_training(cfg)
+        assert h.model.arch == native and 0.0 <= h.last_metrics['auc'] <= 1.0
+    cfg = _config(tmp_path, task='Seq2VecPaperSoftmax', arch='igru', epochs=1)
+    with pytest.raises(Exception, match='gru . avg . att'):
         run_training(cfg)
 
 

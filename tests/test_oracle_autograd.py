@@ -47,12 +47,12 @@ def test_grads_match_autograd(arch, drop):
         np.testing.assert_allclose(g[n], ref, rtol=1e-8, atol=1e-12, err_msg=n)
 
 
-@pytest.mark.parametrize("arch", ["pgru", "vo", "niavg"])
+@pytest.mark.parametrize("arch", ["pgru", "vo", "niavg", "niatt"])
 def test_minor_user_encoders_match_autograd(arch):
     """`-a pgru | vo | niavg` (paper.py:622-630): GRU + user vector, the user vector alone, masked mean of the history."""
     rng = np.random.default_rng(5)
     p = O.init_params(rng, arch=arch, dtype=np.float64, **DIMS)
-    for n in ("conv_b", "att_b", "dense_b", "gru_b"):
+    for n in [n for n in p if n.endswith("_b")]:
         p[n] = rng.normal(0, 0.1, size=p[n].shape)
     B, W, T, K1 = 5, 4, 7, 3
     user, hist, cands = make_batch(rng, B, W, T, K1, DIMS["V"], DIMS["N_u"])

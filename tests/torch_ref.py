@@ -96,6 +96,10 @@ def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0, ke
         u = uvec
     elif arch == "niavg":
         u = hv.sum(1) / (gmask.to(hv.dtype).sum(1, keepdim=True) + EPS)
+    elif arch == "niatt":
+        a = torch.tanh(hv @ p["uatt_w"] + p["uatt_b"])
+        e = torch.exp(a) * gmask.to(a.dtype)
+        u = (hv * (e / (e.sum(1, keepdim=True) + EPS)).unsqueeze(-1)).sum(1)
     else:
         h = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
         if arch == "dgru" and keep_u is not None:       # Dropout(0.5, noise_shape=(None, 1)), paper.py:610
