@@ -112,8 +112,8 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
       return false;
     }
     if (d->arch != LSTUR_ARCH_IGRU && d->arch != LSTUR_ARCH_NIGRU && d->arch != LSTUR_ARCH_NIAVG &&
-        d->arch != LSTUR_ARCH_NIATT) {
-      *why = "the pointwise heads support arch igru, nigru, niavg and niatt";
+        d->arch != LSTUR_ARCH_NIATT && d->arch != LSTUR_ARCH_VO) {
+      *why = "the pointwise heads support arch igru, vo, nigru, niavg and niatt";
       return false;
     }
     if (!(c->gain > 0.f) || c->loss_negatives < 1) {

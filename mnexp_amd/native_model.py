@@ -190,9 +190,9 @@ class NativeModel:
             if arch not in idless:
                 raise _lib.LsturError('id-less task: -a gru | avg | att (got {!r})'.format(arch))
             arch = idless[arch]
-        elif head != 'softmax' and arch != 'igru':
-            # Seq2VecPaperId.get_user_encoder (paper.py:330-354): gru / iigru concatenate to 2U, vo drops the history
-            raise _lib.LsturError('pointwise task with user ids: only -a igru is on the native path (got {!r})'.format(arch))
+        elif head != 'softmax' and arch not in ('igru', 'vo'):
+            # Seq2VecPaperId.get_user_encoder (paper.py:330-354): gru / iigru concatenate to 2U (not on the native path)
+            raise _lib.LsturError('pointwise task with user ids: -a igru | vo are on the native path (got {!r})'.format(arch))
         pretrained = bool(getattr(cfg, 'enable_pretrain_encoder', False))
         model = cls(emb, user_count, cfg.batch_size, cfg.window_size, cfg.title_shape, cfg.negative_samples,
                     int(filters), int(kernel), cfg.user_embedding_dim, arch=arch, dropout=cfg.dropout,

@@ -21,7 +21,7 @@ def build(arch, head, dims, B, W, T, K, drop, gain):
     from mnexp_amd.native_model import NativeModel
     rng = np.random.default_rng(11)
     p = O.init_params(rng, arch=arch, dtype=np.float64, head=head, **dims)
-    for n in ('conv_b', 'att_b', 'dense_b', 'gru_b', 'score_b1', 'score_b2'):
+    for n in ('conv_b', 'att_b', 'dense_b', 'gru_b', 'score_b1', 'score_b2', 'uatt_b'):
         if n in p:
             p[n] = rng.normal(0, 0.1, size=p[n].shape)
     model = NativeModel(p['word_emb'], dims['N_u'], B, W, T, K, dims['F'], dims['k'], dims['U'], arch=arch,
@@ -30,7 +30,7 @@ def build(arch, head, dims, B, W, T, K, drop, gain):
     return O, p, model, rng
 
 
-@pytest.mark.parametrize('arch', ['igru', 'nigru'])
+@pytest.mark.parametrize('arch', ['igru', 'nigru', 'vo', 'niavg', 'niatt'])
 @pytest.mark.parametrize('head', ['point_mlp', 'point_dot'])
 @pytest.mark.parametrize('dims,B,W,T,drop', [(TINY, 6, 4, 7, 0.0), (MID, 19, 9, 11, 0.2), (ODD, 7, 3, 6, 0.25)])
 def test_pointwise_step_matches_oracle(arch, head, dims, B, W, T, drop):
@@ -57,7 +57,7 @@ def test_pointwise_step_matches_oracle(arch, head, dims, B, W, T, drop):
     g = model.get_grads()
     for n in O.dense_param_names(arch, head=head):
         rel_close(g[n].reshape(-1), ref['grads'][n].reshape(-1), 2e-3, n)
-    if arch == 'igru':
+    if arch in ('igru', 'vo'):
         rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
     # model.predict of the pointwise model = the scorer's sigmoid output without dropout
     pr = model.predict([user, hist, cand])
