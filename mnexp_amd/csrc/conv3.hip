@@ -158,13 +158,16 @@ __global__ __launch_bounds__(RW* CW * 64) void conv3_fwd_kernel(const float* __r
   store(0);
   if (nit > 1) load(C3_BK);
   __syncthreads();
-  for (int it = 0; it < nit; ++it) {
-    const int buf = it & 1;
+  // The two waves that share a SIMD (w and w + NW/2) run the two halves of a step in opposite order (see the kernel
+  // gradient below): one stores the next tile while the other issues MFMAs.
+  auto prefetch = [&](int it) {
     if (it + 1 < nit) {
-      store(buf ^ 1);
+      store((it & 1) ^ 1);
       if (it + 2 < nit) load((it + 2) * C3_BK);
     }
-    const unsigned short* st = smem + buf * STAGE;
+  };
+  auto contract = [&](int it) {
+    const unsigned short* st = smem + (it & 1) * STAGE;
     const unsigned short* ap = st + (32 * wm + (lane & 31)) * C3_SA + 8 * (lane >> 5);
     const u16x8 ah = *(const u16x8*)ap, am = *(const u16x8*)(ap + A_IMG), al = *(const u16x8*)(ap + 2 * A_IMG);
     const unsigned short* bp = st + 3 * A_IMG;
@@ -184,6 +187,17 @@ __global__ __launch_bounds__(RW* CW * 64) void conv3_fwd_kernel(const float* __r
         c = mfma32b(ah, bh, c);
         acc[j] = c;
       }
+    }
+  };
+  const bool store_first = true;   // (opposite orders on the two waves of a SIMD pay off in the kernel gradient, whose
+                                   // store phase is 4x heavier; here they measured the same)
+  for (int it = 0; it < nit; ++it) {
+    if (store_first) {
+      prefetch(it);
+      contract(it);
+    } else {
+      contract(it);
+      prefetch(it);
     }
     __syncthreads();
   }
@@ -392,15 +406,19 @@ __global__ __launch_bounds__(W3_THREADS) void conv3_wgrad_kernel(const float* __
     fetch_rows(t_begin + 2 * W3_BK);
     __syncthreads();
   }
-  for (int it = 0; it < nit; ++it) {
-    const int buf = it & 1;
+  // The two waves that share a SIMD (w and w + 4) run the two halves of a step in opposite order: one splits + stores
+  // the next tile while the other issues its MFMAs, then they swap -- both orders are legal inside a step (one barrier
+  // at its end), and the matrix pipe no longer idles while both waves of a SIMD convert and store.
+  auto prefetch = [&](int it) {
     if (it + 1 < nit) {
-      store(buf ^ 1);                                // step it + 1 (its loads were issued a step ago)
+      store((it & 1) ^ 1);                           // step it + 1 (its loads were issued a step ago)
       make_offsets(t_begin + (it + 2) * W3_BK);      // from the rows fetched a step ago
       load();                                        // step it + 2
       fetch_rows(t_begin + (it + 3) * W3_BK);        // consumed in the next step
     }
-    const unsigned short* st = smem + buf * W3_STAGE;
+  };
+  auto contract = [&](int it) {
+    const unsigned short* st = smem + (it & 1) * W3_STAGE;
     const unsigned short* bp = st + 3 * W3_A_IMG;
     const u16x8 ah = tr_frag(st, W3_SA, 0, wv * 32, lane);
     const u16x8 am = tr_frag(st + W3_A_IMG, W3_SA, 0, wv * 32, lane);
@@ -418,6 +436,16 @@ __global__ __launch_bounds__(W3_THREADS) void conv3_wgrad_kernel(const float* __
       c = mfma32b(ah, bm, c);
       c = mfma32b(ah, bh, c);
       acc[j] = c;
+    }
+  };
+  const bool store_first = wv < W3_TM / 2;           // wave-uniform
+  for (int it = 0; it < nit; ++it) {
+    if (store_first) {
+      prefetch(it);
+      contract(it);
+    } else {
+      contract(it);
+      prefetch(it);
     }
     __syncthreads();
   }
