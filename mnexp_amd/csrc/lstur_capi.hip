@@ -486,20 +486,20 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     // kernels with "tokens" = history slots, "filters" = U, no dropout; Masking = any(x != 0), like the title path
     launch_attpool_fwd(w.docvec, nullptr, c->P("uatt_w"), c->P("uatt_b"), w.uservec, w.ua_a, w.ua_w, n, d.W, d.U, 0.f, 0u, s);
   } else {
-  // igru / nigru: the last state IS the user vector (H == U): the recurrence writes it in place
-  const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
-  PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.gru_up,
-                                 w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s));
-  if (d.arch == LSTUR_ARCH_PGRU) {        // GRU(U)(x) + user_vec (paper.py:624-626)
-    launch_add2(w.hlast, w.uvec, w.uservec, (size_t)n * d.U, s);
-  } else if (!direct) {
-    launch_concat2(w.hlast, d.H, w.uvec, d.Ue, w.cat, n, s);
-    if (d.arch == LSTUR_ARCH_GRU)
-      launch_gemm(w.cat, d.H + d.Ue, 0, c->P("con_w"), d.U, 0, w.uservec, d.U, c->P("con_b"), n, d.U, d.H + d.Ue, 1.f,
-                  w.gemm_scratch, s);
-    else   // hgru (U/2 + U/2), ngru / dgru (U + U): the concatenation is the user vector
-      (void)hipMemcpyAsync(w.uservec, w.cat, (size_t)n * d.Uu * 4, hipMemcpyDeviceToDevice, s);
-  }
+    // igru / nigru: the last state IS the user vector (H == U): the recurrence writes it in place
+    const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
+    PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.gru_up,
+                                   w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s));
+    if (d.arch == LSTUR_ARCH_PGRU) {        // GRU(U)(x) + user_vec (paper.py:624-626)
+      launch_add2(w.hlast, w.uvec, w.uservec, (size_t)n * d.U, s);
+    } else if (!direct) {
+      launch_concat2(w.hlast, d.H, w.uvec, d.Ue, w.cat, n, s);
+      if (d.arch == LSTUR_ARCH_GRU)
+        launch_gemm(w.cat, d.H + d.Ue, 0, c->P("con_w"), d.U, 0, w.uservec, d.U, c->P("con_b"), n, d.U, d.H + d.Ue, 1.f,
+                    w.gemm_scratch, s);
+      else   // hgru (U/2 + U/2), ngru / dgru (U + U): the concatenation is the user vector
+        (void)hipMemcpyAsync(w.uservec, w.cat, (size_t)n * d.Uu * 4, hipMemcpyDeviceToDevice, s);
+    }
   }
   c->last_n = n;
   c->last_k1 = k1;
@@ -534,18 +534,18 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   ReduceJob jobs[kMaxReduceJobs];
   int nj = 0;
   if (has_gru) {
-  float *hprev = w.hprev, *rh = w.rh;   // fast path: both already sit row-major in the tape (no copies)
-  gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
-  PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
-                                 d.arch == LSTUR_ARCH_IGRU ? w.duser : w.dh0, n, d.W, d.H, s));
-  // GRU parameter gradients (their split-K / column-sum partials are reduced by ONE launch at the end of the pass)
-  launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
-              w.gemm_scratch_k[0], s, &jobs[nj++]);
-  launch_colsum2(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, w.colsum_scratch_k[0], s, &jobs[nj++]);
-  launch_gemm(hprev, d.H, 1, w.dgates, 3 * d.H, 0, c->G("gru_u"), 3 * d.H, nullptr, d.H, 2 * d.H, nW, 1.f,
-              w.gemm_scratch_k[1], s, &jobs[nj++]);
-  launch_gemm(rh, d.H, 1, w.dgates + 2 * d.H, 3 * d.H, 0, c->G("gru_u") + 2 * d.H, 3 * d.H, nullptr, d.H, d.H, nW,
-              1.f, w.gemm_scratch_k[2], s, &jobs[nj++]);
+    float *hprev = w.hprev, *rh = w.rh;   // fast path: both already sit row-major in the tape (no copies)
+    gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
+    PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
+                                   d.arch == LSTUR_ARCH_IGRU ? w.duser : w.dh0, n, d.W, d.H, s));
+    // GRU parameter gradients (their split-K / column-sum partials are reduced by ONE launch at the end of the pass)
+    launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
+                w.gemm_scratch_k[0], s, &jobs[nj++]);
+    launch_colsum2(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, w.colsum_scratch_k[0], s, &jobs[nj++]);
+    launch_gemm(hprev, d.H, 1, w.dgates, 3 * d.H, 0, c->G("gru_u"), 3 * d.H, nullptr, d.H, 2 * d.H, nW, 1.f,
+                w.gemm_scratch_k[1], s, &jobs[nj++]);
+    launch_gemm(rh, d.H, 1, w.dgates + 2 * d.H, 3 * d.H, 0, c->G("gru_u") + 2 * d.H, 3 * d.H, nullptr, d.H, d.H, nW,
+                1.f, w.gemm_scratch_k[2], s, &jobs[nj++]);
   } else {   // vo / niavg: no GRU in the graph -- its bucket slots get an exact zero gradient
     (void)hipMemsetAsync(c->G("gru_w"), 0, (size_t)(c->G("gru_b") + 3 * d.H - c->G("gru_w")) * sizeof(float), s);
   }
@@ -620,9 +620,9 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     PROF("conv_wgrad", launch_conv3_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vidx,
                                           w.vcount, s, &jobs[nj++], w.offA, w.offB));
   else
-  PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
-                                       w.vidx, w.vcount, s, w.offA, w.offB,
-                                       w.emb + (size_t)d.nt_max * d.Tp * d.D /* zero slack */, &jobs[nj++]));
+    PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
+                                         w.vidx, w.vcount, s, w.offA, w.offB,
+                                         w.emb + (size_t)d.nt_max * d.Tp * d.D /* zero slack */, &jobs[nj++]));
   if (stats) {
     jobs[nj++] = ReduceJob{w.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
     jobs[nj++] = ReduceJob{w.correct_i, stats + 1, 1, 1, 1, n, 1, 1.0f / (float)n};
