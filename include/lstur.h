@@ -53,8 +53,11 @@ enum lstur_arch {            /* user encoders of Seq2VecPaperSoftmaxId.get_user_
   LSTUR_ARCH_VO = 7,         /* the user embedding alone; the history is not used         paper.py:622-623       */
   LSTUR_ARCH_NIAVG = 8,      /* no user id: sum_w x_w / (sum_w mask_w + 1e-7), models.GlobalAveragePoolingMaskSupport
                                 (models.py:433-435)            paper.py:629-630; id-less `avg`, paper.py:213-215 */
-  LSTUR_ARCH_NIATT = 9       /* no user id: SimpleAttentionMaskSupport over the history vectors (models.py:474-489);
+  LSTUR_ARCH_NIATT = 9,      /* no user id: SimpleAttentionMaskSupport over the history vectors (models.py:474-489);
                                 the id-less tasks' `att`, paper.py:207-209; parameters uatt_w [U], uatt_b [1]   */
+  LSTUR_ARCH_IIGRU = 10      /* Dense(U)(concat[GRU(U)(x, initial_state=user_vec), user_vec2]) with a SECOND user table
+                                (paper.py:614-621): needs lstur_buffers.user_emb2 / user_m2 / user_v2; single GPU
+                                only (the data-parallel exchange carries one table's rows)                       */
 };                           /* vo / niavg have no GRU: gru_w / gru_u / gru_b stay in the bucket with zero gradients */
 
 enum lstur_score_model {     /* Seq2VecPaperSoftmax._score_model (--score-model), paper.py:443-458; listwise head only */
@@ -133,6 +136,9 @@ typedef struct lstur_buffers {
   float* word_grad;          /* [V, D]  only with cfg.word_trainable (else NULL): gradient of the word table */
   float* word_m;             /* [V, D]  its Adam moments                                 */
   float* word_v;
+  float* user_emb2;          /* [n_users, Ue]  only with arch IIGRU (else NULL): the second user table + its moments */
+  float* user_m2;
+  float* user_v2;
 } lstur_buffers;
 
 const char* lstur_last_error(void);

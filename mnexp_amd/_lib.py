@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblstur_hip.so')
 
-ARCH = {'igru': 0, 'gru': 1, 'hgru': 2, 'nigru': 3, 'ngru': 4, 'dgru': 5, 'pgru': 6, 'vo': 7, 'niavg': 8, 'niatt': 9}
+ARCH = {'igru': 0, 'gru': 1, 'hgru': 2, 'nigru': 3, 'ngru': 4, 'dgru': 5, 'pgru': 6, 'vo': 7, 'niavg': 8, 'niatt': 9, 'iigru': 10}
 SCORE = {'dot': 0, 'ddot': 1, 'dnn': 2}     # --score-model (paper.py:443-458)
 HEAD = {'softmax': 0, 'point_mlp': 1, 'point_dot': 2}
 ENCODER = {'cnnatt': 0, 'mhsa': 1}     # include/lstur.h: lstur_encoder (mhsa is build-defined, no reference counterpart)
@@ -38,7 +38,8 @@ class Sizes(C.Structure):
 class Buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('word_emb', 'dense_param', 'dense_grad', 'dense_m', 'dense_v',
                                           'user_emb', 'user_m', 'user_v', 'workspace')] + [
-        ('workspace_bytes', C.c_size_t), ('word_grad', C.c_void_p), ('word_m', C.c_void_p), ('word_v', C.c_void_p)]
+        ('workspace_bytes', C.c_size_t), ('word_grad', C.c_void_p), ('word_m', C.c_void_p), ('word_v', C.c_void_p),
+        ('user_emb2', C.c_void_p), ('user_m2', C.c_void_p), ('user_v2', C.c_void_p)]
 
 
 _P, _I, _U, _F, _Z = C.c_void_p, C.c_int32, C.c_uint32, C.c_float, C.c_size_t

@@ -63,7 +63,7 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     *why = "filters must be <= 1024";
     return false;
   }
-  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_NIATT) {
+  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_IIGRU) {
     *why = "unknown arch";
     return false;
   }
@@ -175,7 +175,7 @@ std::vector<ParamSlot> param_layout(const Dims& d, size_t* total) {
   add("gru_w", (size_t)d.U * 3 * d.H);
   add("gru_u", (size_t)d.H * 3 * d.H);
   add("gru_b", 3 * d.H);
-  if (d.arch == LSTUR_ARCH_GRU) {
+  if (d.arch == LSTUR_ARCH_GRU || d.arch == LSTUR_ARCH_IIGRU) {
     add("con_w", (size_t)(d.H + d.Ue) * d.U);
     add("con_b", d.U);
   }
@@ -213,7 +213,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; unsigned short* conv_w3; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
+  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
 };
@@ -323,6 +323,10 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->ua_w = ua ? (float*)take(nW * f4) : nullptr;
   w->ua_parts = ua ? (float*)take(nc * (size_t)(2 * d.U + 1) * f4) : nullptr;
   w->ua_ds = ua ? (float*)take(nW * f4) : nullptr;
+  const bool ii = d.arch == LSTUR_ARCH_IIGRU;   // second user table: gathered rows, their gradients, combined sums
+  w->uvec2 = ii ? (float*)take(nc * d.Ue * f4) : nullptr;
+  w->duser2 = ii ? (float*)take(nc * d.Ue * f4) : nullptr;
+  w->gsum2 = ii ? (float*)take((size_t)d.rows_cap * d.Ue * f4) : nullptr;
   const bool mh = d.enc == LSTUR_ENC_MHSA;
   w->conv_w3 = (!mh && conv3_supported(d.D, d.k, d.F)) ? (unsigned short*)take(conv3_w3_elems(d.D, d.k, d.F) * 2) : nullptr;
   w->qkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;     // bf16 Q | K | V rows
@@ -488,13 +492,19 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   } else {
     // igru / nigru: the last state IS the user vector (H == U): the recurrence writes it in place
     const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
-    PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, d.arch == LSTUR_ARCH_IGRU ? w.uvec : nullptr, w.gru_up,
+    const bool init_user = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_IIGRU;   // initial_state = user_vec
+    PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, init_user ? w.uvec : nullptr, w.gru_up,
                                    w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s));
     if (d.arch == LSTUR_ARCH_PGRU) {        // GRU(U)(x) + user_vec (paper.py:624-626)
       launch_add2(w.hlast, w.uvec, w.uservec, (size_t)n * d.U, s);
     } else if (!direct) {
-      launch_concat2(w.hlast, d.H, w.uvec, d.Ue, w.cat, n, s);
-      if (d.arch == LSTUR_ARCH_GRU)
+      const float* side = w.uvec;
+      if (d.arch == LSTUR_ARCH_IIGRU) {     // the concatenated vector comes from the SECOND table (paper.py:617-619)
+        launch_gather_rows(c->buf.user_emb2, w.user_rows, w.uvec2, n, d.Ue, s);
+        side = w.uvec2;
+      }
+      launch_concat2(w.hlast, d.H, side, d.Ue, w.cat, n, s);
+      if (d.arch == LSTUR_ARCH_GRU || d.arch == LSTUR_ARCH_IIGRU)
         launch_gemm(w.cat, d.H + d.Ue, 0, c->P("con_w"), d.U, 0, w.uservec, d.U, c->P("con_b"), n, d.U, d.H + d.Ue, 1.f,
                     w.gemm_scratch, s);
       else   // hgru (U/2 + U/2), ngru / dgru (U + U): the concatenation is the user vector
@@ -514,13 +524,13 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   const uint32_t key1 = dropout_key(c->cfg.seed, step, 1);
   // user encoder head
   const float* dhl = w.du;
-  if (d.arch == LSTUR_ARCH_GRU) {
+  if (d.arch == LSTUR_ARCH_GRU || d.arch == LSTUR_ARCH_IIGRU) {
     launch_gemm(w.cat, d.H + d.Ue, 1, w.du, d.U, 0, c->G("con_w"), d.U, nullptr, d.H + d.Ue, d.U, n, 1.f,
                 w.gemm_scratch, s);
     launch_colsum2(w.du, n, d.U, d.U, c->G("con_b"), 1.f, w.colsum_scratch, s);
     launch_gemm(w.du, d.U, 0, c->P("con_w"), d.U, 1, w.dcat, d.H + d.Ue, nullptr, n, d.H + d.Ue, d.U, 1.f,
                 w.gemm_scratch, s);
-    launch_split2(w.dcat, d.H, d.Ue, w.dhlast, w.duser, n, s);
+    launch_split2(w.dcat, d.H, d.Ue, w.dhlast, d.arch == LSTUR_ARCH_IIGRU ? w.duser2 : w.duser, n, s);
     dhl = w.dhlast;
   } else if (d.arch == LSTUR_ARCH_HGRU || d.arch == LSTUR_ARCH_NGRU || d.arch == LSTUR_ARCH_DGRU) {
     launch_split2(w.du, d.H, d.Ue, w.dhlast, w.duser, n, s);
@@ -537,7 +547,8 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     float *hprev = w.hprev, *rh = w.rh;   // fast path: both already sit row-major in the tape (no copies)
     gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
     PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
-                                   d.arch == LSTUR_ARCH_IGRU ? w.duser : w.dh0, n, d.W, d.H, s));
+                                   (d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_IIGRU) ? w.duser : w.dh0, n, d.W,
+                                   d.H, s));
     // GRU parameter gradients (their split-K / column-sum partials are reduced by ONE launch at the end of the pass)
     launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
                 w.gemm_scratch_k[0], s, &jobs[nj++]);
@@ -863,6 +874,8 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
     return fail(LSTUR_ERR_ARG, "every buffer must be bound");
   if (d.word_trainable && (!buf->word_grad || !buf->word_m || !buf->word_v))
     return fail(LSTUR_ERR_ARG, "word_trainable needs word_grad / word_m / word_v");
+  if (d.arch == LSTUR_ARCH_IIGRU && (!buf->user_emb2 || !buf->user_m2 || !buf->user_v2))
+    return fail(LSTUR_ERR_ARG, "iigru needs user_emb2 / user_m2 / user_v2");
   if (((uintptr_t)buf->workspace & 255) || ((uintptr_t)buf->word_emb & 15) || ((uintptr_t)buf->dense_param & 15) ||
       ((uintptr_t)buf->dense_grad & 15) || ((uintptr_t)buf->user_emb & 15))
     return fail(LSTUR_ERR_ARG, "buffers must be 16-byte (workspace 256-byte) aligned");
@@ -970,6 +983,8 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
   hipStream_t s = (hipStream_t)stream;
   const Dims& d = ctx->d;
   const lstur_cfg& c = ctx->cfg;
+  if (rows && d.arch == LSTUR_ARCH_IIGRU)
+    return fail(LSTUR_ERR_ARG, "iigru: external (data-parallel) user rows are not supported: the exchange carries one table");
   if (!rows) {
     rows = ctx->ws.user_rows;
     row_grads = ctx->ws.duser;
@@ -994,6 +1009,11 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
     {
       ProfScope _ps(ctx, "adam_user_table", s);
       launch_adam_table(ctx->buf.user_emb, ctx->buf.user_m, ctx->buf.user_v, ctx->ws.slot, ctx->ws.gsum, d.Nu, d.Ue,
+                        lr_t, c.beta1, c.beta2, c.eps, s);
+    }
+    if (d.arch == LSTUR_ARCH_IIGRU) {   // the second table: same rows (hence the same slot map), its own gradients
+      launch_user_grad_combine(rows, ctx->ws.duser2, n_rows, d.Ue, ctx->ws.first, ctx->ws.gsum2, ctx->ws.slot, s);
+      launch_adam_table(ctx->buf.user_emb2, ctx->buf.user_m2, ctx->buf.user_v2, ctx->ws.slot, ctx->ws.gsum2, d.Nu, d.Ue,
                         lr_t, c.beta1, c.beta2, c.eps, s);
     }
     launch_user_slot_clear(rows, n_rows, ctx->ws.slot, s);
@@ -1046,6 +1066,7 @@ int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* coun
       {"emb", w.emb, nt * d.Tp * d.D},      {"pooled", w.pooled, nt * d.F},
       {"loss_i", w.loss_i, n},              {"user_grad", w.duser, n * d.Ue},
       {"dconv", w.dconv, nt * d.T * d.F},
+      {"duser2", w.duser2, d.arch == LSTUR_ARCH_IIGRU ? n * d.Ue : 0},
       {"h_last", (d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU) ? w.uservec : w.hlast, n * d.H},
       {"dgates", w.dgates, n * d.W * 3 * d.H}, {"ddoc_vec", w.ddocvec, nt * d.U},
   };

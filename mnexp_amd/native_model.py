@@ -145,10 +145,17 @@ class NativeModel:
             self.word_m = torch.zeros(V * D, dtype=f32, device=dev)
             self.word_v = torch.zeros(V * D, dtype=f32, device=dev)
             wg, wm, wv = self.word_grad.data_ptr(), self.word_m.data_ptr(), self.word_v.data_ptr()
+        u2 = m2 = v2 = None
+        if arch == 'iigru':            # the second user table of paper.py:617-618 and its Adam moments
+            self.user_emb2 = torch.zeros(self.sizes.user_emb, dtype=f32, device=dev)
+            self.user_m2 = torch.zeros(self.sizes.user_emb, dtype=f32, device=dev)
+            self.user_v2 = torch.zeros(self.sizes.user_emb, dtype=f32, device=dev)
+            u2, m2, v2 = self.user_emb2.data_ptr(), self.user_m2.data_ptr(), self.user_v2.data_ptr()
+            self.shapes['user_emb2'] = self.shapes['user_emb']
         bufs = _lib.Buffers(self.word_emb.data_ptr(), self.dense_param.data_ptr(), self.dense_grad.data_ptr(),
                             self.dense_m.data_ptr(), self.dense_v.data_ptr(), self.user_emb.data_ptr(),
                             self.user_m.data_ptr(), self.user_v.data_ptr(), ws_ptr, self.sizes.workspace_bytes,
-                            wg, wm, wv)
+                            wg, wm, wv, u2, m2, v2)
         self._ctx = C.c_void_p()
         check(lib.lstur_create(C.byref(self.cfg), C.byref(bufs), C.byref(self._ctx)), 'lstur_create')
         self.optimizer = _Optimizer(lr)
@@ -230,9 +237,11 @@ class NativeModel:
         else:
             w['conv_w'] = _glorot(rng, s['conv_w'], k * D, k * F)
             w['conv_b'] = np.zeros(F, np.float32)
-        if self.arch == 'gru':
+        if self.arch in ('gru', 'iigru'):
             w['con_w'] = _glorot(rng, s['con_w'], s['con_w'][0], U)
             w['con_b'] = np.zeros(U, np.float32)
+        if self.arch == 'iigru':
+            w['user_emb2'] = rng.uniform(-0.05, 0.05, size=s['user_emb2']).astype(np.float32)
         if self.arch == 'niatt':         # SimpleAttentionMaskSupport over the history (paper.py:207-209, models.py:448-449)
             w['uatt_w'] = _glorot(rng, s['uatt_w'], U, 1)
             w['uatt_b'] = np.zeros(1, np.float32)
@@ -254,7 +263,7 @@ class NativeModel:
         self.set_weights(w)
 
     def param_names(self):
-        return [n for n, _, _ in self.layout] + ['user_emb']
+        return [n for n, _, _ in self.layout] + ['user_emb'] + (['user_emb2'] if self.arch == 'iigru' else [])
 
     def set_weights(self, weights):
         """weights: dict name -> ndarray (any subset of param_names() + 'word_emb')."""
@@ -262,6 +271,8 @@ class NativeModel:
             a = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)).to(self.device)
             if name == 'user_emb':
                 self.user_emb.copy_(a)
+            elif name == 'user_emb2':
+                self.user_emb2.copy_(a)
             elif name == 'word_emb':
                 self.word_emb.view(-1).copy_(a)
             else:
@@ -279,6 +290,8 @@ class NativeModel:
     def _get(self, flat, name):
         if name == 'user_emb':
             return self.user_emb.cpu().numpy().reshape(self.shapes['user_emb'])
+        if name == 'user_emb2':
+            return self.user_emb2.cpu().numpy().reshape(self.shapes['user_emb2'])
         off, cnt = self._slot(name)
         return flat[off:off + cnt].cpu().numpy().reshape(self.shapes[name])
 
@@ -321,7 +334,9 @@ class NativeModel:
         user_encoder: user Embedding, GRU kernel/recurrent/bias[, concat Dense]), then the frozen word table."""
         tok = ['qkv_w', 'qkv_b'] if self.news_encoder == 'mhsa' else ['conv_w', 'conv_b']
         names = tok + ['att_w', 'att_b', 'dense_w', 'dense_b', 'user_emb', 'gru_w', 'gru_u', 'gru_b']
-        if self.arch == 'gru':
+        if self.arch == 'iigru':
+            names += ['user_emb2']
+        if self.arch in ('gru', 'iigru'):
             names += ['con_w', 'con_b']
         if self.arch == 'niatt':
             names += ['uatt_w', 'uatt_b']
@@ -458,6 +473,8 @@ class NativeModel:
                      self.stats.data_ptr(), s), 'lstur_forward_backward')
         self.optimizer.iterations += 1
         t = self.optimizer.iterations
+        if (self.world > 1 or self.force_collectives) and self.arch == 'iigru':
+            raise _lib.LsturError('iigru (two user tables) is single-GPU only: the data-parallel exchange carries one table')
         if self.world > 1 or self.force_collectives:
             rows, grads = self._allreduce_grads(n)
             check(lib.lstur_adam_step(self._ctx, self.optimizer.lr, t, rows.data_ptr(), grads.data_ptr(),

@@ -38,7 +38,7 @@ import numpy as np
 
 EPS = 1e-7  # keras.backend.epsilon()
 
-ARCHS = ("igru", "gru", "hgru", "nigru", "ngru", "dgru", "pgru", "vo", "niavg", "niatt")
+ARCHS = ("igru", "gru", "hgru", "nigru", "ngru", "dgru", "pgru", "vo", "niavg", "niatt", "iigru")
 SCORE_MODELS = ("dot", "ddot", "dnn")      # Seq2VecPaperSoftmax._score_model, paper.py:443-458
 
 
@@ -122,9 +122,11 @@ def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.fl
     p["gru_w"] = glorot_uniform(rng, (U, 3 * H), U, 3 * H)
     p["gru_u"] = orthogonal(rng, H, 3 * H)
     p["gru_b"] = np.zeros(3 * H)
-    if arch == "gru":
+    if arch in ("gru", "iigru"):
         p["con_w"] = glorot_uniform(rng, (H + Ue, U), H + Ue, U)
         p["con_b"] = np.zeros(U)
+    if arch == "iigru":          # a second user table behind an igru (paper.py:614-621)
+        p["user_emb2"] = rng.uniform(-0.05, 0.05, size=(N_u, Ue))
     if arch == "niatt":          # SimpleAttentionMaskSupport over the history (id-less `att`, paper.py:207-209)
         p["uatt_w"] = glorot_uniform(rng, (U,), U, 1)
         p["uatt_b"] = np.zeros(1)
@@ -156,7 +158,7 @@ def dense_param_names(arch, word_trainable=False, head="softmax", encoder="cnnat
     """Order of the flat dense-parameter bucket (same order in the HIP library)."""
     names = ["qkv_w", "qkv_b"] if encoder == "mhsa" else ["conv_w", "conv_b"]
     names += ["att_w", "att_b", "dense_w", "dense_b", "gru_w", "gru_u", "gru_b"]
-    if arch == "gru":
+    if arch in ("gru", "iigru"):
         names += ["con_w", "con_b"]
     if arch == "niatt":
         names += ["uatt_w", "uatt_b"]
@@ -468,6 +470,10 @@ def user_encoder_fwd(p, arch, user, hv, hist_ids, uvec_keep=None):
         h, gc = gru_fwd(p, hvm, gmask, np.zeros((len(user), H), dtype=hv.dtype))
         u = h + uvec
         extra = None
+    elif arch == "iigru":                           # paper.py:614-621: Dense(U)(concat[igru(x, user_vec), user_vec2])
+        h, gc = gru_fwd(p, hvm, gmask, uvec)
+        extra = np.concatenate([h, p["user_emb2"][user]], axis=1)
+        u = extra @ p["con_w"] + p["con_b"]
     elif arch == "vo":                              # paper.py:622-623: the user embedding alone, the history is unused
         u, gc, extra = uvec, None, None
     elif arch == "niavg":                           # paper.py:629-630 + models.py:433-435: masked mean, no user id
@@ -506,6 +512,13 @@ def user_encoder_bwd(p, cache, du):
     elif arch == "pgru":
         gg, dx, _ = gru_bwd(p, gc, du)
         duser = du
+    elif arch == "iigru":
+        g["con_w"] = cache["cat"].T @ du
+        g["con_b"] = du.sum(axis=0)
+        dcat = du @ p["con_w"].T
+        gg, dx, dh0 = gru_bwd(p, gc, np.ascontiguousarray(dcat[:, :H]))
+        duser = dh0
+        cache["duser2"] = dcat[:, H:]               # row gradients of the second user table
     elif arch in ("vo", "niavg", "niatt"):          # no GRU in the graph: its parameters get no gradient
         gg = {n: np.zeros_like(p[n]) for n in ("gru_w", "gru_u", "gru_b")}
         if arch == "niatt":
@@ -639,6 +652,8 @@ def forward_backward(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0, wor
     out["grads"] = g
     out["user_rows"] = user
     out["user_row_grads"] = duser
+    if arch == "iigru":
+        out["user_row_grads2"] = uc["duser2"]
     return out
 
 
@@ -752,6 +767,9 @@ def point_train_step(p, arch, head, opt, user, hist, cand, labels, gain=1.0, K=4
     g = out["grads"]
     g["user_emb"] = densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"],
                                       p["user_emb"].dtype)
+    if "user_row_grads2" in out:
+        g["user_emb2"] = densify_user_grad(*p["user_emb2"].shape, out["user_rows"], out["user_row_grads2"],
+                                           p["user_emb2"].dtype)
     opt.step(p, g)
     return out
 
@@ -799,5 +817,8 @@ def train_step(p, arch, opt, user, hist, cands, drop_p=0.0, seed=0, step=0, word
     g = out["grads"]
     g["user_emb"] = densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"],
                                       p["user_emb"].dtype)
+    if "user_row_grads2" in out:                    # iigru: the second user table
+        g["user_emb2"] = densify_user_grad(*p["user_emb2"].shape, out["user_rows"], out["user_row_grads2"],
+                                           p["user_emb2"].dtype)
     opt.step(p, g)
     return out

@@ -171,7 +171,7 @@ def test_word_table_adam_steps_track_oracle():
 @pytest.mark.parametrize('arch,score_model', [('igru', 'ddot'), ('igru', 'dnn'), ('gru', 'ddot'), ('hgru', 'dnn'),
                                               ('ngru', 'ddot'), ('ngru', 'dnn'), ('dgru', 'ddot'), ('dgru', 'dnn'),
                                               ('pgru', 'dot'), ('vo', 'dot'), ('niavg', 'dot'), ('pgru', 'ddot'),
-                                              ('niatt', 'dot'), ('niatt', 'dnn')])
+                                              ('niatt', 'dot'), ('niatt', 'dnn'), ('iigru', 'dot'), ('iigru', 'ddot')])
 def test_score_models_and_wide_user_vectors_match_oracle(arch, score_model):
     """--score-model ddot | dnn (paper.py:448-455), and -a ngru | dgru (paper.py:600-602, 608-611: 2U-wide user vectors;
     dgru drops a sample's whole user embedding with p = 0.5 in training): logits, every gradient, three Adam steps and
@@ -189,7 +189,8 @@ def test_score_models_and_wide_user_vectors_match_oracle(arch, score_model):
                         dropout=drop, lr=1e-3, seed=77, score_model=score_model)
     model.set_weights({n: p[n] for n in p if n != 'word_emb'})
     names = O.dense_param_names(arch, score_model=score_model)
-    assert set(names) | {'user_emb'} == set(model.param_names())
+    tables = ['user_emb'] + (['user_emb2'] if arch == 'iigru' else [])     # iigru: a second user table (paper.py:617)
+    assert set(names) | set(tables) == set(model.param_names())
     user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
     user[1] = user[0]
     hist[2] = 0
@@ -209,6 +210,8 @@ def test_score_models_and_wide_user_vectors_match_oracle(arch, score_model):
         rel_close(g[n], ref['grads'][n], 2e-3, n)
     if arch not in ('niavg', 'niatt'):      # no user embedding in these graphs (paper.py:629-630, 207-209)
         rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
+    if arch == 'iigru':
+        rel_close(model.peek('duser2').cpu().numpy().reshape(B, -1), ref['user_row_grads2'], 2e-3, 'user_row_grads2')
     if arch in ('vo', 'niavg', 'niatt'):
         assert not g['gru_w'].any() and not g['gru_u'].any() and not g['gru_b'].any()     # no GRU in these graphs
     if arch == 'dgru':       # dropped samples: exactly no gradient for their user row
@@ -216,7 +219,7 @@ def test_score_models_and_wide_user_vectors_match_oracle(arch, score_model):
         assert 0 < keep.sum() < B and not g['user_row_grads'][~keep].any()
     # three Adam steps
     p32 = {n: a.astype(np.float32) for n, a in p.items()}
-    opt = O.Adam(p32, names + ['user_emb'], lr=1e-3)
+    opt = O.Adam(p32, names + tables, lr=1e-3)
     model.step = 0
     for step in range(3):
         user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
@@ -225,7 +228,7 @@ def test_score_models_and_wide_user_vectors_match_oracle(arch, score_model):
         model.train_on_batch(X, None)
     torch.cuda.synchronize()
     w = model.get_weights()
-    for n in names + ['user_emb']:
+    for n in names + tables:
         if n == 'sn2_b':     # softmax is shift-invariant: this gradient is identically 0, Adam only normalises rounding noise
             continue
         moved = np.abs(p32[n].astype(np.float64) - p[n]).max()

@@ -53,7 +53,7 @@ def test_bad_configs_are_rejected_with_a_message():
     with pytest.raises(_lib.LsturError, match='even'):
         _lib.query_sizes(_lib.make_cfg(4, 3, 5, 2, 10, 8, 8, 3, 7, 4, 'hgru'))
     with pytest.raises(_lib.LsturError, match='not supported'):
-        _lib.make_cfg(4, 3, 5, 2, 10, 8, 8, 3, 8, 4, 'iigru')
+        _lib.make_cfg(4, 3, 5, 2, 10, 8, 8, 3, 8, 4, 'satt')
     with pytest.raises(_lib.LsturError, match='2U wide'):          # dgru / ngru are not dot-compatible (paper.py:600-602)
         _lib.query_sizes(_lib.make_cfg(4, 3, 5, 2, 10, 8, 8, 3, 8, 4, 'dgru'))
     _lib.query_sizes(_lib.make_cfg(4, 3, 5, 2, 10, 8, 8, 3, 8, 4, 'dgru', score_model='dnn'))

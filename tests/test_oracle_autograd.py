@@ -47,7 +47,7 @@ def test_grads_match_autograd(arch, drop):
         np.testing.assert_allclose(g[n], ref, rtol=1e-8, atol=1e-12, err_msg=n)
 
 
-@pytest.mark.parametrize("arch", ["pgru", "vo", "niavg", "niatt"])
+@pytest.mark.parametrize("arch", ["pgru", "vo", "niavg", "niatt", "iigru"])
 def test_minor_user_encoders_match_autograd(arch):
     """`-a pgru | vo | niavg` (paper.py:622-630): GRU + user vector, the user vector alone, masked mean of the history."""
     rng = np.random.default_rng(5)
@@ -66,6 +66,8 @@ def test_minor_user_encoders_match_autograd(arch):
     assert abs(loss.item() - out["loss"]) < 1e-12
     g = dict(out["grads"])
     g["user_emb"] = O.densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"], np.float64)
+    if arch == "iigru":
+        g["user_emb2"] = O.densify_user_grad(*p["user_emb2"].shape, out["user_rows"], out["user_row_grads2"], np.float64)
     for n in names:
         ref = tp[n].grad.numpy() if tp[n].grad is not None else np.zeros_like(p[n])
         np.testing.assert_allclose(g[n], ref, rtol=1e-8, atol=1e-12, err_msg=n)

@@ -92,6 +92,8 @@ def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0, ke
         u = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
     elif arch == "pgru":
         u = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype)) + uvec
+    elif arch == "iigru":
+        u = torch.cat([gru(p, hv, gmask, uvec), p["user_emb2"][user]], dim=1) @ p["con_w"] + p["con_b"]
     elif arch == "vo":
         u = uvec
     elif arch == "niavg":
