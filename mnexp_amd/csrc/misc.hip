@@ -370,12 +370,20 @@ __global__ __launch_bounds__(256) void multi_reduce_kernel(ReduceJobs J) {
     const size_t i = t * 4;
     if (i >= count) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < q.nslices; ++s) {
-      const float4 v = *(const float4*)(q.src + (size_t)s * q.stride + i);
-      acc.x += v.x;
-      acc.y += v.y;
-      acc.z += v.z;
-      acc.w += v.w;
+    // eight slice loads in flight, added in slice order (the order is part of the contract: bitwise reproducible)
+    for (int s0 = 0; s0 < q.nslices; s0 += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(q.src + (size_t)min(s0 + u, q.nslices - 1) * q.stride + i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (s0 + u < q.nslices) {
+          acc.x += v[u].x;
+          acc.y += v[u].y;
+          acc.z += v[u].z;
+          acc.w += v[u].w;
+        }
+      }
     }
     const int r = (int)(i / q.cols), c = (int)(i - (size_t)r * q.cols);
     float4* d = (float4*)(q.dst + (size_t)r * q.ld + c);
