@@ -103,6 +103,29 @@ def cpu_baseline(wl, titles, word, batches, budget_s=20.0):
                        % (steps, el), host_cpus=os.cpu_count())
 
 
+def parity_check(model, wl, titles, batch):
+    """Outside the timed region: logits of one bench batch (dropout off) from the HIP path against the fp64 CPU oracle with
+    the model's CURRENT (trained) weights -- the number that shows the bf16x3 conv kernels are fp32-grade at the bench
+    shapes (BASELINE.json: fp32 logits within 1e-3 relative)."""
+    import torch
+    from oracle import lstur_oracle as O
+    from mnexp_amd._lib import lib, check
+    user, hist, cands = batch
+    tt = titles
+    u, h, c = model._dev_i32(user), model._dev_i32(tt[hist]), model._dev_i32(tt[cands])
+    check(lib.lstur_evaluate(model._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), int(user.shape[0]),
+                             model.stats.data_ptr(), model._stream()), 'lstur_evaluate')
+    torch.cuda.synchronize()
+    got = model.peek('logits').cpu().numpy().reshape(len(user), -1).astype(np.float64)
+    p = {k: np.asarray(v, dtype=np.float64) for k, v in model.get_weights().items()}
+    p['word_emb'] = model.word_emb.cpu().numpy().astype(np.float64)
+    if wl.get('encoder') == 'mhsa':
+        p['mhsa_heads'] = np.int64(wl['heads'])
+    ref = O.forward_backward(p, wl['arch'], user, tt[hist], tt[cands], drop_p=0.0, want_grads=False)['logits']
+    return dict(max_rel_logit_err_vs_fp64_oracle=float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)),
+                logit_scale=float(np.abs(ref).max()), samples=int(len(user)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -228,6 +251,7 @@ def main():
             'train_loss': round(loss, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
+            out['parity'] = parity_check(model, wl, titles, batches[0])
             out['cpu_baseline'] = cpu_baseline(wl, titles, word, batches)
         else:
             out['cpu_baseline'] = None
