@@ -91,6 +91,11 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
       *why = "mhsa: word_dim must be <= 316 (one 320-row tile holds the projection's weight + bias gradient)";
       return false;
     }
+    const size_t ntok = (size_t)d->B * (d->W + d->K1) * d->T;
+    if (ntok * 3 * d->F * 2 >= ((size_t)1 << 32) || ntok * d->D * 4 >= ((size_t)1 << 32)) {
+      *why = "mhsa: max_batch too large (the projection kernels address a step's tokens through 32-bit offsets)";
+      return false;
+    }
   }
   d->word_trainable = c->word_trainable != 0;
   if (d->word_trainable && c->freeze_encoder) {
@@ -328,7 +333,11 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->duser2 = ii ? (float*)take(nc * d.Ue * f4) : nullptr;
   w->gsum2 = ii ? (float*)take((size_t)d.rows_cap * d.Ue * f4) : nullptr;
   const bool mh = d.enc == LSTUR_ENC_MHSA;
-  w->conv_w3 = (!mh && conv3_supported(d.D, d.k, d.F)) ? (unsigned short*)take(conv3_w3_elems(d.D, d.k, d.F) * 2) : nullptr;
+  // the bf16x3 conv kernels address through 32-bit buffer offsets: beyond 4 GiB of embeddings / conv output per step the
+  // exact-fp32 kernels (64-bit pointers) take over
+  const bool fits32 = (nt * d.Tp * d.D + kEmbSlack) * f4 < ((size_t)1 << 32) && nt * d.T * d.F * f4 < ((size_t)1 << 32);
+  w->conv_w3 = (!mh && fits32 && conv3_supported(d.D, d.k, d.F)) ? (unsigned short*)take(conv3_w3_elems(d.D, d.k, d.F) * 2)
+                                                                 : nullptr;
   w->qkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;     // bf16 Q | K | V rows
   w->dqkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;
   w->mh_scratch = mh ? take(proj_wgrad_scratch_bytes(d.D, 3 * d.F, (int)(nt * d.T))) : nullptr;
