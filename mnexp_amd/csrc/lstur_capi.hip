@@ -116,9 +116,10 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
       *why = "the pointwise heads take one candidate per sample (cands == 1)";
       return false;
     }
+    const bool wide_mlp = d->arch == LSTUR_ARCH_NGRU && d->head == LSTUR_HEAD_POINT_MLP;   // Seq2VecPaperId `gru`
     if (d->arch != LSTUR_ARCH_IGRU && d->arch != LSTUR_ARCH_NIGRU && d->arch != LSTUR_ARCH_NIAVG &&
-        d->arch != LSTUR_ARCH_NIATT && d->arch != LSTUR_ARCH_VO) {
-      *why = "the pointwise heads support arch igru, vo, nigru, niavg and niatt";
+        d->arch != LSTUR_ARCH_NIATT && d->arch != LSTUR_ARCH_VO && !wide_mlp) {
+      *why = "the pointwise heads support arch igru, vo, nigru, niavg, niatt (and ngru with the MLP scorer)";
       return false;
     }
     if (!(c->gain > 0.f) || c->loss_negatives < 1) {
@@ -142,7 +143,7 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     *why = "score_model ddot / dnn belong to the listwise head";
     return false;
   }
-  if (d->score == LSTUR_SCORE_DOT && d->Uu != d->U) {
+  if (d->head == LSTUR_HEAD_SOFTMAX && d->score == LSTUR_SCORE_DOT && d->Uu != d->U) {
     *why = "ngru / dgru user vectors are 2U wide: they need score_model ddot or dnn (paper.py:600-602)";
     return false;
   }
@@ -200,7 +201,7 @@ std::vector<ParamSlot> param_layout(const Dims& d, size_t* total) {
     add("sn2_b", 1);
   }
   if (d.head == LSTUR_HEAD_POINT_MLP) {
-    add("score_w1", (size_t)2 * d.U * d.U);
+    add("score_w1", (size_t)(d.Uu + d.U) * d.U);   // [u | d] -> U; u is 2U wide for the pointwise `gru` (paper.py:339-342)
     add("score_b1", d.U);
     add("score_w2", d.U);
     add("score_b2", 1);
@@ -248,9 +249,9 @@ size_t max_gemm_scratch(const Dims& d) {
     upd(d.n_cap, d.Uu, d.U);
     upd(d.U, d.U, rows);
   }
-  upd(d.n_cap, d.U, 2 * d.U);   // pointwise MLP head
-  upd(2 * d.U, d.U, d.n_cap);
-  upd(d.n_cap, 2 * d.U, d.U);
+  upd(d.n_cap, d.U, d.Uu + d.U);   // pointwise MLP head
+  upd(d.Uu + d.U, d.U, d.n_cap);
+  upd(d.n_cap, d.Uu + d.U, d.U);
   // split-K slab bound for any smaller runtime batch: (256/tiles + 1) * tiles * 64*64 floats < 8 MiB
   return std::max(m, (size_t)8 << 20);
 }
@@ -308,11 +309,11 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->first = (int32_t*)take((size_t)d.rows_cap * 4);
   w->gsum = (float*)take((size_t)d.rows_cap * d.Ue * f4);
   w->slot = (int32_t*)take((size_t)d.Nu * 4);
-  w->scat = (float*)take(nc * 2 * d.U * f4);
+  w->scat = (float*)take(nc * (d.Uu + d.U) * f4);
   w->spre = (float*)take(nc * d.U * f4);
   w->sds = (float*)take(nc * f4);
   w->sdhid = (float*)take(nc * d.U * f4);
-  w->sdcat = (float*)take(nc * 2 * d.U * f4);
+  w->sdcat = (float*)take(nc * (d.Uu + d.U) * f4);
   w->dgrad_scratch = d.word_trainable ? (float*)take(conv_dgrad_scratch_floats((int)nt, d.T, d.D, d.k, d.F) * f4) : nullptr;
   const bool lw = d.score != LSTUR_SCORE_DOT;   // scratch of the listwise ddot / dnn score models
   const size_t lrows = nc * d.K1;
@@ -758,20 +759,18 @@ void run_point_head(lstur_ctx* c, const float* labels, int n, float scale, bool 
                      backward ? ddvec : nullptr, n, d.U, gain, K, scale, s);
     return;
   }
-  launch_concat2(w.uservec, d.U, dvec, d.U, w.scat, n, s);
-  launch_gemm(w.scat, 2 * d.U, 0, c->P("score_w1"), d.U, 0, w.spre, d.U, c->P("score_b1"), n, d.U, 2 * d.U, 1.f,
-              w.gemm_scratch, s);
+  const int wc = d.Uu + d.U;
+  launch_concat2(w.uservec, d.Uu, dvec, d.U, w.scat, n, s);
+  launch_gemm(w.scat, wc, 0, c->P("score_w1"), d.U, 0, w.spre, d.U, c->P("score_b1"), n, d.U, wc, 1.f, w.gemm_scratch, s);
   launch_point_mlp_out(w.spre, c->P("score_w2"), c->P("score_b2"), labels, w.logits, w.probs,
                        with_loss ? w.loss_i : nullptr, w.correct_i, backward ? w.sds : nullptr,
                        backward ? w.sdhid : nullptr, n, d.U, gain, K, scale, s);
   if (!backward) return;
   launch_point_w2_grad(w.spre, w.sds, c->G("score_w2"), c->G("score_b2"), n, d.U, s);
-  launch_gemm(w.scat, 2 * d.U, 1, w.sdhid, d.U, 0, c->G("score_w1"), d.U, nullptr, 2 * d.U, d.U, n, 1.f, w.gemm_scratch,
-              s);
+  launch_gemm(w.scat, wc, 1, w.sdhid, d.U, 0, c->G("score_w1"), d.U, nullptr, wc, d.U, n, 1.f, w.gemm_scratch, s);
   launch_colsum2(w.sdhid, n, d.U, d.U, c->G("score_b1"), 1.f, w.colsum_scratch, s);
-  launch_gemm(w.sdhid, d.U, 0, c->P("score_w1"), d.U, 1, w.sdcat, 2 * d.U, nullptr, n, 2 * d.U, d.U, 1.f,
-              w.gemm_scratch, s);
-  launch_split2(w.sdcat, d.U, d.U, w.du, ddvec, n, s);
+  launch_gemm(w.sdhid, d.U, 0, c->P("score_w1"), d.U, 1, w.sdcat, wc, nullptr, n, wc, d.U, 1.f, w.gemm_scratch, s);
+  launch_split2(w.sdcat, d.Uu, d.U, w.du, ddvec, n, s);
 }
 
 int point_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int32_t* cand, const float* labels, int n,
@@ -802,8 +801,8 @@ int predict_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const i
   run_forward(c, user, n, 1, false, 0, s);
   if (d.head == LSTUR_HEAD_POINT_MLP) {   // model.predict of the pointwise model = the scorer's sigmoid output
     Workspace& w = c->ws;
-    launch_concat2(w.uservec, d.U, w.docvec + (size_t)n * d.W * d.U, d.U, w.scat, n, s);
-    launch_gemm(w.scat, 2 * d.U, 0, c->P("score_w1"), d.U, 0, w.spre, d.U, c->P("score_b1"), n, d.U, 2 * d.U, 1.f,
+    launch_concat2(w.uservec, d.Uu, w.docvec + (size_t)n * d.W * d.U, d.U, w.scat, n, s);
+    launch_gemm(w.scat, d.Uu + d.U, 0, c->P("score_w1"), d.U, 0, w.spre, d.U, c->P("score_b1"), n, d.U, d.Uu + d.U, 1.f,
                 w.gemm_scratch, s);
     launch_point_mlp_out(w.spre, c->P("score_w2"), c->P("score_b2"), nullptr, w.logits, scores, nullptr, nullptr,
                          nullptr, nullptr, n, d.U, 1.f, 1, 0.f, s);

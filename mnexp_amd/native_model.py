@@ -114,10 +114,10 @@ class NativeModel:
                            dense_w=(filters, user_dim), dense_b=(user_dim,), gru_w=(user_dim, 3 * H),
                            gru_u=(H, 3 * H), gru_b=(3 * H,), con_w=(H + Ue, user_dim), con_b=(user_dim,),
                            user_emb=(max(1, n_users), Ue), word_emb=(V, D),
-                           score_w1=(2 * user_dim, user_dim), score_b1=(user_dim,), score_w2=(user_dim,),
+                           score_b1=(user_dim,), score_w2=(user_dim,),
                            score_b2=(1,))
         Uu = 2 * user_dim if arch in ('ngru', 'dgru') else user_dim      # width of the user vector
-        self.shapes.update(sdu_w=(Uu, user_dim), sdu_b=(user_dim,), sdd_w=(user_dim, user_dim), sdd_b=(user_dim,),
+        self.shapes.update(score_w1=(Uu + user_dim, user_dim), sdu_w=(Uu, user_dim), sdu_b=(user_dim,), sdd_w=(user_dim, user_dim), sdd_b=(user_dim,),
                            sn1_w=(Uu + user_dim, user_dim), sn1_b=(user_dim,), sn2_w=(user_dim,), sn2_b=(1,),
                            uatt_w=(user_dim,), uatt_b=(1,))
         dev = self.device
@@ -197,9 +197,14 @@ class NativeModel:
             if arch not in idless:
                 raise _lib.LsturError('id-less task: -a gru | avg | att (got {!r})'.format(arch))
             arch = idless[arch]
-        elif head != 'softmax' and arch not in ('igru', 'vo'):
-            # Seq2VecPaperId.get_user_encoder (paper.py:330-354): gru / iigru concatenate to 2U (not on the native path)
-            raise _lib.LsturError('pointwise task with user ids: -a igru | vo are on the native path (got {!r})'.format(arch))
+        elif head != 'softmax':
+            # Seq2VecPaperId.get_user_encoder (paper.py:330-354): its `gru` is the plain concat [GRU(x) | user_vec] (2U wide,
+            # the library's ngru) in front of the MLP scorer; its `iigru` (concat without Dense) is not on the native path
+            if arch == 'gru' and head == 'point_mlp':
+                arch = 'ngru'
+            elif arch not in ('igru', 'vo'):
+                raise _lib.LsturError('pointwise task with user ids: -a igru | vo | gru (MLP scorer) are on the native path '
+                                      '(got {!r})'.format(arch))
         pretrained = bool(getattr(cfg, 'enable_pretrain_encoder', False))
         model = cls(emb, user_count, cfg.batch_size, cfg.window_size, cfg.title_shape, cfg.negative_samples,
                     int(filters), int(kernel), cfg.user_embedding_dim, arch=arch, dropout=cfg.dropout,
@@ -256,7 +261,7 @@ class NativeModel:
             w['sn2_w'] = _glorot(rng, s['sn2_w'], U, 1)
             w['sn2_b'] = np.zeros(1, np.float32)
         if self.head == 'point_mlp':     # concat_dense / socre_dense (paper.py:223-227)
-            w['score_w1'] = _glorot(rng, s['score_w1'], 2 * U, U)
+            w['score_w1'] = _glorot(rng, s['score_w1'], s['score_w1'][0], U)
             w['score_b1'] = np.zeros(U, np.float32)
             w['score_w2'] = _glorot(rng, s['score_w2'], U, 1)
             w['score_b2'] = np.zeros(1, np.float32)

@@ -132,7 +132,7 @@ def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.fl
         p["uatt_b"] = np.zeros(1)
     assert head in HEADS and score_model in SCORE_MODELS
     Uu = 2 * U if arch in ("ngru", "dgru") else U      # width of the user vector (paper.py:600-602, 608-611)
-    assert score_model != "dot" or Uu == U, "ngru / dgru user vectors are 2U wide: not dot-compatible"
+    assert head != "softmax" or score_model != "dot" or Uu == U, "ngru / dgru user vectors are 2U wide: not dot-compatible"
     if score_model == "ddot":    # tanh-Dense on both sides, then dot (paper.py:452-455)
         p["sdu_w"] = glorot_uniform(rng, (Uu, U), Uu, U)
         p["sdu_b"] = np.zeros(U)
@@ -144,7 +144,7 @@ def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.fl
         p["sn2_w"] = glorot_uniform(rng, (U,), U, 1)
         p["sn2_b"] = np.zeros(1)
     if head == "point_mlp":      # concat_dense / socre_dense of Seq2VecPaper.score_encoder (paper.py:223-227)
-        p["score_w1"] = glorot_uniform(rng, (2 * U, U), 2 * U, U)
+        p["score_w1"] = glorot_uniform(rng, (Uu + U, U), Uu + U, U)   # Uu = 2U for Seq2VecPaperId's `gru` (paper.py:339-342)
         p["score_b1"] = np.zeros(U)
         p["score_w2"] = glorot_uniform(rng, (U,), U, 1)
         p["score_b2"] = np.zeros(1)

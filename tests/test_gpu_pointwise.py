@@ -30,11 +30,13 @@ def build(arch, head, dims, B, W, T, K, drop, gain):
     return O, p, model, rng
 
 
-@pytest.mark.parametrize('arch', ['igru', 'nigru', 'vo', 'niavg', 'niatt'])
+@pytest.mark.parametrize('arch', ['igru', 'nigru', 'vo', 'niavg', 'niatt', 'ngru'])
 @pytest.mark.parametrize('head', ['point_mlp', 'point_dot'])
 @pytest.mark.parametrize('dims,B,W,T,drop', [(TINY, 6, 4, 7, 0.0), (MID, 19, 9, 11, 0.2), (ODD, 7, 3, 6, 0.25)])
 def test_pointwise_step_matches_oracle(arch, head, dims, B, W, T, drop):
     _need_gpu()
+    if arch == 'ngru' and head == 'point_dot':
+        pytest.skip('a 2U-wide user vector has no dot scorer (paper.py:339-342 pairs it with the MLP)')
     gain, K = 1.7, 4
     O, p, model, rng = build(arch, head, dims, B, W, T, K, drop, gain)
     user, hist, cands = make_batch(rng, B, W, T, 1, dims['V'], dims['N_u'])
@@ -57,7 +59,7 @@ def test_pointwise_step_matches_oracle(arch, head, dims, B, W, T, drop):
     g = model.get_grads()
     for n in O.dense_param_names(arch, head=head):
         rel_close(g[n].reshape(-1), ref['grads'][n].reshape(-1), 2e-3, n)
-    if arch in ('igru', 'vo'):
+    if arch in ('igru', 'vo', 'ngru'):
         rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
     # model.predict of the pointwise model = the scorer's sigmoid output without dropout
     pr = model.predict([user, hist, cand])
