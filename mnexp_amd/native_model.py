@@ -378,7 +378,10 @@ class NativeModel:
             arrays = pickle.load(f)
         self.set_weights({n: np.asarray(a).reshape(self.shapes[n]) for n, a in zip(meta['order'], arrays)})
 
-    ENCODER_ORDER = ['word_emb', 'conv_w', 'conv_b', 'att_w', 'att_b', 'dense_w', 'dense_b']
+    @property
+    def ENCODER_ORDER(self):
+        tok = ['qkv_w', 'qkv_b'] if self.news_encoder == 'mhsa' else ['conv_w', 'conv_b']
+        return ['word_emb'] + tok + ['att_w', 'att_b', 'dense_w', 'dense_b']
 
     def save_encoder(self, paths):
         """The news encoder alone, as ``utils.save_model(config.encoder_output, doc_encoder)`` would write it
