@@ -171,20 +171,39 @@ __global__ __launch_bounds__(RW* CW * 64) void conv3_fwd_kernel(const float* __r
     const unsigned short* ap = st + (32 * wm + (lane & 31)) * C3_SA + 8 * (lane >> 5);
     const u16x8 ah = *(const u16x8*)ap, am = *(const u16x8*)(ap + A_IMG), al = *(const u16x8*)(ap + 2 * A_IMG);
     const unsigned short* bp = st + 3 * A_IMG;
+    // column tiles two at a time, their six-product chains interleaved (consecutive MFMAs never wait on each other's
+    // accumulator); the `j < my_nt` guards are wave-uniform, so EXEC stays full for the transposed reads
+    auto frags = [&](int j, u16x8 (&b)[3]) {
+      const int x0 = (wn * NTW + j) * 32;                // column inside this workgroup's window
+      b[0] = tr_frag(bp, SB, 0, x0, lane);
+      b[1] = tr_frag(bp + B_IMG, SB, 0, x0, lane);
+      b[2] = tr_frag(bp + 2 * B_IMG, SB, 0, x0, lane);
+    };
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      if (j < my_nt) {                                   // wave-uniform: EXEC stays full for the transposed reads
-        const int x0 = (wn * NTW + j) * 32;              // column inside this workgroup's window
-        const u16x8 bh = tr_frag(bp, SB, 0, x0, lane);
-        const u16x8 bm = tr_frag(bp + B_IMG, SB, 0, x0, lane);
-        const u16x8 bl = tr_frag(bp + 2 * B_IMG, SB, 0, x0, lane);
+    for (int j = 0; j < NTW; j += 2) {
+      if (j + 1 < NTW && j + 1 < my_nt) {
+        u16x8 b0[3], b1[3];
+        frags(j, b0);
+        frags(j + 1, b1);
+        f32x16 c0 = acc[j], c1 = acc[j + 1];
+        c0 = mfma32b(al, b0[0], c0);  c1 = mfma32b(al, b1[0], c1);     // small terms first
+        c0 = mfma32b(ah, b0[2], c0);  c1 = mfma32b(ah, b1[2], c1);
+        c0 = mfma32b(am, b0[1], c0);  c1 = mfma32b(am, b1[1], c1);
+        c0 = mfma32b(am, b0[0], c0);  c1 = mfma32b(am, b1[0], c1);
+        c0 = mfma32b(ah, b0[1], c0);  c1 = mfma32b(ah, b1[1], c1);
+        c0 = mfma32b(ah, b0[0], c0);  c1 = mfma32b(ah, b1[0], c1);
+        acc[j] = c0;
+        acc[j + 1] = c1;
+      } else if (j < my_nt) {
+        u16x8 b0[3];
+        frags(j, b0);
         f32x16 c = acc[j];
-        c = mfma32b(al, bh, c);                          // small terms first
-        c = mfma32b(ah, bl, c);
-        c = mfma32b(am, bm, c);
-        c = mfma32b(am, bh, c);
-        c = mfma32b(ah, bm, c);
-        c = mfma32b(ah, bh, c);
+        c = mfma32b(al, b0[0], c);
+        c = mfma32b(ah, b0[2], c);
+        c = mfma32b(am, b0[1], c);
+        c = mfma32b(am, b0[0], c);
+        c = mfma32b(ah, b0[1], c);
+        c = mfma32b(ah, b0[0], c);
         acc[j] = c;
       }
     }
@@ -423,19 +442,39 @@ __global__ __launch_bounds__(W3_THREADS) void conv3_wgrad_kernel(const float* __
     const u16x8 ah = tr_frag(st, W3_SA, 0, wv * 32, lane);
     const u16x8 am = tr_frag(st + W3_A_IMG, W3_SA, 0, wv * 32, lane);
     const u16x8 al = tr_frag(st + 2 * W3_A_IMG, W3_SA, 0, wv * 32, lane);
+    // two column tiles at a time, their six-product chains interleaved: consecutive MFMAs never wait on each other's
+    // accumulator
+    auto six = [&](f32x16& c0, f32x16& c1, const u16x8 (&b0)[3], const u16x8 (&b1)[3]) {
+      c0 = mfma32b(al, b0[0], c0);  c1 = mfma32b(al, b1[0], c1);
+      c0 = mfma32b(ah, b0[2], c0);  c1 = mfma32b(ah, b1[2], c1);
+      c0 = mfma32b(am, b0[1], c0);  c1 = mfma32b(am, b1[1], c1);
+      c0 = mfma32b(am, b0[0], c0);  c1 = mfma32b(am, b1[0], c1);
+      c0 = mfma32b(ah, b0[1], c0);  c1 = mfma32b(ah, b1[1], c1);
+      c0 = mfma32b(ah, b0[0], c0);  c1 = mfma32b(ah, b1[0], c1);
+    };
+    auto frags = [&](int j, u16x8 (&b)[3]) {
+      b[0] = tr_frag(bp, W3_SB, 0, j * 32, lane);
+      b[1] = tr_frag(bp + W3_B_IMG, W3_SB, 0, j * 32, lane);
+      b[2] = tr_frag(bp + 2 * W3_B_IMG, W3_SB, 0, j * 32, lane);
+    };
 #pragma unroll
-    for (int j = 0; j < W3_TN; ++j) {
-      const u16x8 bh = tr_frag(bp, W3_SB, 0, j * 32, lane);
-      const u16x8 bm = tr_frag(bp + W3_B_IMG, W3_SB, 0, j * 32, lane);
-      const u16x8 bl = tr_frag(bp + 2 * W3_B_IMG, W3_SB, 0, j * 32, lane);
-      f32x16 c = acc[j];
-      c = mfma32b(al, bh, c);
-      c = mfma32b(ah, bl, c);
-      c = mfma32b(am, bm, c);
-      c = mfma32b(am, bh, c);
-      c = mfma32b(ah, bm, c);
-      c = mfma32b(ah, bh, c);
-      acc[j] = c;
+    for (int j = 0; j + 1 < W3_TN; j += 2) {
+      u16x8 b0[3], b1[3];
+      frags(j, b0);
+      frags(j + 1, b1);
+      six(acc[j], acc[j + 1], b0, b1);
+    }
+    if (W3_TN & 1) {
+      u16x8 b0[3];
+      frags(W3_TN - 1, b0);
+      f32x16 c = acc[W3_TN - 1];
+      c = mfma32b(al, b0[0], c);
+      c = mfma32b(ah, b0[2], c);
+      c = mfma32b(am, b0[1], c);
+      c = mfma32b(am, b0[0], c);
+      c = mfma32b(ah, b0[1], c);
+      c = mfma32b(ah, b0[0], c);
+      acc[W3_TN - 1] = c;
     }
   };
   const bool store_first = wv < W3_TM / 2;           // wave-uniform
