@@ -238,6 +238,11 @@ int lstur_point_evaluate(lstur_ctx* ctx, const int32_t* user, const int32_t* his
 int lstur_profile(lstur_ctx* ctx, int enable);
 int lstur_profile_read(lstur_ctx* ctx, int index, const char** name, float* total_ms, int32_t* launches);
 
+/* How the Conv1D contractions of this context run: 0 = none (mhsa encoder), 1 = "bf16x3" (fp32-grade 3-way bf16 split on
+ * the bf16 matrix cores, mnexp_amd/csrc/conv3f.hip), 2 = exact fp32 MFMA (mnexp_amd/csrc/conv.hip: filters > 448, kernel
+ * > 8, or LSTUR_CONV_F32 set in the environment).  Negative: error. */
+int lstur_conv_scheme(lstur_ctx* ctx);
+
 /* Debug/inspection: device pointers to intermediates of the last call (valid until the next call).
  * names: "doc_vec" [N_t,U], "user_vec" [n,U], "logits" [n,K1], "probs" [n,K1], "conv_out" [N_t,T,F] (rows of
  *        non-pad tokens only), "att_w" [N_t,T], "emb" [N_t,T+k-1,D], "h_last" [n,H], "dgates" [n,W,3H] */
@@ -273,6 +278,31 @@ int lstur_conv3_pack_w(const float* w, int32_t dim, int32_t ksize, int32_t filte
 int lstur_conv3_relu_mask_fwd(const float* emb_padded, const uint16_t* w3, const float* bias, const int32_t* ids, float* out,
                               int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters,
                               const int32_t* vidx, const int32_t* vcount, lstur_stream stream);
+/* Second generation of the bf16x3 forward (mnexp_amd/csrc/conv3f.hip): BOTH operands pre-split.  The embedding gather writes
+ * the three bf16 parts of every element into "E3" ([title][title_len + ksize - 1][ceil8(dim) / 8][part][8] bf16,
+ * lstur_conv3_e3_elems() elements incl. slack; Embedding + Dropout of task/paper.py:132-147 like lstur_gather_f32;
+ * skip_unread != 0: rows that no window of a non-pad token covers are left untouched -- e3 must then hold finite values), the
+ * weight image w3 = lstur_conv3_pack_w2(conv_w) holds lstur_conv3_w3_elems2() elements.  variant 0 (10 .. 15 are timing-only
+ * ablation builds with WRONG results, tools/bench_conv3f.py).  scratch: lstur_conv3_fwd2_scratch() bytes for the k-sliced
+ * tiles of the last partial round of workgroups, or NULL (every tile runs whole). */
+size_t lstur_conv3_e3_elems(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize);
+int lstur_gather_split3(const float* table, const int32_t* ids, uint16_t* e3, int32_t n_titles, int32_t title_len,
+                        int32_t dim, int32_t pad_left, int32_t pad_right, float drop, uint32_t key, int32_t skip_unread,
+                        lstur_stream stream);
+size_t lstur_conv3_w3_elems2(int32_t dim, int32_t ksize, int32_t filters);
+int lstur_conv3_pack_w2(const float* w, int32_t dim, int32_t ksize, int32_t filters, uint16_t* w3, lstur_stream stream);
+int lstur_conv3_relu_mask_fwd2(const uint16_t* e3, const uint16_t* w3, const float* bias, const int32_t* ids, float* out,
+                               int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters,
+                               const int32_t* vidx, const int32_t* vcount, int32_t variant, void* scratch,
+                               lstur_stream stream);
+size_t lstur_conv3_fwd2_scratch(void);
+/* ... and its kernel gradient on the same pre-split embeddings (dout fp32 [n_titles * title_len, filters]; rows of pad tokens
+ * are not read when the compacted list is given).  scratch: lstur_conv3_wgrad2_scratch() bytes; offsets: 2 * n_titles *
+ * title_len int32 of scratch (per-token window / row offsets, filled by the call). */
+size_t lstur_conv3_wgrad2_scratch(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters);
+int lstur_conv3_wgrad2(const uint16_t* e3, const float* dout, float* dw, void* scratch, int32_t* offsets, int32_t n_titles,
+                       int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx,
+                       const int32_t* vcount, lstur_stream stream);
 /* ... and the kernel gradient in the same scheme (what the training step uses); scratch: lstur_conv3_wgrad_scratch bytes. */
 size_t lstur_conv3_wgrad_scratch(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters);
 int lstur_conv3_wgrad(const float* emb_padded, const float* dout, float* dw, void* scratch, int32_t n_titles,

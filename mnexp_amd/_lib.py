@@ -69,6 +69,7 @@ SIGNATURES = {
     'lstur_point_evaluate': (_I, [_P, _P, _P, _P, _P, _I, _P, _P]),
     'lstur_profile': (_I, [_P, _I]),
     'lstur_profile_read': (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_F), C.POINTER(_I)]),
+    'lstur_conv_scheme': (_I, [_P]),
     'lstur_peek': (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_Z)]),
     'lstur_gather_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _P]),
     'lstur_valid_tokens_scratch': (_Z, [_I]),
@@ -77,6 +78,14 @@ SIGNATURES = {
     'lstur_conv3_w3_elems': (_Z, [_I, _I, _I]),
     'lstur_conv3_pack_w': (_I, [_P, _I, _I, _I, _P, _P]),
     'lstur_conv3_relu_mask_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'lstur_conv3_e3_elems': (_Z, [_I, _I, _I, _I]),
+    'lstur_gather_split3': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _I, _P]),
+    'lstur_conv3_w3_elems2': (_Z, [_I, _I, _I]),
+    'lstur_conv3_pack_w2': (_I, [_P, _I, _I, _I, _P, _P]),
+    'lstur_conv3_relu_mask_fwd2': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
+    'lstur_conv3_fwd2_scratch': (_Z, []),
+    'lstur_conv3_wgrad2_scratch': (_Z, [_I, _I, _I, _I, _I]),
+    'lstur_conv3_wgrad2': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'lstur_conv3_wgrad_scratch': (_Z, [_I, _I, _I, _I, _I]),
     'lstur_conv3_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'lstur_conv1d_wgrad_scratch': (_Z, [_I, _I, _I]),

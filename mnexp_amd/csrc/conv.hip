@@ -586,10 +586,10 @@ __global__ void token_offsets_kernel(const int32_t* __restrict__ vidx, const int
                                      int Tp, int D, int F, int32_t* __restrict__ offA, int32_t* __restrict__ offB) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M) return;
-  const int count = vcount[0];
-  const int m = vidx[min(i, max(count - 1, 0))];
+  const int count = vcount ? vcount[0] : M;
+  const int m = vidx ? vidx[min(i, max(count - 1, 0))] : i;          // no list: every token
   const int n = m / T, t = m - n * T;
-  offA[i] = (n * Tp + t) * D;
+  offA[i] = (n * Tp + t) * D;                                          // D: units per padded row (floats, or E3 pieces)
   offB[i] = m * F;
 }
 void launch_token_offsets(const int32_t* vidx, const int32_t* vcount, int M, int T, int Tp, int D, int F, int32_t* offA,

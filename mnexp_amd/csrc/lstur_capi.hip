@@ -154,6 +154,17 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
   d->Tp = d->T + d->k - 1;
   d->KD = d->k * d->D;
   d->nt_max = d->B * (d->W + d->K1);
+  {
+    // every kernel addresses a step's token-level tensors through 32-bit buffer offsets (descriptor size and per-lane
+    // offset both wrap at 4 GiB): refuse such batches instead of dropping stores silently
+    const size_t nt = (size_t)d->nt_max, lim = (size_t)1 << 32;
+    const size_t emb = (nt * d->Tp * (size_t)std::max(d->D, conv3_dp(d->D) * 3 / 2) + 1024) * 4;   // fp32 rows or E3 (6 B / element)
+    if (emb >= lim || nt * d->T * d->F * 4 >= lim) {
+      *why = "max_batch too large: a step's embeddings / conv outputs exceed 4 GiB (the kernels address them through 32-bit "
+             "buffer offsets); split the batch";
+      return false;
+    }
+  }
   int pred_rows = d->nt_max / (d->W + 1);
   d->n_cap = ceil16(std::max(d->B, pred_rows));   // GRU kernels process whole 16-sample row tiles
   d->rows_cap = d->B * 8;
@@ -219,7 +230,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
+  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* conv_w3_v1; unsigned short* e3; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   size_t bytes;
 };
@@ -298,7 +309,8 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->conv_wp = (float*)take(pack_b_floats(d.KD, d.F) * f4);
   w->gru_up = (float*)take(gru_pack_floats(d.H) * f4);
   w->wgrad_scratch = take(std::max(conv_wgrad_scratch_bytes(d.D, d.k, d.F),
-                                   conv3_supported(d.D, d.k, d.F) ? conv3_wgrad_scratch_bytes((int)nt, d.T, d.D, d.k, d.F) : 0));
+                                   conv3f_supported(d.D, d.k, d.F) ? std::max(conv3_wgrad2_scratch_bytes((int)nt, d.T, d.D, d.k, d.F),
+                                                                                 conv3_wgrad_scratch_bytes((int)nt, d.T, d.D, d.k, d.F)) : 0));
   w->gemm_scratch_bytes = max_gemm_scratch(d);
   w->gemm_scratch = take(w->gemm_scratch_bytes);
   // weight-gradient GEMMs of the backward pass keep their split-K slabs until the step's single reduction launch
@@ -334,11 +346,12 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->duser2 = ii ? (float*)take(nc * d.Ue * f4) : nullptr;
   w->gsum2 = ii ? (float*)take((size_t)d.rows_cap * d.Ue * f4) : nullptr;
   const bool mh = d.enc == LSTUR_ENC_MHSA;
-  // the bf16x3 conv kernels address through 32-bit buffer offsets: beyond 4 GiB of embeddings / conv output per step the
-  // exact-fp32 kernels (64-bit pointers) take over
-  const bool fits32 = (nt * d.Tp * d.D + kEmbSlack) * f4 < ((size_t)1 << 32) && nt * d.T * d.F * f4 < ((size_t)1 << 32);
-  w->conv_w3 = (!mh && fits32 && conv3_supported(d.D, d.k, d.F)) ? (unsigned short*)take(conv3_w3_elems(d.D, d.k, d.F) * 2)
-                                                                 : nullptr;
+  // bf16x3 conv path (conv3f.hip): split weight image, pre-split embeddings E3, slabs of the k-sliced tail tiles
+  const bool c3 = !mh && conv3f_supported(d.D, d.k, d.F) && d.k <= 8;
+  w->conv_w3 = c3 ? (unsigned short*)take(conv3_w3_elems2(d.D, d.k, d.F) * 2) : nullptr;
+  w->conv_w3_v1 = c3 ? (unsigned short*)take(conv3_w3_elems(d.D, d.k, d.F) * 2) : nullptr;   // A/B switch LSTUR_CONV_GEN1
+  w->e3 = c3 ? (unsigned short*)take(conv3_e3_elems((int)nt, d.T, d.D, d.k) * 2) : nullptr;
+  w->fwd2_scratch = c3 ? take(conv3_fwd2_scratch_bytes()) : nullptr;
   w->qkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;     // bf16 Q | K | V rows
   w->dqkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;
   w->mh_scratch = mh ? take(proj_wgrad_scratch_bytes(d.D, 3 * d.F, (int)(nt * d.T))) : nullptr;
@@ -386,6 +399,7 @@ struct lstur_ctx {
   int32_t n_docs = 0;
   bool lazy_init_done = false;
   int last_n = 0, last_k1 = 0;
+  bool last_use3 = false;   // the last forward ran the bf16x3 conv path (E3 embeddings; the fp32 `emb` layout was not written)
   bool counted = false;   // stage_titles already left the per-block non-pad counts in ws.vscratch
   float* P(const char* name) const {
     for (auto& s : layout)
@@ -444,6 +458,8 @@ void lazy_init(lstur_ctx* c, hipStream_t s) {
   const Dims& d = c->d;
   (void)hipMemsetAsync(c->ws.emb + (size_t)d.nt_max * d.Tp * d.D, 0, kEmbSlack * sizeof(float), s);
   launch_fill_i32(c->ws.slot, -1, d.Nu, s);
+  // E3: the gather skips rows no window covers; the k tail of a window may still touch one (under a zero weight)
+  if (c->ws.e3) (void)hipMemsetAsync(c->ws.e3, 0, conv3_e3_elems(d.nt_max, d.T, d.D, d.k) * 2, s);
   c->lazy_init_done = true;
 }
 
@@ -457,11 +473,13 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   lazy_init(c, s);
   // operand images of the weights used by MFMA kernels this step
   const bool mhsa = d.enc == LSTUR_ENC_MHSA;
-  // conv forward: fp32-grade bf16x3 contraction on the bf16 matrix cores (conv3.hip) unless LSTUR_CONV_F32 asks for the
+  // conv forward: fp32-grade bf16x3 contraction on the bf16 matrix cores (conv3f.hip) unless LSTUR_CONV_F32 asks for the
   // exact-fp32 MFMA kernel of conv.hip
   static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr;
   const bool use3 = !mhsa && w.conv_w3 && !conv_f32;
-  if (use3) launch_conv3_pack_w(c->P("conv_w"), d.KD, d.F, w.conv_w3, s);
+  static const bool gen1 = getenv("LSTUR_CONV_GEN1") != nullptr;   // A/B: first-generation bf16x3 kernels (conv3.hip, fp32 E)
+  if (use3 && gen1) launch_conv3_pack_w(c->P("conv_w"), d.KD, d.F, w.conv_w3_v1, s);
+  else if (use3) launch_conv3_pack_w2(c->P("conv_w"), d.D, d.k, d.F, w.conv_w3, s);
   else if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, s);
   launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, s);
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
@@ -469,14 +487,22 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   // stable list of the non-pad tokens of this batch (+ the kernel gradient's row offsets), two launches
   if (!c->counted) launch_compact_count(w.ids, nt * d.T, w.vscratch, s);
   c->counted = false;
-  launch_compact_write_offsets(w.ids, nt * d.T, w.vscratch, w.vidx, w.vcount, d.T, d.Tp, d.D, d.F, w.offA, w.offB, s);
-  PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
+  // (offA: a token's window offset in the units of its path -- 16-byte pieces of E3, or floats of the fp32 layout)
+  launch_compact_write_offsets(w.ids, nt * d.T, w.vscratch, w.vidx, w.vcount, d.T, d.Tp,
+                               (use3 && !gen1) ? conv3_dp(d.D) / 8 * 3 : d.D, d.F, w.offA, w.offB, s);
+  if (use3 && !gen1)   // Embedding + Dropout straight into the pre-split layout of the bf16x3 conv kernels (rows nobody reads skipped)
+    PROF("gather", launch_gather3(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, s));
+  else
+    PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
   if (mhsa) {   // token stage = multi-head self-attention (build-defined, include/lstur.h: LSTUR_ENC_MHSA)
     PROF("qkv_proj", launch_proj_fwd_bf16(w.emb, c->P("qkv_w"), c->P("qkv_b"), w.qkv, nt * d.T, 3 * d.F, d.D, s));
     PROF("mhsa_fwd", launch_mhsa_fwd_bf16(w.qkv, w.ids, w.conv, nt, d.T, d.F, d.heads, s));
-  } else if (use3) {
-    PROF("conv_fwd", launch_conv3_fwd(w.emb, w.conv_w3, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
+  } else if (use3 && gen1) {
+    PROF("conv_fwd", launch_conv3_fwd(w.emb, w.conv_w3_v1, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
                                       w.vcount, s));
+  } else if (use3) {
+    PROF("conv_fwd", launch_conv3_fwd2(w.e3, w.conv_w3, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
+                                       w.vcount, 0, w.fwd2_scratch, s));
   } else {
     PROF("conv_fwd", launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
                                      w.vcount, s));
@@ -523,6 +549,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   }
   c->last_n = n;
   c->last_k1 = k1;
+  c->last_use3 = use3 && !gen1;
 }
 
 // stats (may be NULL): the batch means of loss_i / correct_i ride the pass's single reduction launch
@@ -637,10 +664,15 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
                                                   d.D, d.k, d.F, drop, dropout_key(c->cfg.seed, step, 0), s));
   }
   static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr;
-  if (w.conv_w3 && !conv_f32)   // fp32-grade bf16x3 contraction (conv3.hip), like the forward
+  static const bool gen1 = getenv("LSTUR_CONV_GEN1") != nullptr;
+  if (w.conv_w3 && !conv_f32 && gen1)
     PROF("conv_wgrad", launch_conv3_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vidx,
                                           w.vcount, s, &jobs[nj++], w.offA, w.offB));
-  else
+  else if (w.conv_w3 && !conv_f32) {   // fp32-grade bf16x3 contraction (conv3f.hip), like the forward; one reduce job per tap
+    ProfScope _ps(c, "conv_wgrad", s);
+    nj += launch_conv3_wgrad2(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, s, &jobs[nj],
+                              w.offA, w.offB);
+  } else
     PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
                                          w.vidx, w.vcount, s, w.offA, w.offB,
                                          w.emb + (size_t)d.nt_max * d.Tp * d.D /* zero slack */, &jobs[nj++]));
@@ -1062,6 +1094,12 @@ int lstur_profile_read(lstur_ctx* ctx, int index, const char** name, float* tota
   return LSTUR_OK;
 }
 
+int lstur_conv_scheme(lstur_ctx* ctx) {
+  if (!ctx) return fail(LSTUR_ERR_ARG, "ctx is NULL");
+  if (ctx->d.enc == LSTUR_ENC_MHSA) return 0;
+  return (ctx->ws.conv_w3 && !getenv("LSTUR_CONV_F32")) ? 1 : 2;
+}
+
 int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* count) {
   if (!ctx || !name || !ptr) return fail(LSTUR_ERR_ARG, "NULL argument");
   const Dims& d = ctx->d;
@@ -1078,6 +1116,8 @@ int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* coun
       {"h_last", (d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU) ? w.uservec : w.hlast, n * d.H},
       {"dgates", w.dgates, n * d.W * 3 * d.H}, {"ddoc_vec", w.ddocvec, nt * d.U},
   };
+  if (!strcmp(name, "emb") && ctx->last_use3)
+    return fail(LSTUR_ERR_STATE, "emb: the bf16x3 conv path keeps the embeddings pre-split (E3); run with LSTUR_CONV_F32=1");
   for (auto& e : tab)
     if (!strcmp(e.nm, name)) {
       *ptr = e.p;
@@ -1156,6 +1196,62 @@ int lstur_conv3_relu_mask_fwd(const float* emb_padded, const uint16_t* w3, const
   if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "conv3_fwd: vidx and vcount go together");
   launch_conv3_fwd(emb_padded, w3, bias, ids, out, n_titles, title_len, dim, ksize, filters, vidx, vcount, (hipStream_t)stream);
   return check_launch("conv3_fwd");
+}
+size_t lstur_conv3_e3_elems(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize) {
+  return conv3_e3_elems(n_titles, title_len, dim, ksize);
+}
+int lstur_gather_split3(const float* table, const int32_t* ids, uint16_t* e3, int32_t n_titles, int32_t title_len,
+                        int32_t dim, int32_t pad_left, int32_t pad_right, float drop, uint32_t key, int32_t skip_unread,
+                        lstur_stream stream) {
+  if (!table || !ids || !e3 || dim % 4 || n_titles < 0) return fail(LSTUR_ERR_ARG, "gather_split3: bad argument (dim % 4)");
+  launch_gather3(table, ids, e3, n_titles, title_len, dim, pad_left, pad_right, drop, key, skip_unread != 0, (hipStream_t)stream);
+  return check_launch("gather_split3");
+}
+size_t lstur_conv3_w3_elems2(int32_t dim, int32_t ksize, int32_t filters) {
+  return conv3f_supported(dim, ksize, filters) ? conv3_w3_elems2(dim, ksize, filters) : 0;
+}
+int lstur_conv3_pack_w2(const float* w, int32_t dim, int32_t ksize, int32_t filters, uint16_t* w3, lstur_stream stream) {
+  if (!w || !w3) return fail(LSTUR_ERR_ARG, "conv3_pack_w2: NULL");
+  if (!conv3f_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
+  launch_conv3_pack_w2(w, dim, ksize, filters, w3, (hipStream_t)stream);
+  return check_launch("conv3_pack_w2");
+}
+int lstur_conv3_relu_mask_fwd2(const uint16_t* e3, const uint16_t* w3, const float* bias, const int32_t* ids, float* out,
+                               int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters,
+                               const int32_t* vidx, const int32_t* vcount, int32_t variant, void* scratch,
+                               lstur_stream stream) {
+  if (!e3 || !w3 || !bias || !ids || !out) return fail(LSTUR_ERR_ARG, "conv3_fwd2: NULL");
+  if (!conv3f_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
+  if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "conv3_fwd2: vidx and vcount go together");
+  if (variant != 0 && (variant < 10 || variant > 15)) return fail(LSTUR_ERR_ARG, "conv3_fwd2: variant 0 (10 .. 15: ablations)");
+  if (conv3_e3_elems(n_titles, title_len, dim, ksize) * 2 >= ((size_t)1 << 32) ||
+      (size_t)n_titles * title_len * filters * 4 >= ((size_t)1 << 32))
+    return fail(LSTUR_ERR_ARG, "conv3_fwd2: more than 4 GiB of embeddings / outputs per call");
+  launch_conv3_fwd2(e3, w3, bias, ids, out, n_titles, title_len, dim, ksize, filters, vidx, vcount, variant, scratch,
+                    (hipStream_t)stream);
+  return check_launch("conv3_fwd2");
+}
+size_t lstur_conv3_fwd2_scratch(void) { return conv3_fwd2_scratch_bytes(); }
+size_t lstur_conv3_wgrad2_scratch(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters) {
+  return conv3f_supported(dim, ksize, filters) ? conv3_wgrad2_scratch_bytes(n_titles, title_len, dim, ksize, filters) : 0;
+}
+int lstur_conv3_wgrad2(const uint16_t* e3, const float* dout, float* dw, void* scratch, int32_t* offsets, int32_t n_titles,
+                       int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx,
+                       const int32_t* vcount, lstur_stream stream) {
+  if (!e3 || !dout || !dw || !scratch || !offsets) return fail(LSTUR_ERR_ARG, "conv3_wgrad2: NULL");
+  if (!conv3f_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
+  if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "conv3_wgrad2: vidx and vcount go together");
+  if (ksize > kMaxReduceJobs) return fail(LSTUR_ERR_ARG, "conv3_wgrad2: ksize too large");
+  const int M = n_titles * title_len;
+  if (conv3_e3_elems(n_titles, title_len, dim, ksize) * 2 >= ((size_t)1 << 32) || (size_t)M * filters * 4 >= ((size_t)1 << 32))
+    return fail(LSTUR_ERR_ARG, "conv3_wgrad2: more than 4 GiB of embeddings / gradients per call");
+  hipStream_t s = (hipStream_t)stream;
+  launch_token_offsets(vidx, vcount, M, title_len, title_len + ksize - 1, conv3_dp(dim) / 8 * 3, filters, offsets, offsets + M, s);
+  ReduceJob jobs[kMaxReduceJobs];
+  const int nj = launch_conv3_wgrad2(e3, dout, dw, scratch, n_titles, title_len, dim, ksize, filters, vcount, s, jobs, offsets,
+                                     offsets + M);
+  if (M > 0) launch_multi_reduce(jobs, nj, s);
+  return check_launch("conv3_wgrad2");
 }
 size_t lstur_conv3_wgrad_scratch(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters) {
   return conv3_supported(dim, ksize, filters) ? conv3_wgrad_scratch_bytes(n_titles, title_len, dim, ksize, filters) : 0;

@@ -22,7 +22,7 @@ struct ReduceJob {
   float alpha;
   float beta;
 };
-constexpr int kMaxReduceJobs = 16;
+constexpr int kMaxReduceJobs = 24;
 void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s);
 
 
@@ -38,6 +38,10 @@ constexpr int kEmbSlack = 256;
 // ---- misc.hip ----------------------------------------------------------------------------------
 void launch_gather(const float* table, const int32_t* ids, float* out, int n_titles, int T, int D,
                    int pad_l, int pad_r, float drop, uint32_t key, hipStream_t s);
+// the gather in the pre-split "E3" form of the bf16x3 conv kernels (layout: conv3f.hip); e3 = conv3_e3_elems() bf16
+// skip_unread: rows no window of a non-pad token covers are neither read nor written (the buffer must hold finite values)
+void launch_gather3(const float* table, const int32_t* ids, unsigned short* e3, int n_titles, int T, int D, int pad_l,
+                    int pad_r, float drop, uint32_t key, bool skip_unread, hipStream_t s);
 void launch_expand_titles(const int32_t* table, const int32_t* doc_ids, int32_t* out, int n, int T,
                           hipStream_t s);
 // stable list of non-pad tokens: vidx[0..*count) ; scratch = compact_scratch_ints(n) int32
@@ -139,6 +143,26 @@ void launch_conv3_wgrad(const float* emb, const float* dout, float* dw, void* sc
 void launch_conv3_fwd(const float* emb, const unsigned short* W3, const float* bias, const int32_t* ids, float* out,
                       int n_titles, int T, int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount,
                       hipStream_t s);
+
+// ---- conv3f.hip: second generation of the bf16x3 forward (both operands pre-split; see the file header) --------
+int conv3_dp(int D);                                              // embedding row length of E3 (D rounded up to 8)
+size_t conv3_e3_elems(int n_titles, int T, int D, int ksize);   // bf16 elements of E3 incl. slack
+size_t conv3_w3_elems2(int D, int ksize, int F);                // bf16 elements of the k'-ordered split weight image
+bool conv3f_supported(int D, int ksize, int F);
+void launch_conv3_pack_w2(const float* W, int D, int ksize, int F, unsigned short* W3, hipStream_t s);
+// variant 0: the product kernel (10 .. 15: timing-only ablations); scratch (conv3_fwd2_scratch_bytes, or NULL): slabs
+// of the k-sliced tail tiles
+size_t conv3_fwd2_scratch_bytes(int ncu = 256);
+void launch_conv3_fwd2(const unsigned short* e3, const unsigned short* W3, const float* bias, const int32_t* ids, float* out,
+                       int n_titles, int T, int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount, int variant,
+                       void* scratch, hipStream_t s);
+
+// kernel gradient on the pre-split embeddings (same file): dw through ksize reduce jobs (one per tap); returns the job
+// count.  offA: per-token window offsets in 16-byte pieces of E3, offB: per-token row offsets in floats of dout.
+size_t conv3_wgrad2_scratch_bytes(int n_titles, int T, int D, int ksize, int F);
+int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
+                        int ksize, int F, const int32_t* vcount, hipStream_t s, ReduceJob* jobs, const int32_t* offA,
+                        const int32_t* offB, float alpha = 1.0f);
 
 // ---- attpool.hip -------------------------------------------------------------------------------
 // ids (nullable): rows with id == 0 are taken as zero without reading c / writing dc

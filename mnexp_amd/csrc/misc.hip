@@ -1,6 +1,6 @@
 // HBM-bound and glue kernels of the LSTUR path (gfx950): embedding gather (+dropout), operand
 // packing, reductions, Keras-Adam (flat bucket and dense user-table sweep), scorer/softmax/CE.
-#include "lstur_device.h"
+#include "bf16_mfma.h"
 #include "lstur_internal.h"
 
 namespace lstur {
@@ -73,6 +73,103 @@ void launch_gather(const float* table, const int32_t* ids, float* out, int n_tit
   else
     hipLaunchKernelGGL(gather_kernel<false>, dim3(blocks), dim3(256), 0, s, (const float4*)table, ids,
                        (float4*)out, (uint32_t)total4, T, Tp, D4, pad_l, 0u, 0u, 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same gather for the bf16x3 conv kernels (conv3f.hip / conv3.hip): every element leaves as its three bf16 parts
+// h | m | l (split3, bf16_mfma.h; h + m + l = the fp32 value the kernel above writes, exact to ~2^-25), in the layout "E3"
+// [title][pad_l + T + pad_r][Dp / 8][part][8]: the three 16-byte pieces of an 8-element chunk side by side, rows padded
+// with zeros to Dp = 8 * ceil(D / 8) elements.  One thread = one chunk: 32 bytes of a table row in, 48 contiguous bytes
+// out (a wave writes 3 KB in one piece); dropout mask and scale are applied in fp32 BEFORE the split, exactly as above.
+// ---------------------------------------------------------------------------------------------
+// Rows that no window of a non-pad token covers are SKIPPED (neither read nor written): the conv kernels run over the
+// non-pad tokens only (see compact_*), so with SKIP a padded row tp is needed iff some token t' in [t - pad_r, t + pad_l]
+// (t = tp - pad_l) of the title is non-pad -- 30 % fewer bytes at config 2 (titles are zero-padded at the end, histories at
+// the front).  The buffer must hold finite values from the start (the k tail of a window can touch a skipped row under a
+// zero weight): the step zeroes it once.
+template <bool DROP, bool SKIP>
+__global__ __launch_bounds__(256) void gather3_kernel(const float4* __restrict__ table, const int32_t* __restrict__ ids,
+                                                      uint4* __restrict__ out, uint32_t total8, int T, int Tp, int D4,
+                                                      int C8, int pad_l, int pad_r, uint32_t thresh, uint32_t key,
+                                                      float scale) {
+  constexpr int U = 2;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < total8; i0 += U * stride) {
+    uint32_t c8[U], tok[U];
+    bool inr[U], real[U];
+    int id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = min(i0 + u * stride, total8 - 1u);
+      inr[u] = i0 + u * stride < total8;
+      const uint32_t row = i / (uint32_t)C8;
+      c8[u] = i - row * (uint32_t)C8;
+      const uint32_t n = row / (uint32_t)Tp;
+      const int t = (int)(row - n * (uint32_t)Tp) - pad_l;
+      real[u] = t >= 0 && t < T;
+      tok[u] = n * (uint32_t)T + (uint32_t)min(max(t, 0), T - 1);
+      id[u] = ids[tok[u]];
+      if (SKIP) {
+        bool need = false;
+        for (int tt = max(t - pad_r, 0); tt <= min(t + pad_l, T - 1); ++tt) need |= ids[n * (uint32_t)T + (uint32_t)tt] != 0;
+        inr[u] = inr[u] && need;
+      }
+    }
+    if (SKIP && !inr[0] && !inr[1]) continue;
+    float4 va[U], vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      va[u] = table[(size_t)id[u] * D4 + min((int)(2u * c8[u]), D4 - 1)];
+      vb[u] = table[(size_t)id[u] * D4 + min((int)(2u * c8[u] + 1u), D4 - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float4 w[2] = {va[u], vb[u]};
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const uint32_t c4 = 2u * c8[u] + hf;
+        if (DROP) {
+          const uint32_t e = (tok[u] * (uint32_t)D4 + c4) * 4u;
+          bool k[4];
+          keep_quad(key, e, thresh, k);
+          w[hf].x = k[0] ? w[hf].x * scale : 0.f;
+          w[hf].y = k[1] ? w[hf].y * scale : 0.f;
+          w[hf].z = k[2] ? w[hf].z * scale : 0.f;
+          w[hf].w = k[3] ? w[hf].w * scale : 0.f;
+        }
+        if (!real[u] || (int)c4 >= D4) w[hf] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      u16x4 h0, m0, l0, h1, m1, l1;
+      split3(w[0], h0, m0, l0);
+      split3(w[1], h1, m1, l1);
+      if (inr[u]) {
+        uint4* o = out + (size_t)(i0 + u * stride) * 3;
+        auto pk = [](u16x4 a, u16x4 b) {
+          return make_uint4((uint32_t)a[0] | ((uint32_t)a[1] << 16), (uint32_t)a[2] | ((uint32_t)a[3] << 16),
+                            (uint32_t)b[0] | ((uint32_t)b[1] << 16), (uint32_t)b[2] | ((uint32_t)b[3] << 16));
+        };
+        o[0] = pk(h0, h1);
+        o[1] = pk(m0, m1);
+        o[2] = pk(l0, l1);
+      }
+    }
+  }
+}
+
+void launch_gather3(const float* table, const int32_t* ids, unsigned short* e3, int n_titles, int T, int D, int pad_l,
+                    int pad_r, float drop, uint32_t key, bool skip_unread, hipStream_t s) {
+  const int Tp = T + pad_l + pad_r, D4 = D / 4, C8 = (D + 7) / 8;
+  const size_t total8 = (size_t)n_titles * Tp * C8;
+  if (total8 == 0) return;
+  const int blocks = (int)std::min<size_t>(cdivz(total8, 256 * 2), 256 * 16);
+  const uint32_t th = drop > 0.f ? dropout_thresh(drop) : 0u;
+  const float sc = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, (const float4*)table, ids, (uint4*)e3, (uint32_t)total8, T, Tp, D4,
+                       C8, pad_l, pad_r, th, key, sc);
+  };
+  if (drop > 0.f) skip_unread ? go(gather3_kernel<true, true>) : go(gather3_kernel<true, false>);
+  else skip_unread ? go(gather3_kernel<false, true>) : go(gather3_kernel<false, false>);
 }
 
 // doc ids -> token ids through the resident title table

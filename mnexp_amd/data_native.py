@@ -44,7 +44,9 @@ def _check(rc, what):
 
 
 class NativeTrainFeed:
-    """Endless iterator of ((user int64[B], hist int32[B,W], cands int32[B,K+1]), labels int64[B,K+1])."""
+    """Endless iterator of ((user int64[B], hist int32[B,W], cands int32[B,K+1]), labels int64[B,K+1]); the id-less
+    Seq2VecPaperSoftmax gets (hist, cands) -- the shape its own ``train_ids`` yields.  Users are sharded by rank exactly
+    like ``Seq2VecPaper._users(shard=True)``."""
 
     def __init__(self, task, seed=None, rank=None, world=None):
         from . import dist
@@ -53,6 +55,7 @@ class NativeTrainFeed:
             raise NotImplementedError('--native-feed covers the Seq2VecPaperSoftmax(Id) sample stream only; use --ids '
                                       'for {}'.format(type(task).__name__))
         self.B, self.W, self.K = cfg.batch_size, cfg.window_size, cfg.negative_samples
+        self.has_user = bool(getattr(task, 'has_user', True))      # id-less task: batches carry no user column
         rank = dist.rank() if rank is None else rank
         world = dist.world_size() if world is None else world
         imp_off, pos_off, neg_off, pos, neg = [0], [0], [0], [], []
@@ -86,6 +89,8 @@ class NativeTrainFeed:
         hist = np.empty((self.B, self.W), np.int32)
         cands = np.empty((self.B, self.K + 1), np.int32)
         _check(lib.lstur_data_next_train(self._h, user.ctypes.data, hist.ctypes.data, cands.ctypes.data), 'next_train')
+        if not self.has_user:
+            return (hist, cands), self.labels
         return (user.astype(np.int64), hist, cands), self.labels
 
     def samples(self, n):

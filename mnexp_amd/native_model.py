@@ -10,6 +10,7 @@ runs in the library.  There is no CPU path.
 import ctypes as C
 import os
 import logging
+import pickle
 
 import numpy as np
 import torch
@@ -21,6 +22,31 @@ from ._lib import lib, check
 class History:
     def __init__(self):
         self.history = {}
+
+
+class _WeightsUnpickler(pickle.Unpickler):
+    """Weights-only reader of the ``pickle(model.get_weights())`` files of utils.save_model (utils.py:74-79): the
+    payload is a list of ndarrays, so only numpy's array reconstruction globals are admitted.  Any other global --
+    what a crafted or foreign pickle would need to run code -- is refused."""
+    _ALLOWED = {('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+                ('numpy', 'ndarray'), ('numpy', 'dtype'),
+                ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+                ('numpy.core.numeric', '_frombuffer'), ('numpy._core.numeric', '_frombuffer'),
+                ('_codecs', 'encode')}       # protocol-2 pickles carry the array bytes as a latin-1 str
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError('weights file references {}.{}: only numpy arrays are accepted'.format(module, name))
+
+
+def load_weight_list(path):
+    """The list of ndarrays in a weights pickle; executes nothing from the file."""
+    with open(path, 'rb') as f:
+        arrays = _WeightsUnpickler(f).load()
+    if not isinstance(arrays, (list, tuple)) or not all(isinstance(a, np.ndarray) and a.dtype != object for a in arrays):
+        raise ValueError('{}: expected a list of numeric ndarrays'.format(path))
+    return list(arrays)
 
 
 class _Optimizer:
@@ -99,10 +125,6 @@ class NativeModel:
                                  score_model=score_model)
         self.score_model = score_model       # listwise --score-model dot | ddot | dnn (paper.py:443-458)
         self.news_encoder = news_encoder     # 'mhsa': build-defined multi-head self-attention token stage (heads x F/heads)
-        # how the Conv1D contractions run: 'bf16x3' = fp32-grade 3-way split on the bf16 matrix cores (conv3.hip, filters
-        # <= 448), 'f32' = exact-fp32 MFMA (conv.hip; forced by LSTUR_CONV_F32=1)
-        self.conv_scheme = ('bf16x3' if filters <= 448 and not os.environ.get('LSTUR_CONV_F32') else 'f32') \
-            if news_encoder == 'cnnatt' else 'n/a'
         self.mhsa_proj_dtype = 'bf16'        # operand type of the mhsa Q|K|V projection GEMMs (attention products: bf16)
         self.freeze_encoder = bool(freeze_encoder)
         self.word_trainable = bool(word_trainable)     # --textual-embedding-trainable (paper.py:132-138)
@@ -158,6 +180,9 @@ class NativeModel:
                             wg, wm, wv, u2, m2, v2)
         self._ctx = C.c_void_p()
         check(lib.lstur_create(C.byref(self.cfg), C.byref(bufs), C.byref(self._ctx)), 'lstur_create')
+        # how the Conv1D contractions run, as the LIBRARY decides it: 'bf16x3' = fp32-grade 3-way split on the bf16 matrix
+        # cores (conv3f.hip), 'f32' = exact-fp32 MFMA (conv.hip; filters > 448 or LSTUR_CONV_F32=1), 'n/a' = mhsa encoder
+        self.conv_scheme = {0: 'n/a', 1: 'bf16x3', 2: 'f32'}[lib.lstur_conv_scheme(self._ctx)]
         self.optimizer = _Optimizer(lr)
         self.step = 0                       # dropout stream / fit step counter
         self.dist_group = dist_group
@@ -355,7 +380,6 @@ class NativeModel:
         """(json_path, pkl_path) like utils.save_model: a JSON description + a pickle of the weight list in
         Keras order and Keras shapes (attention kernel [F,1])."""
         import json
-        import pickle
         json_path, pkl_path = paths
         w = self.get_weights()
         w['word_emb'] = self.word_emb.cpu().numpy()
@@ -368,14 +392,12 @@ class NativeModel:
 
     def load(self, paths):
         import json
-        import pickle
         json_path, pkl_path = paths
         with open(json_path) as f:
             meta = json.load(f)
         if meta.get('arch') != self.arch:
             raise ValueError('saved model is arch {!r}, this model is {!r}'.format(meta.get('arch'), self.arch))
-        with open(pkl_path, 'rb') as f:      # a file written by save() above
-            arrays = pickle.load(f)
+        arrays = load_weight_list(pkl_path)
         self.set_weights({n: np.asarray(a).reshape(self.shapes[n]) for n, a in zip(meta['order'], arrays)})
 
     @property
@@ -388,7 +410,6 @@ class NativeModel:
         (utils.py:73-79): pickle of ``doc_encoder.get_weights()`` -- layer order, i.e. Embedding matrix, Conv1D
         kernel/bias, attention kernel [F,1]/bias, Dense kernel/bias."""
         import json
-        import pickle
         json_path, pkl_path = paths
         w = self.get_weights()
         w['word_emb'] = self.word_emb.cpu().numpy()
@@ -402,9 +423,7 @@ class NativeModel:
     def load_encoder(self, paths):
         """``--enable-pretrain-encoder`` (paper.py:103-107: ``utils.load_model(config.encoder_input)``): takes the 7
         arrays of a saved cnnatt doc encoder (the list order above; the JSON side file is not interpreted)."""
-        import pickle
-        with open(paths[1], 'rb') as f:      # the user's own pre-trained encoder file
-            arrays = pickle.load(f)
+        arrays = load_weight_list(paths[1])
         if len(arrays) != len(self.ENCODER_ORDER):
             raise ValueError('expected the {} weight arrays of a cnnatt doc encoder, found {}'.format(
                 len(self.ENCODER_ORDER), len(arrays)))

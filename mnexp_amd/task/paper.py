@@ -65,8 +65,20 @@ class Seq2VecPaper(Seq2Vec):
     has_user = False
     head = 'point_mlp'                                # score_encoder, paper.py:223-227
 
-    def _users(self):
-        return ((None, d) for d in self.data)
+    def _users(self, shard=False):
+        """(user id or None, (train impressions, valid impressions)) per ClickData row.  ``shard=True`` (the TRAINING
+        generators under data parallelism): only the rows this rank owns, r, r+N, ... (mnexp_amd/dist.py)
+        -- for the id-less tasks too, or every rank would train on the same samples.  Validation / test generators walk
+        every user on every rank, so the reported metrics are those of the single-GPU run."""
+        from .. import dist
+        w, r = dist.world_size(), dist.rank()
+        idx = dist.shard_users(len(self.data), r, w) if (shard and w > 1) else range(len(self.data))
+        return (((u if self.has_user else None), self.data[u]) for u in idx)
+
+    def _no_samples(self):
+        from .. import dist
+        return RuntimeError('rank {} of {}: no user of this rank\'s shard yields a training sample (every rank must feed '
+                            'the same number of steps into the all-reduce)'.format(dist.rank(), dist.world_size()))
 
     def _row(self, user, hist, cand, label):
         head = (user,) if self.has_user else ()
@@ -78,7 +90,8 @@ class Seq2VecPaper(Seq2Vec):
         (``random.sample``) while every click still enters the history."""
         K = self.config.negative_samples
         while True:
-            for user, (ih, _) in self._users():
+            emitted = False
+            for user, (ih, _) in self._users(shard=True):
                 if not ih:
                     continue
                 ch = self.Window(self.docs, self.config.window_size)
@@ -91,10 +104,13 @@ class Seq2VecPaper(Seq2Vec):
                     for pos in impression.pos:
                         if ch.count and trainable:
                             hist = ch.get_ids()
+                            emitted = True
                             yield self._row(user, hist, pos, 1)
                             for neg in impression.negative_samples(K):
                                 yield self._row(user, hist, neg, 0)
                         ch.push(pos)
+            if not emitted:
+                raise self._no_samples()
 
     def valid_gen_ids(self):
         """paper.py:62-77 / :290-305."""
@@ -190,13 +206,6 @@ class Seq2VecPaperId(Seq2VecPaper):
     """User id = row number of ClickData.tsv (paper.py:268)."""
     has_user = True
 
-    def _users(self):
-        from .. import dist
-        w, r = dist.world_size(), dist.rank()
-        if w == 1:
-            return enumerate(self.data)
-        return ((u, self.data[u]) for u in dist.shard_users(len(self.data), r, w))
-
 
 class Seq2VecPaperSoftmax(Seq2VecPaper):
     """Samples: (hist_ids[W], [pos, neg_1..neg_K], label=[1,0..0])."""
@@ -215,15 +224,19 @@ class Seq2VecPaperSoftmax(Seq2VecPaper):
         """paper.py:385-399 / :528-542: history excludes the current click and grows inside an impression."""
         label = self._label()
         while True:
-            for user, (ih, _) in self._users():
+            emitted = False
+            for user, (ih, _) in self._users(shard=True):
                 if not ih:
                     continue
                 ch = self.Window(self.docs, self.config.window_size)
                 for impression in ih:
                     for pos in impression.pos:
                         if ch.count:
+                            emitted = True
                             yield self._sample(user, ch, pos, impression, label)
                         ch.push(pos)
+            if not emitted:
+                raise self._no_samples()
 
     def valid_gen_ids(self):
         """paper.py:401-418 / :544-562: history = all training clicks; pushed after each valid impression."""
@@ -281,15 +294,6 @@ class Seq2VecPaperSoftmaxId(Seq2VecPaperSoftmax):
     """User id = row number of ClickData.tsv (paper.py:531)."""
     has_user = True
 
-    def _users(self):
-        """(user id, impressions) of the users this rank owns: all of them single-process, users
-        r, r+N, ... under data parallelism (mnexp_amd/dist.py)."""
-        from .. import dist
-        w, r = dist.world_size(), dist.rank()
-        if w == 1:
-            return enumerate(self.data)
-        return ((u, self.data[u]) for u in dist.shard_users(len(self.data), r, w))
-
 
 class _ExpiringWindow:
     """Time-aware click window of the `...Days` tasks (paper.py:669-696, 763-792): an entry is visible until
@@ -342,15 +346,19 @@ class Seq2VecPaperSoftmaxDays(Seq2VecPaperSoftmax):
     def train_gen_ids(self):
         label = self._label()
         while True:
-            for user, (ih, _) in self._users():
+            emitted = False
+            for user, (ih, _) in self._users(shard=True):
                 if not ih:
                     continue
                 ch = self.Window(self.docs, self.config.window_size, self.config.days)
                 for impression in ih:
                     for pos in impression.pos:
                         if ch.count(impression.time):
+                            emitted = True
                             yield self._sample_at(user, ch, pos, impression, label)
                         ch.push(pos, impression.time)
+            if not emitted:
+                raise self._no_samples()
 
     def valid_gen_ids(self):
         label = self._label()
@@ -383,4 +391,3 @@ class Seq2VecPaperSoftmaxDaysId(Seq2VecPaperSoftmaxDays):
     """`...Days` with the user-id model of Seq2VecPaperSoftmaxId (paper.py:753-881; the vertical / sub-vertical
     fields its News class also parses are not used by this task's generators or model)."""
     has_user = True
-    _users = Seq2VecPaperSoftmaxId._users

@@ -90,6 +90,15 @@ def test_task_shards_users_across_ranks(monkeypatch):
     for r in range(3):
         monkeypatch.setattr(D, 'world_size', lambda group=None: 3)
         monkeypatch.setattr(D, 'rank', lambda group=None, r=r: r)
-        seen.append([u for u, _ in h._users()])
+        seen.append([u for u, _ in h._users(shard=True)])
+        # validation / test generators walk EVERY user on every rank: the reported metrics are the single-GPU ones
+        assert [u for u, _ in h._users()] == list(range(len(h.data)))
     assert sorted(sum(seen, [])) == list(range(len(h.data)))
     assert seen[1][:3] == [1, 4, 7]
+    # the id-less task shards the same way (or every rank would train on the same samples), user column = None
+    cfg2 = make_config(os.path.join(GOLD, 'tiny'), task='Seq2VecPaperSoftmax', arch='gru')
+    h2 = task.get(cfg2)
+    monkeypatch.setattr(D, 'rank', lambda group=None: 2)
+    got = list(h2._users(shard=True))
+    assert [d is h2.data[i] for (u, d), i in zip(got, range(2, len(h2.data), 3))] == [True] * len(got)
+    assert all(u is None for u, _ in got)

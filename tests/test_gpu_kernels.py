@@ -282,3 +282,143 @@ def test_conv3_bf16x3_forward_is_fp32_grade(N, D, T, F, k):
     check(lib.lstur_conv3_wgrad(Epd.data_ptr(), dC_g.data_ptr(), dw2.data_ptr(), scr.data_ptr(), N, T, D, k, F,
                                 vidx.data_ptr(), vcount.data_ptr(), stream()))
     assert (dw2.double() - ref2).abs().max().item() < 2e-5 * wscale
+
+
+def _split3_np(x):
+    """bf16_mfma.h: split3 -- three round-to-nearest-even bf16 parts of an fp32 array (as uint16 bit patterns)."""
+    def rne(v):
+        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+        return r.astype(np.uint16)
+    def up(b):
+        return (b.astype(np.uint32) << 16).view(np.float32)
+    h = rne(x)
+    r1 = (x - up(h)).astype(np.float32)
+    m = rne(r1)
+    r2 = (r1 - up(m)).astype(np.float32)
+    return h, m, rne(r2)
+
+
+@pytest.mark.parametrize('N,D,T,k,drop', [(37, 300, 30, 3, 0.2), (5, 12, 7, 3, 0.0), (6, 20, 6, 5, 0.5), (3, 48, 11, 1, 0.2)])
+def test_gather_split3_is_the_split_of_the_fp32_gather(N, D, T, k, drop):
+    """misc.hip: gather3_kernel writes h | m | l of exactly the values lstur_gather_f32 writes (same dropout mask, same
+    scale), in the E3 layout [title][Tp][Dp/8][part][8] with zero pad elements -- bit for bit."""
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    rng = np.random.default_rng(D + N)
+    V = 60
+    table = rng.normal(0, 0.3, size=(V, D)).astype(np.float32)
+    ids = rng.integers(0, V, size=(N, T)).astype(np.int32)
+    ids[:, max(1, T - 3):] = 0
+    pl = (k - 1) // 2
+    pr = k - 1 - pl
+    Tp, Dp = T + k - 1, (D + 7) // 8 * 8
+    t_d, i_d = dev(table), dev(ids)
+    ref = torch.full((N * Tp * D + 256,), 9.0, dtype=torch.float32, device='cuda')
+    check(lib.lstur_gather_f32(t_d.data_ptr(), i_d.data_ptr(), ref.data_ptr(), N, T, D, pl, pr, drop, 1234, stream()))
+    n3 = lib.lstur_conv3_e3_elems(N, T, D, k)
+    assert n3 >= N * Tp * Dp * 3
+    e3 = torch.full((n3,), 0x7FC0, dtype=torch.int16, device='cuda')
+    check(lib.lstur_gather_split3(t_d.data_ptr(), i_d.data_ptr(), e3.data_ptr(), N, T, D, pl, pr, drop, 1234, 0, stream()))
+    torch.cuda.synchronize()
+    E = ref[:N * Tp * D].cpu().numpy().reshape(N, Tp, D)
+    Epad = np.zeros((N, Tp, Dp), np.float32)
+    Epad[:, :, :D] = E
+    h, m, l = _split3_np(Epad)
+    want = np.stack([h, m, l], axis=0).reshape(3, N, Tp, Dp // 8, 8).transpose(1, 2, 3, 0, 4)    # [N][Tp][C8][part][8]
+    got = e3[:N * Tp * Dp * 3].cpu().numpy().view(np.uint16).reshape(N, Tp, Dp // 8, 3, 8)
+    assert np.array_equal(got, want)
+    # skip_unread: exactly the rows some non-pad token's window covers are written (same values), the others untouched
+    e3s = torch.full((n3,), 0x1234, dtype=torch.int16, device='cuda')
+    check(lib.lstur_gather_split3(t_d.data_ptr(), i_d.data_ptr(), e3s.data_ptr(), N, T, D, pl, pr, drop, 1234, 1, stream()))
+    gots = e3s[:N * Tp * Dp * 3].cpu().numpy().view(np.uint16).reshape(N, Tp, Dp // 8, 3, 8)
+    nonpad = np.zeros((N, Tp + k), bool)
+    for j in range(k):                                    # token t covers padded rows t .. t + k - 1
+        nonpad[:, j:j + T] |= ids != 0
+    need = nonpad[:, :Tp]
+    assert np.array_equal(gots[need], want[need])
+    assert (gots[~need] == 0x1234).all() and (~need).any()
+
+
+@pytest.mark.parametrize('sliced', [True, False])
+@pytest.mark.parametrize('N,D,T,F,k', [(130, 300, 30, 400, 3), (3, 300, 30, 400, 3), (9, 12, 7, 16, 3), (7, 20, 6, 24, 5),
+                                       (11, 48, 11, 448, 1), (5, 16, 8, 230, 3), (40, 300, 30, 250, 3),
+                                       (1200, 300, 30, 400, 3)])
+def test_conv3_fwd2_presplit_is_fp32_grade(N, D, T, F, k, sliced):
+    """conv3f.hip: the bf16x3 forward on PRE-SPLIT operands (E3 from the gather, k'-ordered split weights).  Same bounds as
+    the first generation: 2e-5 of the output scale against fp64, 4e-6 against the exact-fp32 MFMA kernel, compacted list
+    = the full run.  `sliced`: with the scratch for the k-sliced tail tiles (tiles past the last whole round of 256 are cut
+    into <= 8 k slices summed by the fix-up kernel; N = 1200 gives 282 tiles = one round + a sliced tail)."""
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    rng = np.random.default_rng(N * 7 + F)
+    V = 70
+    Tp, pl = T + k - 1, (k - 1) // 2
+    table = rng.normal(0, 0.3, size=(V, D)).astype(np.float32)
+    ids = rng.integers(0, V, size=(N, T)).astype(np.int32)
+    ids[:, max(1, T - 4):] = 0
+    ids[0, 1] = 0                                           # a pad token INSIDE a title: its row 0 embedding is gathered
+    Wc = rng.normal(0, 0.05, size=(k, D, F)).astype(np.float32)
+    b = rng.normal(0, 0.1, size=F).astype(np.float32)
+    t_d, ids_d, b_d = dev(table), dev(ids), dev(b)
+    e3 = torch.zeros(lib.lstur_conv3_e3_elems(N, T, D, k), dtype=torch.int16, device='cuda')
+    check(lib.lstur_gather_split3(t_d.data_ptr(), ids_d.data_ptr(), e3.data_ptr(), N, T, D, pl, k - 1 - pl, 0.0, 0, 0, stream()))
+    Wd = dev(Wc.reshape(k * D, F))
+    w3 = torch.zeros(lib.lstur_conv3_w3_elems2(D, k, F), dtype=torch.int16, device='cuda')
+    check(lib.lstur_conv3_pack_w2(Wd.data_ptr(), D, k, F, w3.data_ptr(), stream()))
+    out = torch.full((N * T, F), -7.0, dtype=torch.float32, device='cuda')
+    scr = torch.empty(lib.lstur_conv3_fwd2_scratch(), dtype=torch.uint8, device='cuda') if sliced else None
+    scr_p = scr.data_ptr() if sliced else None
+    check(lib.lstur_conv3_relu_mask_fwd2(e3.data_ptr(), w3.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(), out.data_ptr(),
+                                         N, T, D, k, F, None, None, 0, scr_p, stream()))
+    E = dev(table)[dev(ids).long()]                        # [N, T, D]
+    x = torch.nn.functional.pad(E.double().transpose(1, 2), (pl, k - 1 - pl))
+    ref = torch.relu(torch.nn.functional.conv1d(x, dev(Wc).double().permute(2, 1, 0), dev(b).double()))
+    ref = ref.transpose(1, 2) * (dev(ids) != 0).unsqueeze(-1)
+    scale = max(1.0, ref.abs().max().item())
+    err = (out.view(N, T, F).double() - ref).abs().max().item()
+    assert err < 2e-5 * scale, err
+    assert (out.view(N, T, F)[dev(ids) == 0] == 0).all()
+    # against the exact-fp32 MFMA kernel on the fp32 gather
+    Epd = torch.zeros(N * Tp * D + 256, dtype=torch.float32, device='cuda')
+    check(lib.lstur_gather_f32(t_d.data_ptr(), ids_d.data_ptr(), Epd.data_ptr(), N, T, D, pl, k - 1 - pl, 0.0, 0, stream()))
+    Wp = pack_b(Wd)
+    out32 = torch.empty(N * T, F, dtype=torch.float32, device='cuda')
+    check(lib.lstur_conv1d_relu_mask_fwd(Epd.data_ptr(), Wp.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(),
+                                         out32.data_ptr(), N, T, D, k, F, None, None, stream()))
+    assert (out - out32).abs().max().item() < 4e-6 * scale
+    # over the compacted list of non-pad tokens: same rows bit-identical, pad rows untouched
+    vidx = torch.full((N * T,), -1, dtype=torch.int32, device='cuda')
+    vcount = torch.zeros(1, dtype=torch.int32, device='cuda')
+    vs = torch.zeros(max(1, lib.lstur_valid_tokens_scratch(N * T) // 4), dtype=torch.int32, device='cuda')
+    check(lib.lstur_valid_tokens(ids_d.data_ptr(), N * T, vidx.data_ptr(), vcount.data_ptr(), vs.data_ptr(), stream()))
+    out2 = torch.full((N * T, F), -7.0, dtype=torch.float32, device='cuda')
+    check(lib.lstur_conv3_relu_mask_fwd2(e3.data_ptr(), w3.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(), out2.data_ptr(),
+                                         N, T, D, k, F, vidx.data_ptr(), vcount.data_ptr(), 0, scr_p, stream()))
+    valid = dev(ids.reshape(-1) != 0)
+    if sliced:     # a different token count can cut the tail tiles into a different number of k slices
+        assert (out2[valid] - out[valid]).abs().max().item() < 2e-6 * scale
+    else:
+        assert torch.equal(out2[valid], out[valid])
+    assert (out2[~valid] == -7.0).all()
+    if not sliced:
+        return
+    # ---- kernel gradient on the same E3: against fp64, and over the compacted list with NaN in the rows it must not read
+    dC = rng.normal(size=(N * T, F)).astype(np.float32)
+    dC_d = dev(dC)
+    Ep_d = Epd[:N * Tp * D].view(N, Tp, D)
+    cols = torch.stack([Ep_d[:, j:j + T] for j in range(k)], dim=2).reshape(N * T, k * D).double()
+    ref_dw = cols.t() @ dC_d.double()
+    dw = torch.full((k * D, F), 3.0, dtype=torch.float32, device='cuda')
+    wscr = torch.empty(lib.lstur_conv3_wgrad2_scratch(N, T, D, k, F), dtype=torch.uint8, device='cuda')
+    offs = torch.zeros(2 * N * T, dtype=torch.int32, device='cuda')
+    check(lib.lstur_conv3_wgrad2(e3.data_ptr(), dC_d.data_ptr(), dw.data_ptr(), wscr.data_ptr(), offs.data_ptr(), N, T, D, k, F,
+                                 None, None, stream()))
+    wscale = ref_dw.abs().max().item()
+    assert (dw.double() - ref_dw).abs().max().item() < 2e-5 * wscale
+    ref2 = cols.t() @ (dC_d * valid.unsqueeze(-1)).double()
+    dC_g = torch.where(valid.unsqueeze(-1), dC_d, torch.full_like(dC_d, float('nan')))   # pad rows must not be read
+    dw2 = torch.full((k * D, F), 3.0, dtype=torch.float32, device='cuda')
+    check(lib.lstur_conv3_wgrad2(e3.data_ptr(), dC_g.data_ptr(), dw2.data_ptr(), wscr.data_ptr(), offs.data_ptr(), N, T, D, k, F,
+                                 vidx.data_ptr(), vcount.data_ptr(), stream()))
+    assert (dw2.double() - ref2).abs().max().item() < 2e-5 * wscale

@@ -87,3 +87,52 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.h')):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_weight_files_are_read_without_executing_them(tmp_path):
+    """--enable-pretrain-encoder / NativeModel.load take a path from the user's config: the reader admits ndarrays only
+    (reference format: pickle of model.get_weights(), utils.py:74-79) and refuses any other global."""
+    import pickle
+    import numpy as np
+    from mnexp_amd.native_model import load_weight_list
+    good = tmp_path / 'w.pkl'
+    arrays = [np.arange(6, dtype=np.float32).reshape(2, 3), np.zeros(4, np.float64), np.ones((3, 1), np.float32)]
+    with open(good, 'wb') as f:
+        pickle.dump(arrays, f, protocol=pickle.HIGHEST_PROTOCOL)
+    back = load_weight_list(str(good))
+    assert len(back) == 3 and all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(arrays, back))
+    with open(good, 'wb') as f:                        # protocol 2: what Python-3.5-era Keras runs wrote
+        pickle.dump(arrays, f, protocol=2)
+    assert all(np.array_equal(a, b) for a, b in zip(arrays, load_weight_list(str(good))))
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ('echo pwned > %s' % (tmp_path / 'pwned'),))
+    bad = tmp_path / 'evil.pkl'
+    with open(bad, 'wb') as f:
+        pickle.dump([arrays[0], Evil()], f)
+    with pytest.raises(pickle.UnpicklingError):
+        load_weight_list(str(bad))
+    assert not (tmp_path / 'pwned').exists()
+    with open(bad, 'wb') as f:                         # an object array could smuggle arbitrary instances
+        pickle.dump([np.array([{'a': 1}], dtype=object)], f)
+    with pytest.raises((pickle.UnpicklingError, ValueError)):
+        load_weight_list(str(bad))
+    with open(bad, 'wb') as f:
+        pickle.dump({'not': 'a list'}, f)
+    with pytest.raises(ValueError):
+        load_weight_list(str(bad))
+
+
+def test_batches_past_the_32_bit_offset_reach_are_refused():
+    """Every kernel addresses a step's token-level tensors through 32-bit buffer offsets; a max_batch whose embeddings or
+    conv outputs exceed 4 GiB is refused with a message by lstur_query_sizes (it used to be handed to kernels whose
+    descriptors wrap silently)."""
+    ok = _lib.make_cfg(512, 50, 30, 5, 100000, 300, 400, 3, 200, 1000000)          # BASELINE config 4 per GPU
+    assert _lib.query_sizes(ok).workspace_bytes > 0
+    edge = _lib.make_cfg(1300, 50, 30, 5, 1000, 300, 400, 3, 200, 10)
+    assert _lib.query_sizes(edge).workspace_bytes > 0
+    for B in (1400, 2000, 40000):
+        with pytest.raises(_lib.LsturError, match='4 GiB'):
+            _lib.query_sizes(_lib.make_cfg(B, 50, 30, 5, 1000, 300, 400, 3, 200, 10))

@@ -3,7 +3,8 @@ a compacted token list (62 % non-pad), HIP events; for kernel tuning.   python t
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mnexp_amd._lib import lib, check
 
 
