@@ -76,6 +76,17 @@ def pmc_traffic(workload):
     return best
 
 
+def kernel_sources_hash():
+    """Hash of the kernel sources: the PMC traffic file records it; a mismatch means the passes predate the kernels."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, 'mnexp_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.hip', '.h')):
+            h.update(open(os.path.join(d, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(wl, titles, word, batches, budget_s=20.0):
     """The NumPy oracle (kind 'port'; the reference's Keras/TF stack cannot run here) timed on the host
     cores for a bounded number of full training steps of the SAME workload in fp32."""
@@ -98,9 +109,134 @@ def cpu_baseline(wl, titles, word, batches, budget_s=20.0):
         el = time.perf_counter() - t0
         if el > budget_s or steps >= 8:
             break
-    return dict(value=steps * wl['B'] / el, unit='impressions/s', cores=int(threads), kind='port',
-                sample='%d full training steps (fwd+bwd+Adam, fp32 NumPy/BLAS) of the same workload, %.1f s'
-                       % (steps, el), host_cpus=os.cpu_count())
+    out = dict(value=steps * wl['B'] / el, unit='impressions/s', cores=int(threads), kind='port',
+               sample='%d full training steps (fwd+bwd+Adam, fp32 NumPy/BLAS) of the same workload, %.1f s'
+                      % (steps, el), host_cpus=os.cpu_count(), cpu_model=cpu_model_string(), numpy_value=steps * wl['B'] / el)
+    if wl.get('encoder', 'cnnatt') == 'cnnatt':
+        # the torch-CPU fp32 step on all cores beside the NumPy port; `value` is the FASTER of the two
+        tc = cpu_baseline_torch(wl, titles, word, batches)
+        out['torch_cpu'] = tc
+        if tc['value'] > out['value']:
+            out.update(value=tc['value'], cores=tc['threads'], sample=tc['sample'])
+    return out
+
+
+def cpu_model_string():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline_torch(wl, titles, word, batches, budget_s=15.0):
+    """The same training step in torch-CPU fp32 on ALL host cores: F.conv1d, autograd through the masked GRU
+    loop (oracle/torch_ref.py, the torch restatement the oracle is cross-checked against), dense Keras-Adam over every
+    parameter incl. the whole user table.  Dropout masks from torch's generator (throughput only)."""
+    import torch
+    from oracle import lstur_oracle as O, torch_ref as TR
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    enc = wl.get('encoder', 'cnnatt')
+    p = O.init_params(np.random.default_rng(0), V=wl['V'], D=wl['D'], F=wl['F'], k=wl['k'], U=wl['U'], N_u=wl['N_u'],
+                      arch=wl['arch'], word_emb=word, dtype=np.float32, encoder=enc, heads=wl.get('heads', 1))
+    names = O.dense_param_names(wl['arch'], encoder=enc) + ['user_emb']
+    tp = TR.to_t(p, dtype=torch.float32, grad_names=names)
+    m = {n: torch.zeros_like(tp[n]) for n in names}
+    v = {n: torch.zeros_like(tp[n]) for n in names}
+    b1, b2, eps, lr, drop = 0.9, 0.999, 1e-7, 1e-3, 0.2
+    B, W, T, K1 = wl['B'], wl['W'], wl['T'], wl['K1']
+    nt = B * (W + K1)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        user, hist, cands = batches[steps % len(batches)]
+        keep1 = (torch.rand(nt, T, wl['D']) >= drop)
+        keep2 = (torch.rand(nt, T, wl['F']) >= drop)
+        loss, _, _ = TR.model_loss(tp, wl['arch'], user, titles[hist], titles[cands], keep1, keep2, 1.0 / (1.0 - drop))
+        loss.backward()
+        t = steps + 1
+        lr_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+        with torch.no_grad():
+            for n in names:          # (the embedding gradient arrives dense: the sweep covers the whole table, like TF-1 Keras)
+                g = tp[n].grad
+                m[n].mul_(b1).add_(g, alpha=1 - b1)
+                v[n].mul_(b2).addcmul_(g, g, value=1 - b2)
+                tp[n].sub_(lr_t * m[n] / (v[n].sqrt() + eps))
+                tp[n].grad = None
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 12:
+            break
+    return dict(value=steps * B / el, threads=int(torch.get_num_threads()),
+                sample='%d full training steps (fwd+autograd bwd+dense Adam, fp32 torch-CPU %s) of the same workload, %.1f s'
+                       % (steps, torch.__version__, el))
+
+
+def e2e_legs(wl, word, steps, dropout, device):
+    """End-to-end throughput of the drop-in path: files in the reference's formats (mnexp_amd.synth: DocMeta.tsv +
+    ClickData.tsv of the workload's shape; 6 000 users keep the load short) -> task loading -> samples from (a) the C++
+    feed (--native-feed) and (b) the task's own Python generators in id form (--ids) -> host batch -> H2D -> step, ALL
+    inside the timed region.  The samples are real click histories (mostly shorter than the window, so fewer non-pad
+    tokens per step than the device-resident headline, whose histories are 90 % full)."""
+    import contextlib
+    import io
+    import random
+    import shutil
+    import tempfile
+    import torch
+    from mnexp_amd import synth, settings, task as T
+    from mnexp_amd.native_model import NativeModel
+    from mnexp_amd.data_native import NativeTrainFeed
+    d = tempfile.mkdtemp(prefix='lstur_bench_e2e_')
+    try:
+        rng = np.random.default_rng(0)
+        topic, titles = synth.make_docs(wl['N_d'], wl['V'], wl['T'], rng)
+        synth.write_docmeta(os.path.join(d, 'DocMeta.tsv'), titles)
+        synth.write_clickdata(os.path.join(d, 'ClickData.tsv'), 6000, topic, 20, 4, rng)
+        open(os.path.join(d, 'Vocab.tsv'), 'w').close()          # (the word table comes from the bench: same shape)
+        settings.public_config = dict(input_training_data_path=d, input_validation_data_path=d,
+                                      input_previous_model_path=d, output_model_path=d, log_dir=d)
+        base = dict(task='Seq2VecPaperSoftmaxId', arch=wl['arch'], batch_size=wl['B'], window_size=wl['W'],
+                    title_shape=wl['T'], body_shape=4, negative_samples=wl['K1'] - 1, training_step=steps,
+                    validation_step=1, max_impression=200, news_encoder='cnnatt', textual_embedding_dim=wl['D'], days=30,
+                    debug=False, epochs=1, validation_impression=10, testing_impression=10, learning_rate=1e-3,
+                    learning_rate_decay=0.5, dropout=dropout, user_embedding_dim=wl['U'],
+                    title_filter_shape=(wl['F'], wl['k']), score_model='dot', enable_pretrain_encoder=False,
+                    textual_embedding_trainable=False, name='', gain=1.0, seed=1, ids=True, native_feed=True,
+                    background=True, pretrain_name='')
+        with contextlib.redirect_stdout(io.StringIO()):
+            cfg = settings.Config(base)
+        t0 = time.perf_counter()
+        h = T.get(cfg)
+        load_s = time.perf_counter() - t0
+        model = NativeModel(word, len(h.data), wl['B'], wl['W'], wl['T'], wl['K1'] - 1, wl['F'], wl['k'], wl['U'],
+                            arch=wl['arch'], dropout=dropout, lr=1e-3, seed=7, device=device,
+                            title_table=h.docs.title_table)
+        out = dict(users=len(h.data), task_load_s=round(load_s, 1), steps=steps)
+        np.random.seed(0)
+        random.seed(0)
+        for name, feed in (('native_feed', NativeTrainFeed(h, seed=1)), ('python_ids_feed', h.train_ids)):
+            nonpad = []
+            for _ in range(10):
+                X, _ = next(feed)
+                model.train_on_ids(*X)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                X, _ = next(feed)
+                model.train_on_ids(*X)
+                nonpad.append(int((h.docs.title_table[X[1]] != 0).sum() + (h.docs.title_table[X[2]] != 0).sum()))
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            out[name] = dict(value=round(wl['B'] * steps / el, 1), unit='impressions/s wall (feed + H2D + step)',
+                             ms_per_step=round(1e3 * el / steps, 4),
+                             non_pad_token_fraction=round(float(np.mean(nonpad)) / (wl['B'] * (wl['W'] + wl['K1']) * wl['T']), 4))
+        del model
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def parity_check(model, wl, titles, batch):
@@ -128,6 +264,8 @@ def parity_check(model, wl, titles, batch):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--e2e-steps', type=int, default=150,
+                    help='steps of the end-to-end legs (sample feed + H2D inside the timed region; 0: skip)')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
@@ -198,11 +336,14 @@ def main():
         conv_flop_full = 2.0 * n_tok * wl['k'] * wl['D'] * wl['F']        # 720 kFLOP/token at the defaults
         conv_flop = conv_flop_full * real_tok / n_tok
         gather_bytes = n_tok * (4 + 2 * 4 * wl['D'])                       # 2404 B/token stand-alone
-        kern = {k: dict(avg_us=1e3 * ms / max(1, n), launches=n) for k, (ms, n) in prof.items()}
+        # per STEP (a family may launch more than once per step: the two-lane step, the conv tail fix-up)
+        kern = {k: dict(avg_us=1e3 * ms / max(1, args.steps), launches=n) for k, (ms, n) in prof.items()}
         roofline = None
         roofline_gather = None
         pmc = pmc_traffic(args.workload)
         traffic = (lambda k: pmc['kernels'][k]['traffic_bytes'] if pmc and k in pmc['kernels'] else None)
+        # the PMC passes are a committed file: stale when the kernel sources changed since (tools/pmc_traffic.py stamps it)
+        traffic_stale = bool(pmc) and pmc.get('kernel_sources_hash') != kernel_sources_hash()
         mhsa = wl.get('encoder') == 'mhsa'
         if prof and mhsa:
             # token stage = Q|K|V projection GEMMs over ALL tokens (pads included) + the attention kernels
@@ -234,6 +375,20 @@ def main():
             roofline_gather = dict(kernel='gather', bound='hbm', achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                                    frac=round(gb / PEAK_HBM_GBS, 4), traffic=traffic('gather'),
                                    avg_us=round(kern['gather']['avg_us'], 1), bytes_per_launch=gather_bytes)
+            if model.conv_scheme == 'bf16x3':
+                # the gather feeds the bf16x3 conv kernels: it writes three bf16 parts per element (6 B instead of 4) but
+                # only the padded rows some non-pad token's window covers; `achieved` stays the SURVEY's 2404 B/token
+                # over the launch time ("effective": rows skipped count as moved), `moved` is what the kernel moves
+                def rows_written(mask):      # padded rows tp = 0 .. T+1 covered by the window of a non-pad token tp-2 .. tp
+                    T_ = mask.shape[-1]
+                    q = np.pad(mask, [(0, 0)] * (mask.ndim - 1) + [(2, 2)])
+                    return int((q[..., 0:T_ + 2] | q[..., 1:T_ + 3] | q[..., 2:T_ + 4]).sum())
+                rows = sum(rows_written(titles[x] != 0) for b in batches for x in (b[1], b[2])) / float(len(batches))
+                moved = rows * (4 * wl['D'] + 6 * ((wl['D'] + 7) // 8 * 8)) + n_tok * 4
+                roofline_gather.update(layout='E3: 3 x bf16 parts per element, rows no window covers skipped',
+                                       moved_bytes_per_launch=int(moved),
+                                       moved_gbs=round(moved / (kern['gather']['avg_us'] * 1e-6) / 1e9, 1),
+                                       moved_frac=round(moved / (kern['gather']['avg_us'] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4))
         out = {
             'metric': 'training impressions/sec', 'value': round(world * wl['B'] * args.steps / el, 1),
             'unit': 'impressions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -246,12 +401,14 @@ def main():
                        'n_users': wl['N_u'], 'n_docs': wl['N_d'], 'vocab': wl['V'], 'dropout': args.dropout,
                        'news_encoder': wl.get('encoder', 'cnnatt'), 'heads': wl.get('heads', 0),
                        'parallelism': 'dp%d' % world, 'optimizer': 'keras-adam (dense user-table sweep)'},
-            'roofline': roofline, 'roofline_gather': roofline_gather,
+            'roofline': roofline, 'roofline_gather': roofline_gather, 'traffic_stale': traffic_stale,
             'kernels_us': {k: round(v['avg_us'], 1) for k, v in sorted(kern.items())},
             'train_loss': round(loss, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
             out['parity'] = parity_check(model, wl, titles, batches[0])
+            if args.e2e_steps > 0 and wl.get('encoder', 'cnnatt') == 'cnnatt' and wl['B'] <= 64:
+                out['e2e'] = e2e_legs(wl, word, args.e2e_steps, args.dropout, 'cuda:%d' % local)
             out['cpu_baseline'] = cpu_baseline(wl, titles, word, batches)
         else:
             out['cpu_baseline'] = None

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(RW* CW * 64, MT == 1 ? 2 : 1) void conv3_fwd2_kerne
 }
 
 // Epilogue of the k-sliced tiles: out[token] = relu(bias + sum over slices, in slice order) x (id != 0).
-// grid (ncu / 2 tiles at most, BM / 16 row groups); one thread = one column quad of one row
+// grid (ncu / 2 tiles at most, 64 row pairs); one thread = one column quad of one row, all slice loads in flight at once
 __global__ __launch_bounds__(256) void conv3_fwd2_fix_kernel(const float* __restrict__ slabs, const float* __restrict__ bias,
                                                              const int32_t* __restrict__ ids, float* __restrict__ C,
                                                              const int32_t* __restrict__ vidx,
@@ -327,25 +327,26 @@ __global__ __launch_bounds__(256) void conv3_fwd2_fix_kernel(const float* __rest
   const TailPlan tp = tail_plan(count, BM, ncu);
   const int tile = tp.full + blockIdx.x;
   if (tp.S <= 1 || tile * BM >= count) return;
-  const int c4 = threadIdx.x & 127, rsub = threadIdx.x >> 7;        // 112 column quads (448 columns), 2 rows per pass
-  if (c4 >= BCOLS / 4) return;
-  for (int lr = blockIdx.y * 16 + rsub; lr < blockIdx.y * 16 + 16; lr += 2) {
-    const int i = tile * BM + lr;
-    if (i >= count) return;
-    const int m = vidx ? vidx[i] : i;
-    const float* p = slabs + (size_t)blockIdx.x * tp.S * (BM * BCOLS) + (size_t)lr * BCOLS + c4 * 4;
-    float4 a = *(const float4*)p;
-    for (int sl = 1; sl < tp.S; ++sl) {
-      const float4 b = *(const float4*)(p + (size_t)sl * (BM * BCOLS));
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    const float keep = ids[m] != 0 ? 1.f : 0.f;
-    const int col = c4 * 4;
-    float v[4] = {a.x, a.y, a.z, a.w};
+  const int c4 = threadIdx.x & 127, lr = blockIdx.y * 2 + (threadIdx.x >> 7);   // 112 column quads (448 columns), 2 rows
+  const int i = tile * BM + lr;
+  if (c4 >= BCOLS / 4 || i >= count) return;
+  const int m = vidx ? vidx[i] : i;
+  const float* p = slabs + (size_t)blockIdx.x * tp.S * (BM * BCOLS) + (size_t)lr * BCOLS + c4 * 4;
+  float4 v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (col + e < F) C[(size_t)m * F + col + e] = fmaxf(v[e] + bias[col + e], 0.f) * keep;
-  }
+  for (int sl = 0; sl < 8; ++sl) v[sl] = *(const float4*)(p + (size_t)min(sl, tp.S - 1) * (BM * BCOLS));
+  float4 a = v[0];
+#pragma unroll
+  for (int sl = 1; sl < 8; ++sl)
+    if (sl < tp.S) {
+      a.x += v[sl].x; a.y += v[sl].y; a.z += v[sl].z; a.w += v[sl].w;
+    }
+  const float keep = ids[m] != 0 ? 1.f : 0.f;
+  const int col = c4 * 4;
+  const float o[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (col + e < F) C[(size_t)m * F + col + e] = fmaxf(o[e] + bias[col + e], 0.f) * keep;
 }
 
 bool conv3f_supported(int D, int ksize, int F) { return D % 4 == 0 && F >= 1 && F <= 448; }
@@ -367,14 +368,16 @@ static int conv3_ncu() {
 // scratch: conv3_fwd2_scratch_bytes(CUs) for the k-sliced tail tiles (NULL: no tail slicing).
 void launch_conv3_fwd2(const unsigned short* e3, const unsigned short* W3, const float* bias, const int32_t* ids, float* out,
                        int n_titles, int T, int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount, int variant,
-                       void* scratch, hipStream_t s) {
+                       void* scratch, hipStream_t s, int cus) {
   const int M = n_titles * T;
   if (M == 0) return;
   const int Tp = T + ksize - 1, Dp = conv3_dp(D), Np = f2_np(F), Kp = f2_kp(D, ksize);
   const uint32_t e_bytes = (uint32_t)std::min(conv3_e3_elems(n_titles, T, D, ksize) * 2, (size_t)0xFFFFFFFFu);
   const int tiles = cdiv(M, 128);
   // tail slicing needs at least one k-step per slice; without scratch every tile is a plain tile (ncu = "infinite")
-  const int ncu = (scratch && Kp / F2_BK >= 8) ? std::min(conv3_ncu(), 256) : 0;   // scratch holds <= 256 slabs; 0: no slicing
+  // `cus` (0: all): the CUs this launch may count on -- the two-lane step leaves some to the other lane's recurrence, so
+  // whole rounds are rounds of `cus` tiles and what is left over is sliced
+  const int ncu = (scratch && Kp / F2_BK >= 8) ? std::min(cus > 0 ? std::min(cus, conv3_ncu()) : conv3_ncu(), 256) : 0;   // scratch holds <= 256 slabs; 0: no slicing
   auto kern = variant == 10 ? conv3_fwd2_kernel<4, 2, 7, 1, 4> : variant == 11 ? conv3_fwd2_kernel<4, 2, 7, 1, 12> :
               variant == 12 ? conv3_fwd2_kernel<4, 2, 7, 1, 28> : variant == 13 ? conv3_fwd2_kernel<4, 2, 7, 1, 60> :
               variant == 14 ? conv3_fwd2_kernel<4, 2, 7, 1, 16> : variant == 15 ? conv3_fwd2_kernel<4, 2, 7, 1, 32> :
@@ -385,7 +388,7 @@ void launch_conv3_fwd2(const unsigned short* e3, const unsigned short* W3, const
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), f2_lds(4, 2, 7), s, e3, e_bytes, W3, bias, ids, out, vidx, vcount, M, T, Tp,
                      Dp / 8, F, Kp, Np, ncu, (float*)scratch);
   if (ncu > 0)
-    hipLaunchKernelGGL(conv3_fwd2_fix_kernel, dim3(ncu / 2, 8), dim3(256), 0, s, (const float*)scratch, bias, ids, out, vidx,
+    hipLaunchKernelGGL(conv3_fwd2_fix_kernel, dim3(ncu / 2, 64), dim3(256), 0, s, (const float*)scratch, bias, ids, out, vidx,
                        vcount, M, F, ncu);
 }
 
@@ -415,10 +418,12 @@ static_assert(G2_BK * (G2_BMR / 8) * 3 % G2_THREADS == 0, "A pieces divide evenl
 static int g2_mblocks(int Kq) { return cdiv(cdiv(Kq, 32), G2_TM); }
 static int g2_nblocks(int F) { return cdiv(cdiv(F, 32), G2_TN); }
 // slabs: about one workgroup per CU (or whole multiples), at least 512 tokens each
-static int g2_slabs(int M, int Kq, int F) {
+static int g2_slabs(int M, int Kq, int F, int cus = 256) {
   const int per = g2_mblocks(Kq) * g2_nblocks(F);
   const int rounds = std::max(1, cdiv(M, 120000));                 // ~105 600 tokens at B = 64 -> one round
-  const int want = rounds * 256 / per / 8 * 8;                     // whole multiples of 8: the same share for every XCD
+  // all CUs: whole multiples of 8 slabs (the same share for every XCD); fewer CUs (the other lane's recurrence holds some):
+  // as many slabs as fit, a few XCDs then carry one slab less
+  const int want = cus >= 256 ? rounds * 256 / per / 8 * 8 : std::max(1, rounds * cus / per);
   return std::max(1, std::min(std::max(8, want), std::max(1, M / 512)));
 }
 size_t conv3_wgrad2_scratch_bytes(int n_titles, int T, int D, int ksize, int F) {
@@ -596,7 +601,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void conv3_wgrad2_kernel(
 // row offset in floats of dout (token * F) -- launch_compact_write_offsets with rowA = Dp / 8 * 3.  Returns the job count.
 int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
                         int ksize, int F, const int32_t* vcount, hipStream_t s, ReduceJob* jobs, const int32_t* offA,
-                        const int32_t* offB, float alpha) {
+                        const int32_t* offB, float alpha, int cus) {
   const int M = n_titles * T, Dp = conv3_dp(D), Kq = ksize * Dp;
   if (M == 0) {
     for (int j = 0; j < ksize; ++j) jobs[j].nslices = 0;
@@ -607,7 +612,8 @@ int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, 
     (void)hipFuncSetAttribute((const void*)conv3_wgrad2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2_LDS);
     attr_set = true;
   }
-  const int mblocks = g2_mblocks(Kq), nblocks = g2_nblocks(F), ns = g2_slabs(M, Kq, F);
+  // (the scratch is sized for the full-chip slab count; fewer CUs -> fewer slabs)
+  const int mblocks = g2_mblocks(Kq), nblocks = g2_nblocks(F), ns = g2_slabs(M, Kq, F, cus > 0 ? std::min(cus, 256) : 256);
   const uint32_t e_bytes = (uint32_t)std::min(conv3_e3_elems(n_titles, T, D, ksize) * 2, (size_t)0xFFFFFFFFu);
   const uint32_t g_bytes = (uint32_t)std::min((size_t)M * F * 4, (size_t)0xFFFFFFFFu);
   const dim3 grid(cdiv(ns, 8) * 8 * mblocks * nblocks);

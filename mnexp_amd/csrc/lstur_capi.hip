@@ -171,6 +171,30 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
   return true;
 }
 
+// ---- two-lane step: sample ranges ---------------------------------------------------------------------
+constexpr int kPipeMin = 32;     // smallest batch that is cut into two lanes (each lane >= 16 samples)
+// samples of lane 0 (a multiple of 16: the aliased per-sample arrays of lane 1 start on a row-tile boundary)
+inline int lane0_share(int n) { return std::max(16, (n / 2) / 16 * 16); }
+inline int lane1_cap(int B) { return B / 2 + 16; }
+// does this configuration take the two-lane step?  (listwise head on the bf16x3 cnnatt path with the fast GRU kernels)
+bool lanes_supported(const Dims& d) {
+  // opt-in (LSTUR_PIPELINE=1): at B = 64 the step is no faster with two lanes yet -- the recurrences do hide, but the
+  // one-workgroup-per-CU conv kernels of a half batch lose what that wins
+  const bool off = !(getenv("LSTUR_PIPELINE") && !strcmp(getenv("LSTUR_PIPELINE"), "1"));   // (read per context)
+  const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
+  return !off && d.B >= kPipeMin && d.head == LSTUR_HEAD_SOFTMAX && d.enc == LSTUR_ENC_CNNATT && !d.word_trainable &&
+         has_gru && gru4_supported(d.H) && conv3f_supported(d.D, d.k, d.F) && d.k <= 8;
+}
+Dims lane1_dims(const Dims& d) {
+  Dims e = d;
+  e.B = lane1_cap(d.B);
+  e.nt_max = e.B * (e.W + e.K1);
+  e.n_cap = ceil16(e.B);
+  e.rows_cap = 16;          // (the sparse-row scratch of the optimizer lives in lane 0)
+  e.Nu = 1;                 // (so does the slot map)
+  return e;
+}
+
 std::vector<ParamSlot> param_layout(const Dims& d, size_t* total) {
   std::vector<ParamSlot> v;
   size_t off = 0;
@@ -393,6 +417,23 @@ struct lstur_ctx {
   Dims d;
   lstur_buffers buf;
   Workspace ws;
+  // ---- two-lane step (see train_impl): a batch of >= kPipeMin samples is cut into two sample ranges that run out of
+  // step on two streams, so that one lane's recurrence (a latency chain on a few CUs) runs beside the other's encoder.
+  // Lane 0 lives in `ws` (full size), lane 1 in `ws1` (about half a batch) with its own gradient bucket `grad1`; the
+  // kernel-sequence functions below work on the CURRENT lane (`cur`, `cur_grad`, `cur_lane`), set by the orchestrator.
+  Dims d1;
+  Workspace ws1;
+  float* grad1 = nullptr;
+  Workspace* cur = nullptr;
+  float* cur_grad = nullptr;
+  int cur_lane = 0;
+  bool counted1 = false;
+  hipEvent_t cur_ev_enc = nullptr;      // recorded behind the lane's encoder forward when set
+  int conv_cus = 0;                     // CUs the conv kernels plan for (0: all); the other lane's recurrence holds some
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_enc0 = nullptr, ev_done1 = nullptr;
+  bool pipe_ok = false, last_piped = false;
+  int last_nA = 0;
   std::vector<ParamSlot> layout;
   size_t dense_total;
   const int32_t* title_table = nullptr;
@@ -406,11 +447,12 @@ struct lstur_ctx {
       if (!strcmp(s.name, name)) return buf.dense_param + s.offset;
     return nullptr;
   }
-  float* G(const char* name) const {
+  float* G(const char* name) const {      // in the CURRENT lane's gradient bucket
     for (auto& s : layout)
-      if (!strcmp(s.name, name)) return buf.dense_grad + s.offset;
+      if (!strcmp(s.name, name)) return (cur_grad ? cur_grad : buf.dense_grad) + s.offset;
     return nullptr;
   }
+  bool& counted_flag() { return cur_lane ? counted1 : counted; }
 };
 
 namespace {
@@ -460,16 +502,24 @@ void lazy_init(lstur_ctx* c, hipStream_t s) {
   launch_fill_i32(c->ws.slot, -1, d.Nu, s);
   // E3: the gather skips rows no window covers; the k tail of a window may still touch one (under a zero weight)
   if (c->ws.e3) (void)hipMemsetAsync(c->ws.e3, 0, conv3_e3_elems(d.nt_max, d.T, d.D, d.k) * 2, s);
+  if (c->pipe_ok) {
+    (void)hipMemsetAsync(c->ws1.emb + (size_t)c->d1.nt_max * d.Tp * d.D, 0, kEmbSlack * sizeof(float), s);
+    if (c->ws1.e3) (void)hipMemsetAsync(c->ws1.e3, 0, conv3_e3_elems(c->d1.nt_max, d.T, d.D, d.k) * 2, s);
+    (void)hipMemsetAsync(c->grad1, 0, c->dense_total * sizeof(float), s);   // (the alignment gaps between its slots)
+  }
   c->lazy_init_done = true;
 }
 
 // titles already in ws.ids as [n*W history | n*k1 candidates] ; runs the network up to user_vec / doc_vec
 void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training, uint32_t step, hipStream_t s) {
   const Dims& d = c->d;
-  Workspace& w = c->ws;
+  Workspace& w = *c->cur;
   const int nW = n * d.W, nt = nW + n * k1;
   const float drop = training ? c->cfg.dropout : 0.f;
-  const uint32_t key0 = dropout_key(c->cfg.seed, step, 0), key1 = dropout_key(c->cfg.seed, step, 1);
+  // dropout streams 0 (embeddings), 1 (conv outputs), 2 (dgru rows); lane 1 draws from streams 16 + these, at the
+  // element positions of its OWN title layout (restated in oracle/lstur_oracle.py: forward_backward_lanes)
+  const uint32_t lane_stream = 16u * (uint32_t)c->cur_lane;
+  const uint32_t key0 = dropout_key(c->cfg.seed, step, lane_stream), key1 = dropout_key(c->cfg.seed, step, lane_stream + 1);
   lazy_init(c, s);
   // operand images of the weights used by MFMA kernels this step
   const bool mhsa = d.enc == LSTUR_ENC_MHSA;
@@ -478,15 +528,17 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr;
   const bool use3 = !mhsa && w.conv_w3 && !conv_f32;
   static const bool gen1 = getenv("LSTUR_CONV_GEN1") != nullptr;   // A/B: first-generation bf16x3 kernels (conv3.hip, fp32 E)
-  if (use3 && gen1) launch_conv3_pack_w(c->P("conv_w"), d.KD, d.F, w.conv_w3_v1, s);
-  else if (use3) launch_conv3_pack_w2(c->P("conv_w"), d.D, d.k, d.F, w.conv_w3, s);
-  else if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, s);
-  launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, s);
+  if (c->cur_lane == 0) {   // (lane 1 shares lane 0's images: it starts behind lane 0's encoder)
+    if (use3 && gen1) launch_conv3_pack_w(c->P("conv_w"), d.KD, d.F, w.conv_w3_v1, s);
+    else if (use3) launch_conv3_pack_w2(c->P("conv_w"), d.D, d.k, d.F, w.conv_w3, s);
+    else if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, s);
+    launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, s);
+  }
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
   // stable list of the non-pad tokens of this batch (+ the kernel gradient's row offsets), two launches
-  if (!c->counted) launch_compact_count(w.ids, nt * d.T, w.vscratch, s);
-  c->counted = false;
+  if (!c->counted_flag()) launch_compact_count(w.ids, nt * d.T, w.vscratch, s);
+  c->counted_flag() = false;
   // (offA: a token's window offset in the units of its path -- 16-byte pieces of E3, or floats of the fp32 layout)
   launch_compact_write_offsets(w.ids, nt * d.T, w.vscratch, w.vidx, w.vcount, d.T, d.Tp,
                                (use3 && !gen1) ? conv3_dp(d.D) / 8 * 3 : d.D, d.F, w.offA, w.offB, s);
@@ -502,7 +554,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
                                       w.vcount, s));
   } else if (use3) {
     PROF("conv_fwd", launch_conv3_fwd2(w.e3, w.conv_w3, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
-                                       w.vcount, 0, w.fwd2_scratch, s));
+                                       w.vcount, 0, w.fwd2_scratch, s, c->conv_cus));
   } else {
     PROF("conv_fwd", launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
                                      w.vcount, s));
@@ -515,9 +567,10 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   launch_hist_mask(w.ids, w.docvec, w.hmask, w.gmask, nW, d.T, d.U, s, c->buf.user_emb, user, w.user_rows, w.uvec, n,
                    d.Ue);
   if (d.arch == LSTUR_ARCH_DGRU && training)   // Dropout(0.5, noise_shape=(None, 1)) on the user embedding, paper.py:610
-    launch_drop_rows(w.uvec, n, d.Ue, 0.5f, dropout_key(c->cfg.seed, step, 2), s);
+    launch_drop_rows(w.uvec, n, d.Ue, 0.5f, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
   launch_gemm(w.docvec, d.U, 0, c->P("gru_w"), 3 * d.H, 0, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, 1.f,
               w.gemm_scratch, s);
+  if (c->cur_ev_enc) (void)hipEventRecord(c->cur_ev_enc, s);   // the other lane's encoder may start: the recurrence follows
   if (d.arch == LSTUR_ARCH_VO) {          // the user embedding alone (paper.py:622-623)
     (void)hipMemcpyAsync(w.uservec, w.uvec, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
   } else if (d.arch == LSTUR_ARCH_NIAVG) {   // masked mean of the history vectors (paper.py:629-630)
@@ -555,10 +608,11 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
 // stats (may be NULL): the batch means of loss_i / correct_i ride the pass's single reduction launch
 void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats) {
   const Dims& d = c->d;
-  Workspace& w = c->ws;
+  Workspace& w = *c->cur;
   const int nW = n * d.W, nt = nW + n * d.K1;
   const float drop = c->cfg.dropout;
-  const uint32_t key1 = dropout_key(c->cfg.seed, step, 1);
+  const uint32_t lane_stream = 16u * (uint32_t)c->cur_lane;
+  const uint32_t key1 = dropout_key(c->cfg.seed, step, lane_stream + 1);
   // user encoder head
   const float* dhl = w.du;
   if (d.arch == LSTUR_ARCH_GRU || d.arch == LSTUR_ARCH_IIGRU) {
@@ -572,7 +626,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   } else if (d.arch == LSTUR_ARCH_HGRU || d.arch == LSTUR_ARCH_NGRU || d.arch == LSTUR_ARCH_DGRU) {
     launch_split2(w.du, d.H, d.Ue, w.dhlast, w.duser, n, s);
     if (d.arch == LSTUR_ARCH_DGRU)   // the same per-sample mask and scale as the forward
-      launch_drop_rows(w.duser, n, d.Ue, 0.5f, dropout_key(c->cfg.seed, step, 2), s);
+      launch_drop_rows(w.duser, n, d.Ue, 0.5f, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
     dhl = w.dhlast;
   } else if (d.arch == LSTUR_ARCH_PGRU || d.arch == LSTUR_ARCH_VO) {   // u = h + user_vec / u = user_vec
     (void)hipMemcpyAsync(w.duser, w.du, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
@@ -661,7 +715,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   if (d.word_trainable) {   // conv input gradient -> word-table gradient (embedding dropout mask = stream 0 of the step)
     (void)hipMemsetAsync(c->buf.word_grad, 0, (size_t)d.V * d.D * sizeof(float), s);
     PROF("conv_dgrad", launch_conv_dgrad_scatter(w.dconv, c->P("conv_w"), w.ids, c->buf.word_grad, w.dgrad_scratch, nt, d.T,
-                                                  d.D, d.k, d.F, drop, dropout_key(c->cfg.seed, step, 0), s));
+                                                  d.D, d.k, d.F, drop, dropout_key(c->cfg.seed, step, lane_stream), s));
   }
   static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr;
   static const bool gen1 = getenv("LSTUR_CONV_GEN1") != nullptr;
@@ -671,7 +725,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   else if (w.conv_w3 && !conv_f32) {   // fp32-grade bf16x3 contraction (conv3f.hip), like the forward; one reduce job per tap
     ProfScope _ps(c, "conv_wgrad", s);
     nj += launch_conv3_wgrad2(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, s, &jobs[nj],
-                              w.offA, w.offB);
+                              w.offA, w.offB, 1.0f, c->conv_cus);
   } else
     PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
                                          w.vidx, w.vcount, s, w.offA, w.offB,
@@ -687,12 +741,12 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
 
 int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n, int k1, bool ids_form, hipStream_t s) {
   const Dims& d = c->d;
-  Workspace& w = c->ws;
+  Workspace& w = *c->cur;
   const size_t nW = (size_t)n * d.W;
   if (ids_form) {
     if (!c->title_table) return fail(LSTUR_ERR_STATE, "no title table bound (lstur_set_title_table)");
     launch_expand_count(c->title_table, hist, (int)nW, cands, n * k1, d.T, w.ids, w.vscratch, s);
-    c->counted = true;
+    c->counted_flag() = true;
   } else {
     (void)hipMemcpyAsync(w.ids, hist, nW * d.T * 4, hipMemcpyDeviceToDevice, s);
     (void)hipMemcpyAsync(w.ids + nW * d.T, cands, (size_t)n * k1 * d.T * 4, hipMemcpyDeviceToDevice, s);
@@ -705,7 +759,7 @@ int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n,
 //   else: logits / probs / loss (+ `backward`: du, d(candidate doc vectors) and the score model's parameter gradients)
 void run_listwise_score(lstur_ctx* c, int n, int k1, float inv_n, bool backward, float* scores, hipStream_t s) {
   const Dims& d = c->d;
-  Workspace& w = c->ws;
+  Workspace& w = *c->cur;
   const int nW = n * d.W, rows = n * k1;
   const float* dvec = w.docvec + (size_t)nW * d.U;
   float* ddvec = w.ddocvec + (size_t)nW * d.U;
@@ -761,12 +815,101 @@ void run_listwise_score(lstur_ctx* c, int n, int k1, float inv_n, bool backward,
   launch_split_sum(dcat, d.Uu, d.U, k1, w.du, ddvec, n, s);
 }
 
+void set_lane(lstur_ctx* c, int lane) {
+  c->cur_lane = lane;
+  c->cur = lane ? &c->ws1 : &c->ws;
+  c->cur_grad = lane ? c->grad1 : c->buf.dense_grad;
+}
+
+// Two-lane training step.  The recurrence is a latency chain (50 dependent steps forward, 50 backward, ~180 us each) on
+// one workgroup per four samples -- 16 of 256 CUs at B = 64 -- and everything behind it waits.  The batch is therefore cut
+// into two sample ranges ("lanes") that run the whole chain encoder -> GRU -> scorer -> BPTT -> encoder backward one stage
+// apart on two streams: lane 1 starts when lane 0's encoder forward is done, so each lane's recurrences run beside the
+// other lane's encoder kernels (and lane 0's BPTT beside lane 1's forward recurrence).  Per-sample results land in lane
+// 0's arrays (lane 1 writes behind lane 0's rows); dense gradients in two buckets summed at the join; the loss scale is
+// 1 / n of the WHOLE batch in both lanes.  Same kernels, same data with LSTUR_STREAMS=1 (both lanes on the caller's
+// stream): bit-identical results.  Reference: the single Keras graph of task/paper.py:635-665 (no counterpart).
+int train_two_lanes(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int32_t* cands, int n, uint32_t step,
+                    float grad_scale, float* stats, hipStream_t s, bool ids_form) {
+  const Dims& d = c->d;
+  const int nA = lane0_share(n), nB = n - nA;
+  if (nB < 1 || nB > c->d1.B) return fail(LSTUR_ERR_STATE, "two-lane step: lane 1 capacity");
+  Workspace &w0 = c->ws, &w1 = c->ws1;
+  if (!c->side) {
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_enc0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done1, hipEventDisableTiming) != hipSuccess)
+      return fail(LSTUR_ERR_HIP, "two-lane step: stream / event creation failed");
+  }
+  const bool serial = getenv("LSTUR_STREAMS") && !strcmp(getenv("LSTUR_STREAMS"), "1");
+  hipStream_t sB = serial ? s : c->side;
+  // per-sample results of lane 1 behind lane 0's rows: the host-visible arrays stay contiguous over the batch
+  w1.user_rows = w0.user_rows + nA;
+  w1.duser = w0.duser + (size_t)nA * d.Ue;
+  if (w0.duser2) w1.duser2 = w0.duser2 + (size_t)nA * d.Ue;
+  w1.logits = w0.logits + (size_t)nA * d.K1;
+  w1.probs = w0.probs + (size_t)nA * d.K1;
+  w1.loss_i = w0.loss_i + nA;
+  w1.correct_i = w0.correct_i + nA;
+  const float inv_n = grad_scale / (float)n;
+  const size_t tstride = ids_form ? 1 : (size_t)d.T;       // ints per title in the caller's arrays
+  // the conv kernels plan their rounds for the CUs the other lane's recurrence leaves (one workgroup per 4 samples)
+  c->conv_cus = serial ? 0 : 256 - 16;
+  (void)hipEventRecord(c->ev_fork, s);          // lane 1 sees everything the caller enqueued so far (inputs, last Adam step)
+  if (!serial) (void)hipStreamWaitEvent(sB, c->ev_fork, 0);
+  // ---- lane 0 on the caller's stream
+  set_lane(c, 0);
+  int rc = stage_titles(c, hist, cands, nA, d.K1, ids_form, s);
+  if (rc) return rc;
+  c->cur_ev_enc = c->ev_enc0;
+  run_forward(c, user, nA, d.K1, true, step, s);
+  c->cur_ev_enc = nullptr;
+  run_listwise_score(c, nA, d.K1, inv_n, true, nullptr, s);
+  run_backward(c, nA, step, s, nullptr);
+  // ---- lane 1, one stage behind
+  set_lane(c, 1);
+  if (!serial) (void)hipStreamWaitEvent(sB, c->ev_enc0, 0);
+  rc = stage_titles(c, hist + (size_t)nA * d.W * tstride, cands + (size_t)nA * d.K1 * tstride, nB, d.K1, ids_form, sB);
+  if (rc) {
+    set_lane(c, 0);
+    return rc;
+  }
+  run_forward(c, user + nA, nB, d.K1, true, step, sB);
+  run_listwise_score(c, nB, d.K1, inv_n, true, nullptr, sB);
+  run_backward(c, nB, step, sB, nullptr);
+  (void)hipEventRecord(c->ev_done1, sB);
+  // ---- join: one gradient bucket, the batch statistics
+  set_lane(c, 0);
+  c->conv_cus = 0;
+  if (!serial) (void)hipStreamWaitEvent(s, c->ev_done1, 0);
+  launch_add2(c->buf.dense_grad, c->grad1, c->buf.dense_grad, c->dense_total, s);
+  if (stats) {
+    ReduceJob jobs[4];
+    jobs[0] = ReduceJob{w0.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
+    jobs[1] = ReduceJob{w0.correct_i, stats + 1, 1, 1, 1, n, 1, 1.0f / (float)n};
+    jobs[2] = ReduceJob{w0.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
+    jobs[3] = ReduceJob{w0.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
+    launch_multi_reduce(jobs, 4, s);
+  }
+  c->last_n = n;
+  c->last_k1 = d.K1;
+  c->last_piped = true;
+  c->last_nA = nA;
+  return check_launch("forward_backward (two lanes)");
+}
+
 int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int32_t* cands, int n, uint32_t step,
                float grad_scale, float* stats, hipStream_t s, bool ids_form, bool backward, bool training) {
   if (!c || !user || !hist || !cands) return fail(LSTUR_ERR_ARG, "NULL argument");
   const Dims& d = c->d;
   if (d.head != LSTUR_HEAD_SOFTMAX) return fail(LSTUR_ERR_STATE, "context was created with a pointwise head");
   if (n < 1 || n > d.B) return fail(LSTUR_ERR_ARG, "n must be in [1, max_batch]");
+  static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr || getenv("LSTUR_CONV_GEN1") != nullptr;
+  if (backward && training && c->pipe_ok && n >= kPipeMin && !c->cfg.freeze_encoder && !conv_f32)
+    return train_two_lanes(c, user, hist, cands, n, step, grad_scale, stats, s, ids_form);
+  set_lane(c, 0);
+  c->last_piped = false;
   int rc = stage_titles(c, hist, cands, n, d.K1, ids_form, s);
   if (rc) return rc;
   Workspace& w = c->ws;
@@ -812,6 +955,8 @@ int point_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   const Dims& d = c->d;
   if (d.head == LSTUR_HEAD_SOFTMAX) return fail(LSTUR_ERR_STATE, "context was created with the listwise head");
   if (n < 1 || n > d.B) return fail(LSTUR_ERR_ARG, "n must be in [1, max_batch]");
+  set_lane(c, 0);
+  c->last_piped = false;
   int rc = stage_titles(c, hist, cand, n, 1, ids_form, s);
   if (rc) return rc;
   Workspace& w = c->ws;
@@ -828,6 +973,8 @@ int predict_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const i
   const Dims& d = c->d;
   int cap = d.nt_max / (d.W + 1);
   if (n < 1 || n > cap) return fail(LSTUR_ERR_ARG, "n exceeds max_predict_rows");
+  set_lane(c, 0);
+  c->last_piped = false;
   int rc = stage_titles(c, hist, cand, n, 1, ids_form, s);
   if (rc) return rc;
   run_forward(c, user, n, 1, false, 0, s);
@@ -861,10 +1008,16 @@ int lstur_query_sizes(const lstur_cfg* cfg, lstur_sizes* out) {
   param_layout(d, &total);
   Workspace w;
   carve(d, nullptr, &w);
+  size_t ws_bytes = w.bytes;
+  if (lanes_supported(d)) {      // lane 1 of the two-lane step: its own workspace + gradient bucket
+    Workspace w1;
+    carve(lane1_dims(d), nullptr, &w1);
+    ws_bytes += w1.bytes + (total * sizeof(float) + 255) / 256 * 256;
+  }
   out->word_emb = (size_t)d.V * d.D;
   out->dense = total;
   out->user_emb = (size_t)d.Nu * d.Ue;
-  out->workspace_bytes = w.bytes;
+  out->workspace_bytes = ws_bytes;
   out->user_emb_dim = d.Ue;
   out->gru_dim = d.H;
   out->max_predict_rows = d.nt_max / (d.W + 1);
@@ -929,7 +1082,21 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
     return fail(LSTUR_ERR_ARG, "mhsa: qkv_b must follow qkv_w in the bucket");
   }
   carve(d, buf->workspace, &c->ws);
-  if (c->ws.bytes > buf->workspace_bytes) {
+  size_t need = c->ws.bytes;
+  c->pipe_ok = lanes_supported(d);
+  if (c->pipe_ok) {
+    c->d1 = lane1_dims(d);
+    carve(c->d1, (char*)buf->workspace + need, &c->ws1);
+    need += c->ws1.bytes;
+    c->grad1 = (float*)((char*)buf->workspace + need);
+    need += (c->dense_total * sizeof(float) + 255) / 256 * 256;
+    // shared between the lanes: operand images of the weights (packed by lane 0), the optimizer's sparse-row scratch
+    Workspace &a = c->ws, &b = c->ws1;
+    b.conv_w3 = a.conv_w3; b.conv_w3_v1 = a.conv_w3_v1; b.conv_wp = a.conv_wp; b.gru_up = a.gru_up;
+    b.first = a.first; b.gsum = a.gsum; b.gsum2 = a.gsum2; b.slot = a.slot; b.dp_rows = a.dp_rows; b.dp_grads = a.dp_grads;
+  }
+  set_lane(c, 0);
+  if (need > buf->workspace_bytes) {
     delete c;
     return fail(LSTUR_ERR_ARG, "workspace too small (see lstur_query_sizes)");
   }
@@ -938,6 +1105,13 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
 }
 
 int lstur_destroy(lstur_ctx* ctx) {
+  if (ctx && ctx->side) {
+    (void)hipStreamSynchronize(ctx->side);
+    (void)hipEventDestroy(ctx->ev_fork);
+    (void)hipEventDestroy(ctx->ev_enc0);
+    (void)hipEventDestroy(ctx->ev_done1);
+    (void)hipStreamDestroy(ctx->side);
+  }
   if (ctx)
     for (auto& k : ctx->prof)
       for (size_t i = 0; i < k.start.size(); ++i) {
@@ -1116,6 +1290,10 @@ int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* coun
       {"h_last", (d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU) ? w.uservec : w.hlast, n * d.H},
       {"dgates", w.dgates, n * d.W * 3 * d.H}, {"ddoc_vec", w.ddocvec, nt * d.U},
   };
+  if (ctx->last_piped && strcmp(name, "logits") && strcmp(name, "probs") && strcmp(name, "loss_i") && strcmp(name, "user_grad") &&
+      strcmp(name, "duser2"))
+    return fail(LSTUR_ERR_STATE, std::string(name) + ": title-level intermediates of a two-lane step live in two workspaces; "
+                                 "run with LSTUR_PIPELINE=0 to inspect them");
   if (!strcmp(name, "emb") && ctx->last_use3)
     return fail(LSTUR_ERR_STATE, "emb: the bf16x3 conv path keeps the embeddings pre-split (E3); run with LSTUR_CONV_F32=1");
   for (auto& e : tab)

@@ -155,14 +155,14 @@ void launch_conv3_pack_w2(const float* W, int D, int ksize, int F, unsigned shor
 size_t conv3_fwd2_scratch_bytes(int ncu = 256);
 void launch_conv3_fwd2(const unsigned short* e3, const unsigned short* W3, const float* bias, const int32_t* ids, float* out,
                        int n_titles, int T, int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount, int variant,
-                       void* scratch, hipStream_t s);
+                       void* scratch, hipStream_t s, int cus = 0);   // cus: CUs to plan the rounds for (0: all)
 
 // kernel gradient on the pre-split embeddings (same file): dw through ksize reduce jobs (one per tap); returns the job
 // count.  offA: per-token window offsets in 16-byte pieces of E3, offB: per-token row offsets in floats of dout.
 size_t conv3_wgrad2_scratch_bytes(int n_titles, int T, int D, int ksize, int F);
 int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
                         int ksize, int F, const int32_t* vcount, hipStream_t s, ReduceJob* jobs, const int32_t* offA,
-                        const int32_t* offB, float alpha = 1.0f);
+                        const int32_t* offB, float alpha = 1.0f, int cus = 0);
 
 // ---- attpool.hip -------------------------------------------------------------------------------
 // ids (nullable): rows with id == 0 are taken as zero without reading c / writing dc

@@ -622,9 +622,10 @@ def listwise_score_bwd(p, u, dv, cache, dz):
 
 
 def forward_backward(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0, word_trainable=False,
-                     want_grads=True):
+                     want_grads=True, stream_base=0):
     """One training step's loss + gradients.
     user int [B]; hist int [B,W,T]; cands int [B,K+1,T] (candidate 0 is the positive).
+    `stream_base`: first of the three dropout streams (embeddings, conv outputs, dgru rows) this call draws from.
     Returns dict(loss, acc, probs, logits, grads{name: array}, user_rows, user_row_grads)."""
     user = np.asarray(user).astype(np.int64).reshape(-1)
     hist = np.asarray(hist).astype(np.int64)
@@ -632,10 +633,10 @@ def forward_backward(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0, wor
     B, W, T = hist.shape
     K1 = cands.shape[1]
     titles = np.concatenate([hist.reshape(B * W, T), cands.reshape(B * K1, T)], axis=0)
-    keys = (dropout_key(seed, step, 0), dropout_key(seed, step, 1))
+    keys = (dropout_key(seed, step, stream_base), dropout_key(seed, step, stream_base + 1))
     v, nc = news_encoder_fwd(p, titles, drop_p, keys, training=True)
     hv, dv = split_titles(v, B, W, K1)
-    keep_u = dropout_keep(dropout_key(seed, step, 2), B, 0.5) if arch == "dgru" else None   # paper.py:610, training
+    keep_u = dropout_keep(dropout_key(seed, step, stream_base + 2), B, 0.5) if arch == "dgru" else None   # paper.py:610
     u, uc = user_encoder_fwd(p, arch, user, hv, hist, keep_u)
     z, sc = listwise_score_fwd(p, u, dv)
     loss_i, pr, dz = softmax_ce(z)
@@ -654,6 +655,43 @@ def forward_backward(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0, wor
     out["user_row_grads"] = duser
     if arch == "iigru":
         out["user_row_grads2"] = uc["duser2"]
+    return out
+
+
+LANE_MIN_BATCH = 32      # csrc/lstur_capi.hip: kPipeMin
+
+
+def lane_split(n):
+    """Samples of lane 0 of the library's two-lane training step (csrc/lstur_capi.hip: lane0_share); batches below
+    LANE_MIN_BATCH are not cut."""
+    return max(16, (n // 2) // 16 * 16) if n >= LANE_MIN_BATCH else n
+
+
+def forward_backward_lanes(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0):
+    """The same step the way the library runs a batch of >= LANE_MIN_BATCH samples (csrc/lstur_capi.hip:
+    train_two_lanes): two sample ranges, each encoded in its OWN [history | candidates] title layout -- lane 1's dropout
+    masks come from streams 16 + (0, 1, 2) at the element positions of that layout -- the loss is the mean over the whole
+    batch, gradients add.  Mathematically the step of `forward_backward` on the whole batch; only WHICH elements the
+    dropout hash drops differs, so parity tests of large batches go through this function."""
+    user = np.asarray(user).reshape(-1)
+    n = len(user)
+    nA = lane_split(n)
+    if nA >= n:
+        return forward_backward(p, arch, user, hist, cands, drop_p, seed, step)
+    outs, ns = [], []
+    for lane, (a, b) in enumerate(((0, nA), (nA, n))):
+        outs.append(forward_backward(p, arch, user[a:b], np.asarray(hist)[a:b], np.asarray(cands)[a:b], drop_p, seed, step,
+                                     stream_base=16 * lane))
+        ns.append(b - a)
+    wgt = [x / float(n) for x in ns]
+    out = dict(loss=sum(w * o["loss"] for w, o in zip(wgt, outs)), acc=sum(w * o["acc"] for w, o in zip(wgt, outs)),
+               probs=np.concatenate([o["probs"] for o in outs]), logits=np.concatenate([o["logits"] for o in outs]),
+               user_rows=np.concatenate([o["user_rows"] for o in outs]),
+               # each lane's gradients are those of ITS mean loss: weight by its share of the batch
+               user_row_grads=np.concatenate([w * o["user_row_grads"] for w, o in zip(wgt, outs)]),
+               grads={k: sum(w * o["grads"][k] for w, o in zip(wgt, outs)) for k in outs[0]["grads"]})
+    if "user_row_grads2" in outs[0]:
+        out["user_row_grads2"] = np.concatenate([w * o["user_row_grads2"] for w, o in zip(wgt, outs)])
     return out
 
 

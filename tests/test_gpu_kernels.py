@@ -190,17 +190,21 @@ def test_gru_against_oracle(n, W, H, generic, monkeypatch):
     np.testing.assert_allclose((dgn @ p['gru_w'].T).reshape(n, W, U), dx_ref, rtol=2e-3, atol=2e-5)
 
 
-def test_full_step_at_baseline_shapes_small_batch():
-    """LSTUR-ini at D=300/T=30/F=400/U=200 with a batch small enough for the NumPy oracle."""
+@pytest.mark.parametrize('arch', ['igru', 'gru', 'hgru'])
+def test_full_step_at_baseline_shapes_small_batch(arch):
+    """BASELINE.json configs[1] / [2] at their shapes D=300/T=30/F=400/U=200 with a batch small enough for the NumPy
+    oracle: LSTUR-ini (`igru`) and the two LSTUR-con candidates, `gru` (Dense over [GRU | user], paper.py:596-599) and
+    `hgru` (GRU(U/2) | Embedding(U/2), paper.py:603-607 -- the GRU kernels at H = 100)."""
     _need_gpu()
     from test_gpu_model import build, rel_close
     from conftest import make_batch
     from mnexp_amd._lib import lib, check
     dims = dict(V=2000, D=300, F=400, k=3, U=200, N_u=50)
     B, W, T, K1 = 6, 10, 30, 5
-    O, p, model, rng = build('igru', dims, B, W, T, K1, 0.2)
+    O, p, model, rng = build(arch, dims, B, W, T, K1, 0.2)
+    assert model.sizes.gru_dim == (100 if arch == 'hgru' else 200)
     user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
-    ref = O.forward_backward(p, 'igru', user, hist, cands, drop_p=0.2, seed=77, step=0)
+    ref = O.forward_backward(p, arch, user, hist, cands, drop_p=0.2, seed=77, step=0)
     u, h, c = model._dev_i32(user), model._dev_i32(hist), model._dev_i32(cands)
     check(lib.lstur_forward_backward(model._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), B, 0, 1.0,
                                      model.stats.data_ptr(), model._stream()))
@@ -208,9 +212,78 @@ def test_full_step_at_baseline_shapes_small_batch():
     logits = model.peek('logits').cpu().numpy().reshape(B, K1)
     np.testing.assert_allclose(logits, ref['logits'], rtol=1e-3, atol=1e-5)
     g = model.get_grads()
-    for n in O.dense_param_names('igru'):
+    for n in O.dense_param_names(arch):
         rel_close(g[n], ref['grads'][n], 2e-3, n)
     rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
+
+
+def test_config4_shapes_batch_512_one_million_users():
+    """BASELINE.json configs[3] per GPU: B = 512, 1 M users (D=300/T=30/W=50/F=400/U=200).  Logits of the full batch
+    against a forward-only oracle call (fp32), then two Adam steps over the 1 M-row table: rows touched by a step against
+    Keras-Adam restated on the row gradients the library reports, and the m / v DECAY of rows touched by the first step
+    only (TF-1 densifies the IndexedSlices gradient: every row's moments decay every step, paper.py:657)."""
+    _need_gpu()
+    from oracle import lstur_oracle as O
+    from mnexp_amd.native_model import NativeModel
+    from mnexp_amd._lib import lib, check
+    from conftest import make_batch
+    dims = dict(V=3000, D=300, F=400, k=3, U=200, N_u=1000000)
+    B, W, T, K1 = 512, 50, 30, 5
+    rng = np.random.default_rng(3)
+    p = O.init_params(rng, arch='igru', dtype=np.float32, **dims)
+    model = NativeModel(p['word_emb'], dims['N_u'], B, W, T, K1 - 1, dims['F'], dims['k'], dims['U'], arch='igru',
+                        dropout=0.0, lr=1e-3, seed=77)
+    model.set_weights({n: p[n] for n in p if n != 'word_emb'})
+    user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
+    user[:4] = [0, 999999, 123456, 999999]               # first / last row, a duplicate
+    ref = O.forward_backward(p, 'igru', user, hist, cands, drop_p=0.0, want_grads=False)
+    u, h, c = model._dev_i32(user), model._dev_i32(hist), model._dev_i32(cands)
+    check(lib.lstur_forward_backward(model._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), B, 0, 1.0,
+                                     model.stats.data_ptr(), model._stream()))
+    torch.cuda.synchronize()
+    logits = model.peek('logits').cpu().numpy().reshape(B, K1)
+    np.testing.assert_allclose(logits, ref['logits'], rtol=1e-3, atol=2e-5)
+    assert abs(model.stats[0].item() - ref['loss']) < 1e-4
+    # ---- Adam step 1 on the table
+    Ue, lr, b1, b2, eps = 200, 1e-3, 0.9, 0.999, 1e-7
+    g = model.get_grads()
+    rows1, rg1 = g['user_rows'], g['user_row_grads'].astype(np.float64)
+    assert np.array_equal(rows1, user)
+    table0 = model.user_emb.view(-1, Ue)[torch.from_numpy(np.unique(rows1)).cuda().long()].cpu().numpy().astype(np.float64)
+    check(lib.lstur_adam_step(model._ctx, lr, 1, None, None, 0, model._stream()))
+    torch.cuda.synchronize()
+    uniq = np.unique(rows1)
+    gsum = np.zeros((len(uniq), Ue))
+    for r, gr in zip(rows1, rg1):
+        gsum[np.searchsorted(uniq, r)] += gr                        # duplicates summed in ascending sample order
+    m1, v1 = (1 - b1) * gsum, (1 - b2) * gsum ** 2
+    lr1 = lr * np.sqrt(1 - b2) / (1 - b1)
+    want1 = table0 - lr1 * m1 / (np.sqrt(v1) + eps)
+    idx = torch.from_numpy(uniq).cuda().long()
+    got1 = model.user_emb.view(-1, Ue)[idx].cpu().numpy()
+    np.testing.assert_allclose(got1, want1, rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(model.user_m.view(-1, Ue)[idx].cpu().numpy(), m1, rtol=2e-5, atol=1e-12)
+    np.testing.assert_allclose(model.user_v.view(-1, Ue)[idx].cpu().numpy(), v1, rtol=2e-5, atol=1e-20)
+    probe = torch.tensor([1, 2, 500000, 999998], device='cuda')      # never touched: exactly unchanged, moments zero
+    assert not model.user_m.view(-1, Ue)[probe].any() and not model.user_v.view(-1, Ue)[probe].any()
+    assert torch.equal(model.user_emb.view(-1, Ue)[probe].cpu(), torch.from_numpy(p['user_emb'][probe.cpu().numpy()]))
+    # ---- step 2 with other users: rows of step 1 only decay
+    user2 = ((user.astype(np.int64) * 7 + 13) % dims['N_u']).astype(np.int32)
+    old_only = np.setdiff1d(uniq, np.unique(user2))
+    assert len(old_only) > 100
+    u2 = model._dev_i32(user2)
+    check(lib.lstur_forward_backward(model._ctx, u2.data_ptr(), h.data_ptr(), c.data_ptr(), B, 1, 1.0,
+                                     model.stats.data_ptr(), model._stream()))
+    check(lib.lstur_adam_step(model._ctx, lr, 2, None, None, 0, model._stream()))
+    torch.cuda.synchronize()
+    sel = np.searchsorted(uniq, old_only)
+    io = torch.from_numpy(old_only).cuda().long()
+    m2, v2 = b1 * m1[sel], b2 * v1[sel]
+    lr2 = lr * np.sqrt(1 - b2 ** 2) / (1 - b1 ** 2)
+    want2 = got1[sel].astype(np.float64) - lr2 * m2 / (np.sqrt(v2) + eps)
+    np.testing.assert_allclose(model.user_m.view(-1, Ue)[io].cpu().numpy(), m2, rtol=2e-5, atol=1e-12)
+    np.testing.assert_allclose(model.user_v.view(-1, Ue)[io].cpu().numpy(), v2, rtol=2e-5, atol=1e-20)
+    np.testing.assert_allclose(model.user_emb.view(-1, Ue)[io].cpu().numpy(), want2, rtol=2e-5, atol=2e-7)
 
 
 @pytest.mark.parametrize('N,D,T,F,k', [(130, 300, 30, 400, 3), (3, 300, 30, 400, 3), (9, 12, 7, 16, 3), (7, 20, 6, 24, 5),

@@ -84,6 +84,39 @@ def test_cli_train_loop(tmp_path, arch, ids):
     assert h.model.optimizer.iterations == 30
 
 
+@pytest.mark.parametrize('native_feed', [False, True])
+def test_idless_task_with_the_native_feed(tmp_path, native_feed):
+    """Seq2VecPaperSoftmax (no user column) through --ids and through --native-feed: the C++ feed yields (hist, cands)
+    for an id-less task (it used to yield a user column the model then rejected)."""
+    _need_gpu()
+    from mnexp_amd.main import run_training
+    cfg = _config(tmp_path, task='Seq2VecPaperSoftmax', arch='gru', epochs=1, training_step=12, validation_step=1,
+                  validation_impression=10, testing_impression=10, dropout=0.2, seed=1, ids=True, native_feed=native_feed)
+    np.random.seed(0)
+    h = run_training(cfg)
+    assert h.model.arch == 'nigru' and h.model.optimizer.iterations == 12 and 0.0 <= h.last_metrics['auc'] <= 1.0
+
+
+@pytest.mark.parametrize('tname,arch', [('Seq2VecPaperSoftmaxDaysId', 'igru'), ('Seq2VecPaperSoftmaxDaysId', 'dgru'),
+                                        ('Seq2VecPaperSoftmaxDays', 'gru')])
+def test_cli_train_loop_days_variants(tmp_path, tname, arch):
+    """The time-window variants (paper.py:668-881: history entries expire `days` after their click) driven through the
+    native model: one epoch of the CLI loop incl. the evaluation callback.  `dgru` = the LSTUR paper's user-embedding
+    masking (whole-row dropout 0.5, paper.py:608-611) needs a 2U-compatible scorer."""
+    _need_gpu()
+    from mnexp_amd.main import run_training
+    kw = dict(score_model='ddot') if arch == 'dgru' else {}
+    cfg = _config(tmp_path, task=tname, arch=arch, epochs=1, training_step=12, validation_step=2, validation_impression=15,
+                  testing_impression=15, dropout=0.2, seed=1, ids=True, days=3, **kw)
+    np.random.seed(0)
+    h = run_training(cfg)
+    assert h.model.optimizer.iterations == 12 and 0.0 <= h.last_metrics['auc'] <= 1.0 and np.isfinite(h.last_metrics['mrr'])
+    # the window really expires entries: with days = 3 some history slots read as pad that a plain window keeps
+    rows = [r for _, r in zip(range(50), h.train_gen_ids())]
+    hist = np.stack([r[1] if h.has_user else r[0] for r in rows])
+    assert (hist == 0).any()
+
+
 def test_cli_train_loop_mhsa_encoder(tmp_path):
     """`--news-encoder mhsa --title-filter-shape F heads`: the build-defined multi-head self-attention encoder
     (BASELINE.json configs[4]; no reference counterpart) through the same task / CLI loop."""

@@ -1,9 +1,10 @@
 """Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command) into
 profiles/<tag>_pmc_traffic.json: HBM bytes per launch for the kernel families bench.py reports.
 FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md, HBM section)."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-FAMILIES = {'gather': 'gather_kernel', 'conv_fwd': 'conv3_fwd_kernel<4', 'conv_fwd_rest': 'conv3_fwd_kernel<1', 'conv_wgrad': 'conv3_wgrad_kernel',
+FAMILIES = {'gather': 'gather3_kernel', 'gather_f32': 'gather_kernel', 'conv_fwd': 'conv3_fwd2_kernel', 'conv_fwd_fix': 'conv3_fwd2_fix', 'conv_wgrad': 'conv3_wgrad2_kernel',
             'conv_fwd_f32': 'conv_fwd_kernel', 'conv_wgrad_f32': 'conv_wgrad_glds', 'adam_user_table': 'adam_table_kernel',
             'att_fwd': 'att_fwd_title_kernel', 'att_bwd': 'att_bwd_title_kernel', 'att_score': 'att_score_kernel', 'att_pool': 'att_pool_kernel', 'att_bwd_dc': 'att_bwd_dc_kernel',
             'gru_fwd': 'gru4_fwd_kernel', 'gru_bwd': 'gru4_bwd_kernel', 'multi_reduce': 'multi_reduce_kernel'}
@@ -29,7 +30,8 @@ def main(fetch_dir, write_dir, out, workload='lstur_ini_b64'):
         if fc[fam] and wc[fam]:
             fb, wb = int(2 * 1024 * f[fam] / fc[fam]), int(1024 * w[fam] / wc[fam])
             kernels[fam] = dict(fetch_bytes=fb, write_bytes=wb, traffic_bytes=fb + wb, launches=fc[fam])
-    json.dump(dict(workload=workload,
+    import bench
+    json.dump(dict(workload=workload, kernel_sources_hash=bench.kernel_sources_hash(),
                    command='rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 6 --warmup 2 '
                            '--no-cpu-baseline --no-profile (two separate passes)',
                    method='per-launch mean; FETCH_SIZE and WRITE_SIZE are in KB; FETCH_SIZE doubled (gfx950 tallies 128-B '
