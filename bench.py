@@ -87,7 +87,7 @@ def kernel_sources_hash():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(wl, titles, word, batches, budget_s=20.0):
+def cpu_baseline(wl, titles, word, batches, budget_s=15.0):
     """The NumPy oracle (kind 'port'; the reference's Keras/TF stack cannot run here) timed on the host
     cores for a bounded number of full training steps of the SAME workload in fp32."""
     from oracle import lstur_oracle as O
@@ -96,11 +96,14 @@ def cpu_baseline(wl, titles, word, batches, budget_s=20.0):
     p = O.init_params(rng, V=wl['V'], D=wl['D'], F=wl['F'], k=wl['k'], U=wl['U'], N_u=wl['N_u'], arch=wl['arch'],
                       word_emb=word, dtype=np.float32, encoder=enc, heads=wl.get('heads', 1))
     opt = O.Adam(p, O.dense_param_names(wl['arch'], encoder=enc) + ['user_emb'], lr=1e-3)
+    threads, limiter = usable_cpus(), None
     try:
         import threadpoolctl
-        threads = max(i['num_threads'] for i in threadpoolctl.threadpool_info() if i.get('user_api') == 'blas')
+        blas = max(i['num_threads'] for i in threadpoolctl.threadpool_info() if i.get('user_api') == 'blas')
+        threads = min(threads, blas)
+        limiter = threadpoolctl.threadpool_limits(limits=threads, user_api='blas')
     except Exception:
-        threads = os.cpu_count()
+        pass
     steps, t0 = 0, time.perf_counter()
     while True:
         user, hist, cands = batches[steps % len(batches)]
@@ -109,9 +112,11 @@ def cpu_baseline(wl, titles, word, batches, budget_s=20.0):
         el = time.perf_counter() - t0
         if el > budget_s or steps >= 8:
             break
+    if limiter is not None:
+        limiter.restore_original_limits()
     out = dict(value=steps * wl['B'] / el, unit='impressions/s', cores=int(threads), kind='port',
                sample='%d full training steps (fwd+bwd+Adam, fp32 NumPy/BLAS) of the same workload, %.1f s'
-                      % (steps, el), host_cpus=os.cpu_count(), cpu_model=cpu_model_string(), numpy_value=steps * wl['B'] / el)
+                      % (steps, el), host_cpus=os.cpu_count(), usable_cpus=usable_cpus(), cpu_model=cpu_model_string(), numpy_value=steps * wl['B'] / el)
     if wl.get('encoder', 'cnnatt') == 'cnnatt':
         # the torch-CPU fp32 step on all cores beside the NumPy port; `value` is the FASTER of the two
         tc = cpu_baseline_torch(wl, titles, word, batches)
@@ -119,6 +124,30 @@ def cpu_baseline(wl, titles, word, batches, budget_s=20.0):
         if tc['value'] > out['value']:
             out.update(value=tc['value'], cores=tc['threads'], sample=tc['sample'])
     return out
+
+
+def usable_cpus():
+    """Cores this process may actually run on: the affinity mask and the cgroup CPU quota (a GPU box hands one GPU's job
+    a share of the host, e.g. 16 of 256 CPUs -- sizing thread pools by os.cpu_count() there oversubscribes 16x)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
 
 
 def cpu_model_string():
@@ -131,13 +160,13 @@ def cpu_model_string():
     return 'unknown'
 
 
-def cpu_baseline_torch(wl, titles, word, batches, budget_s=15.0):
+def cpu_baseline_torch(wl, titles, word, batches, budget_s=12.0):
     """The same training step in torch-CPU fp32 on ALL host cores: F.conv1d, autograd through the masked GRU
     loop (oracle/torch_ref.py, the torch restatement the oracle is cross-checked against), dense Keras-Adam over every
     parameter incl. the whole user table.  Dropout masks from torch's generator (throughput only)."""
     import torch
     from oracle import lstur_oracle as O, torch_ref as TR
-    nthreads = os.cpu_count() or 1
+    nthreads = usable_cpus()
     torch.set_num_threads(nthreads)
     enc = wl.get('encoder', 'cnnatt')
     p = O.init_params(np.random.default_rng(0), V=wl['V'], D=wl['D'], F=wl['F'], k=wl['k'], U=wl['U'], N_u=wl['N_u'],
@@ -167,7 +196,7 @@ def cpu_baseline_torch(wl, titles, word, batches, budget_s=15.0):
                 tp[n].grad = None
         steps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or steps >= 12:
+        if el > budget_s or steps >= 8:
             break
     return dict(value=steps * B / el, threads=int(torch.get_num_threads()),
                 sample='%d full training steps (fwd+autograd bwd+dense Adam, fp32 torch-CPU %s) of the same workload, %.1f s'
