@@ -2,8 +2,8 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-One "step" = forward + backward + (N > 1: RCCL all-reduce of the dense-gradient bucket and all-gather
-of the sparse user-row gradients) + Keras-Adam over the dense bucket and the whole user table, on one
+One "step" = forward + backward + (N > 1: ONE RCCL all-reduce of the dense-gradient bucket whose tail carries every
+rank's sparse user-row gradients, mnexp_amd/dist.py) + Keras-Adam over the dense bucket and the whole user table, on one
 batch of synthetic doc-id samples that is already resident in HBM.  Default workload = BASELINE.json
 configs[1]: LSTUR-ini (arch igru), 300-d word embeddings, title_len 30, hist_len 50, 1+4 candidates,
 batch 64 per GPU (weak scaling), dropout 0.2 (reference default), 50k users / 20k docs / 50k vocab.

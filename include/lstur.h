@@ -109,6 +109,10 @@ typedef struct lstur_cfg {
   int32_t news_encoder;      /* lstur_encoder; 0 = cnnatt                                              */
   int32_t heads;             /* mhsa: number of attention heads (filters % heads == 0)                 */
   int32_t score_model;       /* lstur_score_model; 0 = dot                                              */
+  float id_keep;             /* probability that a training sample keeps its user embedding (the LSTUR paper's user-
+                                embedding masking; reference task/cook.py:139-142: idx_vec * Dropout(1 - id_keep)(mask),
+                                kept rows scaled by 1 / id_keep).  <= 0 or >= 1: off.  dgru always masks with 0.5
+                                (paper.py:610); iigru masks the same rows of both tables                        */
 } lstur_cfg;
 
 /* Sizes (in floats unless named _bytes) the caller must allocate for a configuration. */

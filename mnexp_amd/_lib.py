@@ -26,7 +26,8 @@ class Cfg(C.Structure):
                                          'filters', 'kernel', 'user_dim', 'n_users', 'arch')] + [
         ('dropout', C.c_float), ('seed', C.c_uint32), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
         ('head', C.c_int32), ('gain', C.c_float), ('loss_negatives', C.c_int32), ('word_trainable', C.c_int32),
-        ('freeze_encoder', C.c_int32), ('news_encoder', C.c_int32), ('heads', C.c_int32), ('score_model', C.c_int32)]
+        ('freeze_encoder', C.c_int32), ('news_encoder', C.c_int32), ('heads', C.c_int32), ('score_model', C.c_int32),
+        ('id_keep', C.c_float)]
 
 
 class Sizes(C.Structure):
@@ -145,7 +146,7 @@ def check(rc, what=''):
 def make_cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
              arch='igru', dropout=0.0, seed=0, beta1=0.9, beta2=0.999, eps=1e-7, head='softmax', gain=1.0,
              loss_negatives=4, freeze_encoder=False, word_trainable=False, news_encoder='cnnatt', heads=0,
-             score_model='dot'):
+             score_model='dot', id_keep=1.0):
     if arch not in ARCH:
         raise LsturError('arch {!r} is not supported by the native path (have {})'.format(arch, sorted(ARCH)))
     if head not in HEAD:
@@ -158,7 +159,7 @@ def make_cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kern
     return Cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
                ARCH[arch], dropout, seed, beta1, beta2, eps, HEAD[head], gain, loss_negatives,
                int(bool(word_trainable)), int(bool(freeze_encoder)), ENCODER[news_encoder], int(heads),
-               SCORE[score_model])
+               SCORE[score_model], float(id_keep))
 
 
 def query_sizes(cfg):

@@ -495,6 +495,15 @@ struct ProfScope {
     stmt;                           \
   } while (0)
 
+// whole-row dropout probability of the user embedding in training (0: none)
+float user_row_drop(const lstur_ctx* c) {
+  const int a = c->d.arch;
+  if (a == LSTUR_ARCH_DGRU) return 0.5f;
+  const bool has_table = a != LSTUR_ARCH_NIGRU && a != LSTUR_ARCH_NIAVG && a != LSTUR_ARCH_NIATT;
+  const float k = c->cfg.id_keep;
+  return (has_table && k > 0.f && k < 1.f) ? 1.0f - k : 0.f;
+}
+
 void lazy_init(lstur_ctx* c, hipStream_t s) {
   if (c->lazy_init_done) return;
   const Dims& d = c->d;
@@ -566,8 +575,10 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   // user encoder (paper.py:584-633)
   launch_hist_mask(w.ids, w.docvec, w.hmask, w.gmask, nW, d.T, d.U, s, c->buf.user_emb, user, w.user_rows, w.uvec, n,
                    d.Ue);
-  if (d.arch == LSTUR_ARCH_DGRU && training)   // Dropout(0.5, noise_shape=(None, 1)) on the user embedding, paper.py:610
-    launch_drop_rows(w.uvec, n, d.Ue, 0.5f, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
+  // whole-row dropout of the user embedding: dgru's Dropout(0.5, noise_shape=(None, 1)) (paper.py:610), or the id_keep
+  // masking of cook.py:139-142 for every arch that reads the table
+  const float row_p = training ? user_row_drop(c) : 0.f;
+  if (row_p > 0.f) launch_drop_rows(w.uvec, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
   launch_gemm(w.docvec, d.U, 0, c->P("gru_w"), 3 * d.H, 0, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, 1.f,
               w.gemm_scratch, s);
   if (c->cur_ev_enc) (void)hipEventRecord(c->cur_ev_enc, s);   // the other lane's encoder may start: the recurrence follows
@@ -590,6 +601,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
       const float* side = w.uvec;
       if (d.arch == LSTUR_ARCH_IIGRU) {     // the concatenated vector comes from the SECOND table (paper.py:617-619)
         launch_gather_rows(c->buf.user_emb2, w.user_rows, w.uvec2, n, d.Ue, s);
+        if (row_p > 0.f) launch_drop_rows(w.uvec2, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
         side = w.uvec2;
       }
       launch_concat2(w.hlast, d.H, side, d.Ue, w.cat, n, s);
@@ -625,8 +637,6 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     dhl = w.dhlast;
   } else if (d.arch == LSTUR_ARCH_HGRU || d.arch == LSTUR_ARCH_NGRU || d.arch == LSTUR_ARCH_DGRU) {
     launch_split2(w.du, d.H, d.Ue, w.dhlast, w.duser, n, s);
-    if (d.arch == LSTUR_ARCH_DGRU)   // the same per-sample mask and scale as the forward
-      launch_drop_rows(w.duser, n, d.Ue, 0.5f, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
     dhl = w.dhlast;
   } else if (d.arch == LSTUR_ARCH_PGRU || d.arch == LSTUR_ARCH_VO) {   // u = h + user_vec / u = user_vec
     (void)hipMemcpyAsync(w.duser, w.du, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
@@ -650,6 +660,14 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
                 1.f, w.gemm_scratch_k[2], s, &jobs[nj++]);
   } else {   // vo / niavg: no GRU in the graph -- its bucket slots get an exact zero gradient
     (void)hipMemsetAsync(c->G("gru_w"), 0, (size_t)(c->G("gru_b") + 3 * d.H - c->G("gru_w")) * sizeof(float), s);
+  }
+  {   // the row gradients of the user table(s) pass the forward's row mask and scale (dgru / id_keep)
+    const float row_p = user_row_drop(c);
+    if (row_p > 0.f) {
+      launch_drop_rows(w.duser, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
+      if (d.arch == LSTUR_ARCH_IIGRU)
+        launch_drop_rows(w.duser2, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
+    }
   }
   if (c->cfg.freeze_encoder) {   // loaded, non-trainable news encoder: nothing behind the doc vectors is trained
     if (stats) {

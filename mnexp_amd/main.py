@@ -28,6 +28,9 @@ _TRAIN_OPTIONS = [
     (('-l', '--learning-rate'), dict(default=0.001)),
     (('-cld', '--learning-rate-decay'), dict(default=0.2)),
     (('-g', '--gain'), dict(default=1.0)),
+    # the LSTUR paper's user-embedding masking probability (reference: the `cook` command's --id-keep, main.py:134,
+    # task/cook.py:139-142), offered to the Paper tasks: a training sample keeps its user embedding with this probability
+    (('--id-keep',), dict(default=1.0)),
     (('-w', '--window-size'), dict(default=10)),
     (('-d', '--dropout'), dict(default=0.2)),
     (('-n', '--negative-samples'), dict(default=4)),
@@ -113,8 +116,10 @@ def run_training(config, task_handler=None):
 def train(config):
     from . import dist
     dist.maybe_init_from_env()
-    logging.basicConfig(format='%(asctime)s : %(levelname)s : %(message)s', level=logging.INFO,
-                        handlers=[logging.FileHandler(config.log_output), logging.StreamHandler()])
+    # under data parallelism every rank trains and evaluates (validation / test walk ALL users on every rank, so the
+    # metrics are the single-GPU ones), but only rank 0 writes the log file and the console
+    handlers = [logging.FileHandler(config.log_output), logging.StreamHandler()] if dist.rank() == 0 else [logging.NullHandler()]
+    logging.basicConfig(format='%(asctime)s : %(levelname)s : %(message)s', level=logging.INFO, handlers=handlers)
     run_training(config)
     return 0
 

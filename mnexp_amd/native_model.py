@@ -104,7 +104,7 @@ class NativeModel:
     def __init__(self, word_emb, n_users, batch_size, window, title_len, negative_samples, filters, kernel,
                  user_dim, arch='igru', dropout=0.2, lr=1e-3, seed=0, device=None, title_table=None,
                  dist_group=None, has_user=True, head='softmax', gain=1.0, freeze_encoder=False,
-                 word_trainable=False, news_encoder='cnnatt', heads=0, score_model='dot'):
+                 word_trainable=False, news_encoder='cnnatt', heads=0, score_model='dot', id_keep=1.0):
         if not torch.cuda.is_available():
             raise _lib.LsturError('no GPU visible: the native LSTUR model has no CPU fallback')
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
@@ -118,11 +118,16 @@ class NativeModel:
         self.metrics_names = ['loss', 'auc_roc'] if self.pointwise else ['loss', 'categorical_accuracy']
         self.arch = arch
         self.has_user = has_user       # False: id-less task (Seq2VecPaperSoftmax), inputs carry no user column
+        # dropout streams are keyed by (seed, step, stream): fold the data-parallel rank into the seed, or every rank would
+        # drop the same element positions of its own samples (weights are still initialised from `seed` on every rank)
+        rank = torch.distributed.get_rank(dist_group) if (torch.distributed.is_available() and
+                                                          torch.distributed.is_initialized()) else 0
         self.cfg = _lib.make_cfg(batch_size, window, title_len, self.K1, V, D, filters, kernel, user_dim,
-                                 max(1, n_users), arch, dropout, seed, head=head, gain=gain,
+                                 max(1, n_users), arch, dropout, (int(seed) + 0x9E3779B1 * rank) & 0xFFFFFFFF, head=head, gain=gain,
                                  loss_negatives=max(1, negative_samples), freeze_encoder=freeze_encoder,
                                  word_trainable=word_trainable, news_encoder=news_encoder, heads=heads,
-                                 score_model=score_model)
+                                 score_model=score_model, id_keep=id_keep)
+        self.id_keep = float(id_keep)        # --id-keep: user-embedding masking probability in training (cook.py:139-142)
         self.score_model = score_model       # listwise --score-model dot | ddot | dnn (paper.py:443-458)
         self.news_encoder = news_encoder     # 'mhsa': build-defined multi-head self-attention token stage (heads x F/heads)
         self.mhsa_proj_dtype = 'bf16'        # operand type of the mhsa Q|K|V projection GEMMs (attention products: bf16)
@@ -238,7 +243,8 @@ class NativeModel:
                     gain=float(getattr(cfg, 'gain', 1.0)),
                     freeze_encoder=pretrained and not getattr(cfg, 'pretrain_encoder_trainable', False),
                     word_trainable=bool(getattr(cfg, 'textual_embedding_trainable', False)) and not pretrained,
-                    news_encoder=enc, heads=int(kernel) if enc == 'mhsa' else 0, score_model=score_model)
+                    news_encoder=enc, heads=int(kernel) if enc == 'mhsa' else 0, score_model=score_model,
+                    id_keep=float(getattr(cfg, 'id_keep', 1.0) or 1.0))
         if pretrained:                      # paper.py:103-107
             model.load_encoder(cfg.encoder_input)
         return model

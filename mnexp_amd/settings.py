@@ -21,7 +21,7 @@ _PATH_KEYS = ('input_training_data_path', 'input_validation_data_path', 'input_p
               'output_model_path', 'log_dir')
 # option keys the `train` command of the LSTUR path defines (reference main.py:12-54)
 _TRAIN_KEYS = ('task arch round days epochs batch_size training_step validation_step '
-               'validation_impression testing_impression learning_rate learning_rate_decay gain '
+               'validation_impression testing_impression learning_rate learning_rate_decay gain id_keep '
                'window_size dropout negative_samples hidden_dim nonlocal_negative_samples '
                'enable_baseline title_filter_shape title_shape body_shape user_embedding_dim '
                'textual_embedding_dim textual_embedding_trainable debug background name '
@@ -30,7 +30,7 @@ _TRAIN_KEYS = ('task arch round days epochs batch_size training_step validation_
                'body_filter_shape max_impression max_impression_pos max_impression_neg '
                'test_window_size vertical_embedding_dim subvertical_embedding_dim').split()
 # keys of the other reference commands, accepted so a shared Config dict still loads
-_OTHER_KEYS = ('evaluate_sessions target use_vertical pipeline_input lrd_on_epochs id_keep '
+_OTHER_KEYS = ('evaluate_sessions target use_vertical pipeline_input lrd_on_epochs '
                'use_generator user_feature_size doc_feature_size use_vertical_type').split()
 _NATIVE_KEYS = ('device', 'world_size', 'seed', 'ids', 'native_feed')
 

@@ -450,13 +450,20 @@ def split_titles(v, B, W, K1):
     return hv, dv
 
 
-def user_encoder_fwd(p, arch, user, hv, hist_ids, uvec_keep=None):
+def user_encoder_fwd(p, arch, user, hv, hist_ids, uvec_keep=None, keep_scale=2.0):
     """paper.py:584-633 for arch in igru|gru|hgru|nigru|ngru|dgru; hv [B,W,U] raw doc vectors of the history.
-    uvec_keep (dgru, training): bool [B], the whole-vector Dropout(0.5, noise_shape=(None, 1)) of paper.py:610."""
+    uvec_keep (training): bool [B], whole-vector dropout of the user embedding, kept rows scaled by `keep_scale` --
+    dgru's Dropout(0.5, noise_shape=(None, 1)) of paper.py:610, or the `id_keep` masking of cook.py:139-142
+    (idx_vec * Dropout(1 - id_keep)(idx_mask): scale 1 / id_keep); iigru: the same rows of both tables."""
     hmask = np.any(hist_ids != 0, axis=-1)           # models.ComputeMasking, paper.py:644
     hvm = hv * hmask[..., None]                      # paper.py:645
     gmask = np.any(hvm != 0, axis=-1)                # Masking() paper.py:592
     uvec = p["user_emb"][user]
+    uvec2 = p["user_emb2"][user] if arch == "iigru" else None
+    if uvec_keep is not None:
+        uvec = uvec * uvec_keep[:, None] * hv.dtype.type(keep_scale)
+        if uvec2 is not None:
+            uvec2 = uvec2 * uvec_keep[:, None] * hv.dtype.type(keep_scale)
     H = p["gru_u"].shape[0]
     if arch == "igru":
         h, gc = gru_fwd(p, hvm, gmask, uvec)
@@ -472,7 +479,7 @@ def user_encoder_fwd(p, arch, user, hv, hist_ids, uvec_keep=None):
         extra = None
     elif arch == "iigru":                           # paper.py:614-621: Dense(U)(concat[igru(x, user_vec), user_vec2])
         h, gc = gru_fwd(p, hvm, gmask, uvec)
-        extra = np.concatenate([h, p["user_emb2"][user]], axis=1)
+        extra = np.concatenate([h, uvec2], axis=1)
         u = extra @ p["con_w"] + p["con_b"]
     elif arch == "vo":                              # paper.py:622-623: the user embedding alone, the history is unused
         u, gc, extra = uvec, None, None
@@ -488,15 +495,13 @@ def user_encoder_fwd(p, arch, user, hv, hist_ids, uvec_keep=None):
         gc, extra = (hvm, a, wgt), None
     else:
         h, gc = gru_fwd(p, hvm, gmask, np.zeros((len(user), H), dtype=hv.dtype))
-        if arch == "dgru" and uvec_keep is not None:
-            uvec = uvec * uvec_keep[:, None] * hv.dtype.type(2.0)
         cat = np.concatenate([h, uvec], axis=1)
         if arch == "gru":
             u = cat @ p["con_w"] + p["con_b"]
         else:  # hgru (H = Ue = U/2), ngru / dgru (H = Ue = U: a 2U-wide user vector)
             u = cat
         extra = cat
-    return u, dict(gc=gc, hmask=hmask, user=user, cat=extra, arch=arch, uvec_keep=uvec_keep)
+    return u, dict(gc=gc, hmask=hmask, user=user, cat=extra, arch=arch, uvec_keep=uvec_keep, keep_scale=keep_scale)
 
 
 def user_encoder_bwd(p, cache, du):
@@ -546,8 +551,10 @@ def user_encoder_bwd(p, cache, du):
             dcat = du
         gg, dx, _ = gru_bwd(p, gc, np.ascontiguousarray(dcat[:, :H]))
         duser = dcat[:, H:]
-        if arch == "dgru" and cache["uvec_keep"] is not None:
-            duser = duser * cache["uvec_keep"][:, None] * du.dtype.type(2.0)
+    if cache["uvec_keep"] is not None:              # the gradient passes the same row mask and scale
+        duser = duser * cache["uvec_keep"][:, None] * du.dtype.type(cache["keep_scale"])
+        if "duser2" in cache:
+            cache["duser2"] = cache["duser2"] * cache["uvec_keep"][:, None] * du.dtype.type(cache["keep_scale"])
     g.update(gg)
     dhv = dx * cache["hmask"][..., None]
     return g, dhv, duser
@@ -622,10 +629,11 @@ def listwise_score_bwd(p, u, dv, cache, dz):
 
 
 def forward_backward(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0, word_trainable=False,
-                     want_grads=True, stream_base=0):
+                     want_grads=True, stream_base=0, id_keep=1.0):
     """One training step's loss + gradients.
     user int [B]; hist int [B,W,T]; cands int [B,K+1,T] (candidate 0 is the positive).
-    `stream_base`: first of the three dropout streams (embeddings, conv outputs, dgru rows) this call draws from.
+    `stream_base`: first of the three dropout streams (embeddings, conv outputs, user-embedding rows) this call draws from.
+    `id_keep` < 1: a sample keeps its user embedding with this probability (cook.py:139-142); dgru always masks with 0.5.
     Returns dict(loss, acc, probs, logits, grads{name: array}, user_rows, user_row_grads)."""
     user = np.asarray(user).astype(np.int64).reshape(-1)
     hist = np.asarray(hist).astype(np.int64)
@@ -636,8 +644,9 @@ def forward_backward(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0, wor
     keys = (dropout_key(seed, step, stream_base), dropout_key(seed, step, stream_base + 1))
     v, nc = news_encoder_fwd(p, titles, drop_p, keys, training=True)
     hv, dv = split_titles(v, B, W, K1)
-    keep_u = dropout_keep(dropout_key(seed, step, stream_base + 2), B, 0.5) if arch == "dgru" else None   # paper.py:610
-    u, uc = user_encoder_fwd(p, arch, user, hv, hist, keep_u)
+    row_p = 0.5 if arch == "dgru" else (1.0 - id_keep if 0.0 < id_keep < 1.0 and arch not in ("nigru", "niavg", "niatt") else 0.0)
+    keep_u = dropout_keep(dropout_key(seed, step, stream_base + 2), B, row_p) if row_p > 0.0 else None   # paper.py:610
+    u, uc = user_encoder_fwd(p, arch, user, hv, hist, keep_u, 1.0 / (1.0 - row_p) if row_p > 0.0 else 1.0)
     z, sc = listwise_score_fwd(p, u, dv)
     loss_i, pr, dz = softmax_ce(z)
     out = dict(loss=float(loss_i.mean()), acc=float((pr.argmax(axis=1) == 0).mean()),
@@ -667,7 +676,7 @@ def lane_split(n):
     return max(16, (n // 2) // 16 * 16) if n >= LANE_MIN_BATCH else n
 
 
-def forward_backward_lanes(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0):
+def forward_backward_lanes(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0, id_keep=1.0):
     """The same step the way the library runs a batch of >= LANE_MIN_BATCH samples (csrc/lstur_capi.hip:
     train_two_lanes): two sample ranges, each encoded in its OWN [history | candidates] title layout -- lane 1's dropout
     masks come from streams 16 + (0, 1, 2) at the element positions of that layout -- the loss is the mean over the whole
@@ -677,11 +686,11 @@ def forward_backward_lanes(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=
     n = len(user)
     nA = lane_split(n)
     if nA >= n:
-        return forward_backward(p, arch, user, hist, cands, drop_p, seed, step)
+        return forward_backward(p, arch, user, hist, cands, drop_p, seed, step, id_keep=id_keep)
     outs, ns = [], []
     for lane, (a, b) in enumerate(((0, nA), (nA, n))):
         outs.append(forward_backward(p, arch, user[a:b], np.asarray(hist)[a:b], np.asarray(cands)[a:b], drop_p, seed, step,
-                                     stream_base=16 * lane))
+                                     stream_base=16 * lane, id_keep=id_keep))
         ns.append(b - a)
     wgt = [x / float(n) for x in ns]
     out = dict(loss=sum(w * o["loss"] for w, o in zip(wgt, outs)), acc=sum(w * o["acc"] for w, o in zip(wgt, outs)),
@@ -848,10 +857,10 @@ def densify_user_grad(N_u, Ue, rows, row_grads, dtype):
     return g
 
 
-def train_step(p, arch, opt, user, hist, cands, drop_p=0.0, seed=0, step=0, word_trainable=False):
+def train_step(p, arch, opt, user, hist, cands, drop_p=0.0, seed=0, step=0, word_trainable=False, id_keep=1.0):
     """forward/backward + Adam over dense params and the (densified) user table (+ the word table when
     --textual-embedding-trainable: `opt` must then list 'word_emb'; its IndexedSlices gradient is densified too)."""
-    out = forward_backward(p, arch, user, hist, cands, drop_p, seed, step, word_trainable=word_trainable)
+    out = forward_backward(p, arch, user, hist, cands, drop_p, seed, step, word_trainable=word_trainable, id_keep=id_keep)
     g = out["grads"]
     g["user_emb"] = densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"],
                                       p["user_emb"].dtype)

@@ -73,7 +73,7 @@ def gru(p, x, mask, h0):
     return h
 
 
-def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0, keep_u=None):
+def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0, keep_u=None, keep_u_scale=2.0):
     user = torch.as_tensor(np.asarray(user), dtype=torch.long).reshape(-1)
     hist_np = np.asarray(hist)
     B, W, T = hist_np.shape
@@ -86,6 +86,12 @@ def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0, ke
     hv = hv * hmask.unsqueeze(-1).to(hv.dtype)
     gmask = (hv.detach() != 0).any(-1)
     uvec = p["user_emb"][user]
+    uvec2 = p["user_emb2"][user] if arch == "iigru" else None
+    if keep_u is not None:          # whole-row dropout of the user embedding: dgru (paper.py:610) / id_keep (cook.py:139-142)
+        km = torch.as_tensor(keep_u, dtype=uvec.dtype).unsqueeze(-1) * keep_u_scale
+        uvec = uvec * km
+        if uvec2 is not None:
+            uvec2 = uvec2 * km
     H = p["gru_u"].shape[0]
     if arch == "igru":
         u = gru(p, hv, gmask, uvec)
@@ -94,7 +100,7 @@ def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0, ke
     elif arch == "pgru":
         u = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype)) + uvec
     elif arch == "iigru":
-        u = torch.cat([gru(p, hv, gmask, uvec), p["user_emb2"][user]], dim=1) @ p["con_w"] + p["con_b"]
+        u = torch.cat([gru(p, hv, gmask, uvec), uvec2], dim=1) @ p["con_w"] + p["con_b"]
     elif arch == "vo":
         u = uvec
     elif arch == "niavg":
@@ -105,8 +111,6 @@ def model_loss(p, arch, user, hist, cands, keep1=None, keep2=None, scale=1.0, ke
         u = (hv * (e / (e.sum(1, keepdim=True) + EPS)).unsqueeze(-1)).sum(1)
     else:
         h = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
-        if arch == "dgru" and keep_u is not None:       # Dropout(0.5, noise_shape=(None, 1)), paper.py:610
-            uvec = uvec * torch.as_tensor(keep_u, dtype=uvec.dtype).unsqueeze(-1) * 2.0
         u = torch.cat([h, uvec], dim=1)
         if arch == "gru":
             u = u @ p["con_w"] + p["con_b"]

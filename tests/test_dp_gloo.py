@@ -32,7 +32,7 @@ def _worker(rank, world, port, out):
     p = O.init_params(rng, arch='igru', dtype=np.float64, **DIMS)
     B, W, T, K1 = 8, 4, 7, 3
     user, hist, cands = make_batch(rng, B, W, T, K1, DIMS['V'], DIMS['N_u'])
-    user[B // 2] = user[0]                       # the same user on both ranks
+    user[B // 2] = user[0]                       # the same user on two ranks
     names = O.dense_param_names('igru')
     # --- single-process reference on the global batch
     ref = O.forward_backward(p, 'igru', user, hist, cands)
@@ -68,17 +68,18 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_equivalence():
+@pytest.mark.parametrize('world', [2, 4])
+def test_n_rank_gradient_equivalence(world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
+    assert sorted(q.get(timeout=5)[0] for _ in range(world)) == list(range(world))
 
 
 def test_task_shards_users_across_ranks(monkeypatch):

@@ -314,3 +314,34 @@ def test_errors_are_reported_not_thrown_across_the_abi():
         model.train_on_batch(X, None)
     with pytest.raises(_lib.LsturError, match='multiple of 4'):
         _lib.query_sizes(_lib.make_cfg(4, 3, 5, 2, 10, 6, 8, 3, 8, 4))
+
+
+@pytest.mark.parametrize('arch', ['igru', 'gru', 'hgru', 'iigru', 'vo'])
+def test_id_keep_user_embedding_masking(arch):
+    """--id-keep (the LSTUR paper's user-embedding masking; reference task/cook.py:139-142): logits, gradients and the row
+    gradients of the user table(s) against the oracle with the same row mask; inference ignores it."""
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    dims, B, W, T, K1 = MID, 16, 6, 9, 5
+    O, p, model, rng = build(arch, dims, B, W, T, K1, 0.2, id_keep=0.7)
+    user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
+    ref = O.forward_backward(p, arch, user, hist, cands, drop_p=0.2, seed=77, step=0, id_keep=0.7)
+    keep = O.dropout_keep(O.dropout_key(77, 0, 2), B, 1.0 - 0.7)
+    assert 0 < keep.sum() < B
+    u, h, c = model._dev_i32(user), model._dev_i32(hist), model._dev_i32(cands)
+    check(lib.lstur_forward_backward(model._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), B, 0, 1.0,
+                                     model.stats.data_ptr(), model._stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(model.peek('logits').cpu().numpy().reshape(B, K1), ref['logits'], rtol=1e-3, atol=1e-5)
+    g = model.get_grads()
+    for n in O.dense_param_names(arch):
+        rel_close(g[n], ref['grads'][n], 2e-3, n)
+    rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
+    assert not g['user_row_grads'][~keep].any()
+    if arch == 'iigru':
+        rel_close(model.peek('duser2').cpu().numpy().reshape(B, -1), ref['user_row_grads2'], 2e-3, 'user_row_grads2')
+    # the test model (inference) uses every user embedding unmasked
+    X = [user.astype(np.int64), hist.astype(np.float64), cands[:, 0].astype(np.float64)]
+    got = model.predict(X)[:, 0]
+    want = O.predict(p, arch, user, hist, cands[:, 0])
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-5)

@@ -47,6 +47,36 @@ def test_grads_match_autograd(arch, drop):
         np.testing.assert_allclose(g[n], ref, rtol=1e-8, atol=1e-12, err_msg=n)
 
 
+@pytest.mark.parametrize("arch", ["igru", "gru", "hgru", "pgru", "vo", "iigru", "nigru"])
+def test_id_keep_user_embedding_masking_matches_autograd(arch):
+    """`id_keep` (cook.py:139-142: idx_vec * Dropout(1 - id_keep)(idx_mask)): a training sample keeps its user embedding
+    with probability id_keep, kept rows scaled by 1 / id_keep; the row gradients pass the same mask.  Against autograd."""
+    rng = np.random.default_rng(9)
+    p = O.init_params(rng, arch=arch, dtype=np.float64, **DIMS)
+    B, W, T, K1 = 12, 4, 7, 3
+    user, hist, cands = make_batch(rng, B, W, T, K1, DIMS["V"], DIMS["N_u"])
+    out = O.forward_backward(p, arch, user, hist, cands, drop_p=0.0, seed=7, step=2, id_keep=0.6)
+    keep_u = O.dropout_keep(O.dropout_key(7, 2, 2), B, 0.4)
+    assert 0 < keep_u.sum() < B
+    names = [n for n in p if n != "word_emb"]
+    tp = TR.to_t(p, grad_names=names)
+    has_table = arch != "nigru"
+    loss, z, _ = TR.model_loss(tp, arch, user, hist, cands, keep_u=keep_u if has_table else None, keep_u_scale=1.0 / 0.6)
+    loss.backward()
+    assert abs(loss.item() - out["loss"]) < 1e-12
+    g = dict(out["grads"])
+    g["user_emb"] = O.densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"], np.float64)
+    if arch == "iigru":
+        g["user_emb2"] = O.densify_user_grad(*p["user_emb2"].shape, out["user_rows"], out["user_row_grads2"], np.float64)
+    for n in names:
+        if tp[n].grad is None:          # not part of this arch's graph (nigru: the table; vo: the GRU)
+            assert not g[n].any(), n
+            continue
+        np.testing.assert_allclose(g[n], tp[n].grad.numpy(), rtol=1e-8, atol=1e-12, err_msg=n)
+    if has_table:
+        assert not out["user_row_grads"][~keep_u].any()          # a dropped sample trains no user row
+
+
 @pytest.mark.parametrize("arch", ["pgru", "vo", "niavg", "niatt", "iigru"])
 def test_minor_user_encoders_match_autograd(arch):
     """`-a pgru | vo | niavg` (paper.py:622-630): GRU + user vector, the user vector alone, masked mean of the history."""
