@@ -238,7 +238,10 @@ int lstur_point_evaluate(lstur_ctx* ctx, const int32_t* user, const int32_t* his
  * the launch stream.  lstur_profile(ctx, 1) also resets the counters.  lstur_profile_read SYNCHRONISES on
  * the recorded events (the only call that does) and returns the summed duration and launch count of the
  * index-th family; it returns 1 past the last family.  Families: gather, conv_fwd, attpool_fwd, gru_fwd,
- * gru_bwd, attpool_bwd, conv_wgrad, adam_user_table, forward_total, backward_total. */
+ * gru_bwd, attpool_bwd, conv_wgrad, adam_user_table, forward_total, backward_total.
+ * enable = 2: only the roofline kernels (gather, conv_fwd, conv_wgrad; mhsa: qkv_proj, qkv_wgrad) are bracketed -- every
+ * bracket costs the step ~6 us (two event records that also drain the launch pipeline), so the timed region of the
+ * benchmark carries these three only and the full breakdown comes from a separate, untimed run of steps. */
 int lstur_profile(lstur_ctx* ctx, int enable);
 int lstur_profile_read(lstur_ctx* ctx, int index, const char** name, float* total_ms, int32_t* launches);
 

@@ -405,6 +405,7 @@ struct ProfKernel {
 
 struct lstur_ctx {
   bool prof_on = false;
+  bool prof_roofline_only = false;   // lstur_profile(ctx, 2): brackets around gather / conv_fwd / conv_wgrad only
   std::deque<ProfKernel> prof;  // deque: nested ProfScopes hold pointers across push_back
   ProfKernel* prof_slot(const char* name) {
     for (auto& k : prof)
@@ -432,6 +433,10 @@ struct lstur_ctx {
   int conv_cus = 0;                     // CUs the conv kernels plan for (0: all); the other lane's recurrence holds some
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_enc0 = nullptr, ev_done1 = nullptr;
+  // weight-gradient side stream (run_backward): the GRU / Dense parameter-gradient GEMMs only feed the step's final
+  // reduction, so they run beside the chain d(doc vectors) -> attention backward -> conv kernel gradient
+  hipStream_t side_w = nullptr;
+  hipEvent_t ev_w1 = nullptr, ev_w2 = nullptr, ev_w3 = nullptr;
   bool pipe_ok = false, last_piped = false;
   int last_nA = 0;
   std::vector<ParamSlot> layout;
@@ -470,6 +475,9 @@ struct ProfScope {
   hipStream_t s;
   ProfScope(lstur_ctx* ctx, const char* name, hipStream_t st) : c(ctx), s(st) {
     if (!c->prof_on) return;
+    if (c->prof_roofline_only && strcmp(name, "gather") && strcmp(name, "conv_fwd") && strcmp(name, "conv_wgrad") &&
+        strcmp(name, "qkv_proj") && strcmp(name, "qkv_wgrad"))
+      return;
     k = c->prof_slot(name);
     if (k->used == k->start.size()) {
       hipEvent_t a, b;
@@ -494,6 +502,22 @@ struct ProfScope {
     ProfScope _ps(c, name, s);      \
     stmt;                           \
   } while (0)
+
+// the side stream of the parameter-gradient GEMMs (nullptr: keep them on the caller's stream)
+hipStream_t wgrad_stream(lstur_ctx* c) {
+  const bool off = getenv("LSTUR_WG_STREAM") && !strcmp(getenv("LSTUR_WG_STREAM"), "0");
+  if (off || c->cur_lane != 0 || c->conv_cus != 0) return nullptr;     // (the two-lane step has its own streams)
+  if (!c->side_w) {
+    if (hipStreamCreateWithFlags(&c->side_w, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_w1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_w2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_w3, hipEventDisableTiming) != hipSuccess) {
+      c->side_w = nullptr;
+      return nullptr;
+    }
+  }
+  return c->side_w;
+}
 
 // whole-row dropout probability of the user embedding in training (0: none)
 float user_row_drop(const lstur_ctx* c) {
@@ -644,20 +668,35 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
   ReduceJob jobs[kMaxReduceJobs];
   int nj = 0;
+  hipStream_t sw = wgrad_stream(c);
+  if (!sw) sw = s;
+  bool forked = false;
+  auto join = [&]() {     // the step's single reduction (on s) reads what the side stream produced
+    if (forked) {
+      (void)hipEventRecord(c->ev_w3, sw);
+      (void)hipStreamWaitEvent(s, c->ev_w3, 0);
+    }
+  };
   if (has_gru) {
     float *hprev = w.hprev, *rh = w.rh;   // fast path: both already sit row-major in the tape (no copies)
     gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
     PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
                                    (d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_IIGRU) ? w.duser : w.dh0, n, d.W,
                                    d.H, s));
-    // GRU parameter gradients (their split-K / column-sum partials are reduced by ONE launch at the end of the pass)
+    // GRU parameter gradients (their split-K / column-sum partials are reduced by ONE launch at the end of the pass), on
+    // the side stream: nothing but that reduction reads them
+    if (sw != s) {
+      (void)hipEventRecord(c->ev_w1, s);
+      (void)hipStreamWaitEvent(sw, c->ev_w1, 0);
+      forked = true;
+    }
     launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
-                w.gemm_scratch_k[0], s, &jobs[nj++]);
-    launch_colsum2(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, w.colsum_scratch_k[0], s, &jobs[nj++]);
+                w.gemm_scratch_k[0], sw, &jobs[nj++]);
+    launch_colsum2(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, w.colsum_scratch_k[0], sw, &jobs[nj++]);
     launch_gemm(hprev, d.H, 1, w.dgates, 3 * d.H, 0, c->G("gru_u"), 3 * d.H, nullptr, d.H, 2 * d.H, nW, 1.f,
-                w.gemm_scratch_k[1], s, &jobs[nj++]);
+                w.gemm_scratch_k[1], sw, &jobs[nj++]);
     launch_gemm(rh, d.H, 1, w.dgates + 2 * d.H, 3 * d.H, 0, c->G("gru_u") + 2 * d.H, 3 * d.H, nullptr, d.H, d.H, nW,
-                1.f, w.gemm_scratch_k[2], s, &jobs[nj++]);
+                1.f, w.gemm_scratch_k[2], sw, &jobs[nj++]);
   } else {   // vo / niavg: no GRU in the graph -- its bucket slots get an exact zero gradient
     (void)hipMemsetAsync(c->G("gru_w"), 0, (size_t)(c->G("gru_b") + 3 * d.H - c->G("gru_w")) * sizeof(float), s);
   }
@@ -676,6 +715,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
       jobs[nj++] = ReduceJob{w.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
       jobs[nj++] = ReduceJob{w.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
     }
+    join();
     launch_multi_reduce(jobs, nj, s);
     return;
   }
@@ -698,9 +738,14 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   // (the history mask needs no pass here: a padded slot is a masked GRU step, its dgates row -- hence its ddocvec
   //  row -- is exactly 0, cf. paper.py:644-645)
   // news encoder backward (candidate rows of ddocvec were written by the scorer)
+  if (sw != s) {          // Dense(U) parameter gradients: beside d(pooled) -> attention backward -> conv kernel gradient
+    (void)hipEventRecord(c->ev_w2, s);
+    (void)hipStreamWaitEvent(sw, c->ev_w2, 0);
+    forked = true;
+  }
   launch_gemm(w.pooled, d.F, 1, w.ddocvec, d.U, 0, c->G("dense_w"), d.U, nullptr, d.F, d.U, nt, 1.f,
-              w.gemm_scratch_k[3], s, &jobs[nj++]);
-  launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], s, &jobs[nj++]);
+              w.gemm_scratch_k[3], sw, &jobs[nj++]);
+  launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], sw, &jobs[nj++]);
   launch_gemm(w.ddocvec, d.U, 0, c->P("dense_w"), d.U, 1, w.dpooled, d.F, nullptr, nt, d.F, d.U, 1.f, w.gemm_scratch, s);
   // partial sums laid out like the bucket slice conv_b .. att_b -> one reduction straight into dense_grad
   if (d.enc == LSTUR_ENC_MHSA) {
@@ -722,6 +767,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
       jobs[nj++] = ReduceJob{w.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
       jobs[nj++] = ReduceJob{w.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
     }
+    join();
     launch_multi_reduce(jobs, nj, s);
     return;
   }
@@ -754,6 +800,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     jobs[nj++] = ReduceJob{w.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};      // running sums for the
     jobs[nj++] = ReduceJob{w.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};   // host's epoch means
   }
+  join();
   launch_multi_reduce(jobs, nj, s);
 }
 
@@ -1130,6 +1177,13 @@ int lstur_destroy(lstur_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_done1);
     (void)hipStreamDestroy(ctx->side);
   }
+  if (ctx && ctx->side_w) {
+    (void)hipStreamSynchronize(ctx->side_w);
+    (void)hipEventDestroy(ctx->ev_w1);
+    (void)hipEventDestroy(ctx->ev_w2);
+    (void)hipEventDestroy(ctx->ev_w3);
+    (void)hipStreamDestroy(ctx->side_w);
+  }
   if (ctx)
     for (auto& k : ctx->prof)
       for (size_t i = 0; i < k.start.size(); ++i) {
@@ -1265,6 +1319,7 @@ int lstur_predict_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_i
 int lstur_profile(lstur_ctx* ctx, int enable) {
   if (!ctx) return fail(LSTUR_ERR_ARG, "ctx is NULL");
   ctx->prof_on = enable != 0;
+  ctx->prof_roofline_only = enable == 2;
   for (auto& k : ctx->prof) k.used = 0;
   return LSTUR_OK;
 }

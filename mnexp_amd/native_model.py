@@ -443,8 +443,9 @@ class NativeModel:
         self.set_weights(w)
 
     def profile(self, enable=True):
-        """Bracket each kernel family with HIP events on the launch stream (bench.py roofline figures)."""
-        check(lib.lstur_profile(self._ctx, 1 if enable else 0), 'lstur_profile')
+        """Bracket each kernel family with HIP events on the launch stream (bench.py roofline figures); enable = 2: the
+        roofline kernels only (gather and the two conv contractions)."""
+        check(lib.lstur_profile(self._ctx, int(enable)), 'lstur_profile')
 
     def profile_read(self):
         """{family: (total_ms, launches)}; synchronises on the recorded events."""
