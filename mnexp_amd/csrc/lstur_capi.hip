@@ -561,11 +561,24 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr;
   const bool use3 = !mhsa && w.conv_w3 && !conv_f32;
   static const bool gen1 = getenv("LSTUR_CONV_GEN1") != nullptr;   // A/B: first-generation bf16x3 kernels (conv3.hip, fp32 E)
+  bool packs_forked = false;
+  hipStream_t sp = nullptr;
   if (c->cur_lane == 0) {   // (lane 1 shares lane 0's images: it starts behind lane 0's encoder)
-    if (use3 && gen1) launch_conv3_pack_w(c->P("conv_w"), d.KD, d.F, w.conv_w3_v1, s);
-    else if (use3) launch_conv3_pack_w2(c->P("conv_w"), d.D, d.k, d.F, w.conv_w3, s);
-    else if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, s);
-    launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, s);
+    // the two weight images depend on nothing in the batch: they are packed on the side stream, beside the title staging and
+    // the gather, and joined in front of the conv forward
+    sp = wgrad_stream(c);
+    if (sp) {
+      (void)hipEventRecord(c->ev_w1, s);
+      (void)hipStreamWaitEvent(sp, c->ev_w1, 0);
+      packs_forked = true;
+    } else {
+      sp = s;
+    }
+    if (use3 && gen1) launch_conv3_pack_w(c->P("conv_w"), d.KD, d.F, w.conv_w3_v1, sp);
+    else if (use3) launch_conv3_pack_w2(c->P("conv_w"), d.D, d.k, d.F, w.conv_w3, sp);
+    else if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, sp);
+    launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, sp);
+    if (packs_forked) (void)hipEventRecord(c->ev_w3, sp);
   }
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
@@ -579,6 +592,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     PROF("gather", launch_gather3(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, s));
   else
     PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
+  if (packs_forked) (void)hipStreamWaitEvent(s, c->ev_w3, 0);   // the weight images are ready
   if (mhsa) {   // token stage = multi-head self-attention (build-defined, include/lstur.h: LSTUR_ENC_MHSA)
     PROF("qkv_proj", launch_proj_fwd_bf16(w.emb, c->P("qkv_w"), c->P("qkv_b"), w.qkv, nt * d.T, 3 * d.F, d.D, s));
     PROF("mhsa_fwd", launch_mhsa_fwd_bf16(w.qkv, w.ids, w.conv, nt, d.T, d.F, d.heads, s));
