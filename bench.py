@@ -440,7 +440,10 @@ def main():
                        'candidates': wl['K1'], 'word_dim': wl['D'], 'filters': wl['F'], 'user_dim': wl['U'],
                        'n_users': wl['N_u'], 'n_docs': wl['N_d'], 'vocab': wl['V'], 'dropout': args.dropout,
                        'news_encoder': wl.get('encoder', 'cnnatt'), 'heads': wl.get('heads', 0),
-                       'parallelism': 'dp%d' % world, 'optimizer': 'keras-adam (dense user-table sweep)'},
+                       'parallelism': 'dp%d' % world, 'optimizer': 'keras-adam (dense user-table sweep)',
+                       # the synthetic histories are 90 % full windows (62 % non-pad tokens): heavier than real click
+                       # histories (the `e2e` legs run at ~49 % non-pad tokens)
+                       'history_fill': 'synthetic: 90 %% of the samples have a full %d-slot history' % wl['W']},
             'roofline': roofline, 'roofline_gather': roofline_gather, 'traffic_stale': traffic_stale,
             'kernels_us': {k: round(v['avg_us'], 1) for k, v in sorted(kern.items())},
             'train_loss': round(loss, 4),
