@@ -248,15 +248,21 @@ def e2e_legs(wl, word, steps, dropout, device):
         random.seed(0)
         for name, feed in (('native_feed', NativeTrainFeed(h, seed=1)), ('python_ids_feed', h.train_ids)):
             nonpad = []
+            # one batch of look-ahead, as NativeModel.fit_generator does: the next batch is uploaded and announced to the
+            # library (lstur_prefetch_ids) before the current step is launched
+            X, _ = next(feed)
+            staged = None
             for _ in range(10):
-                X, _ = next(feed)
-                model.train_on_ids(*X)
+                Xn, _ = next(feed)
+                staged = model.train_on_ids(*X, next_ids=Xn, staged=staged)
+                X = Xn
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
-                X, _ = next(feed)
-                model.train_on_ids(*X)
+                Xn, _ = next(feed)
+                staged = model.train_on_ids(*X, next_ids=Xn, staged=staged)
                 nonpad.append(int((h.docs.title_table[X[1]] != 0).sum() + (h.docs.title_table[X[2]] != 0).sum()))
+                X = Xn
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
             out[name] = dict(value=round(wl['B'] * steps / el, 1), unit='impressions/s wall (feed + H2D + step)',
@@ -301,6 +307,7 @@ def main():
     ap.add_argument('--workload', default='lstur_ini_b64', choices=sorted(WORKLOADS))
     ap.add_argument('--dropout', type=float, default=0.2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prefetch', action='store_true', help='stage every batch inside its own step (no lstur_prefetch_ids)')
     ap.add_argument('--no-profile', action='store_true', help='skip the HIP-event brackets around kernels')
     ap.add_argument('--force-dp', action='store_true', help='diagnostic: run the RCCL collectives of the data-parallel step even with one rank')
     args = ap.parse_args()
@@ -334,6 +341,9 @@ def main():
     def run(nsteps, offset):
         for i in range(nsteps):
             u, h, c = dev[(offset + i) % len(dev)]
+            if not args.no_prefetch and i + 1 < nsteps:      # announce the next batch: its staging overlaps this step
+                _, h2, c2 = dev[(offset + i + 1) % len(dev)]
+                model.prefetch_ids(h2, c2)
             model._train_step(u, h, c, True)
 
     run(args.warmup, 0)

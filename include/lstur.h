@@ -186,6 +186,17 @@ int lstur_forward_backward(lstur_ctx* ctx, const int32_t* user, const int32_t* h
 int lstur_forward_backward_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_ids,
                                const int32_t* cand_ids, int32_t n, uint32_t step, float grad_scale,
                                float* stats, lstur_stream stream);
+/* Optional software pipelining across steps: announce the doc-id batch of the NEXT training step (its hist_ids / cand_ids
+ * device arrays, n and step number) BEFORE calling lstur_forward_backward_ids for the current one.  The library then
+ * stages that batch -- title expansion, compaction of the non-pad tokens, embedding gather incl. its dropout mask -- on
+ * a stream of its own while the current step's GRU recurrence runs (a latency chain on 16 CUs: HBM and 240 CUs idle), and
+ * the next lstur_forward_backward_ids call with the SAME arrays, n and step picks the staged batch up instead of staging
+ * it inline.  The arrays must stay alive and unchanged until that call; any other call sequence simply stages inline.
+ * Same kernels on the same data: results are bit-identical with and without the announcement.  No-op for configurations
+ * that stage inline anyway (trainable word table, exact-fp32 conv path, pointwise heads, mhsa). */
+int lstur_prefetch_ids(lstur_ctx* ctx, const int32_t* hist_ids, const int32_t* cand_ids, int32_t n, uint32_t step);
+/* how many training calls picked up a prefetched batch so far (diagnostics / tests) */
+int32_t lstur_prefetch_hits(lstur_ctx* ctx);
 
 /* Per-sample sparse user-table gradient of the last forward_backward: rows int32 [n], grads [n,Ue]
  * (device pointers into the workspace; what a DP host all-gathers). */

@@ -57,6 +57,8 @@ SIGNATURES = {
     'lstur_set_title_table': (_I, [_P, _P, _I]),
     'lstur_forward_backward': (_I, [_P, _P, _P, _P, _I, _U, _F, _P, _P]),
     'lstur_forward_backward_ids': (_I, [_P, _P, _P, _P, _I, _U, _F, _P, _P]),
+    'lstur_prefetch_ids': (_I, [_P, _P, _P, _I, _U]),
+    'lstur_prefetch_hits': (_I, [_P]),
     'lstur_user_grad': (_I, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I)]),
     'lstur_adam_step': (_I, [_P, _F, _I, _P, _P, _I, _P]),
     'lstur_dp_tail_floats': (_Z, [C.POINTER(Cfg), _I]),

@@ -256,6 +256,10 @@ struct Workspace {
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
   int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* conv_w3_v1; unsigned short* e3; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
+  // the staged form of a batch (token ids, their compacted list + offsets, the gathered embeddings) exists twice: while a
+  // step runs on one set, the NEXT batch can be staged into the other (lstur_prefetch_ids); ids / e3 / vidx / ... above
+  // always point at the set of the running step
+  struct StageSet { int32_t* ids; unsigned short* e3; int32_t* vidx; int32_t* vcount; int32_t* vscratch; int32_t* offA; int32_t* offB; } set[2];
   size_t bytes;
 };
 
@@ -392,6 +396,17 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->offA = (int32_t*)take(nt * d.T * 4);
   w->offB = (int32_t*)take(nt * d.T * 4);
   w->vscratch = (int32_t*)take(compact_scratch_ints((int)(nt * d.T)) * 4);
+  w->set[0] = Workspace::StageSet{w->ids, w->e3, w->vidx, w->vcount, w->vscratch, w->offA, w->offB};
+  w->set[1] = w->set[0];
+  if (c3 && d.head == LSTUR_HEAD_SOFTMAX && !d.word_trainable) {   // second staging set (prefetch of the next batch)
+    w->set[1].ids = (int32_t*)take(nt * d.T * 4);
+    w->set[1].e3 = (unsigned short*)take(conv3_e3_elems((int)nt, d.T, d.D, d.k) * 2);
+    w->set[1].vidx = (int32_t*)take(nt * d.T * 4);
+    w->set[1].vcount = (int32_t*)take(256);
+    w->set[1].offA = (int32_t*)take(nt * d.T * 4);
+    w->set[1].offB = (int32_t*)take(nt * d.T * 4);
+    w->set[1].vscratch = (int32_t*)take(compact_scratch_ints((int)(nt * d.T)) * 4);
+  }
   w->bytes = off;
 }
 
@@ -437,6 +452,15 @@ struct lstur_ctx {
   // reduction, so they run beside the chain d(doc vectors) -> attention backward -> conv kernel gradient
   hipStream_t side_w = nullptr;
   hipEvent_t ev_w1 = nullptr, ev_w2 = nullptr, ev_w3 = nullptr;
+  // staging prefetch (lstur_prefetch_ids): the next batch's title expansion, compaction and embedding gather run on a
+  // side stream under the current step's forward recurrence (HBM and 240 CUs idle there)
+  struct Pending { const int32_t* hist = nullptr; const int32_t* cands = nullptr; int n = 0; uint32_t step = 0;
+                   bool valid = false, launched = false; } pend, ready;   // announced | staged in the other set
+  int prefetch_hits = 0;
+  int cur_set = 0;
+  bool staged_hit = false;              // this step's staging was prefetched: run_forward skips it
+  hipStream_t side_p = nullptr;
+  hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;
   bool pipe_ok = false, last_piped = false;
   int last_nA = 0;
   std::vector<ParamSlot> layout;
@@ -519,6 +543,47 @@ hipStream_t wgrad_stream(lstur_ctx* c) {
   return c->side_w;
 }
 
+void use_set(lstur_ctx* c, int k) {
+  Workspace& w = c->ws;
+  c->cur_set = k;
+  w.ids = w.set[k].ids; w.e3 = w.set[k].e3; w.vidx = w.set[k].vidx; w.vcount = w.set[k].vcount;
+  w.vscratch = w.set[k].vscratch; w.offA = w.set[k].offA; w.offB = w.set[k].offB;
+}
+
+// enqueue the pending prefetch (if any) on the side stream, behind everything `s` holds so far
+void launch_prefetch(lstur_ctx* c, hipStream_t s) {
+  auto& q = c->pend;
+  const Dims& d = c->d;
+  Workspace& w = c->ws;
+  if (!q.valid || c->ready.valid || c->cur_lane != 0 || c->conv_cus != 0 || w.set[1].ids == w.set[0].ids) return;
+  if (!c->side_p) {
+    if (hipStreamCreateWithFlags(&c->side_p, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_p0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming) != hipSuccess) {
+      c->side_p = nullptr;
+      q.valid = false;
+      return;
+    }
+  }
+  const Workspace::StageSet& t = w.set[c->cur_set ^ 1];
+  hipStream_t p = c->side_p;
+  (void)hipEventRecord(c->ev_p0, s);
+  (void)hipStreamWaitEvent(p, c->ev_p0, 0);
+  const int nW = q.n * d.W, nt = nW + q.n * d.K1, pl = (d.k - 1) / 2;
+  launch_expand_count(c->title_table, q.hist, nW, q.cands, q.n * d.K1, d.T, t.ids, t.vscratch, p);
+  launch_compact_write_offsets(t.ids, nt * d.T, t.vscratch, t.vidx, t.vcount, d.T, d.Tp, conv3_dp(d.D) / 8 * 3, d.F, t.offA,
+                               t.offB, p);
+  {
+    ProfScope _ps(c, "gather", p);
+    launch_gather3(c->buf.word_emb, t.ids, t.e3, nt, d.T, d.D, pl, d.k - 1 - pl, c->cfg.dropout,
+                   dropout_key(c->cfg.seed, q.step, 0), true, p);
+  }
+  (void)hipEventRecord(c->ev_p1, p);
+  q.launched = true;
+  c->ready = q;                      // staged: the next training call may pick it up
+  q = lstur_ctx::Pending();
+}
+
 // whole-row dropout probability of the user embedding in training (0: none)
 float user_row_drop(const lstur_ctx* c) {
   const int a = c->d.arch;
@@ -535,6 +600,8 @@ void lazy_init(lstur_ctx* c, hipStream_t s) {
   launch_fill_i32(c->ws.slot, -1, d.Nu, s);
   // E3: the gather skips rows no window covers; the k tail of a window may still touch one (under a zero weight)
   if (c->ws.e3) (void)hipMemsetAsync(c->ws.e3, 0, conv3_e3_elems(d.nt_max, d.T, d.D, d.k) * 2, s);
+  if (c->ws.set[1].e3 && c->ws.set[1].e3 != c->ws.set[0].e3)
+    (void)hipMemsetAsync(c->ws.set[1].e3, 0, conv3_e3_elems(d.nt_max, d.T, d.D, d.k) * 2, s);
   if (c->pipe_ok) {
     (void)hipMemsetAsync(c->ws1.emb + (size_t)c->d1.nt_max * d.Tp * d.D, 0, kEmbSlack * sizeof(float), s);
     if (c->ws1.e3) (void)hipMemsetAsync(c->ws1.e3, 0, conv3_e3_elems(c->d1.nt_max, d.T, d.D, d.k) * 2, s);
@@ -583,6 +650,10 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
   // stable list of the non-pad tokens of this batch (+ the kernel gradient's row offsets), two launches
+  if (c->staged_hit && c->cur_lane == 0) {
+    // token ids, compacted list, offsets and E3 of this batch were staged by the prefetch of the previous step
+    (void)hipStreamWaitEvent(s, c->ev_p1, 0);
+  } else {
   if (!c->counted_flag()) launch_compact_count(w.ids, nt * d.T, w.vscratch, s);
   c->counted_flag() = false;
   // (offA: a token's window offset in the units of its path -- 16-byte pieces of E3, or floats of the fp32 layout)
@@ -592,6 +663,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     PROF("gather", launch_gather3(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, s));
   else
     PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
+  }
   if (packs_forked) (void)hipStreamWaitEvent(s, c->ev_w3, 0);   // the weight images are ready
   if (mhsa) {   // token stage = multi-head self-attention (build-defined, include/lstur.h: LSTUR_ENC_MHSA)
     PROF("qkv_proj", launch_proj_fwd_bf16(w.emb, c->P("qkv_w"), c->P("qkv_b"), w.qkv, nt * d.T, 3 * d.F, d.D, s));
@@ -631,6 +703,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     // igru / nigru: the last state IS the user vector (H == U): the recurrence writes it in place
     const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
     const bool init_user = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_IIGRU;   // initial_state = user_vec
+    if (training && use3 && !gen1) launch_prefetch(c, s);   // the next batch's staging runs under the recurrence
     PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, init_user ? w.uvec : nullptr, w.gru_up,
                                    w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s));
     if (d.arch == LSTUR_ARCH_PGRU) {        // GRU(U)(x) + user_vec (paper.py:624-626)
@@ -989,10 +1062,19 @@ int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
     return train_two_lanes(c, user, hist, cands, n, step, grad_scale, stats, s, ids_form);
   set_lane(c, 0);
   c->last_piped = false;
-  int rc = stage_titles(c, hist, cands, n, d.K1, ids_form, s);
+  // was this batch staged by a prefetch during the previous step?  (same arrays, same size, same step)
+  auto& q = c->ready;
+  c->staged_hit = backward && training && ids_form && q.valid && q.hist == hist && q.cands == cands && q.n == n &&
+                  q.step == step;
+  if (backward && training) q = lstur_ctx::Pending();   // consumed, or stale: either way the other set is free again
+  if (c->staged_hit) c->prefetch_hits++;
+  int rc = LSTUR_OK;
+  if (c->staged_hit) use_set(c, c->cur_set ^ 1);
+  else rc = stage_titles(c, hist, cands, n, d.K1, ids_form, s);
   if (rc) return rc;
   Workspace& w = c->ws;
   PROF("forward_total", run_forward(c, user, n, d.K1, training, step, s));
+  c->staged_hit = false;
   run_listwise_score(c, n, d.K1, grad_scale / (float)n, backward, nullptr, s);
   if (stats && !backward) launch_mean2(w.loss_i, w.correct_i, n, stats, s);
   if (backward) PROF("backward_total", run_backward(c, n, step, s, stats));
@@ -1191,6 +1273,12 @@ int lstur_destroy(lstur_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_done1);
     (void)hipStreamDestroy(ctx->side);
   }
+  if (ctx && ctx->side_p) {
+    (void)hipStreamSynchronize(ctx->side_p);
+    (void)hipEventDestroy(ctx->ev_p0);
+    (void)hipEventDestroy(ctx->ev_p1);
+    (void)hipStreamDestroy(ctx->side_p);
+  }
   if (ctx && ctx->side_w) {
     (void)hipStreamSynchronize(ctx->side_w);
     (void)hipEventDestroy(ctx->ev_w1);
@@ -1223,6 +1311,22 @@ int lstur_forward_backward_ids(lstur_ctx* ctx, const int32_t* user, const int32_
                                int32_t n, uint32_t step, float grad_scale, float* stats, lstur_stream stream) {
   return train_impl(ctx, user, hist_ids, cand_ids, n, step, grad_scale, stats, (hipStream_t)stream, true, true, true);
 }
+int lstur_prefetch_ids(lstur_ctx* ctx, const int32_t* hist_ids, const int32_t* cand_ids, int32_t n, uint32_t step) {
+  if (!ctx || !hist_ids || !cand_ids) return fail(LSTUR_ERR_ARG, "prefetch: NULL argument");
+  if (n < 1 || n > ctx->d.B) return fail(LSTUR_ERR_ARG, "prefetch: n must be in [1, max_batch]");
+  if (!ctx->title_table) return fail(LSTUR_ERR_STATE, "no title table bound (lstur_set_title_table)");
+  ctx->pend = lstur_ctx::Pending();      // (replaces an announcement that was never staged; a staged batch stays `ready`)
+  if (ctx->ws.set[1].ids == ctx->ws.set[0].ids) return LSTUR_OK;      // this configuration stages inline: a no-op
+  ctx->pend.hist = hist_ids;
+  ctx->pend.cands = cand_ids;
+  ctx->pend.n = n;
+  ctx->pend.step = step;
+  ctx->pend.valid = true;
+  return LSTUR_OK;
+}
+
+int32_t lstur_prefetch_hits(lstur_ctx* ctx) { return ctx ? ctx->prefetch_hits : -1; }
+
 int lstur_evaluate(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands, int32_t n,
                    float* stats, lstur_stream stream) {
   return train_impl(ctx, user, hist, cands, n, 0, 1.f, stats, (hipStream_t)stream, false, false, false);

@@ -493,6 +493,15 @@ class NativeModel:
             return a.to(device=self.device, dtype=torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.float32)).to(self.device, non_blocking=True)
 
+    def prefetch_ids(self, hist_ids, cand_ids):
+        """Announce the NEXT training step's doc-id batch (device int32 tensors; kept alive here until that step): the
+        library stages it under the current step's GRU recurrence (include/lstur.h: lstur_prefetch_ids)."""
+        if self.pointwise:
+            return
+        self._prefetched = (hist_ids, cand_ids)
+        check(lib.lstur_prefetch_ids(self._ctx, hist_ids.data_ptr(), cand_ids.data_ptr(), int(hist_ids.shape[0]),
+                                     self.step + 1), 'lstur_prefetch_ids')
+
     def _train_step(self, user, hist, cands, ids_form, labels=None):
         n = int(user.shape[0])
         s = self._stream()
@@ -555,13 +564,24 @@ class NativeModel:
         else:
             self._train_step(user, hist, cands, False)
 
-    def train_on_ids(self, *ids, labels=None):
-        """(user, hist_ids, cand_ids), or (hist_ids, cand_ids) for an id-less task; pointwise: + labels."""
+    def _ids_to_dev(self, ids):
         if not self.has_user:
             ids = (np.zeros(len(ids[0]), dtype=np.int32),) + tuple(ids)
         user, hist_ids, cand_ids = ids
+        return self._dev_i32(user), self._dev_i32(hist_ids), self._dev_i32(cand_ids)
+
+    def train_on_ids(self, *ids, labels=None, next_ids=None, staged=None):
+        """(user, hist_ids, cand_ids), or (hist_ids, cand_ids) for an id-less task; pointwise: + labels.
+        next_ids: the batch of the FOLLOWING step, if known -- it is uploaded and announced to the library now, so its
+        staging overlaps this step (returns its device tensors: pass them back as `staged` for that step)."""
+        dev = staged if staged is not None else self._ids_to_dev(ids)
+        nxt = None
+        if next_ids is not None and not self.pointwise:
+            nxt = self._ids_to_dev(next_ids)
+            self.prefetch_ids(nxt[1], nxt[2])
         lab = self._dev_f32(np.asarray(labels).reshape(-1)) if self.pointwise else None
-        self._train_step(self._dev_i32(user), self._dev_i32(hist_ids), self._dev_i32(cand_ids), True, lab)
+        self._train_step(dev[0], dev[1], dev[2], True, lab)
+        return nxt
 
     def fit_generator(self, generator, steps_per_epoch, epochs=1, initial_epoch=0, verbose=2, ids_form=False,
                       **_ignored):
@@ -569,10 +589,20 @@ class NativeModel:
         hist = History()
         for epoch in range(initial_epoch, epochs):
             self.stats_acc.zero_()
-            for _ in range(steps_per_epoch):
+            look = ids_form and not self.pointwise      # one batch of look-ahead: the next batch is staged under this step
+            cur = next(generator) if look else None
+            staged = None
+            for i in range(steps_per_epoch):
+                if look:
+                    (X, Y), nxt = cur, None
+                    if i + 1 < steps_per_epoch:
+                        cur = next(generator)
+                        nxt = cur[0]
+                    staged = self.train_on_ids(*X, next_ids=nxt, staged=staged)
+                    continue
                 X, Y = next(generator)
                 if ids_form:
-                    self.train_on_ids(*X, labels=Y) if self.pointwise else self.train_on_ids(*X)
+                    self.train_on_ids(*X, labels=Y)
                 else:
                     self.train_on_batch(X, Y)
             loss, acc = (self.stats_acc / steps_per_epoch).tolist()

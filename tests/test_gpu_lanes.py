@@ -117,3 +117,41 @@ def test_two_streams_are_bit_identical_to_one_stream(tmp_path):
         outs.append(np.load(f))
     for k in ('grad', 'param', 'user', 'logits'):
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_prefetched_staging_is_bit_identical_to_inline_staging():
+    """lstur_prefetch_ids: the next batch's title expansion, token compaction and embedding gather (dropout included) run on
+    a side stream under the current step's recurrence.  Six steps with every batch announced one step ahead (one of them
+    announced and then NOT used: the library falls back to inline staging) against six steps staged inline: identical
+    gradients, parameters, user table and losses."""
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    B, W, T, K1 = 24, 7, 11, 5
+    outs = []
+    for mode in ('prefetch', 'inline'):
+        O, p, model, rng = build('igru', MID, B, W, T, K1, 0.2)
+        tt = np.random.default_rng(1).integers(1, MID['V'], size=(200, T)).astype(np.int32)
+        tt[0] = 0
+        tt[:, 8:] = 0
+        model.set_title_table(tt)
+        r2 = np.random.default_rng(2)
+        batches = [(r2.integers(0, MID['N_u'], size=B).astype(np.int32), r2.integers(0, 200, size=(B, W)).astype(np.int32),
+                    r2.integers(1, 200, size=(B, K1)).astype(np.int32)) for _ in range(6)]
+        dev = [tuple(model._dev_i32(a) for a in b) for b in batches]
+        decoy = tuple(model._dev_i32(a) for a in batches[0])
+        losses = []
+        for i, (u, h, c) in enumerate(dev):
+            if mode == 'prefetch' and i + 1 < len(dev):
+                nh, nc = (decoy[1], decoy[2]) if i == 2 else (dev[i + 1][1], dev[i + 1][2])    # step 3 was mis-announced
+                model.prefetch_ids(nh, nc)
+            model._train_step(u, h, c, True)
+            losses.append(model.stats[0].item())
+        torch.cuda.synchronize()
+        # steps 2, 3, 5, 6 ran on a prefetched batch; step 4 was mis-announced (staged inline, the staged decoy dropped)
+        assert lib.lstur_prefetch_hits(model._ctx) == (4 if mode == 'prefetch' else 0)
+        outs.append(dict(loss=np.array(losses), grad=model.dense_grad.cpu().numpy(), param=model.dense_param.cpu().numpy(),
+                         user=model.user_emb.cpu().numpy()))
+        del model
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert np.isfinite(outs[0]['loss']).all() and len(set(outs[0]['loss'])) > 1
