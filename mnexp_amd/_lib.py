@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblstur_hip.so')
 
-ARCH = {'igru': 0, 'gru': 1, 'hgru': 2, 'nigru': 3, 'ngru': 4, 'dgru': 5, 'pgru': 6, 'vo': 7, 'niavg': 8, 'niatt': 9, 'iigru': 10}
+ARCH = {'igru': 0, 'gru': 1, 'hgru': 2, 'nigru': 3, 'ngru': 4, 'dgru': 5, 'pgru': 6, 'vo': 7, 'niavg': 8, 'niatt': 9, 'iigru': 10, 'iicgru': 11}
 SCORE = {'dot': 0, 'ddot': 1, 'dnn': 2}     # --score-model (paper.py:443-458)
 HEAD = {'softmax': 0, 'point_mlp': 1, 'point_dot': 2}
 ENCODER = {'cnnatt': 0, 'mhsa': 1}     # include/lstur.h: lstur_encoder (mhsa is build-defined, no reference counterpart)

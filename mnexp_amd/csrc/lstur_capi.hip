@@ -36,6 +36,9 @@ struct Dims {
   int rows_cap; // sparse user-grad rows per adam step
 };
 
+// iigru / iicgru: a SECOND user table, gathered with the same rows (paper.py:614-621, 343-348)
+static inline bool two_tables(const Dims& d) { return d.arch == LSTUR_ARCH_IIGRU || d.arch == LSTUR_ARCH_IICGRU; }
+
 constexpr size_t kParamAlign = 64;  // floats
 
 bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
@@ -63,7 +66,7 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     *why = "filters must be <= 1024";
     return false;
   }
-  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_IIGRU) {
+  if (d->arch < LSTUR_ARCH_IGRU || d->arch > LSTUR_ARCH_IICGRU) {
     *why = "unknown arch";
     return false;
   }
@@ -116,10 +119,11 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
       *why = "the pointwise heads take one candidate per sample (cands == 1)";
       return false;
     }
-    const bool wide_mlp = d->arch == LSTUR_ARCH_NGRU && d->head == LSTUR_HEAD_POINT_MLP;   // Seq2VecPaperId `gru`
+    // Seq2VecPaperId `gru` / `iigru`: 2U-wide concatenations in front of the concat-MLP scorer (paper.py:339-348)
+    const bool wide_mlp = (d->arch == LSTUR_ARCH_NGRU || d->arch == LSTUR_ARCH_IICGRU) && d->head == LSTUR_HEAD_POINT_MLP;
     if (d->arch != LSTUR_ARCH_IGRU && d->arch != LSTUR_ARCH_NIGRU && d->arch != LSTUR_ARCH_NIAVG &&
         d->arch != LSTUR_ARCH_NIATT && d->arch != LSTUR_ARCH_VO && !wide_mlp) {
-      *why = "the pointwise heads support arch igru, vo, nigru, niavg, niatt (and ngru with the MLP scorer)";
+      *why = "the pointwise heads support arch igru, vo, nigru, niavg, niatt (and ngru / iicgru with the MLP scorer)";
       return false;
     }
     if (!(c->gain > 0.f) || c->loss_negatives < 1) {
@@ -133,7 +137,7 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
   }
   d->H = d->arch == LSTUR_ARCH_HGRU ? d->U / 2 : d->U;
   d->Ue = d->arch == LSTUR_ARCH_HGRU ? d->U / 2 : d->U;
-  d->Uu = (d->arch == LSTUR_ARCH_NGRU || d->arch == LSTUR_ARCH_DGRU) ? 2 * d->U : d->U;   // width of the user vector
+  d->Uu = (d->arch == LSTUR_ARCH_NGRU || d->arch == LSTUR_ARCH_DGRU || d->arch == LSTUR_ARCH_IICGRU) ? 2 * d->U : d->U;   // user vector
   d->score = c->score_model;
   if (d->score < LSTUR_SCORE_DOT || d->score > LSTUR_SCORE_DNN) {
     *why = "unknown score_model";
@@ -369,7 +373,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->ua_w = ua ? (float*)take(nW * f4) : nullptr;
   w->ua_parts = ua ? (float*)take(nc * (size_t)(2 * d.U + 1) * f4) : nullptr;
   w->ua_ds = ua ? (float*)take(nW * f4) : nullptr;
-  const bool ii = d.arch == LSTUR_ARCH_IIGRU;   // second user table: gathered rows, their gradients, combined sums
+  const bool ii = two_tables(d);   // second user table: gathered rows, their gradients, combined sums
   w->uvec2 = ii ? (float*)take(nc * d.Ue * f4) : nullptr;
   w->duser2 = ii ? (float*)take(nc * d.Ue * f4) : nullptr;
   w->gsum2 = ii ? (float*)take((size_t)d.rows_cap * d.Ue * f4) : nullptr;
@@ -702,7 +706,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   } else {
     // igru / nigru: the last state IS the user vector (H == U): the recurrence writes it in place
     const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
-    const bool init_user = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_IIGRU;   // initial_state = user_vec
+    const bool init_user = d.arch == LSTUR_ARCH_IGRU || two_tables(d);   // initial_state = user_vec
     if (training && use3 && !gen1) launch_prefetch(c, s);   // the next batch's staging runs under the recurrence
     PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, init_user ? w.uvec : nullptr, w.gru_up,
                                    w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s));
@@ -710,7 +714,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
       launch_add2(w.hlast, w.uvec, w.uservec, (size_t)n * d.U, s);
     } else if (!direct) {
       const float* side = w.uvec;
-      if (d.arch == LSTUR_ARCH_IIGRU) {     // the concatenated vector comes from the SECOND table (paper.py:617-619)
+      if (two_tables(d)) {     // the concatenated vector comes from the SECOND table (paper.py:617-619, 345-347)
         launch_gather_rows(c->buf.user_emb2, w.user_rows, w.uvec2, n, d.Ue, s);
         if (row_p > 0.f) launch_drop_rows(w.uvec2, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
         side = w.uvec2;
@@ -719,7 +723,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
       if (d.arch == LSTUR_ARCH_GRU || d.arch == LSTUR_ARCH_IIGRU)
         launch_gemm(w.cat, d.H + d.Ue, 0, c->P("con_w"), d.U, 0, w.uservec, d.U, c->P("con_b"), n, d.U, d.H + d.Ue, 1.f,
                     w.gemm_scratch, s);
-      else   // hgru (U/2 + U/2), ngru / dgru (U + U): the concatenation is the user vector
+      else   // hgru (U/2 + U/2), ngru / dgru / iicgru (U + U): the concatenation is the user vector
         (void)hipMemcpyAsync(w.uservec, w.cat, (size_t)n * d.Uu * 4, hipMemcpyDeviceToDevice, s);
     }
   }
@@ -746,6 +750,9 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
                 w.gemm_scratch, s);
     launch_split2(w.dcat, d.H, d.Ue, w.dhlast, d.arch == LSTUR_ARCH_IIGRU ? w.duser2 : w.duser, n, s);
     dhl = w.dhlast;
+  } else if (d.arch == LSTUR_ARCH_IICGRU) {          // u = [h | user_vec2], no Dense between (paper.py:343-348)
+    launch_split2(w.du, d.H, d.Ue, w.dhlast, w.duser2, n, s);
+    dhl = w.dhlast;
   } else if (d.arch == LSTUR_ARCH_HGRU || d.arch == LSTUR_ARCH_NGRU || d.arch == LSTUR_ARCH_DGRU) {
     launch_split2(w.du, d.H, d.Ue, w.dhlast, w.duser, n, s);
     dhl = w.dhlast;
@@ -768,7 +775,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     float *hprev = w.hprev, *rh = w.rh;   // fast path: both already sit row-major in the tape (no copies)
     gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
     PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
-                                   (d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_IIGRU) ? w.duser : w.dh0, n, d.W,
+                                   (d.arch == LSTUR_ARCH_IGRU || two_tables(d)) ? w.duser : w.dh0, n, d.W,
                                    d.H, s));
     // GRU parameter gradients (their split-K / column-sum partials are reduced by ONE launch at the end of the pass), on
     // the side stream: nothing but that reduction reads them
@@ -791,7 +798,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     const float row_p = user_row_drop(c);
     if (row_p > 0.f) {
       launch_drop_rows(w.duser, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
-      if (d.arch == LSTUR_ARCH_IIGRU)
+      if (two_tables(d))
         launch_drop_rows(w.duser2, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
     }
   }
@@ -1228,8 +1235,8 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
     return fail(LSTUR_ERR_ARG, "every buffer must be bound");
   if (d.word_trainable && (!buf->word_grad || !buf->word_m || !buf->word_v))
     return fail(LSTUR_ERR_ARG, "word_trainable needs word_grad / word_m / word_v");
-  if (d.arch == LSTUR_ARCH_IIGRU && (!buf->user_emb2 || !buf->user_m2 || !buf->user_v2))
-    return fail(LSTUR_ERR_ARG, "iigru needs user_emb2 / user_m2 / user_v2");
+  if (two_tables(d) && (!buf->user_emb2 || !buf->user_m2 || !buf->user_v2))
+    return fail(LSTUR_ERR_ARG, "iigru / iicgru need user_emb2 / user_m2 / user_v2");
   if (((uintptr_t)buf->workspace & 255) || ((uintptr_t)buf->word_emb & 15) || ((uintptr_t)buf->dense_param & 15) ||
       ((uintptr_t)buf->dense_grad & 15) || ((uintptr_t)buf->user_emb & 15))
     return fail(LSTUR_ERR_ARG, "buffers must be 16-byte (workspace 256-byte) aligned");
@@ -1387,7 +1394,7 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
   hipStream_t s = (hipStream_t)stream;
   const Dims& d = ctx->d;
   const lstur_cfg& c = ctx->cfg;
-  if (rows && d.arch == LSTUR_ARCH_IIGRU)
+  if (rows && two_tables(d))
     return fail(LSTUR_ERR_ARG, "iigru: external (data-parallel) user rows are not supported: the exchange carries one table");
   if (!rows) {
     rows = ctx->ws.user_rows;
@@ -1415,7 +1422,7 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
       launch_adam_table(ctx->buf.user_emb, ctx->buf.user_m, ctx->buf.user_v, ctx->ws.slot, ctx->ws.gsum, d.Nu, d.Ue,
                         lr_t, c.beta1, c.beta2, c.eps, s);
     }
-    if (d.arch == LSTUR_ARCH_IIGRU) {   // the second table: same rows (hence the same slot map), its own gradients
+    if (two_tables(d)) {   // the second table: same rows (hence the same slot map), its own gradients
       launch_user_grad_combine(rows, ctx->ws.duser2, n_rows, d.Ue, ctx->ws.first, ctx->ws.gsum2, ctx->ws.slot, s);
       launch_adam_table(ctx->buf.user_emb2, ctx->buf.user_m2, ctx->buf.user_v2, ctx->ws.slot, ctx->ws.gsum2, d.Nu, d.Ue,
                         lr_t, c.beta1, c.beta2, c.eps, s);
@@ -1477,7 +1484,7 @@ int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* coun
       {"emb", w.emb, nt * d.Tp * d.D},      {"pooled", w.pooled, nt * d.F},
       {"loss_i", w.loss_i, n},              {"user_grad", w.duser, n * d.Ue},
       {"dconv", w.dconv, nt * d.T * d.F},
-      {"duser2", w.duser2, d.arch == LSTUR_ARCH_IIGRU ? n * d.Ue : 0},
+      {"duser2", w.duser2, two_tables(d) ? n * d.Ue : 0},
       {"h_last", (d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU) ? w.uservec : w.hlast, n * d.H},
       {"dgates", w.dgates, n * d.W * 3 * d.H}, {"ddoc_vec", w.ddocvec, nt * d.U},
   };

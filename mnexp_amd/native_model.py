@@ -143,7 +143,7 @@ class NativeModel:
                            user_emb=(max(1, n_users), Ue), word_emb=(V, D),
                            score_b1=(user_dim,), score_w2=(user_dim,),
                            score_b2=(1,))
-        Uu = 2 * user_dim if arch in ('ngru', 'dgru') else user_dim      # width of the user vector
+        Uu = 2 * user_dim if arch in ('ngru', 'dgru', 'iicgru') else user_dim      # width of the user vector
         self.shapes.update(score_w1=(Uu + user_dim, user_dim), sdu_w=(Uu, user_dim), sdu_b=(user_dim,), sdd_w=(user_dim, user_dim), sdd_b=(user_dim,),
                            sn1_w=(Uu + user_dim, user_dim), sn1_b=(user_dim,), sn2_w=(user_dim,), sn2_b=(1,),
                            uatt_w=(user_dim,), uatt_b=(1,))
@@ -173,7 +173,7 @@ class NativeModel:
             self.word_v = torch.zeros(V * D, dtype=f32, device=dev)
             wg, wm, wv = self.word_grad.data_ptr(), self.word_m.data_ptr(), self.word_v.data_ptr()
         u2 = m2 = v2 = None
-        if arch == 'iigru':            # the second user table of paper.py:617-618 and its Adam moments
+        if arch in ('iigru', 'iicgru'):   # the second user table of paper.py:617-618 and its Adam moments
             self.user_emb2 = torch.zeros(self.sizes.user_emb, dtype=f32, device=dev)
             self.user_m2 = torch.zeros(self.sizes.user_emb, dtype=f32, device=dev)
             self.user_v2 = torch.zeros(self.sizes.user_emb, dtype=f32, device=dev)
@@ -229,12 +229,15 @@ class NativeModel:
             arch = idless[arch]
         elif head != 'softmax':
             # Seq2VecPaperId.get_user_encoder (paper.py:330-354): its `gru` is the plain concat [GRU(x) | user_vec] (2U wide,
-            # the library's ngru) in front of the MLP scorer; its `iigru` (concat without Dense) is not on the native path
+            # the library's ngru) in front of the MLP scorer; its `iigru` is that concat behind an igru with a row of a SECOND
+            # table and no Dense (paper.py:343-348: the library's iicgru)
             if arch == 'gru' and head == 'point_mlp':
                 arch = 'ngru'
+            elif arch == 'iigru' and head == 'point_mlp':
+                arch = 'iicgru'
             elif arch not in ('igru', 'vo'):
-                raise _lib.LsturError('pointwise task with user ids: -a igru | vo | gru (MLP scorer) are on the native path '
-                                      '(got {!r})'.format(arch))
+                raise _lib.LsturError('pointwise task with user ids: -a igru | vo | gru | iigru (the last two with the MLP '
+                                      'scorer) are on the native path (got {!r})'.format(arch))
         pretrained = bool(getattr(cfg, 'enable_pretrain_encoder', False))
         model = cls(emb, user_count, cfg.batch_size, cfg.window_size, cfg.title_shape, cfg.negative_samples,
                     int(filters), int(kernel), cfg.user_embedding_dim, arch=arch, dropout=cfg.dropout,
@@ -276,7 +279,7 @@ class NativeModel:
         if self.arch in ('gru', 'iigru'):
             w['con_w'] = _glorot(rng, s['con_w'], s['con_w'][0], U)
             w['con_b'] = np.zeros(U, np.float32)
-        if self.arch == 'iigru':
+        if self.arch in ('iigru', 'iicgru'):
             w['user_emb2'] = rng.uniform(-0.05, 0.05, size=s['user_emb2']).astype(np.float32)
         if self.arch == 'niatt':         # SimpleAttentionMaskSupport over the history (paper.py:207-209, models.py:448-449)
             w['uatt_w'] = _glorot(rng, s['uatt_w'], U, 1)
@@ -299,7 +302,7 @@ class NativeModel:
         self.set_weights(w)
 
     def param_names(self):
-        return [n for n, _, _ in self.layout] + ['user_emb'] + (['user_emb2'] if self.arch == 'iigru' else [])
+        return [n for n, _, _ in self.layout] + ['user_emb'] + (['user_emb2'] if self.arch in ('iigru', 'iicgru') else [])
 
     def set_weights(self, weights):
         """weights: dict name -> ndarray (any subset of param_names() + 'word_emb')."""
@@ -370,7 +373,7 @@ class NativeModel:
         user_encoder: user Embedding, GRU kernel/recurrent/bias[, concat Dense]), then the frozen word table."""
         tok = ['qkv_w', 'qkv_b'] if self.news_encoder == 'mhsa' else ['conv_w', 'conv_b']
         names = tok + ['att_w', 'att_b', 'dense_w', 'dense_b', 'user_emb', 'gru_w', 'gru_u', 'gru_b']
-        if self.arch == 'iigru':
+        if self.arch in ('iigru', 'iicgru'):
             names += ['user_emb2']
         if self.arch in ('gru', 'iigru'):
             names += ['con_w', 'con_b']
@@ -516,7 +519,7 @@ class NativeModel:
                      self.stats.data_ptr(), s), 'lstur_forward_backward')
         self.optimizer.iterations += 1
         t = self.optimizer.iterations
-        if (self.world > 1 or self.force_collectives) and self.arch == 'iigru':
+        if (self.world > 1 or self.force_collectives) and self.arch in ('iigru', 'iicgru'):
             raise _lib.LsturError('iigru (two user tables) is single-GPU only: the data-parallel exchange carries one table')
         if self.world > 1 or self.force_collectives:
             rows, grads = self._allreduce_grads(n)

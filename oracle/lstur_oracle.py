@@ -38,7 +38,7 @@ import numpy as np
 
 EPS = 1e-7  # keras.backend.epsilon()
 
-ARCHS = ("igru", "gru", "hgru", "nigru", "ngru", "dgru", "pgru", "vo", "niavg", "niatt", "iigru")
+ARCHS = ("igru", "gru", "hgru", "nigru", "ngru", "dgru", "pgru", "vo", "niavg", "niatt", "iigru", "iicgru")
 SCORE_MODELS = ("dot", "ddot", "dnn")      # Seq2VecPaperSoftmax._score_model, paper.py:443-458
 
 
@@ -125,13 +125,13 @@ def init_params(rng, V, D, F, k, U, N_u, arch="igru", word_emb=None, dtype=np.fl
     if arch in ("gru", "iigru"):
         p["con_w"] = glorot_uniform(rng, (H + Ue, U), H + Ue, U)
         p["con_b"] = np.zeros(U)
-    if arch == "iigru":          # a second user table behind an igru (paper.py:614-621)
+    if arch in ("iigru", "iicgru"):   # a second user table behind an igru (paper.py:614-621; pointwise: paper.py:343-348)
         p["user_emb2"] = rng.uniform(-0.05, 0.05, size=(N_u, Ue))
     if arch == "niatt":          # SimpleAttentionMaskSupport over the history (id-less `att`, paper.py:207-209)
         p["uatt_w"] = glorot_uniform(rng, (U,), U, 1)
         p["uatt_b"] = np.zeros(1)
     assert head in HEADS and score_model in SCORE_MODELS
-    Uu = 2 * U if arch in ("ngru", "dgru") else U      # width of the user vector (paper.py:600-602, 608-611)
+    Uu = 2 * U if arch in ("ngru", "dgru", "iicgru") else U      # width of the user vector (paper.py:600-602, 608-611)
     assert head != "softmax" or score_model != "dot" or Uu == U, "ngru / dgru user vectors are 2U wide: not dot-compatible"
     if score_model == "ddot":    # tanh-Dense on both sides, then dot (paper.py:452-455)
         p["sdu_w"] = glorot_uniform(rng, (Uu, U), Uu, U)
@@ -459,7 +459,7 @@ def user_encoder_fwd(p, arch, user, hv, hist_ids, uvec_keep=None, keep_scale=2.0
     hvm = hv * hmask[..., None]                      # paper.py:645
     gmask = np.any(hvm != 0, axis=-1)                # Masking() paper.py:592
     uvec = p["user_emb"][user]
-    uvec2 = p["user_emb2"][user] if arch == "iigru" else None
+    uvec2 = p["user_emb2"][user] if arch in ("iigru", "iicgru") else None
     if uvec_keep is not None:
         uvec = uvec * uvec_keep[:, None] * hv.dtype.type(keep_scale)
         if uvec2 is not None:
@@ -481,6 +481,9 @@ def user_encoder_fwd(p, arch, user, hv, hist_ids, uvec_keep=None, keep_scale=2.0
         h, gc = gru_fwd(p, hvm, gmask, uvec)
         extra = np.concatenate([h, uvec2], axis=1)
         u = extra @ p["con_w"] + p["con_b"]
+    elif arch == "iicgru":                          # Seq2VecPaperId's `iigru` (paper.py:343-348): the same concat, NO Dense
+        h, gc = gru_fwd(p, hvm, gmask, uvec)
+        u = extra = np.concatenate([h, uvec2], axis=1)
     elif arch == "vo":                              # paper.py:622-623: the user embedding alone, the history is unused
         u, gc, extra = uvec, None, None
     elif arch == "niavg":                           # paper.py:629-630 + models.py:433-435: masked mean, no user id
@@ -524,6 +527,10 @@ def user_encoder_bwd(p, cache, du):
         gg, dx, dh0 = gru_bwd(p, gc, np.ascontiguousarray(dcat[:, :H]))
         duser = dh0
         cache["duser2"] = dcat[:, H:]               # row gradients of the second user table
+    elif arch == "iicgru":
+        gg, dx, dh0 = gru_bwd(p, gc, np.ascontiguousarray(du[:, :H]))
+        duser = dh0
+        cache["duser2"] = du[:, H:]
     elif arch in ("vo", "niavg", "niatt"):          # no GRU in the graph: its parameters get no gradient
         gg = {n: np.zeros_like(p[n]) for n in ("gru_w", "gru_u", "gru_b")}
         if arch == "niatt":
@@ -662,7 +669,7 @@ def forward_backward(p, arch, user, hist, cands, drop_p=0.0, seed=0, step=0, wor
     out["grads"] = g
     out["user_rows"] = user
     out["user_row_grads"] = duser
-    if arch == "iigru":
+    if arch in ("iigru", "iicgru"):
         out["user_row_grads2"] = uc["duser2"]
     return out
 
@@ -793,6 +800,8 @@ def point_forward_backward(p, arch, head, user, hist, cand, labels, gain=1.0, K=
     out["grads"] = g
     out["user_rows"] = user
     out["user_row_grads"] = duser
+    if "duser2" in uc:
+        out["user_row_grads2"] = uc["duser2"]
     return out
 
 

@@ -140,8 +140,13 @@ def user_vector(p, arch, user, hist, v):
     H = p["gru_u"].shape[0]
     if arch == "igru":
         return gru(p, hv, gmask, p["user_emb"][user])
+    if arch == "iicgru":      # Seq2VecPaperId's `iigru` (paper.py:343-348): [igru | row of the second table], no Dense
+        return torch.cat([gru(p, hv, gmask, p["user_emb"][user]), p["user_emb2"][user]], dim=1)
+    h = gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
+    if arch == "ngru":        # Seq2VecPaperId's `gru` (paper.py:339-342)
+        return torch.cat([h, p["user_emb"][user]], dim=1)
     assert arch == "nigru"
-    return gru(p, hv, gmask, torch.zeros(B, H, dtype=hv.dtype))
+    return h
 
 
 def point_loss(p, arch, head, user, hist, cand, labels, gain, K, keep1=None, keep2=None, scale=1.0):

@@ -30,12 +30,12 @@ def build(arch, head, dims, B, W, T, K, drop, gain):
     return O, p, model, rng
 
 
-@pytest.mark.parametrize('arch', ['igru', 'nigru', 'vo', 'niavg', 'niatt', 'ngru'])
+@pytest.mark.parametrize('arch', ['igru', 'nigru', 'vo', 'niavg', 'niatt', 'ngru', 'iicgru'])
 @pytest.mark.parametrize('head', ['point_mlp', 'point_dot'])
 @pytest.mark.parametrize('dims,B,W,T,drop', [(TINY, 6, 4, 7, 0.0), (MID, 19, 9, 11, 0.2), (ODD, 7, 3, 6, 0.25)])
 def test_pointwise_step_matches_oracle(arch, head, dims, B, W, T, drop):
     _need_gpu()
-    if arch == 'ngru' and head == 'point_dot':
+    if arch in ('ngru', 'iicgru') and head == 'point_dot':
         pytest.skip('a 2U-wide user vector has no dot scorer (paper.py:339-342 pairs it with the MLP)')
     gain, K = 1.7, 4
     O, p, model, rng = build(arch, head, dims, B, W, T, K, drop, gain)
@@ -59,21 +59,25 @@ def test_pointwise_step_matches_oracle(arch, head, dims, B, W, T, drop):
     g = model.get_grads()
     for n in O.dense_param_names(arch, head=head):
         rel_close(g[n].reshape(-1), ref['grads'][n].reshape(-1), 2e-3, n)
-    if arch in ('igru', 'vo', 'ngru'):
+    if arch in ('igru', 'vo', 'ngru', 'iicgru'):
         rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
+    if arch == 'iicgru':      # Seq2VecPaperId's `iigru`: the second table's rows get the tail half of d(user vector)
+        rel_close(model.peek('duser2').cpu().numpy()[:B * dims['U']], ref['user_row_grads2'].reshape(-1), 2e-3, 'user_row_grads2')
     # model.predict of the pointwise model = the scorer's sigmoid output without dropout
     pr = model.predict([user, hist, cand])
     np.testing.assert_allclose(pr.reshape(-1), O.point_predict(p, arch, head, user, hist, cand), rtol=1e-3, atol=1e-6)
 
 
-def test_pointwise_training_tracks_oracle_and_auc_metric():
-    """5 Adam steps: per-step loss and the updated parameters follow the oracle; the running tf.metrics.auc
-    restatement equals a direct evaluation of its published definition on all predictions so far."""
+@pytest.mark.parametrize('arch', ['igru', 'iicgru'])
+def test_pointwise_training_tracks_oracle_and_auc_metric(arch):
+    """5 Adam steps: per-step loss and the updated parameters (for iicgru: both user tables) follow the oracle; the
+    running tf.metrics.auc restatement equals a direct evaluation of its published definition on all predictions so far."""
     _need_gpu()
-    arch, head, dims, B, W, T, K, gain = 'igru', 'point_mlp', MID, 24, 6, 9, 4, 1.0
+    head, dims, B, W, T, K, gain = 'point_mlp', MID, 24, 6, 9, 4, 1.0
     O, p, model, rng = build(arch, head, dims, B, W, T, K, 0.2, gain)
     pf = {n: a.astype(np.float32) for n, a in p.items()}
-    opt = O.Adam(pf, O.dense_param_names(arch, head=head) + ['user_emb'], lr=1e-3)
+    tables = ['user_emb'] + (['user_emb2'] if arch == 'iicgru' else [])
+    opt = O.Adam(pf, O.dense_param_names(arch, head=head) + tables, lr=1e-3)
     probs, labs = [], []
     for step in range(5):
         user, hist, cands = make_batch(rng, B, W, T, 1, dims['V'], dims['N_u'])
@@ -86,7 +90,7 @@ def test_pointwise_training_tracks_oracle_and_auc_metric():
         probs.append(ref['probs'])
         labs.append(labels)
     w = model.get_weights()
-    for n in O.dense_param_names(arch, head=head) + ['user_emb']:
+    for n in O.dense_param_names(arch, head=head) + tables:
         rel_close(w[n].reshape(-1), pf[n].reshape(-1), 2e-3, n)
     # tf.metrics.auc over everything seen (200 thresholds, trapezoidal), evaluated directly
     pr, y = np.concatenate(probs), np.concatenate(labs) > 0.5

@@ -251,6 +251,7 @@ def test_save_load_round_trip(tmp_path):
 
 
 @pytest.mark.parametrize('tname,arch,ids', [('Seq2VecPaperId', 'igru', False), ('Seq2VecPaperId', 'igru', True),
+                                            ('Seq2VecPaperId', 'iigru', True), ('Seq2VecPaperId', 'gru', False),
                                             ('Seq2VecPaper', 'gru', False), ('Seq2VecPaperDot', 'gru', True)])
 def test_pointwise_cli_train_loop(tmp_path, tname, arch, ids):
     """the pointwise sibling through the reference's train loop (fit_generator / callback of
@@ -269,6 +270,9 @@ def test_pointwise_cli_train_loop(tmp_path, tname, arch, ids):
     assert abs(h.model.optimizer.lr - 1e-3 * 0.2 ** 2) < 1e-12
     assert h.model.optimizer.iterations == 30
     assert abs(h.model.cfg.gain - 1.5) < 1e-7 and h.model.cfg.loss_negatives == cfg.negative_samples
+    if tname == 'Seq2VecPaperId' and arch != 'igru':      # paper.py:339-348: 2U-wide concatenations, `iigru` with a second table
+        assert h.model.arch == {'gru': 'ngru', 'iigru': 'iicgru'}[arch]
+        assert h.model.shapes['score_w1'][0] == 3 * cfg.user_embedding_dim
 
 
 def test_pointwise_training_through_the_task_tracks_oracle(tmp_path):

@@ -229,11 +229,14 @@ def test_adam_matches_keras_formula():
         np.testing.assert_allclose(p["w"], w, rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("arch", ["igru", "nigru"])
+@pytest.mark.parametrize("arch", ["igru", "nigru", "ngru", "iicgru"])
 @pytest.mark.parametrize("head", ["point_mlp", "point_dot"])
 @pytest.mark.parametrize("drop", [0.0, 0.25])
 def test_pointwise_grads_match_autograd(arch, head, drop):
-    """the pointwise sibling (concat-MLP / dot scorer, weighted BCE of seq2vec.py:213-216)."""
+    """the pointwise sibling (concat-MLP / dot scorer, weighted BCE of seq2vec.py:213-216); ngru / iicgru are
+    Seq2VecPaperId's `gru` / `iigru` (paper.py:339-348): 2U-wide user vectors in front of the MLP scorer."""
+    if arch in ("ngru", "iicgru") and head == "point_dot":
+        pytest.skip("a 2U-wide user vector has no dot scorer")
     rng = np.random.default_rng(5)
     p = O.init_params(rng, arch=arch, dtype=np.float64, head=head, **DIMS)
     for n in ("conv_b", "att_b", "dense_b", "gru_b", "score_b1", "score_b2"):
@@ -261,6 +264,8 @@ def test_pointwise_grads_match_autograd(arch, head, drop):
     np.testing.assert_allclose(out["probs"], pr.detach().numpy(), rtol=1e-10, atol=1e-12)
     g = dict(out["grads"])
     g["user_emb"] = O.densify_user_grad(*p["user_emb"].shape, out["user_rows"], out["user_row_grads"], np.float64)
+    if arch == "iicgru":
+        g["user_emb2"] = O.densify_user_grad(*p["user_emb2"].shape, out["user_rows"], out["user_row_grads2"], np.float64)
     for n in names:
         if n == "word_emb":
             continue                                  # frozen table on this path
