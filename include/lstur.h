@@ -222,6 +222,22 @@ int lstur_dp_unpack(lstur_ctx* ctx, const float* tail, int32_t world, int32_t n,
 int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, const float* row_grads,
                     int32_t n_rows, lstur_stream stream);
 
+/* The caller wrote parameters (dense_param, word_emb) from outside -- set_weights, a checkpoint load: the weight images
+ * the library keeps for its MFMA kernels (packed behind every Adam step, for the NEXT forward) and a batch staged by
+ * lstur_prefetch_ids are stale.  Not needed after lstur_adam_step / lstur_train_step. */
+int lstur_params_changed(lstur_ctx* ctx);
+
+/* model.train_on_batch in ONE call for a single process (no gradient exchange between backward and optimizer):
+ * lstur_(point_)forward_backward(_ids) with grad_scale 1 followed by lstur_adam_step(lr, t, own rows) -- same arithmetic,
+ * bit-identical results -- but scheduled as one unit: the dense sweep of the user table(s) starts when the recurrence has
+ * produced the row gradients and runs on a stream of its own under the news encoder's backward.  `labels` is read by the
+ * pointwise heads only (NULL for the listwise head).  (main.py:73-78: fit_generator -> train_on_batch.) */
+int lstur_train_step(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands, const float* labels,
+                     int32_t n, uint32_t step, float lr, int32_t t, float* stats, lstur_stream stream);
+int lstur_train_step_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_ids, const int32_t* cand_ids,
+                         const float* labels, int32_t n, uint32_t step, float lr, int32_t t, float* stats,
+                         lstur_stream stream);
+
 /* test_model.predict (paper.py:661-665; task/seq2vec.py:206): sigmoid(u . d), one candidate per row.
  *   user int32 [n]; hist int32 [n,W,T]; cand int32 [n,T]; scores float [n]; n <= max_predict_rows */
 int lstur_predict(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cand,

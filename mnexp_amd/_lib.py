@@ -61,6 +61,9 @@ SIGNATURES = {
     'lstur_prefetch_hits': (_I, [_P]),
     'lstur_user_grad': (_I, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I)]),
     'lstur_adam_step': (_I, [_P, _F, _I, _P, _P, _I, _P]),
+    'lstur_params_changed': (_I, [_P]),
+    'lstur_train_step': (_I, [_P, _P, _P, _P, _P, _I, _U, _F, _I, _P, _P]),
+    'lstur_train_step_ids': (_I, [_P, _P, _P, _P, _P, _I, _U, _F, _I, _P, _P]),
     'lstur_dp_tail_floats': (_Z, [C.POINTER(Cfg), _I]),
     'lstur_dp_stage': (_I, [_P, _P, _I, _I, _P]),
     'lstur_dp_unpack': (_I, [_P, _P, _I, _I, C.POINTER(_P), C.POINTER(_P), _P]),

@@ -467,6 +467,15 @@ struct lstur_ctx {
   hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;
   bool pipe_ok = false, last_piped = false;
   int last_nA = 0;
+  // fused training step (lstur_train_step*): the optimizer is part of the call, so the library schedules it -- the dense
+  // sweep of the user table(s) needs only the recurrence's row gradients and runs on a stream of its own under the news
+  // encoder's backward (HBM-bound beside MFMA-bound kernels); the weight images of the NEXT step are packed behind the
+  // dense Adam instead of in front of the next conv forward
+  struct Fused { bool on = false, swept = false, table_done = false; float lr_t = 0.f; } fused;
+  hipStream_t side_t = nullptr;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+  hipEvent_t ev_f0 = nullptr;           // the forward's one fork point (staging prefetch + table sweep)
+  bool images_valid = false;            // conv / GRU weight images match dense_param (packed behind the last Adam)
   std::vector<ParamSlot> layout;
   size_t dense_total;
   const int32_t* title_table = nullptr;
@@ -554,38 +563,165 @@ void use_set(lstur_ctx* c, int k) {
   w.vscratch = w.set[k].vscratch; w.offA = w.set[k].offA; w.offB = w.set[k].offB;
 }
 
-// enqueue the pending prefetch (if any) on the side stream, behind everything `s` holds so far
-void launch_prefetch(lstur_ctx* c, hipStream_t s) {
+// enqueue the pending prefetch (if any) on the side stream, behind everything `s` holds so far; true: something was launched
+bool fork_events(lstur_ctx* c) {
+  if (c->ev_f0) return true;
+  if (hipEventCreateWithFlags(&c->ev_f0, hipEventDisableTiming) != hipSuccess) c->ev_f0 = nullptr;
+  return c->ev_f0 != nullptr;
+}
+bool prefetch_wanted(const lstur_ctx* c) {
+  const Workspace& w = c->ws;
+  return c->pend.valid && !c->ready.valid && c->cur_lane == 0 && c->conv_cus == 0 && w.set[1].ids != w.set[0].ids;
+}
+// `forked`: recorded on the caller's stream behind everything the staging must wait for
+bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
   auto& q = c->pend;
   const Dims& d = c->d;
   Workspace& w = c->ws;
-  if (!q.valid || c->ready.valid || c->cur_lane != 0 || c->conv_cus != 0 || w.set[1].ids == w.set[0].ids) return;
+  if (!prefetch_wanted(c)) return false;
   if (!c->side_p) {
     if (hipStreamCreateWithFlags(&c->side_p, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_p0, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming) != hipSuccess) {
       c->side_p = nullptr;
       q.valid = false;
-      return;
+      return false;
     }
   }
   const Workspace::StageSet& t = w.set[c->cur_set ^ 1];
   hipStream_t p = c->side_p;
-  (void)hipEventRecord(c->ev_p0, s);
-  (void)hipStreamWaitEvent(p, c->ev_p0, 0);
+  (void)hipStreamWaitEvent(p, forked, 0);
   const int nW = q.n * d.W, nt = nW + q.n * d.K1, pl = (d.k - 1) / 2;
   launch_expand_count(c->title_table, q.hist, nW, q.cands, q.n * d.K1, d.T, t.ids, t.vscratch, p);
   launch_compact_write_offsets(t.ids, nt * d.T, t.vscratch, t.vidx, t.vcount, d.T, d.Tp, conv3_dp(d.D) / 8 * 3, d.F, t.offA,
                                t.offB, p);
   {
     ProfScope _ps(c, "gather", p);
+    static const int pf_blocks = getenv("LSTUR_PREFETCH_BLOCKS") ? atoi(getenv("LSTUR_PREFETCH_BLOCKS")) : 0;
     launch_gather3(c->buf.word_emb, t.ids, t.e3, nt, d.T, d.D, pl, d.k - 1 - pl, c->cfg.dropout,
-                   dropout_key(c->cfg.seed, q.step, 0), true, p);
+                   dropout_key(c->cfg.seed, q.step, 0), true, p, pf_blocks);
   }
   (void)hipEventRecord(c->ev_p1, p);
   q.launched = true;
   c->ready = q;                      // staged: the next training call may pick it up
   q = lstur_ctx::Pending();
+  return true;
+}
+
+// operand images of the weights the MFMA kernels read (conv: bf16x3 parts or the fp32 pack; GRU: resident strips)
+void pack_weight_images(lstur_ctx* c, hipStream_t sp) {
+  const Dims& d = c->d;
+  Workspace& w = c->ws;
+  const bool mhsa = d.enc == LSTUR_ENC_MHSA;
+  static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr;
+  static const bool gen1 = getenv("LSTUR_CONV_GEN1") != nullptr;
+  const bool use3 = !mhsa && w.conv_w3 && !conv_f32;
+  if (use3 && gen1) launch_conv3_pack_w(c->P("conv_w"), d.KD, d.F, w.conv_w3_v1, sp);
+  else if (use3) launch_conv3_pack_w2(c->P("conv_w"), d.D, d.k, d.F, w.conv_w3, sp);
+  else if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, sp);
+  launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, sp);
+}
+
+bool has_user_table(const Dims& d) {
+  return d.arch != LSTUR_ARCH_NIGRU && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
+}
+
+// Keras-Adam sweep of the user table(s) for the rows / row gradients of this batch (duplicates combined in sample order)
+void adam_user_tables(lstur_ctx* c, const int32_t* rows, const float* row_grads, int n_rows, float lr_t, bool combine_first,
+                      hipStream_t s) {
+  const Dims& d = c->d;
+  const lstur_cfg& cf = c->cfg;
+  if (combine_first) launch_user_grad_combine(rows, row_grads, n_rows, d.Ue, c->ws.first, c->ws.gsum, c->ws.slot, s);
+  {
+    ProfScope _ps(c, "adam_user_table", s);
+    launch_adam_table(c->buf.user_emb, c->buf.user_m, c->buf.user_v, c->ws.slot, c->ws.gsum, d.Nu, d.Ue, lr_t, cf.beta1,
+                      cf.beta2, cf.eps, s);
+  }
+  if (two_tables(d)) {   // the second table: same rows (hence the same slot map), its own gradients
+    launch_user_grad_combine(rows, c->ws.duser2, n_rows, d.Ue, c->ws.first, c->ws.gsum2, c->ws.slot, s);
+    launch_adam_table(c->buf.user_emb2, c->buf.user_m2, c->buf.user_v2, c->ws.slot, c->ws.gsum2, d.Nu, d.Ue, lr_t,
+                      cf.beta1, cf.beta2, cf.eps, s);
+  }
+  launch_user_slot_clear(rows, n_rows, c->ws.slot, s);
+}
+
+// Fused step: the dense sweep of the user table(s) in two halves.  A row outside the batch takes the zero-gradient Adam
+// update, which needs nothing from this step but lr_t: that half (all but <= n rows; 3 reads + 3 writes per element) runs
+// on a stream of its own under the forward recurrence, where HBM and 240 CUs idle.  (Beside the conv kernels it finds no
+// registers, beside the small GEMMs / attention backward it takes the bandwidth they are bound by: both were measured.)
+// The batch's own rows are marked first (their table reads of this forward see the old values) and finished behind the
+// recurrence's backward from their combined gradients.  Same arithmetic per element as the one-piece sweep.
+bool table_stream(lstur_ctx* c) {
+  if (c->side_t) return true;
+  if (hipStreamCreateWithFlags(&c->side_t, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_t0, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming) != hipSuccess) {
+    c->side_t = nullptr;
+    return false;
+  }
+  return true;
+}
+// The recurrence beside it is a latency chain (its gate inputs and tape cross HBM every step): a sweep at full bandwidth
+// stretched it by most of what the sweep took (176 -> 216 us at 50 k users), and at 256 workgroups by more.  So the sweep
+// is launched THIN -- as many workgroups as finish it inside the two recurrences (~14 GB/s each at this load; 64 at 50 k
+// users: 234 us, recurrence unchanged) -- unless that takes more than 128, where it runs at full width as before (1 M
+// users: the sweep outlasts the recurrences, nothing to hide it under).  after_prefetch: it also queues behind the next
+// batch's embedding gather, which keeps the bandwidth it is measured on.
+bool early_table_sweep_wanted(const lstur_ctx* c) {
+  const auto& f = c->fused;
+  return f.on && !f.swept && c->cur_lane == 0 && c->conv_cus == 0 && has_user_table(c->d);
+}
+void early_table_sweep(lstur_ctx* c, int n, hipEvent_t forked, bool recurrent, bool after_prefetch) {
+  auto& f = c->fused;
+  const Dims& d = c->d;
+  const lstur_cfg& cf = c->cfg;
+  if (!early_table_sweep_wanted(c) || !table_stream(c)) return;
+  hipStream_t st = c->side_t;
+  (void)hipStreamWaitEvent(st, forked, 0);
+  launch_user_rows_mark(c->ws.user_rows, n, c->ws.slot, st);
+  if (after_prefetch) (void)hipStreamWaitEvent(st, c->ev_p1, 0);
+  static const int env_blocks = getenv("LSTUR_SWEEP_BLOCKS") ? atoi(getenv("LSTUR_SWEEP_BLOCKS")) : -1;
+  int sweep_blocks = 0;   // 0: full width
+  if (recurrent) {
+    const double bytes = (double)d.Nu * d.Ue * 4.0 * 6.0 * (two_tables(d) ? 2.0 : 1.0);
+    const double window_s = d.W * 3.4e-6 * 2.0 * 0.8;
+    const double need = bytes / (window_s * 14e9);
+    if (need <= 128.0) sweep_blocks = need < 32.0 ? 32 : (int)need;
+  }
+  if (env_blocks >= 0) sweep_blocks = env_blocks;
+  {
+    ProfScope _ps(c, "adam_user_table", st);
+    launch_adam_table_unmarked(c->buf.user_emb, c->buf.user_m, c->buf.user_v, c->ws.slot, d.Nu, d.Ue, f.lr_t, cf.beta1,
+                               cf.beta2, cf.eps, sweep_blocks, st);
+  }
+  if (two_tables(d))
+    launch_adam_table_unmarked(c->buf.user_emb2, c->buf.user_m2, c->buf.user_v2, c->ws.slot, d.Nu, d.Ue, f.lr_t, cf.beta1,
+                               cf.beta2, cf.eps, sweep_blocks, st);
+  f.swept = true;
+}
+bool finish_table_rows_wanted(const lstur_ctx* c) {
+  const auto& f = c->fused;
+  return f.on && f.swept && !f.table_done && c->cur_lane == 0;
+}
+// behind the row gradients (and their row masks): `forked` was recorded there on the caller's stream
+void finish_table_rows(lstur_ctx* c, int n, hipEvent_t forked) {
+  auto& f = c->fused;
+  const Dims& d = c->d;
+  const lstur_cfg& cf = c->cfg;
+  hipStream_t st = c->side_t;
+  const int32_t* rows = c->ws.user_rows;
+  (void)hipStreamWaitEvent(st, forked, 0);
+  launch_user_grad_combine(rows, c->ws.duser, n, d.Ue, c->ws.first, c->ws.gsum, c->ws.slot, st);
+  launch_adam_rows(c->buf.user_emb, c->buf.user_m, c->buf.user_v, rows, c->ws.slot, c->ws.gsum, n, d.Ue, f.lr_t, cf.beta1,
+                   cf.beta2, cf.eps, st);
+  if (two_tables(d)) {
+    launch_user_grad_combine(rows, c->ws.duser2, n, d.Ue, c->ws.first, c->ws.gsum2, c->ws.slot, st);
+    launch_adam_rows(c->buf.user_emb2, c->buf.user_m2, c->buf.user_v2, rows, c->ws.slot, c->ws.gsum2, n, d.Ue, f.lr_t,
+                     cf.beta1, cf.beta2, cf.eps, st);
+  }
+  launch_user_slot_clear(rows, n, c->ws.slot, st);
+  (void)hipEventRecord(c->ev_t1, st);
+  f.table_done = true;
 }
 
 // whole-row dropout probability of the user embedding in training (0: none)
@@ -634,10 +770,12 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   static const bool gen1 = getenv("LSTUR_CONV_GEN1") != nullptr;   // A/B: first-generation bf16x3 kernels (conv3.hip, fp32 E)
   bool packs_forked = false;
   hipStream_t sp = nullptr;
-  if (c->cur_lane == 0) {   // (lane 1 shares lane 0's images: it starts behind lane 0's encoder)
+  if (c->cur_lane == 0 && !c->images_valid) {   // (lane 1 shares lane 0's images: it starts behind lane 0's encoder)
+    // (the Adam entry points leave valid images behind: this runs on a first step, after lstur_params_changed or in eval)
     // the two weight images depend on nothing in the batch: they are packed on the side stream, beside the title staging and
-    // the gather, and joined in front of the conv forward
-    sp = wgrad_stream(c);
+    // the gather, and joined in front of the conv forward; with the staging prefetched there is nothing to hide them under,
+    // and two 5-us kernels in line cost less than a fork / join across queues (~10 us each way)
+    sp = c->staged_hit ? nullptr : wgrad_stream(c);
     if (sp) {
       (void)hipEventRecord(c->ev_w1, s);
       (void)hipStreamWaitEvent(sp, c->ev_w1, 0);
@@ -645,11 +783,9 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     } else {
       sp = s;
     }
-    if (use3 && gen1) launch_conv3_pack_w(c->P("conv_w"), d.KD, d.F, w.conv_w3_v1, sp);
-    else if (use3) launch_conv3_pack_w2(c->P("conv_w"), d.D, d.k, d.F, w.conv_w3, sp);
-    else if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, sp);
-    launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, sp);
+    pack_weight_images(c, sp);
     if (packs_forked) (void)hipEventRecord(c->ev_w3, sp);
+    c->images_valid = true;
   }
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
@@ -696,6 +832,16 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   launch_gemm(w.docvec, d.U, 0, c->P("gru_w"), 3 * d.H, 0, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, 1.f,
               w.gemm_scratch, s);
   if (c->cur_ev_enc) (void)hipEventRecord(c->cur_ev_enc, s);   // the other lane's encoder may start: the recurrence follows
+  const bool recurrent = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
+  if (training) {   // background work for the recurrence to hide: the next batch's staging, then (fused step) the zero-gradient
+                    // half of the user-table sweep
+    const bool want_pf = recurrent && use3 && !gen1 && prefetch_wanted(c), want_sw = early_table_sweep_wanted(c);
+    if ((want_pf || want_sw) && fork_events(c)) {   // ONE event record on `s` for both side streams
+      (void)hipEventRecord(c->ev_f0, s);
+      const bool pf = want_pf && launch_prefetch(c, c->ev_f0);
+      early_table_sweep(c, n, c->ev_f0, recurrent, pf);
+    }
+  }
   if (d.arch == LSTUR_ARCH_VO) {          // the user embedding alone (paper.py:622-623)
     (void)hipMemcpyAsync(w.uservec, w.uvec, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
   } else if (d.arch == LSTUR_ARCH_NIAVG) {   // masked mean of the history vectors (paper.py:629-630)
@@ -707,7 +853,6 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     // igru / nigru: the last state IS the user vector (H == U): the recurrence writes it in place
     const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
     const bool init_user = d.arch == LSTUR_ARCH_IGRU || two_tables(d);   // initial_state = user_vec
-    if (training && use3 && !gen1) launch_prefetch(c, s);   // the next batch's staging runs under the recurrence
     PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, init_user ? w.uvec : nullptr, w.gru_up,
                                    w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s));
     if (d.arch == LSTUR_ARCH_PGRU) {        // GRU(U)(x) + user_vec (paper.py:624-626)
@@ -777,11 +922,28 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
                                    (d.arch == LSTUR_ARCH_IGRU || two_tables(d)) ? w.duser : w.dh0, n, d.W,
                                    d.H, s));
+  }
+  {   // the row gradients of the user table(s) pass the forward's row mask and scale (dgru / id_keep)
+    const float row_p = user_row_drop(c);
+    if (row_p > 0.f) {
+      launch_drop_rows(w.duser, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
+      if (two_tables(d))
+        launch_drop_rows(w.duser2, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
+    }
+  }
+  // ONE event behind the recurrence serves both side streams (an event record between two kernels of a stream is a ~6 us
+  // bubble on this stack: forks are merged wherever the dependencies allow)
+  const bool fork_t = finish_table_rows_wanted(c);
+  hipEvent_t fe = sw != s ? c->ev_w1 : c->ev_t0;   // (ev_t0 exists whenever fork_t does)
+  if ((has_gru && sw != s) || fork_t) (void)hipEventRecord(fe, s);
+  if (fork_t) finish_table_rows(c, n, fe);   // fused step: the batch's own rows of the user table(s)
+  if (has_gru) {
+    float *hprev = w.hprev, *rh = w.rh;
+    gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
     // GRU parameter gradients (their split-K / column-sum partials are reduced by ONE launch at the end of the pass), on
     // the side stream: nothing but that reduction reads them
     if (sw != s) {
-      (void)hipEventRecord(c->ev_w1, s);
-      (void)hipStreamWaitEvent(sw, c->ev_w1, 0);
+      (void)hipStreamWaitEvent(sw, fe, 0);
       forked = true;
     }
     launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
@@ -793,14 +955,6 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
                 1.f, w.gemm_scratch_k[2], sw, &jobs[nj++]);
   } else {   // vo / niavg: no GRU in the graph -- its bucket slots get an exact zero gradient
     (void)hipMemsetAsync(c->G("gru_w"), 0, (size_t)(c->G("gru_b") + 3 * d.H - c->G("gru_w")) * sizeof(float), s);
-  }
-  {   // the row gradients of the user table(s) pass the forward's row mask and scale (dgru / id_keep)
-    const float row_p = user_row_drop(c);
-    if (row_p > 0.f) {
-      launch_drop_rows(w.duser, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
-      if (two_tables(d))
-        launch_drop_rows(w.duser2, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
-    }
   }
   if (c->cfg.freeze_encoder) {   // loaded, non-trainable news encoder: nothing behind the doc vectors is trained
     if (stats) {
@@ -869,6 +1023,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   const int ldp = off_ab + 1;
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
                                          w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab));
+  // (on the side stream this one found no free CU beside the conv kernel gradient and finished behind it)
   launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch_k[2], s, &jobs[nj++]);
   if (d.word_trainable) {   // conv input gradient -> word-table gradient (embedding dropout mask = stream 0 of the step)
     (void)hipMemsetAsync(c->buf.word_grad, 0, (size_t)d.V * d.D * sizeof(float), s);
@@ -1065,8 +1220,10 @@ int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   if (d.head != LSTUR_HEAD_SOFTMAX) return fail(LSTUR_ERR_STATE, "context was created with a pointwise head");
   if (n < 1 || n > d.B) return fail(LSTUR_ERR_ARG, "n must be in [1, max_batch]");
   static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr || getenv("LSTUR_CONV_GEN1") != nullptr;
-  if (backward && training && c->pipe_ok && n >= kPipeMin && !c->cfg.freeze_encoder && !conv_f32)
+  if (backward && training && c->pipe_ok && n >= kPipeMin && !c->cfg.freeze_encoder && !conv_f32) {
+    c->fused.on = false;   // (the two-lane step keeps the one-piece sweep behind both lanes)
     return train_two_lanes(c, user, hist, cands, n, step, grad_scale, stats, s, ids_form);
+  }
   set_lane(c, 0);
   c->last_piped = false;
   // was this batch staged by a prefetch during the previous step?  (same arrays, same size, same step)
@@ -1286,6 +1443,13 @@ int lstur_destroy(lstur_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_p1);
     (void)hipStreamDestroy(ctx->side_p);
   }
+  if (ctx && ctx->ev_f0) (void)hipEventDestroy(ctx->ev_f0);
+  if (ctx && ctx->side_t) {
+    (void)hipStreamSynchronize(ctx->side_t);
+    (void)hipEventDestroy(ctx->ev_t0);
+    (void)hipEventDestroy(ctx->ev_t1);
+    (void)hipStreamDestroy(ctx->side_t);
+  }
   if (ctx && ctx->side_w) {
     (void)hipStreamSynchronize(ctx->side_w);
     (void)hipEventDestroy(ctx->ev_w1);
@@ -1388,10 +1552,10 @@ int lstur_dp_unpack(lstur_ctx* ctx, const float* tail, int32_t world, int32_t n,
   return check_launch("dp_unpack");
 }
 
-int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, const float* row_grads, int32_t n_rows,
-                    lstur_stream stream) {
-  if (!ctx || t < 1) return fail(LSTUR_ERR_ARG, "bad adam step");
-  hipStream_t s = (hipStream_t)stream;
+// Keras Adam over everything trainable.  rows == NULL: this process's own rows of the last step.  skip_table: the fused
+// step already swept the user table(s) on its side stream (joined here).  Leaves valid weight images for the next forward.
+static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, const float* row_grads, int32_t n_rows,
+                     hipStream_t s, bool skip_table) {
   const Dims& d = ctx->d;
   const lstur_cfg& c = ctx->cfg;
   if (rows && two_tables(d))
@@ -1404,8 +1568,8 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
   if (n_rows < 0 || n_rows > d.rows_cap) return fail(LSTUR_ERR_ARG, "too many sparse rows for one adam step");
   const float lr_t = lr * (sqrtf(1.0f - powf(c.beta2, (float)t)) / (1.0f - powf(c.beta1, (float)t)));
   lazy_init(ctx, s);
-  const bool no_user = d.arch == LSTUR_ARCH_NIGRU || d.arch == LSTUR_ARCH_NIAVG || d.arch == LSTUR_ARCH_NIATT;
-  if (no_user) {
+  const bool no_user = !has_user_table(d);
+  if (no_user || skip_table) {
     launch_adam_flat(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v, ctx->dense_total,
                      lr_t, c.beta1, c.beta2, c.eps, s);
   } else {
@@ -1413,23 +1577,68 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
                              ctx->dense_total, lr_t, c.beta1, c.beta2, c.eps, rows, row_grads, n_rows, d.Ue,
                              ctx->ws.gsum, ctx->ws.slot, s);
   }
+  // the next forward's weight images, behind the dense update (in front of the next conv forward they would be a bubble:
+  // with the staging prefetched nothing else is left to hide them under)
+  pack_weight_images(ctx, s);
+  ctx->images_valid = true;
   if (d.word_trainable)   // dense Keras-Adam sweep of the word table (TF-1 densifies the IndexedSlices gradient)
     launch_adam_flat(ctx->buf.word_emb, ctx->buf.word_grad, ctx->buf.word_m, ctx->buf.word_v, (size_t)d.V * d.D, lr_t,
                      c.beta1, c.beta2, c.eps, s);
-  if (!no_user) {   // nigru / niavg: the user embedding is not part of the graph (paper.py:627-630)
-    {
-      ProfScope _ps(ctx, "adam_user_table", s);
-      launch_adam_table(ctx->buf.user_emb, ctx->buf.user_m, ctx->buf.user_v, ctx->ws.slot, ctx->ws.gsum, d.Nu, d.Ue,
-                        lr_t, c.beta1, c.beta2, c.eps, s);
-    }
-    if (two_tables(d)) {   // the second table: same rows (hence the same slot map), its own gradients
-      launch_user_grad_combine(rows, ctx->ws.duser2, n_rows, d.Ue, ctx->ws.first, ctx->ws.gsum2, ctx->ws.slot, s);
-      launch_adam_table(ctx->buf.user_emb2, ctx->buf.user_m2, ctx->buf.user_v2, ctx->ws.slot, ctx->ws.gsum2, d.Nu, d.Ue,
-                        lr_t, c.beta1, c.beta2, c.eps, s);
-    }
-    launch_user_slot_clear(rows, n_rows, ctx->ws.slot, s);
-  }
+  if (!no_user && !skip_table)   // nigru / niavg: the user embedding is not part of the graph (paper.py:627-630)
+    adam_user_tables(ctx, rows, row_grads, n_rows, lr_t, false, s);
+  if (skip_table) (void)hipStreamWaitEvent(s, ctx->ev_t1, 0);
   return check_launch("adam_step");
+}
+
+int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, const float* row_grads, int32_t n_rows,
+                    lstur_stream stream) {
+  if (!ctx || t < 1) return fail(LSTUR_ERR_ARG, "bad adam step");
+  return adam_impl(ctx, lr, t, rows, row_grads, n_rows, (hipStream_t)stream, false);
+}
+
+int lstur_params_changed(lstur_ctx* ctx) {
+  if (!ctx) return fail(LSTUR_ERR_ARG, "ctx is NULL");
+  ctx->images_valid = false;
+  ctx->ready = lstur_ctx::Pending();    // a staged batch holds embeddings of the old word table
+  return LSTUR_OK;
+}
+
+// forward + backward + Adam of ONE process's step in one call (no gradient exchange in between)
+static int train_step_impl(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands,
+                           const float* labels, int32_t n, uint32_t step, float lr, int32_t t, float* stats, hipStream_t s,
+                           bool ids_form) {
+  if (!ctx || t < 1) return fail(LSTUR_ERR_ARG, "bad train step");
+  const lstur_cfg& c = ctx->cfg;
+  static const bool off = getenv("LSTUR_FUSED_ADAM") && !strcmp(getenv("LSTUR_FUSED_ADAM"), "0");
+  ctx->fused.on = !off;
+  ctx->fused.swept = ctx->fused.table_done = false;
+  ctx->fused.lr_t = lr * (sqrtf(1.0f - powf(c.beta2, (float)t)) / (1.0f - powf(c.beta1, (float)t)));
+  int rc;
+  if (ctx->d.head == LSTUR_HEAD_SOFTMAX)
+    rc = train_impl(ctx, user, hist, cands, n, step, 1.f, stats, s, ids_form, true, true);
+  else
+    rc = point_impl(ctx, user, hist, cands, labels, n, step, 1.f, stats, s, ids_form, true, true);
+  const bool done = ctx->fused.table_done;
+  if (ctx->fused.swept && !done) {   // (not reached: every path that sweeps runs the backward; keep the table whole anyway)
+    ctx->fused.on = false;
+    return fail(LSTUR_ERR_STATE, "fused step: the user-table sweep was left half done");
+  }
+  ctx->fused.on = false;
+  ctx->fused.swept = ctx->fused.table_done = false;
+  if (rc) {
+    if (done) (void)hipStreamWaitEvent(s, ctx->ev_t1, 0);
+    return rc;
+  }
+  return adam_impl(ctx, lr, t, nullptr, nullptr, 0, s, done);
+}
+int lstur_train_step(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cands, const float* labels,
+                     int32_t n, uint32_t step, float lr, int32_t t, float* stats, lstur_stream stream) {
+  return train_step_impl(ctx, user, hist, cands, labels, n, step, lr, t, stats, (hipStream_t)stream, false);
+}
+int lstur_train_step_ids(lstur_ctx* ctx, const int32_t* user, const int32_t* hist_ids, const int32_t* cand_ids,
+                         const float* labels, int32_t n, uint32_t step, float lr, int32_t t, float* stats,
+                         lstur_stream stream) {
+  return train_step_impl(ctx, user, hist_ids, cand_ids, labels, n, step, lr, t, stats, (hipStream_t)stream, true);
 }
 
 int lstur_predict(lstur_ctx* ctx, const int32_t* user, const int32_t* hist, const int32_t* cand, int32_t n,

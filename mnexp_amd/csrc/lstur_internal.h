@@ -41,7 +41,7 @@ void launch_gather(const float* table, const int32_t* ids, float* out, int n_tit
 // the gather in the pre-split "E3" form of the bf16x3 conv kernels (layout: conv3f.hip); e3 = conv3_e3_elems() bf16
 // skip_unread: rows no window of a non-pad token covers are neither read nor written (the buffer must hold finite values)
 void launch_gather3(const float* table, const int32_t* ids, unsigned short* e3, int n_titles, int T, int D, int pad_l,
-                    int pad_r, float drop, uint32_t key, bool skip_unread, hipStream_t s);
+                    int pad_r, float drop, uint32_t key, bool skip_unread, hipStream_t s, int max_blocks = 0);
 void launch_expand_titles(const int32_t* table, const int32_t* doc_ids, int32_t* out, int n, int T,
                           hipStream_t s);
 // stable list of non-pad tokens: vidx[0..*count) ; scratch = compact_scratch_ints(n) int32
@@ -81,6 +81,13 @@ void launch_dp_stage(const int32_t* rows, const float* g, int n, int B, int Ue, 
                      hipStream_t s);
 void launch_dp_unpack(const float* tail, int n, int B, int Ue, int world, int32_t* rows, float* g, hipStream_t s);
 void launch_user_slot_clear(const int32_t* rows, int n, int32_t* slot, hipStream_t s);
+// the sweep in two halves (fused step): mark the batch's rows, move every OTHER row with its zero gradient (independent of
+// the step's backward), later finish the marked rows from their combined gradients (first occurrences, slot[row] == i)
+void launch_user_rows_mark(const int32_t* rows, int n, int32_t* slot, hipStream_t s);
+void launch_adam_table_unmarked(float* p, float* m, float* v, const int32_t* slot, int n_rows, int dim, float lr_t,
+                                float b1, float b2, float eps, int max_blocks, hipStream_t s);
+void launch_adam_rows(float* p, float* m, float* v, const int32_t* rows, const int32_t* slot, const float* gsum, int n,
+                      int dim, float lr_t, float b1, float b2, float eps, hipStream_t s);
 void launch_fill_i32(int32_t* p, int32_t v, size_t n, hipStream_t s);
 // history mask (ComputeMasking) applied to doc vectors + GRU step mask:  hv[b,w,:] *= any(ids != 0);
 // gmask[b,w] = any(hv != 0)

@@ -171,11 +171,12 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float4* __restrict__
 }
 
 void launch_gather3(const float* table, const int32_t* ids, unsigned short* e3, int n_titles, int T, int D, int pad_l,
-                    int pad_r, float drop, uint32_t key, bool skip_unread, hipStream_t s) {
+                    int pad_r, float drop, uint32_t key, bool skip_unread, hipStream_t s, int max_blocks) {
   const int Tp = T + pad_l + pad_r, D4 = D / 4, C8 = (D + 7) / 8;
   const size_t total8 = (size_t)n_titles * Tp * C8;
   if (total8 == 0) return;
-  const int blocks = (int)std::min<size_t>(cdivz(total8, 256 * 4), 256 * 16);
+  // (max_blocks: a background launch beside latency-bound kernels takes a fraction of the chip on purpose)
+  const int blocks = (int)std::min<size_t>(cdivz(total8, 256 * 4), max_blocks > 0 ? max_blocks : 256 * 16);
   const uint32_t th = drop > 0.f ? dropout_thresh(drop) : 0u;
   const float sc = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
   auto go = [&](auto kern) {
@@ -549,8 +550,11 @@ void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s) {
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr_t * m / (sqrt(v) + eps)
 // with lr_t = lr sqrt(1-b2^t)/(1-b1^t) computed by the caller.
 // ---------------------------------------------------------------------------------------------
+// (no FMA contraction: every kernel that applies the update -- full sweep, zero-gradient sweep, single rows -- must round
+//  alike whatever the compiler would fuse in its surroundings; separately rounded products are also what NumPy does)
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr_t, float b1, float b2,
                                       float eps) {
+#pragma clang fp contract(off)
   m = b1 * m + (1.0f - b1) * g;
   v = b2 * v + (1.0f - b2) * (g * g);
   p = p - lr_t * m / (sqrtf(v) + eps);
@@ -607,7 +611,9 @@ void launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, fl
 
 // Dense sweep of the user table: TF-1 Keras densifies the embedding gradient, so every row's m and v
 // decay and every row moves each step.  HBM-bound: 3 reads + 3 writes / elem.
-template <int VEC>
+// UNMARKED: only the rows without a slot (not in this batch) move, with their zero gradient -- the first half of the
+// fused step's sweep, which needs nothing from the step's backward (launch_adam_rows finishes the batch's rows).
+template <int VEC, bool UNMARKED = false>
 __global__ __launch_bounds__(256) void adam_table_kernel(float* __restrict__ p, float* __restrict__ m,
                                                          float* __restrict__ v, const int32_t* __restrict__ slot,
                                                          const float* __restrict__ gsum, size_t total, int dimv,
@@ -616,6 +622,7 @@ __global__ __launch_bounds__(256) void adam_table_kernel(float* __restrict__ p, 
     size_t row = i / dimv;
     int c = (int)(i - row * dimv);
     int sl = slot[row];
+    if (UNMARKED && sl >= 0) continue;
     if (VEC == 4) {
       float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -651,6 +658,51 @@ void launch_adam_table(float* p, float* m, float* v, const int32_t* slot, const 
     hipLaunchKernelGGL(adam_table_kernel<1>, dim3(blocks), dim3(256), 0, s, p, m, v, slot, gsum, total, dim, lr_t,
                        b1, b2, eps);
   }
+}
+
+void launch_adam_table_unmarked(float* p, float* m, float* v, const int32_t* slot, int n_rows, int dim, float lr_t,
+                                float b1, float b2, float eps, int max_blocks, hipStream_t s) {
+  if (!n_rows) return;
+  if (max_blocks <= 0) max_blocks = 256 * 32;
+  if (dim % 4 == 0) {
+    size_t total = (size_t)n_rows * (dim / 4);
+    int blocks = (int)std::min<size_t>(cdivz(total, 256), max_blocks);
+    hipLaunchKernelGGL((adam_table_kernel<4, true>), dim3(blocks), dim3(256), 0, s, p, m, v, slot, (const float*)nullptr,
+                       total, dim / 4, lr_t, b1, b2, eps);
+  } else {
+    size_t total = (size_t)n_rows * dim;
+    int blocks = (int)std::min<size_t>(cdivz(total, 256), max_blocks);
+    hipLaunchKernelGGL((adam_table_kernel<1, true>), dim3(blocks), dim3(256), 0, s, p, m, v, slot, (const float*)nullptr,
+                       total, dim, lr_t, b1, b2, eps);
+  }
+}
+// the batch's rows: marked before the unmarked sweep (any non-negative value; launch_user_grad_combine then writes the
+// first-occurrence index), updated from their combined gradients afterwards -- one wave per sample, first occurrences only
+__global__ void mark_rows_kernel(const int32_t* __restrict__ rows, int n, int32_t* __restrict__ slot) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) slot[rows[i]] = i;
+}
+void launch_user_rows_mark(const int32_t* rows, int n, int32_t* slot, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(mark_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, rows, n, slot);
+}
+__global__ __launch_bounds__(64) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                       const int32_t* __restrict__ rows, const int32_t* __restrict__ slot,
+                                                       const float* __restrict__ gsum, int dim, float lr_t, float b1,
+                                                       float b2, float eps) {
+  const int i = blockIdx.x, r = rows[i];
+  if (slot[r] != i) return;
+  for (int c = threadIdx.x; c < dim; c += 64) {
+    const size_t e = (size_t)r * dim + c;
+    float pp = p[e], mm = m[e], vv = v[e];
+    adam1(pp, gsum[(size_t)i * dim + c], mm, vv, lr_t, b1, b2, eps);
+    p[e] = pp;
+    m[e] = mm;
+    v[e] = vv;
+  }
+}
+void launch_adam_rows(float* p, float* m, float* v, const int32_t* rows, const int32_t* slot, const float* gsum, int n,
+                      int dim, float lr_t, float b1, float b2, float eps, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(adam_rows_kernel, dim3(n), dim3(64), 0, s, p, m, v, rows, slot, gsum, dim, lr_t, b1, b2, eps);
 }
 
 // first[i] = smallest j with rows[j] == rows[i]

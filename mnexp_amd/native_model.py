@@ -319,6 +319,8 @@ class NativeModel:
                 if a.numel() != cnt:
                     raise ValueError('{}: expected {} values, got {}'.format(name, cnt, a.numel()))
                 self.dense_param[off:off + cnt].copy_(a)
+        if getattr(self, '_ctx', None):      # the library's weight images / a staged batch are stale now
+            check(lib.lstur_params_changed(self._ctx), 'lstur_params_changed')
 
     def _slot(self, name):
         for n, off, cnt in self.layout:
@@ -508,6 +510,19 @@ class NativeModel:
     def _train_step(self, user, hist, cands, ids_form, labels=None):
         n = int(user.shape[0])
         s = self._stream()
+        if self.world == 1 and not self.force_collectives:
+            # one process: forward + backward + Adam as ONE library call (include/lstur.h: lstur_train_step) -- the user-table
+            # sweep runs under the encoder backward; same arithmetic as the split calls below
+            fn = lib.lstur_train_step_ids if ids_form else lib.lstur_train_step
+            t = self.optimizer.iterations + 1
+            check(fn(self._ctx, user.data_ptr(), hist.data_ptr(), cands.data_ptr(),
+                     labels.data_ptr() if self.pointwise else None, n, self.step, self.optimizer.lr, t,
+                     self.stats.data_ptr(), s), 'lstur_train_step')
+            if self.pointwise:
+                self.auc.update(labels, self.peek_device('probs')[:n])
+            self.optimizer.iterations = t
+            self.step += 1
+            return
         if self.pointwise:
             fn = lib.lstur_point_forward_backward_ids if ids_form else lib.lstur_point_forward_backward
             check(fn(self._ctx, user.data_ptr(), hist.data_ptr(), cands.data_ptr(), labels.data_ptr(), n, self.step,
