@@ -135,46 +135,79 @@ constexpr int kTitleTok = 8;   // token rows per wave (4 waves)
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-// rows of this wave: t = wv + 4 i.  live[i] = the row exists and is not a pad token; x = dropout(c[row]) (0 otherwise)
-__device__ __forceinline__ void title_load(const float* __restrict__ c, const int32_t* __restrict__ ids, int n, int T, int F,
-                                           int wv, int lane, uint32_t thresh, uint32_t key, float scale,
-                                           float4 (&x)[kTitleTok][2], bool (&live)[kTitleTok], bool (&nz)[kTitleTok]) {
+// The title's non-pad bit mask (bit t = token t exists and is not a pad), in an SGPR.  `live` (one word per title,
+// written by the token compaction) makes it ONE scalar load; without it the wave derives it from the ids by ballot.
+// (The per-row `ids[row]` reads this replaces were a vector-load round trip in FRONT of the row loads: the kernels are
+// latency chains per workgroup -- ids -> rows -> score -> barrier -> pool -- at 3-4 workgroups per CU, and that hop was a
+// quarter of the chain.)
+__device__ __forceinline__ uint32_t title_mask(const uint32_t* __restrict__ live, const int32_t* __restrict__ ids, int n, int T,
+                                               int lane) {
+  const uint32_t all = T >= 32 ? 0xFFFFFFFFu : ((1u << T) - 1u);
+  if (live) return __builtin_amdgcn_readfirstlane(live[n]) & all;
+  if (!ids) return all;
+  const unsigned long long b = __ballot(lane < T && ids[(size_t)n * T + min(lane, T - 1)] != 0);
+  return (uint32_t)b & all;
+}
+// rows of this wave: t = wv + 4 i (live iff bit t of lm).  x = dropout(c[row]) (0 for dead rows); nz = "my 8 values of row i
+// hold a non-zero" (before dropout)
+__device__ __forceinline__ void title_load(const float* __restrict__ c, uint32_t lm, int n, int T, int F, int wv, int lane,
+                                           uint32_t thresh, uint32_t key, float scale, float4 (&x)[kTitleTok][2],
+                                           bool (&nz)[kTitleTok]) {
   const int F4 = F / 4;
-#pragma unroll
-  for (int i = 0; i < kTitleTok; ++i) {
-    const int t = wv + 4 * i;
-    const int row = n * T + min(t, T - 1);
-    live[i] = t < T && (!ids || ids[row] != 0);
-  }
   // all 16 row pieces in flight at once: buffer loads with the out-of-range offset for pad / missing rows and columns
   // past F (a guarded load is a branch + s_waitcnt each, i.e. 16 serialised round trips)
   const __amdgpu_buffer_rsrc_t rsc = make_rsrc(c + (size_t)n * T * F, (uint32_t)T * (uint32_t)F * 4u);
 #pragma unroll
   for (int i = 0; i < kTitleTok; ++i) {
-    const int t = min(wv + 4 * i, T - 1);
+    const int t = wv + 4 * i;
+    const bool lv = (lm >> t) & 1u;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int f4 = lane + 64 * h;
-      x[i][h] = buf_load4(rsc, (live[i] && f4 < F4) ? ((uint32_t)t * (uint32_t)F + (uint32_t)f4 * 4u) * 4u : kBufOob, 0);
+      x[i][h] = buf_load4(rsc, (lv && f4 < F4) ? ((uint32_t)t * (uint32_t)F + (uint32_t)f4 * 4u) * 4u : kBufOob, 0);
     }
   }
 #pragma unroll
   for (int i = 0; i < kTitleTok; ++i) {
-    const int row = n * T + min(wv + 4 * i, T - 1);
+    const int t = wv + 4 * i;
+    const uint32_t row = (uint32_t)n * (uint32_t)T + (uint32_t)t;
     bool any = false;
-    if (live[i]) {   // wave-uniform: pad / missing rows cost no hash work
+    if ((lm >> t) & 1u) {   // wave-uniform (scalar): pad / missing rows cost no hash work
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const float4 v = x[i][h];
         any |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
-        x[i][h] = drop4(v, key, (uint32_t)row * (uint32_t)F + (uint32_t)(lane + 64 * h) * 4u, thresh, scale);
+        x[i][h] = drop4(v, key, row * (uint32_t)F + (uint32_t)(lane + 64 * h) * 4u, thresh, scale);
       }
     }
     nz[i] = any;
   }
 }
+// Sums of 8 per-lane partials over the wave, one row per 8-lane group: 10 cross-lane exchanges instead of 8 x 6.  On
+// return every lane of group g = lane >> 3 holds the wave total of p[g].  (Halving exchange: at distance 32 the lower half
+// keeps rows 0-3 and hands 4-7 over, and so on; three plain butterfly steps finish inside the group.)
+__device__ __forceinline__ float rows8_sum(const float (&p)[kTitleTok], int lane) {
+  float q4[4], q2[2];
+  const bool hi5 = lane & 32, hi4 = lane & 16, hi3 = lane & 8;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float keep = hi5 ? p[4 + j] : p[j], send = hi5 ? p[j] : p[4 + j];
+    q4[j] = keep + __shfl_xor(send, 32, 64);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float keep = hi4 ? q4[2 + j] : q4[j], send = hi4 ? q4[j] : q4[2 + j];
+    q2[j] = keep + __shfl_xor(send, 16, 64);
+  }
+  float r = (hi3 ? q2[1] : q2[0]) + __shfl_xor(hi3 ? q2[0] : q2[1], 8, 64);
+  r += __shfl_xor(r, 4, 64);
+  r += __shfl_xor(r, 2, 64);
+  r += __shfl_xor(r, 1, 64);
+  return r;
+}
 
 __global__ __launch_bounds__(256) void att_fwd_title_kernel(const float* __restrict__ c, const int32_t* __restrict__ ids,
+                                                            const uint32_t* __restrict__ live,
                                                             const float* __restrict__ att_w,
                                                             const float* __restrict__ att_b, float* __restrict__ a_out,
                                                             float* __restrict__ w_out, float* __restrict__ pooled, int T,
@@ -182,26 +215,32 @@ __global__ __launch_bounds__(256) void att_fwd_title_kernel(const float* __restr
   extern __shared__ __attribute__((aligned(16))) float sm[];   // e[32] | part[4][F]
   float* eL = sm;
   float* part = sm + 32;
-  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, F4 = F / 4;
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), F4 = F / 4;
+  const uint32_t lm = title_mask(live, ids, n, T, lane);
   float4 x[kTitleTok][2];
-  bool live[kTitleTok], nz[kTitleTok];
-  title_load(c, ids, n, T, F, wv, lane, thresh, key, scale, x, live, nz);
+  bool nz[kTitleTok];
+  title_load(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz);
   float4 kf[2];
   const __amdgpu_buffer_rsrc_t rs_aw = make_rsrc(att_w, (uint32_t)F * 4u);
 #pragma unroll
   for (int h = 0; h < 2; ++h) kf[h] = buf_load4(rs_aw, (uint32_t)(lane + 64 * h) * 16u, 0);   // past F: zeros
   const float b = att_b[0];
+  // scores: the 8 rows' dot products are reduced together; group g = lane >> 3 ends up with row g, so tanh / exp run once
+  // per wave instead of once per row (each was a whole-wave instruction stream for one lane's value)
+  float ps[kTitleTok];
+  uint32_t mrow = 0;   // bit i: row i holds a non-zero before dropout (Masking: any(c != 0))
 #pragma unroll
   for (int i = 0; i < kTitleTok; ++i) {
-    const int t = wv + 4 * i;
-    float s = wave_sum(dot4(x[i][0], kf[0]) + dot4(x[i][1], kf[1]));
-    const bool m = __any(nz[i]);
-    if (t < T && lane == 0) {
-      float a = 0.f, e = 0.f;
-      if (live[i]) {
-        a = tanhf(s + b);
-        e = m ? expf(a) : 0.f;
-      }
+    ps[i] = dot4(x[i][0], kf[0]) + dot4(x[i][1], kf[1]);
+    mrow |= __any(nz[i]) ? (1u << i) : 0u;
+  }
+  const float srow = rows8_sum(ps, lane);
+  {
+    const int g = lane >> 3, t = wv + 4 * g;
+    const bool lv = (lm >> t) & 1u;
+    const float a = lv ? tanhf(srow + b) : 0.f;
+    const float e = (lv && ((mrow >> g) & 1u)) ? expf(a) : 0.f;
+    if ((lane & 7) == 0 && t < T) {
       a_out[(size_t)n * T + t] = a;
       eL[t] = e;
     }
@@ -243,6 +282,7 @@ __global__ __launch_bounds__(256) void att_fwd_title_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restrict__ c, const int32_t* __restrict__ ids,
+                                                            const uint32_t* __restrict__ live,
                                                             const float* __restrict__ att_w, const float* __restrict__ a,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ dpooled, float* __restrict__ dc,
@@ -253,11 +293,12 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
   float* dwL = sm;
   float* dsL = sm + 32;
   float* red = sm + 64;
-  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, F4 = F / 4;
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), F4 = F / 4;
+  const uint32_t lm = title_mask(live, ids, n, T, lane);
   float4 x[kTitleTok][2];
-  bool live[kTitleTok], nz[kTitleTok];
+  bool nz[kTitleTok];
   float wt[kTitleTok];
-  title_load(c, ids, n, T, F, wv, lane, thresh, key, scale, x, live, nz);
+  title_load(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz);
   float4 dp[2], kf[2];
   const __amdgpu_buffer_rsrc_t rs_aw = make_rsrc(att_w, (uint32_t)F * 4u);
   const __amdgpu_buffer_rsrc_t rs_dp = make_rsrc(dpooled + (size_t)n * F, (uint32_t)F * 4u);
@@ -268,14 +309,21 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
     dp[h] = buf_load4(rs_dp, (uint32_t)(lane + 64 * h) * 16u, 0);
     kf[h] = buf_load4(rs_aw, (uint32_t)(lane + 64 * h) * 16u, 0);
   }
-  float av_[kTitleTok];
+  float av_[kTitleTok], ps[kTitleTok];
 #pragma unroll
   for (int i = 0; i < kTitleTok; ++i) {
     const int t = wv + 4 * i;
-    wt[i] = buf_load1(rs_w, live[i] ? (uint32_t)t * 4u : kBufOob, 0);   // masked rows: weight 0, they contribute nothing
-    av_[i] = buf_load1(rs_a, (uint32_t)t * 4u, 0);                        // t >= T: 0
-    const float s = wave_sum(dot4(x[i][0], dp[0]) + dot4(x[i][1], dp[1]));
-    if (t < T && lane == 0) dwL[t] = wt[i] != 0.f ? s : 0.f;
+    wt[i] = buf_load1(rs_w, ((lm >> t) & 1u) ? (uint32_t)t * 4u : kBufOob, 0);   // masked rows: weight 0, they contribute nothing
+    av_[i] = buf_load1(rs_a, (uint32_t)t * 4u, 0);                                // t >= T: 0
+    ps[i] = dot4(x[i][0], dp[0]) + dot4(x[i][1], dp[1]);
+  }
+  {   // dw_t = dp . x_t for the wave's 8 rows at once (group g = lane >> 3 holds row g)
+    const float srow = rows8_sum(ps, lane);
+    const int g = lane >> 3, t = wv + 4 * g;
+    float wg = wt[0];
+#pragma unroll
+    for (int i = 1; i < kTitleTok; ++i) wg = g == i ? wt[i] : wg;
+    if ((lane & 7) == 0 && t < T) dwL[t] = wg != 0.f ? srow : 0.f;
   }
   __syncthreads();
   float sum = 0.f;
@@ -290,7 +338,7 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
     const float av = av_[i];
     const float dst = (dwL[t] - sum) * wt[i] * (1.0f - av * av);
     if (lane == 0) dsL[t] = dst;
-    if (!live[i]) continue;                            // pad token: its dconv row is neither read nor written
+    if (!((lm >> t) & 1u)) continue;                   // pad token: its dconv row is neither read nor written
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -336,13 +384,14 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
 static bool title_path(int T, int F) { return T <= 4 * kTitleTok && F <= 512 && F % 4 == 0 && !getenv("LSTUR_ATT_STREAMING"); }
 
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
-                        float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s) {
+                        float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s,
+                        const uint32_t* live) {
   if (!n_titles) return;
   uint32_t thresh = drop > 0.f ? dropout_thresh(drop) : 0u;
   float scale = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
   int rows = n_titles * T;
   if (title_path(T, F)) {
-    hipLaunchKernelGGL(att_fwd_title_kernel, dim3(n_titles), dim3(256), (32 + 4 * F) * sizeof(float), s, c, ids, att_w,
+    hipLaunchKernelGGL(att_fwd_title_kernel, dim3(n_titles), dim3(256), (32 + 4 * F) * sizeof(float), s, c, ids, live, att_w,
                        att_b, a, w, pooled, T, F, thresh, key, scale);
     return;
   }
@@ -517,7 +566,8 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
 
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
-                        float drop, uint32_t key, hipStream_t s, int ldp, int off_aw, int off_cb, int off_ab, int relu) {
+                        float drop, uint32_t key, hipStream_t s, int ldp, int off_aw, int off_cb, int off_ab, int relu,
+                        const uint32_t* live) {
   if (ldp <= 0) {   // default layout of the public entry point: datt_w[F] | dconv_b[F] | datt_b
     ldp = 2 * F + 1;
     off_aw = 0;
@@ -530,8 +580,8 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
   const int rows = n_titles * T;
   const int nparts = attpool_bwd_parts(n_titles);
   if (title_path(T, F)) {
-    hipLaunchKernelGGL(att_bwd_title_kernel, dim3(n_titles), dim3(256), (64 + 8 * F) * sizeof(float), s, c, ids, att_w, a, w,
-                       dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu);
+    hipLaunchKernelGGL(att_bwd_title_kernel, dim3(n_titles), dim3(256), (64 + 8 * F) * sizeof(float), s, c, ids, live, att_w, a,
+                       w, dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu);
     return;
   }
   if (F % 4 == 0) {

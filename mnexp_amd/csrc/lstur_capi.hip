@@ -263,7 +263,8 @@ struct Workspace {
   // the staged form of a batch (token ids, their compacted list + offsets, the gathered embeddings) exists twice: while a
   // step runs on one set, the NEXT batch can be staged into the other (lstur_prefetch_ids); ids / e3 / vidx / ... above
   // always point at the set of the running step
-  struct StageSet { int32_t* ids; unsigned short* e3; int32_t* vidx; int32_t* vcount; int32_t* vscratch; int32_t* offA; int32_t* offB; } set[2];
+  uint32_t* live;   // per title: bit t = token t is not a pad (written with the token compaction, read by the attention kernels)
+  struct StageSet { int32_t* ids; unsigned short* e3; int32_t* vidx; int32_t* vcount; int32_t* vscratch; int32_t* offA; int32_t* offB; uint32_t* live; } set[2];
   size_t bytes;
 };
 
@@ -400,7 +401,8 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->offA = (int32_t*)take(nt * d.T * 4);
   w->offB = (int32_t*)take(nt * d.T * 4);
   w->vscratch = (int32_t*)take(compact_scratch_ints((int)(nt * d.T)) * 4);
-  w->set[0] = Workspace::StageSet{w->ids, w->e3, w->vidx, w->vcount, w->vscratch, w->offA, w->offB};
+  w->live = (uint32_t*)take(nt * 4);
+  w->set[0] = Workspace::StageSet{w->ids, w->e3, w->vidx, w->vcount, w->vscratch, w->offA, w->offB, w->live};
   w->set[1] = w->set[0];
   if (c3 && d.head == LSTUR_HEAD_SOFTMAX && !d.word_trainable) {   // second staging set (prefetch of the next batch)
     w->set[1].ids = (int32_t*)take(nt * d.T * 4);
@@ -410,6 +412,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
     w->set[1].offA = (int32_t*)take(nt * d.T * 4);
     w->set[1].offB = (int32_t*)take(nt * d.T * 4);
     w->set[1].vscratch = (int32_t*)take(compact_scratch_ints((int)(nt * d.T)) * 4);
+    w->set[1].live = (uint32_t*)take(nt * 4);
   }
   w->bytes = off;
 }
@@ -560,7 +563,7 @@ void use_set(lstur_ctx* c, int k) {
   Workspace& w = c->ws;
   c->cur_set = k;
   w.ids = w.set[k].ids; w.e3 = w.set[k].e3; w.vidx = w.set[k].vidx; w.vcount = w.set[k].vcount;
-  w.vscratch = w.set[k].vscratch; w.offA = w.set[k].offA; w.offB = w.set[k].offB;
+  w.vscratch = w.set[k].vscratch; w.offA = w.set[k].offA; w.offB = w.set[k].offB; w.live = w.set[k].live;
 }
 
 // enqueue the pending prefetch (if any) on the side stream, behind everything `s` holds so far; true: something was launched
@@ -594,7 +597,7 @@ bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
   const int nW = q.n * d.W, nt = nW + q.n * d.K1, pl = (d.k - 1) / 2;
   launch_expand_count(c->title_table, q.hist, nW, q.cands, q.n * d.K1, d.T, t.ids, t.vscratch, p);
   launch_compact_write_offsets(t.ids, nt * d.T, t.vscratch, t.vidx, t.vcount, d.T, d.Tp, conv3_dp(d.D) / 8 * 3, d.F, t.offA,
-                               t.offB, p);
+                               t.offB, p, t.live);
   {
     ProfScope _ps(c, "gather", p);
     static const int pf_blocks = getenv("LSTUR_PREFETCH_BLOCKS") ? atoi(getenv("LSTUR_PREFETCH_BLOCKS")) : 0;
@@ -798,7 +801,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   c->counted_flag() = false;
   // (offA: a token's window offset in the units of its path -- 16-byte pieces of E3, or floats of the fp32 layout)
   launch_compact_write_offsets(w.ids, nt * d.T, w.vscratch, w.vidx, w.vcount, d.T, d.Tp,
-                               (use3 && !gen1) ? conv3_dp(d.D) / 8 * 3 : d.D, d.F, w.offA, w.offB, s);
+                               (use3 && !gen1) ? conv3_dp(d.D) / 8 * 3 : d.D, d.F, w.offA, w.offB, s, w.live);
   if (use3 && !gen1)   // Embedding + Dropout straight into the pre-split layout of the bf16x3 conv kernels (rows nobody reads skipped)
     PROF("gather", launch_gather3(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, s));
   else
@@ -819,7 +822,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
                                      w.vcount, s));
   }
   PROF("attpool_fwd", launch_attpool_fwd(w.conv, w.ids, c->P("att_w"), c->P("att_b"), w.pooled, w.att_a, w.att_wt, nt, d.T, d.F,
-                                         drop, key1, s));
+                                         drop, key1, s, w.live));
   launch_gemm(w.pooled, d.F, 0, c->P("dense_w"), d.U, 0, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, 1.f,
               w.gemm_scratch, s);
   // user encoder (paper.py:584-633)
@@ -1001,7 +1004,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     const int off_aw = 0, off_ab = (int)(c->G("att_b") - c->G("att_w")), off_cb = off_ab + (int)kParamAlign;
     const int ldp = off_cb + (int)((d.F + kParamAlign - 1) / kParamAlign * kParamAlign);
     PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
-                                           w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 0));
+                                           w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 0, w.live));
     launch_colsum2(w.parts, attpool_bwd_parts(nt), off_ab + 1, ldp, c->G("att_w"), 1.f, w.colsum_scratch_k[2], s,
                    &jobs[nj++]);
     PROF("mhsa_bwd", launch_mhsa_bwd_bf16(w.qkv, w.dconv, w.ids, w.dqkv, nt, d.T, d.F, d.heads, s));
@@ -1022,7 +1025,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   const int off_cb = 0, off_aw = (int)(c->G("att_w") - c->G("conv_b")), off_ab = (int)(c->G("att_b") - c->G("conv_b"));
   const int ldp = off_ab + 1;
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
-                                         w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab));
+                                         w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 1, w.live));
   // (on the side stream this one found no free CU beside the conv kernel gradient and finished behind it)
   launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch_k[2], s, &jobs[nj++]);
   if (d.word_trainable) {   // conv input gradient -> word-table gradient (embedding dropout mask = stream 0 of the step)

@@ -54,7 +54,8 @@ void launch_expand_count(const int32_t* table, const int32_t* hist_ids, int n_hi
                          int T, int32_t* out, int32_t* block_counts, hipStream_t s);
 void launch_compact_count(const int32_t* ids, int n, int32_t* block_counts, hipStream_t s);
 void launch_compact_write_offsets(const int32_t* ids, int n, const int32_t* block_counts, int32_t* vidx, int32_t* count,
-                                  int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s);
+                                  int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s,
+                                  uint32_t* live = nullptr);   // live != NULL: + the titles' non-pad bit masks
 size_t pack_b_floats(int K, int N);
 void launch_pack_b(const float* B, int ldb, int K, int N, float* packed, hipStream_t s);
 void launch_pack_b_t(const float* Bt, int ldb, int K, int N, float* packed, hipStream_t s);
@@ -172,15 +173,17 @@ int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, 
                         const int32_t* offB, float alpha = 1.0f, int cus = 0);
 
 // ---- attpool.hip -------------------------------------------------------------------------------
-// ids (nullable): rows with id == 0 are taken as zero without reading c / writing dc
+// ids (nullable): rows with id == 0 are taken as zero without reading c / writing dc.  live (nullable): the titles' non-pad
+// bit masks of launch_compact_write_offsets for the same ids -- one scalar per title instead of an ids read per row
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
-                        float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s);
+                        float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s,
+                        const uint32_t* live = nullptr);
 int attpool_bwd_parts(int n_titles);
 // row_scratch: n_titles*T floats (dw -> ds)
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
                         float drop, uint32_t key, hipStream_t s, int ldp = 0, int off_aw = 0, int off_cb = 0,
-                        int off_ab = 0, int relu = 1);
+                        int off_ab = 0, int relu = 1, const uint32_t* live = nullptr);
 
 // ---- mhsa.hip (build-defined multi-head self-attention token stage; T <= 32, F/heads in {16, 32, 64}) -------
 bool mhsa_supported(int T, int F, int heads);

@@ -311,7 +311,17 @@ __global__ __launch_bounds__(256) void compact_write_offsets_kernel(const int32_
                                                                     int32_t* __restrict__ vidx,
                                                                     int32_t* __restrict__ count_out, int T, int Tp, int D,
                                                                     int F, int32_t* __restrict__ offA,
-                                                                    int32_t* __restrict__ offB) {
+                                                                    int32_t* __restrict__ offB, int nblk,
+                                                                    uint32_t* __restrict__ live) {
+  if ((int)blockIdx.x >= nblk) {   // trailing blocks: bit t of live[title] = token t is not a pad (t < 32): the attention
+    const int title = ((int)blockIdx.x - nblk) * 256 + threadIdx.x;   // kernels read ONE scalar per title instead of ids
+    if (title * T < n) {
+      uint32_t m = 0;
+      for (int t = 0; t < T && t < 32; ++t) m |= (ids[title * T + t] != 0 ? 1u : 0u) << t;
+      live[title] = m;
+    }
+    return;
+  }
   __shared__ int red[4];
   int part = 0;
   for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += block_counts[b];
@@ -343,14 +353,16 @@ __global__ __launch_bounds__(256) void compact_write_offsets_kernel(const int32_
       }
       ++pos;
     }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) count_out[0] = base + total;
+  if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) count_out[0] = base + total;
 }
 size_t compact_scratch_ints(int n) { return (size_t)cdiv(n, kCompactBlock); }
 void launch_compact_write_offsets(const int32_t* ids, int n, const int32_t* block_counts, int32_t* vidx, int32_t* count,
-                                  int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s) {
+                                  int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s,
+                                  uint32_t* live) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(compact_write_offsets_kernel, dim3(cdiv(n, kCompactBlock)), dim3(256), 0, s, ids, n, block_counts,
-                     vidx, count, T, Tp, D, F, offA, offB);
+  const int nblk = cdiv(n, kCompactBlock), lblk = live ? cdiv(n / T, 256) : 0;
+  hipLaunchKernelGGL(compact_write_offsets_kernel, dim3(nblk + lblk), dim3(256), 0, s, ids, n, block_counts, vidx, count, T,
+                     Tp, D, F, offA, offB, nblk, live);
 }
 void launch_compact_count(const int32_t* ids, int n, int32_t* block_counts, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(compact_count_kernel, dim3(cdiv(n, kCompactBlock)), dim3(256), 0, s, ids, n, block_counts);
