@@ -150,6 +150,7 @@ __device__ __forceinline__ uint32_t title_mask(const uint32_t* __restrict__ live
 }
 // rows of this wave: t = wv + 4 i (live iff bit t of lm).  x = dropout(c[row]) (0 for dead rows); nz = "my 8 values of row i
 // hold a non-zero" (before dropout)
+template <bool NZ = true>
 __device__ __forceinline__ void title_load(const float* __restrict__ c, uint32_t lm, int n, int T, int F, int wv, int lane,
                                            uint32_t thresh, uint32_t key, float scale, float4 (&x)[kTitleTok][2],
                                            bool (&nz)[kTitleTok]) {
@@ -176,7 +177,7 @@ __device__ __forceinline__ void title_load(const float* __restrict__ c, uint32_t
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const float4 v = x[i][h];
-        any |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+        if (NZ) any |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
         x[i][h] = drop4(v, key, row * (uint32_t)F + (uint32_t)(lane + 64 * h) * 4u, thresh, scale);
       }
     }
@@ -281,6 +282,12 @@ __global__ __launch_bounds__(256) void att_fwd_title_kernel(const float* __restr
   }
 }
 
+// the value lane `l` (wave-uniform) holds, as a scalar
+__device__ __forceinline__ float lane_value(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+// (per-row scalars -- weight, 1 - a^2, ds -- live in LANE t of every wave and reach the row loops through v_readlane, i.e.
+//  as SGPRs: the kernel sits at 128 VGPRs = 4 workgroups per CU; with them in per-row registers it was 132 = 3)
 __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restrict__ c, const int32_t* __restrict__ ids,
                                                             const uint32_t* __restrict__ live,
                                                             const float* __restrict__ att_w, const float* __restrict__ a,
@@ -289,16 +296,14 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
                                                             float* __restrict__ parts, int T, int F, uint32_t thresh,
                                                             uint32_t key, float scale, int ldp, int off_aw, int off_cb,
                                                             int off_ab, int relu) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // dw[32] | ds[32] | red[4][2][F]
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // dw[32] | (unused)[32] | red[4][2][F]
   float* dwL = sm;
-  float* dsL = sm + 32;
   float* red = sm + 64;
   const int n = blockIdx.x, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), F4 = F / 4;
   const uint32_t lm = title_mask(live, ids, n, T, lane);
   float4 x[kTitleTok][2];
   bool nz[kTitleTok];
-  float wt[kTitleTok];
-  title_load(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz);
+  title_load<false>(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz);
   float4 dp[2], kf[2];
   const __amdgpu_buffer_rsrc_t rs_aw = make_rsrc(att_w, (uint32_t)F * 4u);
   const __amdgpu_buffer_rsrc_t rs_dp = make_rsrc(dpooled + (size_t)n * F, (uint32_t)F * 4u);
@@ -309,49 +314,41 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
     dp[h] = buf_load4(rs_dp, (uint32_t)(lane + 64 * h) * 16u, 0);
     kf[h] = buf_load4(rs_aw, (uint32_t)(lane + 64 * h) * 16u, 0);
   }
-  float av_[kTitleTok], ps[kTitleTok];
-#pragma unroll
-  for (int i = 0; i < kTitleTok; ++i) {
-    const int t = wv + 4 * i;
-    wt[i] = buf_load1(rs_w, ((lm >> t) & 1u) ? (uint32_t)t * 4u : kBufOob, 0);   // masked rows: weight 0, they contribute nothing
-    av_[i] = buf_load1(rs_a, (uint32_t)t * 4u, 0);                                // t >= T: 0
-    ps[i] = dot4(x[i][0], dp[0]) + dot4(x[i][1], dp[1]);
-  }
+  // lane t: the title's attention weight (0 for masked / pad rows, and past T) and tanh output of token t
+  const float w_t = buf_load1(rs_w, (uint32_t)lane * 4u, 0), a_t = buf_load1(rs_a, (uint32_t)lane * 4u, 0);
   {   // dw_t = dp . x_t for the wave's 8 rows at once (group g = lane >> 3 holds row g)
-    const float srow = rows8_sum(ps, lane);
-    const int g = lane >> 3, t = wv + 4 * g;
-    float wg = wt[0];
+    float ps[kTitleTok];
 #pragma unroll
-    for (int i = 1; i < kTitleTok; ++i) wg = g == i ? wt[i] : wg;
-    if ((lane & 7) == 0 && t < T) dwL[t] = wg != 0.f ? srow : 0.f;
+    for (int i = 0; i < kTitleTok; ++i) ps[i] = dot4(x[i][0], dp[0]) + dot4(x[i][1], dp[1]);
+    const float srow = rows8_sum(ps, lane);
+    const int t = wv + 4 * (lane >> 3);
+    if ((lane & 7) == 0 && t < T) dwL[t] = srow;
   }
   __syncthreads();
-  float sum = 0.f;
-  for (int t = 0; t < T; ++t) sum += dwL[t] * w[(size_t)n * T + t];
+  // every wave: lane t holds dw_t (0 where the weight is 0: those rows contribute nothing), then ds_t
+  const float dw_t = (lane < T && w_t != 0.f) ? dwL[lane] : 0.f;
+  const float sum = wave_sum(dw_t * w_t);
+  const float ds_t = (dw_t - sum) * w_t * (1.0f - a_t * a_t);
   const __amdgpu_buffer_rsrc_t rs_dc = make_rsrc(dc + (size_t)n * T * F, (uint32_t)T * (uint32_t)F * 4u);
   float4 gaw[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, gcb[2] = {gaw[0], gaw[0]};
 #pragma unroll
   for (int i = 0; i < kTitleTok; ++i) {
     const int t = wv + 4 * i;
-    if (t >= T) continue;
-    const size_t row = (size_t)n * T + t;
-    const float av = av_[i];
-    const float dst = (dwL[t] - sum) * wt[i] * (1.0f - av * av);
-    if (lane == 0) dsL[t] = dst;
-    if (!((lm >> t) & 1u)) continue;                   // pad token: its dconv row is neither read nor written
+    if (!((lm >> t) & 1u)) continue;                   // pad / missing token: its dconv row is neither read nor written
+    const float wt = lane_value(w_t, t), dst = lane_value(ds_t, t);   // SGPRs
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (wt[i] != 0.f) {
+      if (wt != 0.f) {                                 // (scalar branch)
         const float4 xv = x[i][h];
         gaw[h].x += dst * xv.x;
         gaw[h].y += dst * xv.y;
         gaw[h].z += dst * xv.z;
         gaw[h].w += dst * xv.w;
-        o.x = grad_gate(xv.x, relu) ? (dp[h].x * wt[i] + dst * kf[h].x) * scale : 0.f;
-        o.y = grad_gate(xv.y, relu) ? (dp[h].y * wt[i] + dst * kf[h].y) * scale : 0.f;
-        o.z = grad_gate(xv.z, relu) ? (dp[h].z * wt[i] + dst * kf[h].z) * scale : 0.f;
-        o.w = grad_gate(xv.w, relu) ? (dp[h].w * wt[i] + dst * kf[h].w) * scale : 0.f;
+        o.x = grad_gate(xv.x, relu) ? (dp[h].x * wt + dst * kf[h].x) * scale : 0.f;
+        o.y = grad_gate(xv.y, relu) ? (dp[h].y * wt + dst * kf[h].y) * scale : 0.f;
+        o.z = grad_gate(xv.z, relu) ? (dp[h].z * wt + dst * kf[h].z) * scale : 0.f;
+        o.w = grad_gate(xv.w, relu) ? (dp[h].w * wt + dst * kf[h].w) * scale : 0.f;
         gcb[h].x += o.x;
         gcb[h].y += o.y;
         gcb[h].z += o.z;
@@ -375,10 +372,10 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
     for (int k = 0; k < 4; ++k) r += red[(k * 2 + which) * F + f];
     pr[(which ? off_cb : off_aw) + f] = r;
   }
-  if (threadIdx.x == 0) {
+  if (wv == 0) {   // datt_b = sum_t ds_t, in lane order (lanes past T hold 0)
     float gab = 0.f;
-    for (int t = 0; t < T; ++t) gab += dsL[t];
-    pr[off_ab] = gab;
+    for (int t = 0; t < T; ++t) gab += lane_value(ds_t, t);
+    if (lane == 0) pr[off_ab] = gab;
   }
 }
 static bool title_path(int T, int F) { return T <= 4 * kTitleTok && F <= 512 && F % 4 == 0 && !getenv("LSTUR_ATT_STREAMING"); }

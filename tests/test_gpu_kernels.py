@@ -495,3 +495,64 @@ def test_conv3_fwd2_presplit_is_fp32_grade(N, D, T, F, k, sliced):
     check(lib.lstur_conv3_wgrad2(e3.data_ptr(), dC_g.data_ptr(), dw2.data_ptr(), wscr.data_ptr(), offs.data_ptr(), N, T, D, k, F,
                                  vidx.data_ptr(), vcount.data_ptr(), stream()))
     assert (dw2.double() - ref2).abs().max().item() < 2e-5 * wscale
+
+
+@pytest.mark.parametrize('N,T,F,drop', [(37, 30, 400, 0.2), (9, 32, 512, 0.0), (21, 11, 80, 0.25), (5, 30, 404, 0.2)])
+def test_attpool_title_kernels_against_fp64(N, T, F, drop):
+    """Masking -> Dropout -> SimpleAttentionMaskSupport (paper.py:157-158, models.py:474-489) forward and backward through
+    lstur_attpool_fwd / _bwd (the title-resident kernels) against the formulas in fp64.  Pad tokens sit at the tail, in the
+    middle and over whole titles; their conv rows hold NaN (the kernels must neither read nor write them); a live token whose
+    conv row is all zero is masked out of the softmax (Masking = any(c != 0))."""
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    from oracle import lstur_oracle as O
+    rng = np.random.default_rng(3)
+    ids = rng.integers(1, 50, size=(N, T)).astype(np.int32)
+    for n in range(N):
+        ids[n, rng.integers(T // 2, T + 1):] = 0          # padded tail (possibly none)
+    ids[1, 2] = 0                                          # a pad inside a title
+    ids[2] = 0                                             # an all-pad title
+    c = np.maximum(rng.normal(0, 1, size=(N, T, F)), 0).astype(np.float32)
+    c[3, 1] = 0                                            # live token, all-zero conv row: Masking drops it
+    live = ids != 0
+    k = rng.normal(0, 0.2, size=F).astype(np.float32)
+    b = np.float32(0.1)
+    dp = rng.normal(0, 1, size=(N, F)).astype(np.float32)
+    key = O.dropout_key(7, 3, 1)
+    keep = np.ones(N * T * F, bool) if drop == 0 else O.dropout_keep(key, N * T * F, drop)
+    scale = 1.0 / (1.0 - drop)
+    x = np.where(live[..., None], c.astype(np.float64), 0.0) * keep.reshape(N, T, F) * scale
+    a = np.where(live, np.tanh(x @ k.astype(np.float64) + np.float64(b)), 0.0)
+    m = live & (c != 0).any(-1)
+    e = np.exp(a) * m
+    w = e / (e.sum(-1, keepdims=True) + 1e-7)
+    pooled = (x * w[..., None]).sum(1)
+    dw = (x * dp[:, None, :].astype(np.float64)).sum(-1)
+    ds = (dw - (dw * w).sum(-1, keepdims=True)) * w * (1 - a * a)
+    dx = dp[:, None, :].astype(np.float64) * w[..., None] + ds[..., None] * k.astype(np.float64)
+    dc = dx * keep.reshape(N, T, F) * scale * (c > 0) * live[..., None]
+    c_dev = c.copy()
+    c_dev[~live] = np.nan
+    cd, idd, kd, bd, dpd = dev(c_dev), dev(ids), dev(k), dev(np.array([b], np.float32)), dev(dp)
+    f32 = dict(dtype=torch.float32, device='cuda')
+    pool_g, a_g, w_g = torch.zeros(N, F, **f32), torch.zeros(N, T, **f32), torch.zeros(N, T, **f32)
+    check(lib.lstur_attpool_fwd(cd.data_ptr(), idd.data_ptr(), kd.data_ptr(), bd.data_ptr(), pool_g.data_ptr(), a_g.data_ptr(),
+                                w_g.data_ptr(), N, T, F, drop, key, stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(a_g.cpu().numpy(), a, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(w_g.cpu().numpy(), w, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(pool_g.cpu().numpy(), pooled, rtol=2e-5, atol=2e-6)
+    nparts = lib.lstur_attpool_bwd_parts(N)
+    dc_g = torch.full((N, T, F), float('nan'), **f32)
+    parts = torch.zeros(nparts, 2 * F + 1, **f32)
+    scratch = torch.zeros(N * T, **f32)
+    check(lib.lstur_attpool_bwd(cd.data_ptr(), idd.data_ptr(), kd.data_ptr(), a_g.data_ptr(), w_g.data_ptr(), dpd.data_ptr(),
+                                dc_g.data_ptr(), parts.data_ptr(), scratch.data_ptr(), N, T, F, drop, key, stream()))
+    torch.cuda.synchronize()
+    got = dc_g.cpu().numpy()
+    assert np.isnan(got[~live]).all()                      # pad rows untouched
+    np.testing.assert_allclose(got[live], dc[live], rtol=2e-5, atol=2e-6)
+    red = parts.cpu().numpy().astype(np.float64).sum(0)
+    np.testing.assert_allclose(red[:F], (ds[..., None] * x).sum((0, 1)), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(red[F:2 * F], dc.sum((0, 1)), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(red[2 * F], ds.sum(), rtol=1e-4, atol=1e-5)
