@@ -132,6 +132,7 @@ __global__ __launch_bounds__(128) void att_pool_kernel(const float* __restrict__
 // registers.  Cross-wave sums go through LDS in fixed wave order (bitwise reproducible).
 // ---------------------------------------------------------------------------------------------
 constexpr int kTitleTok = 8;   // token rows per wave (4 waves)
+static bool title_path(int T, int F) { return T <= 4 * kTitleTok && F <= 512 && F % 4 == 0 && !getenv("LSTUR_ATT_STREAMING"); }
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
@@ -150,11 +151,25 @@ __device__ __forceinline__ uint32_t title_mask(const uint32_t* __restrict__ live
 }
 // rows of this wave: t = wv + 4 i (live iff bit t of lm).  x = dropout(c[row]) (0 for dead rows); nz = "my 8 values of row i
 // hold a non-zero" (before dropout)
+// v * scale where the keep bit is set, else 0: bit -> all-ones / zero word (v_bfe_i32) -> AND, 2 instructions per element
+__device__ __forceinline__ float keep_scaled(float v, uint32_t bits, int pos, float scale) {
+  const int m = __builtin_amdgcn_sbfe((int)bits, pos, 1);
+  return __int_as_float(__float_as_int(v * scale) & m);
+}
+// kbits (nullable): the keep decisions of this title's conv-output dropout, precomputed by launch_attpool_keep_bits for the
+// same (key, thresh): word h of thread (wv, lane) holds bit 4 i + e for element e of piece h of row i.  Both attention
+// passes are VALU-bound once the id loads are gone, and two hashes per piece (three quarter-rate integer multiplies each)
+// were a quarter of their instruction stream; the bits are made off the critical path (with the next batch's staging).
 template <bool NZ = true>
 __device__ __forceinline__ void title_load(const float* __restrict__ c, uint32_t lm, int n, int T, int F, int wv, int lane,
                                            uint32_t thresh, uint32_t key, float scale, float4 (&x)[kTitleTok][2],
-                                           bool (&nz)[kTitleTok]) {
+                                           bool (&nz)[kTitleTok], const uint32_t* __restrict__ kbits = nullptr) {
   const int F4 = F / 4;
+  uint32_t kb[2] = {0u, 0u};
+  if (kbits) {
+    kb[0] = kbits[((size_t)n * 2 + 0) * 256 + threadIdx.x];
+    kb[1] = kbits[((size_t)n * 2 + 1) * 256 + threadIdx.x];
+  }
   // all 16 row pieces in flight at once: buffer loads with the out-of-range offset for pad / missing rows and columns
   // past F (a guarded load is a branch + s_waitcnt each, i.e. 16 serialised round trips)
   const __amdgpu_buffer_rsrc_t rsc = make_rsrc(c + (size_t)n * T * F, (uint32_t)T * (uint32_t)F * 4u);
@@ -173,7 +188,18 @@ __device__ __forceinline__ void title_load(const float* __restrict__ c, uint32_t
     const int t = wv + 4 * i;
     const uint32_t row = (uint32_t)n * (uint32_t)T + (uint32_t)t;
     bool any = false;
-    if ((lm >> t) & 1u) {   // wave-uniform (scalar): pad / missing rows cost no hash work
+    if (kbits) {            // (dead rows were loaded as zeros and stay zero: no branch)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float4 v = x[i][h];
+        if (NZ) any |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+        v.x = keep_scaled(v.x, kb[h], 4 * i + 0, scale);
+        v.y = keep_scaled(v.y, kb[h], 4 * i + 1, scale);
+        v.z = keep_scaled(v.z, kb[h], 4 * i + 2, scale);
+        v.w = keep_scaled(v.w, kb[h], 4 * i + 3, scale);
+        x[i][h] = v;
+      }
+    } else if ((lm >> t) & 1u) {   // wave-uniform (scalar): pad / missing rows cost no hash work
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const float4 v = x[i][h];
@@ -207,12 +233,43 @@ __device__ __forceinline__ float rows8_sum(const float (&p)[kTitleTok], int lane
   return r;
 }
 
+// keep bits of the conv-output dropout in the title kernels' thread layout (see title_load); dead rows and columns past F: 0
+__global__ __launch_bounds__(256) void att_keep_bits_kernel(const uint32_t* __restrict__ live, uint32_t* __restrict__ kbits,
+                                                            int T, int F, uint32_t thresh, uint32_t key) {
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), F4 = F / 4;
+  const uint32_t lm = title_mask(live, nullptr, n, T, lane);
+  uint32_t kb[2] = {0u, 0u};
+#pragma unroll
+  for (int i = 0; i < kTitleTok; ++i) {
+    const int t = wv + 4 * i;
+    if (!((lm >> t) & 1u)) continue;
+    const uint32_t row = (uint32_t)n * (uint32_t)T + (uint32_t)t;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (lane + 64 * h >= F4) continue;
+      bool k[4];
+      keep_quad(key, row * (uint32_t)F + (uint32_t)(lane + 64 * h) * 4u, thresh, k);
+      kb[h] |= ((k[0] ? 1u : 0u) | (k[1] ? 2u : 0u) | (k[2] ? 4u : 0u) | (k[3] ? 8u : 0u)) << (4 * i);
+    }
+  }
+  kbits[((size_t)n * 2 + 0) * 256 + threadIdx.x] = kb[0];
+  kbits[((size_t)n * 2 + 1) * 256 + threadIdx.x] = kb[1];
+}
+size_t attpool_keep_bits_words(int n_titles) { return (size_t)n_titles * 512; }
+bool launch_attpool_keep_bits(const uint32_t* live, uint32_t* kbits, int n_titles, int T, int F, float drop, uint32_t key,
+                              hipStream_t s) {
+  if (!n_titles || !live || !kbits || !(drop > 0.f) || !title_path(T, F)) return false;
+  hipLaunchKernelGGL(att_keep_bits_kernel, dim3(n_titles), dim3(256), 0, s, live, kbits, T, F, dropout_thresh(drop), key);
+  return true;
+}
+
 __global__ __launch_bounds__(256) void att_fwd_title_kernel(const float* __restrict__ c, const int32_t* __restrict__ ids,
                                                             const uint32_t* __restrict__ live,
                                                             const float* __restrict__ att_w,
                                                             const float* __restrict__ att_b, float* __restrict__ a_out,
                                                             float* __restrict__ w_out, float* __restrict__ pooled, int T,
-                                                            int F, uint32_t thresh, uint32_t key, float scale) {
+                                                            int F, uint32_t thresh, uint32_t key, float scale,
+                                                            const uint32_t* __restrict__ kbits) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // e[32] | part[4][F]
   float* eL = sm;
   float* part = sm + 32;
@@ -220,7 +277,7 @@ __global__ __launch_bounds__(256) void att_fwd_title_kernel(const float* __restr
   const uint32_t lm = title_mask(live, ids, n, T, lane);
   float4 x[kTitleTok][2];
   bool nz[kTitleTok];
-  title_load(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz);
+  title_load(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz, kbits);
   float4 kf[2];
   const __amdgpu_buffer_rsrc_t rs_aw = make_rsrc(att_w, (uint32_t)F * 4u);
 #pragma unroll
@@ -295,7 +352,7 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
                                                             const float* __restrict__ dpooled, float* __restrict__ dc,
                                                             float* __restrict__ parts, int T, int F, uint32_t thresh,
                                                             uint32_t key, float scale, int ldp, int off_aw, int off_cb,
-                                                            int off_ab, int relu) {
+                                                            int off_ab, int relu, const uint32_t* __restrict__ kbits) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // dw[32] | (unused)[32] | red[4][2][F]
   float* dwL = sm;
   float* red = sm + 64;
@@ -303,7 +360,7 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
   const uint32_t lm = title_mask(live, ids, n, T, lane);
   float4 x[kTitleTok][2];
   bool nz[kTitleTok];
-  title_load<false>(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz);
+  title_load<false>(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz, kbits);
   float4 dp[2], kf[2];
   const __amdgpu_buffer_rsrc_t rs_aw = make_rsrc(att_w, (uint32_t)F * 4u);
   const __amdgpu_buffer_rsrc_t rs_dp = make_rsrc(dpooled + (size_t)n * F, (uint32_t)F * 4u);
@@ -378,18 +435,17 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
     if (lane == 0) pr[off_ab] = gab;
   }
 }
-static bool title_path(int T, int F) { return T <= 4 * kTitleTok && F <= 512 && F % 4 == 0 && !getenv("LSTUR_ATT_STREAMING"); }
 
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
                         float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s,
-                        const uint32_t* live) {
+                        const uint32_t* live, const uint32_t* kbits) {
   if (!n_titles) return;
   uint32_t thresh = drop > 0.f ? dropout_thresh(drop) : 0u;
   float scale = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
   int rows = n_titles * T;
   if (title_path(T, F)) {
     hipLaunchKernelGGL(att_fwd_title_kernel, dim3(n_titles), dim3(256), (32 + 4 * F) * sizeof(float), s, c, ids, live, att_w,
-                       att_b, a, w, pooled, T, F, thresh, key, scale);
+                       att_b, a, w, pooled, T, F, thresh, key, scale, thresh ? kbits : nullptr);
     return;
   }
   if (F % 4 == 0) {
@@ -564,7 +620,7 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
                         float drop, uint32_t key, hipStream_t s, int ldp, int off_aw, int off_cb, int off_ab, int relu,
-                        const uint32_t* live) {
+                        const uint32_t* live, const uint32_t* kbits) {
   if (ldp <= 0) {   // default layout of the public entry point: datt_w[F] | dconv_b[F] | datt_b
     ldp = 2 * F + 1;
     off_aw = 0;
@@ -578,7 +634,8 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
   const int nparts = attpool_bwd_parts(n_titles);
   if (title_path(T, F)) {
     hipLaunchKernelGGL(att_bwd_title_kernel, dim3(n_titles), dim3(256), (64 + 8 * F) * sizeof(float), s, c, ids, live, att_w, a,
-                       w, dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu);
+                       w, dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu,
+                       thresh ? kbits : nullptr);
     return;
   }
   if (F % 4 == 0) {

@@ -264,7 +264,9 @@ struct Workspace {
   // step runs on one set, the NEXT batch can be staged into the other (lstur_prefetch_ids); ids / e3 / vidx / ... above
   // always point at the set of the running step
   uint32_t* live;   // per title: bit t = token t is not a pad (written with the token compaction, read by the attention kernels)
-  struct StageSet { int32_t* ids; unsigned short* e3; int32_t* vidx; int32_t* vcount; int32_t* vscratch; int32_t* offA; int32_t* offB; uint32_t* live; } set[2];
+  uint32_t* kbits;  // conv-output dropout keep bits of a PREFETCHED batch (attention kernels' thread layout)
+  bool kbits_valid = false;
+  struct StageSet { int32_t* ids; unsigned short* e3; int32_t* vidx; int32_t* vcount; int32_t* vscratch; int32_t* offA; int32_t* offB; uint32_t* live; uint32_t* kbits; } set[2];
   size_t bytes;
 };
 
@@ -402,7 +404,8 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->offB = (int32_t*)take(nt * d.T * 4);
   w->vscratch = (int32_t*)take(compact_scratch_ints((int)(nt * d.T)) * 4);
   w->live = (uint32_t*)take(nt * 4);
-  w->set[0] = Workspace::StageSet{w->ids, w->e3, w->vidx, w->vcount, w->vscratch, w->offA, w->offB, w->live};
+  w->kbits = nullptr;
+  w->set[0] = Workspace::StageSet{w->ids, w->e3, w->vidx, w->vcount, w->vscratch, w->offA, w->offB, w->live, nullptr};
   w->set[1] = w->set[0];
   if (c3 && d.head == LSTUR_HEAD_SOFTMAX && !d.word_trainable) {   // second staging set (prefetch of the next batch)
     w->set[1].ids = (int32_t*)take(nt * d.T * 4);
@@ -413,6 +416,8 @@ void carve(const Dims& d, void* base, Workspace* w) {
     w->set[1].offB = (int32_t*)take(nt * d.T * 4);
     w->set[1].vscratch = (int32_t*)take(compact_scratch_ints((int)(nt * d.T)) * 4);
     w->set[1].live = (uint32_t*)take(nt * 4);
+    w->set[0].kbits = (uint32_t*)take(attpool_keep_bits_words((int)nt) * 4);   // (only prefetched batches carry them)
+    w->set[1].kbits = (uint32_t*)take(attpool_keep_bits_words((int)nt) * 4);
   }
   w->bytes = off;
 }
@@ -462,7 +467,7 @@ struct lstur_ctx {
   // staging prefetch (lstur_prefetch_ids): the next batch's title expansion, compaction and embedding gather run on a
   // side stream under the current step's forward recurrence (HBM and 240 CUs idle there)
   struct Pending { const int32_t* hist = nullptr; const int32_t* cands = nullptr; int n = 0; uint32_t step = 0;
-                   bool valid = false, launched = false; } pend, ready;   // announced | staged in the other set
+                   bool valid = false, launched = false, kbits = false; } pend, ready;   // announced | staged in the other set
   int prefetch_hits = 0;
   int cur_set = 0;
   bool staged_hit = false;              // this step's staging was prefetched: run_forward skips it
@@ -564,6 +569,7 @@ void use_set(lstur_ctx* c, int k) {
   c->cur_set = k;
   w.ids = w.set[k].ids; w.e3 = w.set[k].e3; w.vidx = w.set[k].vidx; w.vcount = w.set[k].vcount;
   w.vscratch = w.set[k].vscratch; w.offA = w.set[k].offA; w.offB = w.set[k].offB; w.live = w.set[k].live;
+  w.kbits = w.set[k].kbits;
 }
 
 // enqueue the pending prefetch (if any) on the side stream, behind everything `s` holds so far; true: something was launched
@@ -604,6 +610,8 @@ bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
     launch_gather3(c->buf.word_emb, t.ids, t.e3, nt, d.T, d.D, pl, d.k - 1 - pl, c->cfg.dropout,
                    dropout_key(c->cfg.seed, q.step, 0), true, p, pf_blocks);
   }
+  // the attention passes' dropout decisions for that batch (stream 1 of its step), behind the gather
+  q.kbits = launch_attpool_keep_bits(t.live, t.kbits, nt, d.T, d.F, c->cfg.dropout, dropout_key(c->cfg.seed, q.step, 1), p);
   (void)hipEventRecord(c->ev_p1, p);
   q.launched = true;
   c->ready = q;                      // staged: the next training call may pick it up
@@ -822,7 +830,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
                                      w.vcount, s));
   }
   PROF("attpool_fwd", launch_attpool_fwd(w.conv, w.ids, c->P("att_w"), c->P("att_b"), w.pooled, w.att_a, w.att_wt, nt, d.T, d.F,
-                                         drop, key1, s, w.live));
+                                         drop, key1, s, w.live, (training && w.kbits_valid) ? w.kbits : nullptr));
   launch_gemm(w.pooled, d.F, 0, c->P("dense_w"), d.U, 0, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, 1.f,
               w.gemm_scratch, s);
   // user encoder (paper.py:584-633)
@@ -1004,7 +1012,8 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     const int off_aw = 0, off_ab = (int)(c->G("att_b") - c->G("att_w")), off_cb = off_ab + (int)kParamAlign;
     const int ldp = off_cb + (int)((d.F + kParamAlign - 1) / kParamAlign * kParamAlign);
     PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
-                                           w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 0, w.live));
+                                           w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 0, w.live,
+                                           w.kbits_valid ? w.kbits : nullptr));
     launch_colsum2(w.parts, attpool_bwd_parts(nt), off_ab + 1, ldp, c->G("att_w"), 1.f, w.colsum_scratch_k[2], s,
                    &jobs[nj++]);
     PROF("mhsa_bwd", launch_mhsa_bwd_bf16(w.qkv, w.dconv, w.ids, w.dqkv, nt, d.T, d.F, d.heads, s));
@@ -1025,7 +1034,8 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   const int off_cb = 0, off_aw = (int)(c->G("att_w") - c->G("conv_b")), off_ab = (int)(c->G("att_b") - c->G("conv_b"));
   const int ldp = off_ab + 1;
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
-                                         w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 1, w.live));
+                                         w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 1, w.live,
+                                         w.kbits_valid ? w.kbits : nullptr));
   // (on the side stream this one found no free CU beside the conv kernel gradient and finished behind it)
   launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch_k[2], s, &jobs[nj++]);
   if (d.word_trainable) {   // conv input gradient -> word-table gradient (embedding dropout mask = stream 0 of the step)
@@ -1225,6 +1235,7 @@ int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr || getenv("LSTUR_CONV_GEN1") != nullptr;
   if (backward && training && c->pipe_ok && n >= kPipeMin && !c->cfg.freeze_encoder && !conv_f32) {
     c->fused.on = false;   // (the two-lane step keeps the one-piece sweep behind both lanes)
+    c->ws.kbits_valid = false;
     return train_two_lanes(c, user, hist, cands, n, step, grad_scale, stats, s, ids_form);
   }
   set_lane(c, 0);
@@ -1233,6 +1244,7 @@ int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   auto& q = c->ready;
   c->staged_hit = backward && training && ids_form && q.valid && q.hist == hist && q.cands == cands && q.n == n &&
                   q.step == step;
+  c->ws.kbits_valid = c->staged_hit && q.kbits;
   if (backward && training) q = lstur_ctx::Pending();   // consumed, or stale: either way the other set is free again
   if (c->staged_hit) c->prefetch_hits++;
   int rc = LSTUR_OK;
@@ -1285,6 +1297,7 @@ int point_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   if (n < 1 || n > d.B) return fail(LSTUR_ERR_ARG, "n must be in [1, max_batch]");
   set_lane(c, 0);
   c->last_piped = false;
+  c->ws.kbits_valid = false;
   int rc = stage_titles(c, hist, cand, n, 1, ids_form, s);
   if (rc) return rc;
   Workspace& w = c->ws;
@@ -1303,6 +1316,7 @@ int predict_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const i
   if (n < 1 || n > cap) return fail(LSTUR_ERR_ARG, "n exceeds max_predict_rows");
   set_lane(c, 0);
   c->last_piped = false;
+  c->ws.kbits_valid = false;
   int rc = stage_titles(c, hist, cand, n, 1, ids_form, s);
   if (rc) return rc;
   run_forward(c, user, n, 1, false, 0, s);

@@ -177,13 +177,18 @@ int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, 
 // bit masks of launch_compact_write_offsets for the same ids -- one scalar per title instead of an ids read per row
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
                         float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s,
-                        const uint32_t* live = nullptr);
+                        const uint32_t* live = nullptr, const uint32_t* kbits = nullptr);
+// kbits: the dropout keep decisions of (key, drop) for these titles in the title kernels' thread layout, made ahead of time
+// (attpool_keep_bits_words(n_titles) words; false: not applicable to this shape / drop == 0 -- pass NULL to the passes)
+size_t attpool_keep_bits_words(int n_titles);
+bool launch_attpool_keep_bits(const uint32_t* live, uint32_t* kbits, int n_titles, int T, int F, float drop, uint32_t key,
+                              hipStream_t s);
 int attpool_bwd_parts(int n_titles);
 // row_scratch: n_titles*T floats (dw -> ds)
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
                         float drop, uint32_t key, hipStream_t s, int ldp = 0, int off_aw = 0, int off_cb = 0,
-                        int off_ab = 0, int relu = 1, const uint32_t* live = nullptr);
+                        int off_ab = 0, int relu = 1, const uint32_t* live = nullptr, const uint32_t* kbits = nullptr);
 
 // ---- mhsa.hip (build-defined multi-head self-attention token stage; T <= 32, F/heads in {16, 32, 64}) -------
 bool mhsa_supported(int T, int F, int heads);
