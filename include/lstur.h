@@ -396,6 +396,12 @@ size_t lstur_gemm_scratch(int32_t M, int32_t N, int32_t K);
 int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int32_t ldb, int32_t tb,
                    float* C, int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K,
                    float alpha, void* scratch, lstur_stream stream);
+/* C[M,N] = A[M,K] . op(B) + bias with fp32 operands, fp32-grade on the bf16 matrix cores (three bf16 parts per operand,
+ * six products, fp32 accumulate: csrc/gemm3.hip) -- the kernel of the Dense(U) / GRU input projections on the step's
+ * critical path (paper.py:159, 592-613).  b_nk != 0: B is stored [N][K] (C = A . B^T), else [K][N].  K, lda, ldb must be
+ * multiples of 4 (LSTUR_ERR_ARG otherwise: use lstur_gemm_f32). */
+int lstur_gemm_bf16x3(const float* A, int32_t lda, const float* B, int32_t ldb, int32_t b_nk, float* C, int32_t ldc,
+                      const float* bias, int32_t M, int32_t N, int32_t K, lstur_stream stream);
 /* Operand images of the recurrent matrix gru_u [H,3H] (z|r|h) for the two GRU kernels, written in one launch into
  * ONE opaque buffer of lstur_gru_pack_floats(H) floats (re-pack after every update of gru_u). */
 size_t lstur_gru_pack_floats(int32_t H);

@@ -1,0 +1,154 @@
+// fp32-grade GEMM on the bf16 matrix cores for the small dense layers ON the step's critical path (gfx950):
+//   C[M,N] = A[M,K] . op(B) + bias      A row-major fp32; B fp32, [K][N] (B_NK = false) or [N][K] (B_NK = true: C = A . B^T)
+// i.e. Dense(U) forward, the GRU input projection, and the input gradients of both (reference task/paper.py:159, 592-613):
+// 0.6 - 0.8 GFLOP each, four of them per step between the big kernels.  Both operands are split into three bf16 parts
+// on their way into LDS (bf16_mfma.h: split3) and six products per k-step reproduce the fp32 product to ~2^-23 -- the
+// scheme of the conv kernels (conv3f.hip); the exact-fp32 MFMA kernel of gemm.hip stays for everything else.
+//
+// Why a second kernel: at these sizes the fp32 MFMA kernel is a sum of small latencies -- 32 v_mfma_f32_16x16x4_f32 per
+// wave and k-step behind scalar LDS reads, 64-byte store segments -- and took 16 - 30 us per GEMM.  Here a k-step of a
+// 64 x 64 tile is 12 v_mfma_f32_32x32x16_bf16 per wave behind 16-byte fragment reads, the operand loads of EIGHT k-steps
+// are in flight from the start (a register ring with compile-time slots; K = 200 is seven steps: the whole operand panel
+// is requested before the first MFMA), LDS is double-buffered with one barrier per step, and an output row segment is 128
+// contiguous bytes per store.
+#include "bf16_mfma.h"
+#include "lstur_internal.h"
+
+namespace lstur {
+
+constexpr int G3_T = 64, G3_K = 32, G3_NS = 8;        // tile, k-step, k-steps of loads in flight (even: LDS buffer = step & 1)
+constexpr int G3_SA = G3_K + 8;                        // [x][k] image row: 80 bytes (conflict-free 16-byte fragment reads)
+constexpr int G3_SB = tr_stride(G3_T);                 // [k][n] image row (transposed fragment reads)
+constexpr int G3_AIMG = G3_T * G3_SA;                  // elements of one part of an [x][k] tile
+constexpr int G3_BIMG = G3_K * G3_SB > G3_AIMG ? G3_K * G3_SB : G3_AIMG;
+constexpr int G3_BUF = 3 * G3_AIMG + 3 * G3_BIMG;     // elements of one LDS buffer
+
+// one operand tile = 2 float4 per thread.  XK: the operand is stored [x][k] (k contiguous); else [k][x].
+template <bool XK>
+__device__ __forceinline__ void g3_load(__amdgpu_buffer_rsrc_t rs, int ld, int x0, int k0, int tid, float4 (&r)[2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + q * 256;
+    uint32_t off;
+    if (XK) off = ((uint32_t)(x0 + (idx >> 3)) * (uint32_t)ld + (uint32_t)(k0 + (idx & 7) * 4)) * 4u;
+    else off = ((uint32_t)(k0 + (idx >> 4)) * (uint32_t)ld + (uint32_t)(x0 + (idx & 15) * 4)) * 4u;
+    r[q] = buf_load4(rs, off, 0);
+  }
+}
+// split into the three bf16 images of the tile; k >= K is stored as zeros (an [x][k] row runs on into the next row there;
+// past the end of a [k][x] operand the descriptor already returned zeros)
+template <bool XK>
+__device__ __forceinline__ void g3_store(unsigned short* img, int img_elems, int tid, const float4 (&r)[2], int k0, int K) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + q * 256;
+    float4 v = r[q];
+    int pos;
+    if (XK) {
+      if (k0 + (idx & 7) * 4 >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      pos = (idx >> 3) * G3_SA + (idx & 7) * 4;
+    } else {
+      pos = (idx >> 4) * G3_SB + (idx & 15) * 4;
+    }
+    u16x4 h, m, l;
+    split3(v, h, m, l);
+    *(u16x4*)(img + pos) = h;
+    *(u16x4*)(img + img_elems + pos) = m;
+    *(u16x4*)(img + 2 * img_elems + pos) = l;
+  }
+}
+
+template <bool B_NK>
+__global__ __launch_bounds__(256) void gemm3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                    float* __restrict__ C, int ldc, const float* __restrict__ bias, int M,
+                                                    int N, int K, uint32_t bytesA, uint32_t bytesB) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short sm3[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int m0 = blockIdx.y * G3_T, n0 = blockIdx.x * G3_T;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, bytesA), rsB = make_rsrc(B, bytesB);
+  float4 ra[G3_NS][2], rb[G3_NS][2];
+#pragma unroll
+  for (int u = 0; u < G3_NS; ++u) {
+    g3_load<true>(rsA, lda, m0, u * G3_K, tid, ra[u]);
+    g3_load<B_NK>(rsB, ldb, n0, u * G3_K, tid, rb[u]);
+  }
+  g3_store<true>(sm3, G3_AIMG, tid, ra[0], 0, K);
+  g3_store<B_NK>(sm3 + 3 * G3_AIMG, G3_BIMG, tid, rb[0], 0, K);
+  g3_load<true>(rsA, lda, m0, G3_NS * G3_K, tid, ra[0]);
+  g3_load<B_NK>(rsB, ldb, n0, G3_NS * G3_K, tid, rb[0]);
+  __syncthreads();
+  for (int k0 = 0; k0 < K;) {
+#pragma unroll
+    for (int u = 0; u < G3_NS; ++u) {      // step k0 / G3_K == u (mod G3_NS); its tile is in LDS buffer u & 1
+      const int kn = k0 + G3_K;
+      {   // stage the next step (loaded G3_NS - 1 steps ago), unconditionally: past K it stores zeros nobody reads -- a
+          // branch here makes the compiler wait for ALL outstanding loads
+        const int nx = (u + 1) % G3_NS;
+        unsigned short* nb = sm3 + ((u + 1) & 1) * G3_BUF;
+        g3_store<true>(nb, G3_AIMG, tid, ra[nx], kn, K);
+        g3_store<B_NK>(nb + 3 * G3_AIMG, G3_BIMG, tid, rb[nx], kn, K);
+        g3_load<true>(rsA, lda, m0, kn + G3_NS * G3_K, tid, ra[nx]);
+        g3_load<B_NK>(rsB, ldb, n0, kn + G3_NS * G3_K, tid, rb[nx]);
+      }
+      const unsigned short* as = sm3 + (u & 1) * G3_BUF;
+      const unsigned short* bs = as + 3 * G3_AIMG;
+#pragma unroll
+      for (int s = 0; s < G3_K / 16; ++s) {
+        u16x8 fa[3], fb[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          fa[p] = *(const u16x8*)(as + p * G3_AIMG + (wm * 32 + (lane & 31)) * G3_SA + 16 * s + 8 * (lane >> 5));
+          if (B_NK) fb[p] = *(const u16x8*)(bs + p * G3_BIMG + (wn * 32 + (lane & 31)) * G3_SA + 16 * s + 8 * (lane >> 5));
+          else fb[p] = tr_frag(bs + p * G3_BIMG, G3_SB, 16 * s, wn * 32, lane);
+        }
+        acc = mfma32b(fa[2], fb[0], acc);   // l h   (small terms first)
+        acc = mfma32b(fa[0], fb[2], acc);   // h l
+        acc = mfma32b(fa[1], fb[1], acc);   // m m
+        acc = mfma32b(fa[1], fb[0], acc);   // m h
+        acc = mfma32b(fa[0], fb[1], acc);   // h m
+        acc = mfma32b(fa[0], fb[0], acc);   // h h
+      }
+      __syncthreads();
+      k0 = kn;
+      if (k0 >= K) break;
+    }
+  }
+  // rows >= M fall outside the descriptor, columns >= N get the out-of-range offset: no branches
+  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(C, (uint32_t)(((size_t)(M - 1) * ldc + N) * 4));
+  const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias, bias ? (uint32_t)N * 4u : 0u);
+  const int col = n0 + wn * 32 + (lane & 31);
+  const float bv = buf_load1(rsBias, (uint32_t)col * 4u, 0);     // no bias / col >= N: 0
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    buf_store1(acc[r] + bv, rsC, col < N ? ((uint32_t)row * (uint32_t)ldc + (uint32_t)col) * 4u : kBufOob, 0);
+  }
+}
+
+bool gemm3_supported(int lda, int ldb, int M, int N, int K) {
+  static const bool off = getenv("LSTUR_GEMM_F32") != nullptr;
+  return !off && M > 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+         (size_t)M * lda * 4 < ((size_t)1 << 32) && (size_t)std::max(N, K) * ldb * 4 < ((size_t)1 << 32);
+}
+
+// b_nk: B is [N][K] (C = A . B^T); else [K][N].  The caller checks gemm3_supported.
+void launch_gemm3(const float* A, int lda, const float* B, int ldb, bool b_nk, float* C, int ldc, const float* bias, int M,
+                  int N, int K, hipStream_t s) {
+  constexpr size_t lds = 2 * G3_BUF * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const uint32_t bytesA = (uint32_t)(((size_t)(M - 1) * lda + K) * 4);
+  const uint32_t bytesB = (uint32_t)((b_nk ? (size_t)(N - 1) * ldb + K : (size_t)(K - 1) * ldb + N) * 4);
+  const dim3 grid(cdiv(N, G3_T), cdiv(M, G3_T));
+  if (b_nk) hipLaunchKernelGGL(gemm3_kernel<true>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB);
+  else hipLaunchKernelGGL(gemm3_kernel<false>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB);
+}
+
+}  // namespace lstur

@@ -619,6 +619,13 @@ bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
   return true;
 }
 
+// C = A . op(B) + bias for the dense layers on the critical path: the bf16x3 kernel where it applies, else the fp32 MFMA one
+void dense_gemm(const float* A, int lda, const float* B, int ldb, bool b_nk, float* C, int ldc, const float* bias, int M, int N,
+                int K, void* scratch, hipStream_t s) {
+  if (gemm3_supported(lda, ldb, M, N, K)) launch_gemm3(A, lda, B, ldb, b_nk, C, ldc, bias, M, N, K, s);
+  else launch_gemm(A, lda, 0, B, ldb, b_nk ? 1 : 0, C, ldc, bias, M, N, K, 1.f, scratch, s);
+}
+
 // operand images of the weights the MFMA kernels read (conv: bf16x3 parts or the fp32 pack; GRU: resident strips)
 void pack_weight_images(lstur_ctx* c, hipStream_t sp) {
   const Dims& d = c->d;
@@ -831,8 +838,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   }
   PROF("attpool_fwd", launch_attpool_fwd(w.conv, w.ids, c->P("att_w"), c->P("att_b"), w.pooled, w.att_a, w.att_wt, nt, d.T, d.F,
                                          drop, key1, s, w.live, (training && w.kbits_valid) ? w.kbits : nullptr));
-  launch_gemm(w.pooled, d.F, 0, c->P("dense_w"), d.U, 0, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, 1.f,
-              w.gemm_scratch, s);
+  dense_gemm(w.pooled, d.F, c->P("dense_w"), d.U, false, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, w.gemm_scratch, s);
   // user encoder (paper.py:584-633)
   launch_hist_mask(w.ids, w.docvec, w.hmask, w.gmask, nW, d.T, d.U, s, c->buf.user_emb, user, w.user_rows, w.uvec, n,
                    d.Ue);
@@ -840,8 +846,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   // masking of cook.py:139-142 for every arch that reads the table
   const float row_p = training ? user_row_drop(c) : 0.f;
   if (row_p > 0.f) launch_drop_rows(w.uvec, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
-  launch_gemm(w.docvec, d.U, 0, c->P("gru_w"), 3 * d.H, 0, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, 1.f,
-              w.gemm_scratch, s);
+  dense_gemm(w.docvec, d.U, c->P("gru_w"), 3 * d.H, false, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, w.gemm_scratch, s);
   if (c->cur_ev_enc) (void)hipEventRecord(c->cur_ev_enc, s);   // the other lane's encoder may start: the recurrence follows
   const bool recurrent = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
   if (training) {   // background work for the recurrence to hide: the next batch's staging, then (fused step) the zero-gradient
@@ -980,8 +985,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   }
   // d(history doc vectors) = dgates . gru_w^T, masked by the history mask (paper.py:644-645)
   if (has_gru)
-    launch_gemm(w.dgates, 3 * d.H, 0, c->P("gru_w"), 3 * d.H, 1, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, 1.f,
-                w.gemm_scratch, s);
+    dense_gemm(w.dgates, 3 * d.H, c->P("gru_w"), 3 * d.H, true, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, w.gemm_scratch, s);
   else if (d.arch == LSTUR_ARCH_NIAVG)   // dx[b,w] = mask[b,w] * du[b] / (count_b + eps)
     launch_masked_mean(nullptr, w.gmask, nullptr, w.du, w.ddocvec, n, d.W, d.U, s);
   else if (d.arch == LSTUR_ARCH_NIATT) {   // backward of the attention over the history (no ReLU behind it: relu = 0)
@@ -1005,7 +1009,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   launch_gemm(w.pooled, d.F, 1, w.ddocvec, d.U, 0, c->G("dense_w"), d.U, nullptr, d.F, d.U, nt, 1.f,
               w.gemm_scratch_k[3], sw, &jobs[nj++]);
   launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], sw, &jobs[nj++]);
-  launch_gemm(w.ddocvec, d.U, 0, c->P("dense_w"), d.U, 1, w.dpooled, d.F, nullptr, nt, d.F, d.U, 1.f, w.gemm_scratch, s);
+  dense_gemm(w.ddocvec, d.U, c->P("dense_w"), d.U, true, w.dpooled, d.F, nullptr, nt, d.F, d.U, w.gemm_scratch, s);
   // partial sums laid out like the bucket slice conv_b .. att_b -> one reduction straight into dense_grad
   if (d.enc == LSTUR_ENC_MHSA) {
     // partial sums: datt_w | datt_b like the bucket slice att_w .. att_b, the (unused) column sums of dconv behind them
@@ -1922,6 +1926,13 @@ int lstur_colsum(const float* x, int32_t rows, int32_t cols, int32_t ld, float* 
   return check_launch("colsum");
 }
 size_t lstur_gemm_scratch(int32_t M, int32_t N, int32_t K) { return gemm_scratch_bytes(M, N, K); }
+int lstur_gemm_bf16x3(const float* A, int32_t lda, const float* B, int32_t ldb, int32_t b_nk, float* C, int32_t ldc,
+                      const float* bias, int32_t M, int32_t N, int32_t K, lstur_stream stream) {
+  if (!A || !B || !C) return fail(LSTUR_ERR_ARG, "NULL argument");
+  if (!gemm3_supported(lda, ldb, M, N, K)) return fail(LSTUR_ERR_ARG, "gemm_bf16x3: K, lda, ldb must be positive multiples of 4");
+  launch_gemm3(A, lda, B, ldb, b_nk != 0, C, ldc, bias, M, N, K, (hipStream_t)stream);
+  return check_launch("gemm_bf16x3");
+}
 int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int32_t ldb, int32_t tb, float* C,
                    int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, void* scratch,
                    lstur_stream stream) {

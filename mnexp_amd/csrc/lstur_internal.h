@@ -172,6 +172,12 @@ int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, 
                         int ksize, int F, const int32_t* vcount, hipStream_t s, ReduceJob* jobs, const int32_t* offA,
                         const int32_t* offB, float alpha = 1.0f, int cus = 0);
 
+// ---- gemm3.hip: C = A[M,K] . op(B) + bias, fp32-grade on the bf16 matrix cores (bf16x3), for the dense layers on the
+// step's critical path.  b_nk: B is [N][K] (C = A . B^T), else [K][N].  Check gemm3_supported first.
+bool gemm3_supported(int lda, int ldb, int M, int N, int K);
+void launch_gemm3(const float* A, int lda, const float* B, int ldb, bool b_nk, float* C, int ldc, const float* bias, int M,
+                  int N, int K, hipStream_t s);
+
 // ---- attpool.hip -------------------------------------------------------------------------------
 // ids (nullable): rows with id == 0 are taken as zero without reading c / writing dc.  live (nullable): the titles' non-pad
 // bit masks of launch_compact_write_offsets for the same ids -- one scalar per title instead of an ids read per row

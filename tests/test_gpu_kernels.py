@@ -138,6 +138,38 @@ def test_gemm_variants(ta, tb, M, N, K):
     assert err < 1e-5 * ref.abs().max().item() + 1e-6, err
 
 
+@pytest.mark.parametrize('b_nk', [0, 1])
+@pytest.mark.parametrize('M,N,K', [(3520, 200, 400), (3200, 600, 200), (3200, 200, 600), (3520, 400, 200), (37, 20, 72),
+                                   (64, 64, 2048), (100, 52, 332), (8, 12, 260), (130, 70, 4)])
+def test_gemm_bf16x3_is_fp32_grade(b_nk, M, N, K):
+    """csrc/gemm3.hip (the Dense(U) / GRU input projections on the critical path): three bf16 parts per operand, six
+    products -- held to the exact-fp32 kernel's bound against fp64, with the k tail inside a 32-wide step, ragged tiles
+    and operands embedded in wider rows (lda / ldb > K)."""
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    g = torch.Generator(device='cuda').manual_seed(1)
+    lda = K + 8
+    Afull = torch.randn(M, lda, device='cuda', generator=g)
+    Bfull = torch.randn((N, K + 4) if b_nk else (K, (N + 15) // 4 * 4), device='cuda', generator=g)   # ld % 4 == 0
+    A, B = Afull[:, :K], (Bfull[:, :K] if b_nk else Bfull[:, :N])
+    bias = torch.randn(N, device='cuda', generator=g)
+    ldc = N + 3
+    Cm = torch.full((M, ldc), float('nan'), device='cuda')
+    check(lib.lstur_gemm_bf16x3(Afull.data_ptr(), lda, Bfull.data_ptr(), Bfull.stride(0), b_nk, Cm.data_ptr(), ldc,
+                                bias.data_ptr(), M, N, K, stream()))
+    torch.cuda.synchronize()
+    ref = A.double() @ (B.t() if b_nk else B).double() + bias.double()
+    err = (Cm[:, :N].double() - ref).abs().max().item()
+    assert err < 1e-5 * ref.abs().max().item() + 1e-6, err
+    assert torch.isnan(Cm[:, N:]).all()                       # nothing written past column N
+    # and against the exact-fp32 MFMA kernel: a few ulp
+    C2 = torch.empty(M, N, device='cuda')
+    scratch = torch.empty(max(1, lib.lstur_gemm_scratch(M, N, K)), dtype=torch.uint8, device='cuda')
+    check(lib.lstur_gemm_f32(Afull.data_ptr(), lda, 0, Bfull.data_ptr(), Bfull.stride(0), b_nk, C2.data_ptr(), N,
+                             bias.data_ptr(), M, N, K, 1.0, scratch.data_ptr(), stream()))
+    assert (Cm[:, :N] - C2).abs().max().item() < 4e-6 * ref.abs().max().item() + 1e-6
+
+
 @pytest.mark.parametrize('generic', [False, True], ids=['resident', 'generic'])
 @pytest.mark.parametrize('n,W,H', [(21, 12, 200), (5, 7, 40), (33, 9, 128), (6, 5, 150), (9, 4, 224), (7, 70, 40),
                                    (3, 130, 200)])   # W > 64: the step-mask words are reloaded per 64-step chunk
