@@ -402,6 +402,11 @@ int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int3
  * multiples of 4 (LSTUR_ERR_ARG otherwise: use lstur_gemm_f32). */
 int lstur_gemm_bf16x3(const float* A, int32_t lda, const float* B, int32_t ldb, int32_t b_nk, float* C, int32_t ldc,
                       const float* bias, int32_t M, int32_t N, int32_t K, lstur_stream stream);
+/* The parameter-gradient form of the same kernel: C[M,N] = A^T . B with A [K][M], B [K][N] (K = tokens / history slots),
+ * split along K into slabs (scratch: lstur_gemm_bf16x3_tn_scratch bytes) that are summed in slab order. */
+size_t lstur_gemm_bf16x3_tn_scratch(int32_t M, int32_t N, int32_t K);
+int lstur_gemm_bf16x3_tn(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t M, int32_t N,
+                         int32_t K, void* scratch, lstur_stream stream);
 /* Operand images of the recurrent matrix gru_u [H,3H] (z|r|h) for the two GRU kernels, written in one launch into
  * ONE opaque buffer of lstur_gru_pack_floats(H) floats (re-pack after every update of gru_u). */
 size_t lstur_gru_pack_floats(int32_t H);

@@ -110,6 +110,8 @@ SIGNATURES = {
     'lstur_colsum': (_I, [_P, _I, _I, _I, _P, _F, _P]),
     'lstur_gemm_scratch': (_Z, [_I, _I, _I]),
     'lstur_gemm_bf16x3': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P]),
+    'lstur_gemm_bf16x3_tn_scratch': (_Z, [_I, _I, _I]),
+    'lstur_gemm_bf16x3_tn': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
     'lstur_gemm_f32': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),
     'lstur_gru_pack_floats': (_Z, [_I]),
     'lstur_gru_pack_u': (_I, [_P, _I, _P, _P]),

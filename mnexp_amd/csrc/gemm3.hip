@@ -48,6 +48,7 @@ __device__ __forceinline__ void g3_store(unsigned short* img, int img_elems, int
       if (k0 + (idx & 7) * 4 >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
       pos = (idx >> 3) * G3_SA + (idx & 7) * 4;
     } else {
+      if (k0 + (idx >> 4) >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);   // (a slab's tail: the next slab's rows)
       pos = (idx >> 4) * G3_SB + (idx & 15) * 4;
     }
     u16x4 h, m, l;
@@ -58,13 +59,19 @@ __device__ __forceinline__ void g3_store(unsigned short* img, int img_elems, int
   }
 }
 
-template <bool B_NK>
+// A_KM: A is stored [K][M] (C = A^T . B: the parameter gradients, contraction over the rows of both operands); such
+// launches are split along K into gridDim.z slabs of k_per_split rows, written as C + z * M * N (ld N, no bias) and summed
+// in fixed order by the caller's reduction (bitwise reproducible).
+template <bool A_KM, bool B_NK>
 __global__ __launch_bounds__(256) void gemm3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                     float* __restrict__ C, int ldc, const float* __restrict__ bias, int M,
-                                                    int N, int K, uint32_t bytesA, uint32_t bytesB) {
+                                                    int N, int Kfull, uint32_t bytesA, uint32_t bytesB, int k_per_split) {
   extern __shared__ __attribute__((aligned(16))) unsigned short sm3[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int m0 = blockIdx.y * G3_T, n0 = blockIdx.x * G3_T;
+  const int kbeg = A_KM ? (int)blockIdx.z * k_per_split : 0, K = A_KM ? min(Kfull, kbeg + k_per_split) : Kfull;
+  constexpr int AIMG = A_KM ? G3_BIMG : G3_AIMG;      // elements of one part of the A tile image
+  constexpr int BUF = 3 * AIMG + 3 * G3_BIMG;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -72,35 +79,36 @@ __global__ __launch_bounds__(256) void gemm3_kernel(const float* __restrict__ A,
   float4 ra[G3_NS][2], rb[G3_NS][2];
 #pragma unroll
   for (int u = 0; u < G3_NS; ++u) {
-    g3_load<true>(rsA, lda, m0, u * G3_K, tid, ra[u]);
-    g3_load<B_NK>(rsB, ldb, n0, u * G3_K, tid, rb[u]);
+    g3_load<!A_KM>(rsA, lda, m0, kbeg + u * G3_K, tid, ra[u]);
+    g3_load<B_NK>(rsB, ldb, n0, kbeg + u * G3_K, tid, rb[u]);
   }
-  g3_store<true>(sm3, G3_AIMG, tid, ra[0], 0, K);
-  g3_store<B_NK>(sm3 + 3 * G3_AIMG, G3_BIMG, tid, rb[0], 0, K);
-  g3_load<true>(rsA, lda, m0, G3_NS * G3_K, tid, ra[0]);
-  g3_load<B_NK>(rsB, ldb, n0, G3_NS * G3_K, tid, rb[0]);
+  g3_store<!A_KM>(sm3, AIMG, tid, ra[0], kbeg, K);
+  g3_store<B_NK>(sm3 + 3 * AIMG, G3_BIMG, tid, rb[0], kbeg, K);
+  g3_load<!A_KM>(rsA, lda, m0, kbeg + G3_NS * G3_K, tid, ra[0]);
+  g3_load<B_NK>(rsB, ldb, n0, kbeg + G3_NS * G3_K, tid, rb[0]);
   __syncthreads();
-  for (int k0 = 0; k0 < K;) {
+  for (int k0 = kbeg; k0 < K;) {
 #pragma unroll
     for (int u = 0; u < G3_NS; ++u) {      // step k0 / G3_K == u (mod G3_NS); its tile is in LDS buffer u & 1
       const int kn = k0 + G3_K;
       {   // stage the next step (loaded G3_NS - 1 steps ago), unconditionally: past K it stores zeros nobody reads -- a
           // branch here makes the compiler wait for ALL outstanding loads
         const int nx = (u + 1) % G3_NS;
-        unsigned short* nb = sm3 + ((u + 1) & 1) * G3_BUF;
-        g3_store<true>(nb, G3_AIMG, tid, ra[nx], kn, K);
-        g3_store<B_NK>(nb + 3 * G3_AIMG, G3_BIMG, tid, rb[nx], kn, K);
-        g3_load<true>(rsA, lda, m0, kn + G3_NS * G3_K, tid, ra[nx]);
+        unsigned short* nb = sm3 + ((u + 1) & 1) * BUF;
+        g3_store<!A_KM>(nb, AIMG, tid, ra[nx], kn, K);
+        g3_store<B_NK>(nb + 3 * AIMG, G3_BIMG, tid, rb[nx], kn, K);
+        g3_load<!A_KM>(rsA, lda, m0, kn + G3_NS * G3_K, tid, ra[nx]);
         g3_load<B_NK>(rsB, ldb, n0, kn + G3_NS * G3_K, tid, rb[nx]);
       }
-      const unsigned short* as = sm3 + (u & 1) * G3_BUF;
-      const unsigned short* bs = as + 3 * G3_AIMG;
+      const unsigned short* as = sm3 + (u & 1) * BUF;
+      const unsigned short* bs = as + 3 * AIMG;
 #pragma unroll
       for (int s = 0; s < G3_K / 16; ++s) {
         u16x8 fa[3], fb[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          fa[p] = *(const u16x8*)(as + p * G3_AIMG + (wm * 32 + (lane & 31)) * G3_SA + 16 * s + 8 * (lane >> 5));
+          if (A_KM) fa[p] = tr_frag(as + p * AIMG, G3_SB, 16 * s, wm * 32, lane);
+          else fa[p] = *(const u16x8*)(as + p * AIMG + (wm * 32 + (lane & 31)) * G3_SA + 16 * s + 8 * (lane >> 5));
           if (B_NK) fb[p] = *(const u16x8*)(bs + p * G3_BIMG + (wn * 32 + (lane & 31)) * G3_SA + 16 * s + 8 * (lane >> 5));
           else fb[p] = tr_frag(bs + p * G3_BIMG, G3_SB, 16 * s, wn * 32, lane);
         }
@@ -117,8 +125,12 @@ __global__ __launch_bounds__(256) void gemm3_kernel(const float* __restrict__ A,
     }
   }
   // rows >= M fall outside the descriptor, columns >= N get the out-of-range offset: no branches
+  if (A_KM) {
+    C += (size_t)blockIdx.z * M * N;
+    ldc = N;
+  }
   const __amdgpu_buffer_rsrc_t rsC = make_rsrc(C, (uint32_t)(((size_t)(M - 1) * ldc + N) * 4));
-  const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias, bias ? (uint32_t)N * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias, (bias && !A_KM) ? (uint32_t)N * 4u : 0u);
   const int col = n0 + wn * 32 + (lane & 31);
   const float bv = buf_load1(rsBias, (uint32_t)col * 4u, 0);     // no bias / col >= N: 0
 #pragma unroll
@@ -134,21 +146,53 @@ bool gemm3_supported(int lda, int ldb, int M, int N, int K) {
          (size_t)M * lda * 4 < ((size_t)1 << 32) && (size_t)std::max(N, K) * ldb * 4 < ((size_t)1 << 32);
 }
 
+static void g3_attrs() {
+  static bool attr_set = false;
+  if (attr_set) return;
+  constexpr int lds = 2 * (6 * G3_BIMG) * (int)sizeof(unsigned short);   // the largest variant
+  (void)hipFuncSetAttribute((const void*)gemm3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)gemm3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)gemm3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  attr_set = true;
+}
 // b_nk: B is [N][K] (C = A . B^T); else [K][N].  The caller checks gemm3_supported.
 void launch_gemm3(const float* A, int lda, const float* B, int ldb, bool b_nk, float* C, int ldc, const float* bias, int M,
                   int N, int K, hipStream_t s) {
   constexpr size_t lds = 2 * G3_BUF * sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  g3_attrs();
   const uint32_t bytesA = (uint32_t)(((size_t)(M - 1) * lda + K) * 4);
   const uint32_t bytesB = (uint32_t)((b_nk ? (size_t)(N - 1) * ldb + K : (size_t)(K - 1) * ldb + N) * 4);
   const dim3 grid(cdiv(N, G3_T), cdiv(M, G3_T));
-  if (b_nk) hipLaunchKernelGGL(gemm3_kernel<true>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB);
-  else hipLaunchKernelGGL(gemm3_kernel<false>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB);
+  if (b_nk)
+    hipLaunchKernelGGL((gemm3_kernel<false, true>), grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA,
+                       bytesB, K);
+  else
+    hipLaunchKernelGGL((gemm3_kernel<false, false>), grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA,
+                       bytesB, K);
+}
+
+// C[M,N] = A^T . B with A [K][M], B [K][N] (parameter gradients: long K, small M x N), split along K into slabs in
+// `scratch` (gemm3_tn_scratch_bytes) that *job sums in slab order.
+static int g3_tn_splits(int M, int N, int K) {
+  const int tiles = cdiv(M, G3_T) * cdiv(N, G3_T);
+  return std::max(1, std::min(cdiv(512, tiles), K / (4 * G3_K)));
+}
+bool gemm3_tn_supported(int lda, int ldb, int M, int N, int K) {
+  static const bool off = getenv("LSTUR_GEMM_F32") != nullptr;
+  return !off && M > 0 && N > 0 && K > 0 && lda % 4 == 0 && ldb % 4 == 0 && (size_t)K * std::max(lda, ldb) * 4 < ((size_t)1 << 32);
+}
+size_t gemm3_tn_scratch_bytes(int M, int N, int K) { return (size_t)g3_tn_splits(M, N, K) * M * N * sizeof(float); }
+void launch_gemm3_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, float alpha,
+                     void* scratch, hipStream_t s, ReduceJob* job) {
+  constexpr size_t lds = 2 * (6 * G3_BIMG) * sizeof(unsigned short);
+  g3_attrs();
+  int ns = g3_tn_splits(M, N, K);
+  const int kps = cdiv(cdiv(K, ns), G3_K) * G3_K;
+  ns = std::max(1, cdiv(K, kps));
+  const uint32_t bytesA = (uint32_t)(((size_t)(K - 1) * lda + M) * 4), bytesB = (uint32_t)(((size_t)(K - 1) * ldb + N) * 4);
+  hipLaunchKernelGGL((gemm3_kernel<true, false>), dim3(cdiv(N, G3_T), cdiv(M, G3_T), ns), dim3(256), lds, s, A, lda, B, ldb,
+                     (float*)scratch, N, (const float*)nullptr, M, N, K, bytesA, bytesB, kps);
+  *job = ReduceJob{(const float*)scratch, C, M, N, ldc, ns, (size_t)M * N, alpha};
 }
 
 }  // namespace lstur

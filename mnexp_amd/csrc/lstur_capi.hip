@@ -349,10 +349,11 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->gemm_scratch_bytes = max_gemm_scratch(d);
   w->gemm_scratch = take(w->gemm_scratch_bytes);
   // weight-gradient GEMMs of the backward pass keep their split-K slabs until the step's single reduction launch
-  w->gemm_scratch_k[0] = take(std::max(gemm_scratch_bytes(d.U, 3 * d.H, (int)nW), (size_t)4 << 20));
-  w->gemm_scratch_k[1] = take(std::max(gemm_scratch_bytes(d.H, 2 * d.H, (int)nW), (size_t)4 << 20));
-  w->gemm_scratch_k[2] = take(std::max(gemm_scratch_bytes(d.H, d.H, (int)nW), (size_t)4 << 20));
-  w->gemm_scratch_k[3] = take(std::max(gemm_scratch_bytes(d.F, d.U, (int)nt), (size_t)4 << 20));
+  auto tn_bytes = [](int M, int N, int K) { return std::max(std::max(gemm_scratch_bytes(M, N, K), gemm3_tn_scratch_bytes(M, N, K)), (size_t)4 << 20); };
+  w->gemm_scratch_k[0] = take(tn_bytes(d.U, 3 * d.H, (int)nW));
+  w->gemm_scratch_k[1] = take(tn_bytes(d.H, 2 * d.H, (int)nW));
+  w->gemm_scratch_k[2] = take(tn_bytes(d.H, d.H, (int)nW));
+  w->gemm_scratch_k[3] = take(tn_bytes(d.F, d.U, (int)nt));
   w->first = (int32_t*)take((size_t)d.rows_cap * 4);
   w->gsum = (float*)take((size_t)d.rows_cap * d.Ue * f4);
   w->slot = (int32_t*)take((size_t)d.Nu * 4);
@@ -553,7 +554,13 @@ hipStream_t wgrad_stream(lstur_ctx* c) {
   const bool off = getenv("LSTUR_WG_STREAM") && !strcmp(getenv("LSTUR_WG_STREAM"), "0");
   if (off || c->cur_lane != 0 || c->conv_cus != 0) return nullptr;     // (the two-lane step has its own streams)
   if (!c->side_w) {
-    if (hipStreamCreateWithFlags(&c->side_w, hipStreamNonBlocking) != hipSuccess ||
+    // highest priority: its thin kernels are to slip in as soon as a workgroup of the main stream's kernel retires -- at
+    // equal priority they waited behind the attention backward's 3520 workgroups and spilled into the conv kernel gradient,
+    // which shares a CU with nothing (it then ran ~10 % slower and the step's reduction waited for the stragglers)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    static const bool flat = getenv("LSTUR_WG_PRIORITY") && !strcmp(getenv("LSTUR_WG_PRIORITY"), "0");
+    if (hipStreamCreateWithPriority(&c->side_w, hipStreamNonBlocking, flat ? lo : hi) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w3, hipEventDisableTiming) != hipSuccess) {
@@ -624,6 +631,18 @@ void dense_gemm(const float* A, int lda, const float* B, int ldb, bool b_nk, flo
                 int K, void* scratch, hipStream_t s) {
   if (gemm3_supported(lda, ldb, M, N, K)) launch_gemm3(A, lda, B, ldb, b_nk, C, ldc, bias, M, N, K, s);
   else launch_gemm(A, lda, 0, B, ldb, b_nk ? 1 : 0, C, ldc, bias, M, N, K, 1.f, scratch, s);
+}
+
+// G[M,N] = A^T . B (A [K][M], B [K][N]) as a deferred reduction: the parameter gradients behind the recurrence / Dense(U)
+void wgrad_gemm(const float* A, int lda, const float* B, int ldb, float* G, int ldg, int M, int N, int K, void* scratch,
+                hipStream_t s, ReduceJob* job) {
+  // These run on the side stream BESIDE the attention backward and have to fit into what its workgroups leave of a SIMD's
+  // registers: the fp32 MFMA kernel (68 VGPRs, 20 KB LDS) does, the bf16x3 kernel (188 VGPRs, 72 KB) waits for whole
+  // CUs to drain and then runs into the conv kernel gradient (measured: 59 us instead of 41 for dgru_u, and the last
+  // product finished BEHIND the conv kernel gradient).  LSTUR_WGRAD_BF16X3=1 selects it for A/B runs.
+  static const bool x3 = getenv("LSTUR_WGRAD_BF16X3") != nullptr;
+  if (x3 && gemm3_tn_supported(lda, ldb, M, N, K)) launch_gemm3_tn(A, lda, B, ldb, G, ldg, M, N, K, 1.f, scratch, s, job);
+  else launch_gemm(A, lda, 1, B, ldb, 0, G, ldg, nullptr, M, N, K, 1.f, scratch, s, job);
 }
 
 // operand images of the weights the MFMA kernels read (conv: bf16x3 parts or the fp32 pack; GRU: resident strips)
@@ -962,13 +981,11 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
       (void)hipStreamWaitEvent(sw, fe, 0);
       forked = true;
     }
-    launch_gemm(w.docvec, d.U, 1, w.dgates, 3 * d.H, 0, c->G("gru_w"), 3 * d.H, nullptr, d.U, 3 * d.H, nW, 1.f,
-                w.gemm_scratch_k[0], sw, &jobs[nj++]);
+    wgrad_gemm(w.docvec, d.U, w.dgates, 3 * d.H, c->G("gru_w"), 3 * d.H, d.U, 3 * d.H, nW, w.gemm_scratch_k[0], sw, &jobs[nj++]);
     launch_colsum2(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, w.colsum_scratch_k[0], sw, &jobs[nj++]);
-    launch_gemm(hprev, d.H, 1, w.dgates, 3 * d.H, 0, c->G("gru_u"), 3 * d.H, nullptr, d.H, 2 * d.H, nW, 1.f,
-                w.gemm_scratch_k[1], sw, &jobs[nj++]);
-    launch_gemm(rh, d.H, 1, w.dgates + 2 * d.H, 3 * d.H, 0, c->G("gru_u") + 2 * d.H, 3 * d.H, nullptr, d.H, d.H, nW,
-                1.f, w.gemm_scratch_k[2], sw, &jobs[nj++]);
+    wgrad_gemm(hprev, d.H, w.dgates, 3 * d.H, c->G("gru_u"), 3 * d.H, d.H, 2 * d.H, nW, w.gemm_scratch_k[1], sw, &jobs[nj++]);
+    wgrad_gemm(rh, d.H, w.dgates + 2 * d.H, 3 * d.H, c->G("gru_u") + 2 * d.H, 3 * d.H, d.H, d.H, nW, w.gemm_scratch_k[2], sw,
+               &jobs[nj++]);
   } else {   // vo / niavg: no GRU in the graph -- its bucket slots get an exact zero gradient
     (void)hipMemsetAsync(c->G("gru_w"), 0, (size_t)(c->G("gru_b") + 3 * d.H - c->G("gru_w")) * sizeof(float), s);
   }
@@ -1006,8 +1023,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     (void)hipStreamWaitEvent(sw, c->ev_w2, 0);
     forked = true;
   }
-  launch_gemm(w.pooled, d.F, 1, w.ddocvec, d.U, 0, c->G("dense_w"), d.U, nullptr, d.F, d.U, nt, 1.f,
-              w.gemm_scratch_k[3], sw, &jobs[nj++]);
+  wgrad_gemm(w.pooled, d.F, w.ddocvec, d.U, c->G("dense_w"), d.U, d.F, d.U, nt, w.gemm_scratch_k[3], sw, &jobs[nj++]);
   launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], sw, &jobs[nj++]);
   dense_gemm(w.ddocvec, d.U, c->P("dense_w"), d.U, true, w.dpooled, d.F, nullptr, nt, d.F, d.U, w.gemm_scratch, s);
   // partial sums laid out like the bucket slice conv_b .. att_b -> one reduction straight into dense_grad
@@ -1932,6 +1948,16 @@ int lstur_gemm_bf16x3(const float* A, int32_t lda, const float* B, int32_t ldb, 
   if (!gemm3_supported(lda, ldb, M, N, K)) return fail(LSTUR_ERR_ARG, "gemm_bf16x3: K, lda, ldb must be positive multiples of 4");
   launch_gemm3(A, lda, B, ldb, b_nk != 0, C, ldc, bias, M, N, K, (hipStream_t)stream);
   return check_launch("gemm_bf16x3");
+}
+size_t lstur_gemm_bf16x3_tn_scratch(int32_t M, int32_t N, int32_t K) { return gemm3_tn_scratch_bytes(M, N, K); }
+int lstur_gemm_bf16x3_tn(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t M, int32_t N,
+                         int32_t K, void* scratch, lstur_stream stream) {
+  if (!A || !B || !C || !scratch) return fail(LSTUR_ERR_ARG, "NULL argument");
+  if (!gemm3_tn_supported(lda, ldb, M, N, K)) return fail(LSTUR_ERR_ARG, "gemm_bf16x3_tn: lda, ldb must be multiples of 4");
+  ReduceJob job;
+  launch_gemm3_tn(A, lda, B, ldb, C, ldc, M, N, K, 1.f, scratch, (hipStream_t)stream, &job);
+  launch_multi_reduce(&job, 1, (hipStream_t)stream);
+  return check_launch("gemm_bf16x3_tn");
 }
 int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int32_t ldb, int32_t tb, float* C,
                    int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, void* scratch,

@@ -178,6 +178,13 @@ bool gemm3_supported(int lda, int ldb, int M, int N, int K);
 void launch_gemm3(const float* A, int lda, const float* B, int ldb, bool b_nk, float* C, int ldc, const float* bias, int M,
                   int N, int K, hipStream_t s);
 
+// C[M,N] = alpha * A^T . B, A [K][M], B [K][N] (parameter gradients), same arithmetic; K is split into slabs in `scratch`
+// (gemm3_tn_scratch_bytes) that *job sums in slab order
+bool gemm3_tn_supported(int lda, int ldb, int M, int N, int K);
+size_t gemm3_tn_scratch_bytes(int M, int N, int K);
+void launch_gemm3_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, float alpha,
+                     void* scratch, hipStream_t s, ReduceJob* job);
+
 // ---- attpool.hip -------------------------------------------------------------------------------
 // ids (nullable): rows with id == 0 are taken as zero without reading c / writing dc.  live (nullable): the titles' non-pad
 // bit masks of launch_compact_write_offsets for the same ids -- one scalar per title instead of an ids read per row

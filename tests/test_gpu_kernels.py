@@ -170,6 +170,28 @@ def test_gemm_bf16x3_is_fp32_grade(b_nk, M, N, K):
     assert (Cm[:, :N] - C2).abs().max().item() < 4e-6 * ref.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize('M,N,K', [(200, 600, 3200), (200, 400, 3200), (200, 200, 3200), (400, 200, 3520), (70, 36, 1000),
+                                   (8, 12, 260), (130, 68, 5), (64, 64, 128)])
+def test_gemm_bf16x3_tn_is_fp32_grade(M, N, K):
+    """The parameter-gradient form (A^T . B over tokens / history slots, K split into slabs): GRU kernel / recurrent /
+    Dense(U) weight gradients at the baseline shapes, plus ragged tiles, a k tail inside a step and K below one step."""
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    g = torch.Generator(device='cuda').manual_seed(2)
+    lda, ldb, ldc = (M + 11) // 4 * 4, (N + 7) // 4 * 4, N + 5
+    Afull = torch.randn(K, lda, device='cuda', generator=g)
+    Bfull = torch.randn(K, ldb, device='cuda', generator=g)
+    Cm = torch.full((M, ldc), float('nan'), device='cuda')
+    scratch = torch.empty(max(1, lib.lstur_gemm_bf16x3_tn_scratch(M, N, K)), dtype=torch.uint8, device='cuda')
+    check(lib.lstur_gemm_bf16x3_tn(Afull.data_ptr(), lda, Bfull.data_ptr(), ldb, Cm.data_ptr(), ldc, M, N, K,
+                                   scratch.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    ref = Afull[:, :M].double().t() @ Bfull[:, :N].double()
+    err = (Cm[:, :N].double() - ref).abs().max().item()
+    assert err < 1e-5 * ref.abs().max().item() + 1e-6, err
+    assert torch.isnan(Cm[:, N:]).all()
+
+
 @pytest.mark.parametrize('generic', [False, True], ids=['resident', 'generic'])
 @pytest.mark.parametrize('n,W,H', [(21, 12, 200), (5, 7, 40), (33, 9, 128), (6, 5, 150), (9, 4, 224), (7, 70, 40),
                                    (3, 130, 200)])   # W > 64: the step-mask words are reloaded per 64-step chunk
