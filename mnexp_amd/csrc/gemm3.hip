@@ -164,11 +164,9 @@ void launch_gemm3(const float* A, int lda, const float* B, int ldb, bool b_nk, f
   const uint32_t bytesB = (uint32_t)((b_nk ? (size_t)(N - 1) * ldb + K : (size_t)(K - 1) * ldb + N) * 4);
   const dim3 grid(cdiv(N, G3_T), cdiv(M, G3_T));
   if (b_nk)
-    hipLaunchKernelGGL((gemm3_kernel<false, true>), grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA,
-                       bytesB, K);
+    launch_k(gemm3_kernel<false, true>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB, K);
   else
-    hipLaunchKernelGGL((gemm3_kernel<false, false>), grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA,
-                       bytesB, K);
+    launch_k(gemm3_kernel<false, false>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB, K);
 }
 
 // C[M,N] = A^T . B with A [K][M], B [K][N] (parameter gradients: long K, small M x N), split along K into slabs in

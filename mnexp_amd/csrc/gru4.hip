@@ -775,7 +775,7 @@ void launch_gru4_bwd(const float* dh_last, const uint8_t* gmask, float* tape, co
 #define LSTUR_G4B(Q)                                              \
   {                                                               \
     set_lds(gru4_bwd_kernel<Q>, lds);                             \
-    hipLaunchKernelGGL(gru4_bwd_kernel<Q>, grid, block, lds, s, a); \
+    launch_k(gru4_bwd_kernel<Q>, grid, block, lds, s, a);          \
   }
   if (KQ == 10) LSTUR_G4B(10) else if (KQ == 32) LSTUR_G4B(32) else LSTUR_G4B(50)
 #undef LSTUR_G4B

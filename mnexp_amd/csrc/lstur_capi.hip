@@ -463,8 +463,8 @@ struct lstur_ctx {
   hipEvent_t ev_fork = nullptr, ev_enc0 = nullptr, ev_done1 = nullptr;
   // weight-gradient side stream (run_backward): the GRU / Dense parameter-gradient GEMMs only feed the step's final
   // reduction, so they run beside the chain d(doc vectors) -> attention backward -> conv kernel gradient
-  hipStream_t side_w = nullptr;
-  hipEvent_t ev_w1 = nullptr, ev_w2 = nullptr, ev_w3 = nullptr;
+  hipStream_t side_w = nullptr, side_w2 = nullptr;   // (second one: the Dense(U) parameter gradients, beside the GRU's)
+  hipEvent_t ev_w1 = nullptr, ev_w2 = nullptr, ev_w3 = nullptr, ev_w4 = nullptr;
   // staging prefetch (lstur_prefetch_ids): the next batch's title expansion, compaction and embedding gather run on a
   // side stream under the current step's forward recurrence (HBM and 240 CUs idle there)
   struct Pending { const int32_t* hist = nullptr; const int32_t* cands = nullptr; int n = 0; uint32_t step = 0;
@@ -505,6 +505,8 @@ struct lstur_ctx {
   }
   bool& counted_flag() { return cur_lane ? counted1 : counted; }
 };
+
+thread_local hipEvent_t lstur::g_stop_event = nullptr;
 
 namespace {
 
@@ -561,6 +563,8 @@ hipStream_t wgrad_stream(lstur_ctx* c) {
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     static const bool flat = getenv("LSTUR_WG_PRIORITY") && !strcmp(getenv("LSTUR_WG_PRIORITY"), "0");
     if (hipStreamCreateWithPriority(&c->side_w, hipStreamNonBlocking, flat ? lo : hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->side_w2, hipStreamNonBlocking, flat ? lo : hi) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_w4, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w3, hipEventDisableTiming) != hipSuccess) {
@@ -865,17 +869,22 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   // masking of cook.py:139-142 for every arch that reads the table
   const float row_p = training ? user_row_drop(c) : 0.f;
   if (row_p > 0.f) launch_drop_rows(w.uvec, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
-  dense_gemm(w.docvec, d.U, c->P("gru_w"), 3 * d.H, false, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, w.gemm_scratch, s);
-  if (c->cur_ev_enc) (void)hipEventRecord(c->cur_ev_enc, s);   // the other lane's encoder may start: the recurrence follows
   const bool recurrent = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
-  if (training) {   // background work for the recurrence to hide: the next batch's staging, then (fused step) the zero-gradient
-                    // half of the user-table sweep
-    const bool want_pf = recurrent && use3 && !gen1 && prefetch_wanted(c), want_sw = early_table_sweep_wanted(c);
-    if ((want_pf || want_sw) && fork_events(c)) {   // ONE event record on `s` for both side streams
-      (void)hipEventRecord(c->ev_f0, s);
-      const bool pf = want_pf && launch_prefetch(c, c->ev_f0);
-      early_table_sweep(c, n, c->ev_f0, recurrent, pf);
-    }
+  // background work for the recurrence to hide: the next batch's staging, then (fused step) the zero-gradient half of the
+  // user-table sweep.  ONE fork point for both side streams, attached to the input projection's completion.
+  const bool want_pf = training && recurrent && use3 && !gen1 && prefetch_wanted(c);
+  const bool want_sw = training && early_table_sweep_wanted(c);
+  const bool fork_f = (want_pf || want_sw) && fork_events(c);
+  if (fork_f) arm_stop_event(c->ev_f0);
+  dense_gemm(w.docvec, d.U, c->P("gru_w"), 3 * d.H, false, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, w.gemm_scratch, s);
+  if (stop_event_pending()) {   // (the fp32 kernel took the launch: record the classic way)
+    arm_stop_event(nullptr);
+    (void)hipEventRecord(c->ev_f0, s);
+  }
+  if (c->cur_ev_enc) (void)hipEventRecord(c->cur_ev_enc, s);   // the other lane's encoder may start: the recurrence follows
+  if (fork_f) {
+    const bool pf = want_pf && launch_prefetch(c, c->ev_f0);
+    early_table_sweep(c, n, c->ev_f0, recurrent, pf);
   }
   if (d.arch == LSTUR_ARCH_VO) {          // the user embedding alone (paper.py:622-623)
     (void)hipMemcpyAsync(w.uservec, w.uvec, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
@@ -944,19 +953,39 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   int nj = 0;
   hipStream_t sw = wgrad_stream(c);
   if (!sw) sw = s;
-  bool forked = false;
-  auto join = [&]() {     // the step's single reduction (on s) reads what the side stream produced
+  // LSTUR_WG_STREAMS=2: the Dense(U) parameter gradients on a side stream of their own (in ONE queue behind the GRU's three
+  // products they start ~100 us after their inputs are ready and can run into the conv kernel gradient, which shares a CU
+  // with nothing).  Measured A/B on one box: the second queue takes more from the attention backward than it saves
+  // (1.69 / 1.72 ms against 1.58 / 1.59 ms per step), so one queue at high priority is the default.
+  static const bool one_side = !(getenv("LSTUR_WG_STREAMS") && !strcmp(getenv("LSTUR_WG_STREAMS"), "2"));
+  hipStream_t sw2 = (sw != s && c->side_w2 && !one_side) ? c->side_w2 : sw;
+  bool forked = false, forked2 = false;
+  auto join = [&]() {     // the step's single reduction (on s) reads what the side streams produced
     if (forked) {
       (void)hipEventRecord(c->ev_w3, sw);
       (void)hipStreamWaitEvent(s, c->ev_w3, 0);
     }
+    if (forked2) {
+      (void)hipEventRecord(c->ev_w4, sw2);
+      (void)hipStreamWaitEvent(s, c->ev_w4, 0);
+    }
   };
+  // ONE event behind the recurrence serves both side streams (forks are merged wherever the dependencies allow), attached
+  // to the recurrence kernel's own completion when nothing else sits between it and the fork
+  const bool fork_t = finish_table_rows_wanted(c);
+  hipEvent_t fe = sw != s ? c->ev_w1 : c->ev_t0;   // (ev_t0 exists whenever fork_t does)
+  const bool fork_b = (has_gru && sw != s) || fork_t;
+  bool fe_recorded = false;
   if (has_gru) {
     float *hprev = w.hprev, *rh = w.rh;   // fast path: both already sit row-major in the tape (no copies)
     gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
+    const bool attach = fork_b && !(user_row_drop(c) > 0.f) && !(c->prof_on && !c->prof_roofline_only);   // (a bracketed launch records behind it anyway)
+    if (attach) arm_stop_event(fe);
     PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
                                    (d.arch == LSTUR_ARCH_IGRU || two_tables(d)) ? w.duser : w.dh0, n, d.W,
                                    d.H, s));
+    fe_recorded = attach && !stop_event_pending();
+    arm_stop_event(nullptr);
   }
   {   // the row gradients of the user table(s) pass the forward's row mask and scale (dgru / id_keep)
     const float row_p = user_row_drop(c);
@@ -966,11 +995,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
         launch_drop_rows(w.duser2, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
     }
   }
-  // ONE event behind the recurrence serves both side streams (an event record between two kernels of a stream is a ~6 us
-  // bubble on this stack: forks are merged wherever the dependencies allow)
-  const bool fork_t = finish_table_rows_wanted(c);
-  hipEvent_t fe = sw != s ? c->ev_w1 : c->ev_t0;   // (ev_t0 exists whenever fork_t does)
-  if ((has_gru && sw != s) || fork_t) (void)hipEventRecord(fe, s);
+  if (fork_b && !fe_recorded) (void)hipEventRecord(fe, s);
   if (fork_t) finish_table_rows(c, n, fe);   // fused step: the batch's own rows of the user table(s)
   if (has_gru) {
     float *hprev = w.hprev, *rh = w.rh;
@@ -1001,8 +1026,13 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     return;
   }
   // d(history doc vectors) = dgates . gru_w^T, masked by the history mask (paper.py:644-645)
-  if (has_gru)
+  bool w2_recorded = false;
+  if (has_gru) {
+    if (sw != s) arm_stop_event(c->ev_w2);   // the Dense(U) parameter gradients fork behind this product
     dense_gemm(w.dgates, 3 * d.H, c->P("gru_w"), 3 * d.H, true, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, w.gemm_scratch, s);
+    w2_recorded = sw != s && !stop_event_pending();
+    arm_stop_event(nullptr);
+  }
   else if (d.arch == LSTUR_ARCH_NIAVG)   // dx[b,w] = mask[b,w] * du[b] / (count_b + eps)
     launch_masked_mean(nullptr, w.gmask, nullptr, w.du, w.ddocvec, n, d.W, d.U, s);
   else if (d.arch == LSTUR_ARCH_NIATT) {   // backward of the attention over the history (no ReLU behind it: relu = 0)
@@ -1019,12 +1049,13 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   //  row -- is exactly 0, cf. paper.py:644-645)
   // news encoder backward (candidate rows of ddocvec were written by the scorer)
   if (sw != s) {          // Dense(U) parameter gradients: beside d(pooled) -> attention backward -> conv kernel gradient
-    (void)hipEventRecord(c->ev_w2, s);
-    (void)hipStreamWaitEvent(sw, c->ev_w2, 0);
-    forked = true;
+    if (!w2_recorded) (void)hipEventRecord(c->ev_w2, s);
+    (void)hipStreamWaitEvent(sw2, c->ev_w2, 0);
+    if (sw2 == sw) forked = true;
+    else forked2 = true;
   }
-  wgrad_gemm(w.pooled, d.F, w.ddocvec, d.U, c->G("dense_w"), d.U, d.F, d.U, nt, w.gemm_scratch_k[3], sw, &jobs[nj++]);
-  launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], sw, &jobs[nj++]);
+  wgrad_gemm(w.pooled, d.F, w.ddocvec, d.U, c->G("dense_w"), d.U, d.F, d.U, nt, w.gemm_scratch_k[3], sw2, &jobs[nj++]);
+  launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], sw2, &jobs[nj++]);
   dense_gemm(w.ddocvec, d.U, c->P("dense_w"), d.U, true, w.dpooled, d.F, nullptr, nt, d.F, d.U, w.gemm_scratch, s);
   // partial sums laid out like the bucket slice conv_b .. att_b -> one reduction straight into dense_grad
   if (d.enc == LSTUR_ENC_MHSA) {
@@ -1493,6 +1524,11 @@ int lstur_destroy(lstur_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_w2);
     (void)hipEventDestroy(ctx->ev_w3);
     (void)hipStreamDestroy(ctx->side_w);
+    if (ctx->side_w2) {
+      (void)hipStreamSynchronize(ctx->side_w2);
+      (void)hipStreamDestroy(ctx->side_w2);
+    }
+    if (ctx->ev_w4) (void)hipEventDestroy(ctx->ev_w4);
   }
   if (ctx)
     for (auto& k : ctx->prof)

@@ -2,6 +2,7 @@
 // orchestrated by lstur_capi.hip.  All launch on the given stream and never synchronise.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -23,6 +24,24 @@ struct ReduceJob {
   float beta;
 };
 constexpr int kMaxReduceJobs = 24;
+
+// Fork points without a bubble: hipEventRecord between two kernels of a stream is a barrier packet of its own and costs
+// ~6 us of idle GPU on this stack.  A launcher that goes through launch_k attaches the event to the kernel's OWN completion
+// signal instead (hipExtLaunchKernelGGL's stopEvent) when the orchestration armed one with arm_stop_event(); it consumes
+// the armed event, so the caller can tell (stop_event_pending()) whether it still has to record the classic way.
+extern thread_local hipEvent_t g_stop_event;
+inline void arm_stop_event(hipEvent_t e) { g_stop_event = e; }
+inline bool stop_event_pending() { return g_stop_event != nullptr; }
+template <typename F, typename... Args>
+inline void launch_k(F kern, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
+  if (g_stop_event) {
+    hipEvent_t e = g_stop_event;
+    g_stop_event = nullptr;
+    hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, nullptr, e, 0, args...);
+  } else {
+    hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
+  }
+}
 void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s);
 
 
