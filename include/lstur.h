@@ -56,8 +56,8 @@ enum lstur_arch {            /* user encoders of Seq2VecPaperSoftmaxId.get_user_
   LSTUR_ARCH_NIATT = 9,      /* no user id: SimpleAttentionMaskSupport over the history vectors (models.py:474-489);
                                 the id-less tasks' `att`, paper.py:207-209; parameters uatt_w [U], uatt_b [1]   */
   LSTUR_ARCH_IIGRU = 10,     /* Dense(U)(concat[GRU(U)(x, initial_state=user_vec), user_vec2]) with a SECOND user table
-                                (paper.py:614-621): needs lstur_buffers.user_emb2 / user_m2 / user_v2; single GPU
-                                only (the data-parallel exchange carries one table's rows)                       */
+                                (paper.py:614-621): needs lstur_buffers.user_emb2 / user_m2 / user_v2; the data-parallel
+                                tail (lstur_dp_stage) then carries the row gradients of both tables               */
   LSTUR_ARCH_IICGRU = 11     /* concat[GRU(U)(x, initial_state=user_vec), user_vec2], second table, NO Dense: the `iigru`
                                 of the pointwise Seq2VecPaperId (paper.py:343-348); a 2U-wide user vector, so it needs
                                 head POINT_MLP (or score_model ddot / dnn); same buffers and limits as IIGRU      */

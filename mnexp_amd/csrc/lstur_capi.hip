@@ -258,7 +258,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* dp_rows; float* dp_grads; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* conv_w3_v1; unsigned short* e3; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
+  int32_t* dp_rows; float* dp_grads; float* dp_grads2; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* conv_w3_v1; unsigned short* e3; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   // the staged form of a batch (token ids, their compacted list + offsets, the gathered embeddings) exists twice: while a
   // step runs on one set, the NEXT batch can be staged into the other (lstur_prefetch_ids); ids / e3 / vidx / ... above
@@ -393,6 +393,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->mh_scratch = mh ? take(proj_wgrad_scratch_bytes(d.D, 3 * d.F, (int)(nt * d.T))) : nullptr;
   w->dp_rows = (int32_t*)take((size_t)d.rows_cap * 4);
   w->dp_grads = (float*)take((size_t)d.rows_cap * d.Ue * f4);
+  w->dp_grads2 = ii ? (float*)take((size_t)d.rows_cap * d.Ue * f4) : nullptr;
   w->user_rows = (int32_t*)take(nc * 4);
   w->scores = (float*)take(nc * f4);
   w->colsum_scratch = (float*)take((size_t)kColsumSlices * std::max(std::max(3 * d.H, d.U), (int)(3 * ((d.F + kParamAlign - 1) / kParamAlign * kParamAlign) + 64)) * f4);
@@ -669,7 +670,7 @@ bool has_user_table(const Dims& d) {
 
 // Keras-Adam sweep of the user table(s) for the rows / row gradients of this batch (duplicates combined in sample order)
 void adam_user_tables(lstur_ctx* c, const int32_t* rows, const float* row_grads, int n_rows, float lr_t, bool combine_first,
-                      hipStream_t s) {
+                      hipStream_t s, const float* row_grads2 = nullptr) {
   const Dims& d = c->d;
   const lstur_cfg& cf = c->cfg;
   if (combine_first) launch_user_grad_combine(rows, row_grads, n_rows, d.Ue, c->ws.first, c->ws.gsum, c->ws.slot, s);
@@ -679,7 +680,8 @@ void adam_user_tables(lstur_ctx* c, const int32_t* rows, const float* row_grads,
                       cf.beta2, cf.eps, s);
   }
   if (two_tables(d)) {   // the second table: same rows (hence the same slot map), its own gradients
-    launch_user_grad_combine(rows, c->ws.duser2, n_rows, d.Ue, c->ws.first, c->ws.gsum2, c->ws.slot, s);
+    launch_user_grad_combine(rows, row_grads2 ? row_grads2 : c->ws.duser2, n_rows, d.Ue, c->ws.first, c->ws.gsum2,
+                             c->ws.slot, s);
     launch_adam_table(c->buf.user_emb2, c->buf.user_m2, c->buf.user_v2, c->ws.slot, c->ws.gsum2, d.Nu, d.Ue, lr_t,
                       cf.beta1, cf.beta2, cf.eps, s);
   }
@@ -1486,7 +1488,7 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
     // shared between the lanes: operand images of the weights (packed by lane 0), the optimizer's sparse-row scratch
     Workspace &a = c->ws, &b = c->ws1;
     b.conv_w3 = a.conv_w3; b.conv_w3_v1 = a.conv_w3_v1; b.conv_wp = a.conv_wp; b.gru_up = a.gru_up;
-    b.first = a.first; b.gsum = a.gsum; b.gsum2 = a.gsum2; b.slot = a.slot; b.dp_rows = a.dp_rows; b.dp_grads = a.dp_grads;
+    b.first = a.first; b.gsum = a.gsum; b.gsum2 = a.gsum2; b.slot = a.slot; b.dp_rows = a.dp_rows; b.dp_grads = a.dp_grads; b.dp_grads2 = a.dp_grads2;
   }
   set_lane(c, 0);
   if (need > buf->workspace_bytes) {
@@ -1604,14 +1606,15 @@ size_t lstur_dp_tail_floats(const lstur_cfg* cfg, int32_t world) {
   Dims d;
   std::string why;
   if (world < 1 || !make_dims(cfg, &d, &why)) return 0;
-  return (size_t)world * d.B * (1 + d.Ue);
+  return (size_t)world * d.B * (1 + (two_tables(d) ? 2 : 1) * d.Ue);   // iigru / iicgru: both tables' row gradients
 }
 int lstur_dp_stage(lstur_ctx* ctx, float* tail, int32_t rank, int32_t world, lstur_stream stream) {
   if (!ctx || !tail || world < 1 || rank < 0 || rank >= world) return fail(LSTUR_ERR_ARG, "dp stage: bad argument");
   const Dims& d = ctx->d;
   if ((size_t)world * d.B > (size_t)d.rows_cap) return fail(LSTUR_ERR_ARG, "dp stage: world size above 8");
   if (d.Nu >= (1 << 24)) return fail(LSTUR_ERR_ARG, "dp stage: row numbers above 2^24 are not exact as float");
-  launch_dp_stage(ctx->ws.user_rows, ctx->ws.duser, ctx->last_n, d.B, d.Ue, tail, rank, world, (hipStream_t)stream);
+  launch_dp_stage(ctx->ws.user_rows, ctx->ws.duser, two_tables(d) ? ctx->ws.duser2 : nullptr, ctx->last_n, d.B, d.Ue, tail,
+                  rank, world, (hipStream_t)stream);
   return check_launch("dp_stage");
 }
 int lstur_dp_unpack(lstur_ctx* ctx, const float* tail, int32_t world, int32_t n, const int32_t** rows, const float** grads,
@@ -1619,7 +1622,8 @@ int lstur_dp_unpack(lstur_ctx* ctx, const float* tail, int32_t world, int32_t n,
   if (!ctx || !tail || !rows || !grads || world < 1 || n < 0) return fail(LSTUR_ERR_ARG, "dp unpack: bad argument");
   const Dims& d = ctx->d;
   if (n > d.B || (size_t)world * n > (size_t)d.rows_cap) return fail(LSTUR_ERR_ARG, "dp unpack: too many rows");
-  launch_dp_unpack(tail, n, d.B, d.Ue, world, ctx->ws.dp_rows, ctx->ws.dp_grads, (hipStream_t)stream);
+  launch_dp_unpack(tail, n, d.B, d.Ue, world, ctx->ws.dp_rows, ctx->ws.dp_grads, two_tables(d) ? ctx->ws.dp_grads2 : nullptr,
+                   (hipStream_t)stream);
   *rows = ctx->ws.dp_rows;
   *grads = ctx->ws.dp_grads;
   return check_launch("dp_unpack");
@@ -1631,8 +1635,12 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
                      hipStream_t s, bool skip_table) {
   const Dims& d = ctx->d;
   const lstur_cfg& c = ctx->cfg;
-  if (rows && two_tables(d))
-    return fail(LSTUR_ERR_ARG, "iigru: external (data-parallel) user rows are not supported: the exchange carries one table");
+  const float* row_grads2 = nullptr;   // second table (iigru / iicgru): own rows -> ws.duser2, exchanged rows -> ws.dp_grads2
+  if (rows && two_tables(d)) {
+    if (rows != ctx->ws.dp_rows || row_grads != ctx->ws.dp_grads)
+      return fail(LSTUR_ERR_ARG, "iigru: external user rows must come from lstur_dp_unpack (it carries both tables' gradients)");
+    row_grads2 = ctx->ws.dp_grads2;
+  }
   if (!rows) {
     rows = ctx->ws.user_rows;
     row_grads = ctx->ws.duser;
@@ -1658,7 +1666,7 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
     launch_adam_flat(ctx->buf.word_emb, ctx->buf.word_grad, ctx->buf.word_m, ctx->buf.word_v, (size_t)d.V * d.D, lr_t,
                      c.beta1, c.beta2, c.eps, s);
   if (!no_user && !skip_table)   // nigru / niavg: the user embedding is not part of the graph (paper.py:627-630)
-    adam_user_tables(ctx, rows, row_grads, n_rows, lr_t, false, s);
+    adam_user_tables(ctx, rows, row_grads, n_rows, lr_t, false, s, row_grads2);
   if (skip_table) (void)hipStreamWaitEvent(s, ctx->ev_t1, 0);
   return check_launch("adam_step");
 }

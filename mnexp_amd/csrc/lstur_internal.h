@@ -97,9 +97,9 @@ void launch_adam_table(float* p, float* m, float* v, const int32_t* slot, const 
 void launch_user_grad_combine(const int32_t* rows, const float* g, int n, int dim, int32_t* first,
                               float* gsum, int32_t* slot, hipStream_t s);
 // data-parallel exchange of the sparse user rows through the dense bucket's all-reduce (see misc.hip)
-void launch_dp_stage(const int32_t* rows, const float* g, int n, int B, int Ue, float* tail, int rank, int world,
-                     hipStream_t s);
-void launch_dp_unpack(const float* tail, int n, int B, int Ue, int world, int32_t* rows, float* g, hipStream_t s);
+void launch_dp_stage(const int32_t* rows, const float* g, const float* g2, int n, int B, int Ue, float* tail, int rank,
+                     int world, hipStream_t s);
+void launch_dp_unpack(const float* tail, int n, int B, int Ue, int world, int32_t* rows, float* g, float* g2, hipStream_t s);
 void launch_user_slot_clear(const int32_t* rows, int n, int32_t* slot, hipStream_t s);
 // the sweep in two halves (fused step): mark the batch's rows, move every OTHER row with its zero gradient (independent of
 // the step's backward), later finish the marked rows from their combined gradients (first occurrences, slot[row] == i)

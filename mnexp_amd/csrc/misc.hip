@@ -772,9 +772,9 @@ void launch_user_grad_combine(const int32_t* rows, const float* g, int n, int di
 // ---- data-parallel exchange of the sparse user-row gradients inside the dense bucket's ONE all-reduce -------------
 // tail (behind the dense gradients in the caller's bucket) = world slots of [B row numbers as float | B x Ue grads];
 // a rank fills its own slot and zeroes the others, so the sum over ranks IS the concatenation (x + 0 + ... + 0 = x).
-__global__ void dp_stage_kernel(const int32_t* __restrict__ rows, const float* __restrict__ g, int n, int B, int Ue,
-                                float* __restrict__ tail, int rank, int world) {
-  const int S = B * (1 + Ue);
+__global__ void dp_stage_kernel(const int32_t* __restrict__ rows, const float* __restrict__ g, const float* __restrict__ g2,
+                                int n, int B, int Ue, float* __restrict__ tail, int rank, int world) {
+  const int ntab = g2 ? 2 : 1, S = B * (1 + ntab * Ue);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= world * S) return;
   const int k = i / S, e = i - k * S;
@@ -782,32 +782,36 @@ __global__ void dp_stage_kernel(const int32_t* __restrict__ rows, const float* _
   if (k == rank) {
     if (e < B) v = e < n ? (float)rows[e] : 0.f;
     else {
-      const int j = (e - B) / Ue;
-      v = j < n ? g[e - B] : 0.f;
+      const int x = e - B, tab = x / (B * Ue), r = x - tab * (B * Ue);   // r = j * Ue + c
+      v = r / Ue < n ? (tab ? g2 : g)[r] : 0.f;
     }
   }
   tail[i] = v;
 }
-void launch_dp_stage(const int32_t* rows, const float* g, int n, int B, int Ue, float* tail, int rank, int world,
-                     hipStream_t s) {
-  const int total = world * B * (1 + Ue);
-  hipLaunchKernelGGL(dp_stage_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, rows, g, n, B, Ue, tail, rank, world);
+// g2 != NULL: a second table's row gradients travel in the same slot (iigru / iicgru: [B rows | B x Ue | B x Ue])
+void launch_dp_stage(const int32_t* rows, const float* g, const float* g2, int n, int B, int Ue, float* tail, int rank,
+                     int world, hipStream_t s) {
+  const int total = world * B * (1 + (g2 ? 2 : 1) * Ue);
+  hipLaunchKernelGGL(dp_stage_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, rows, g, g2, n, B, Ue, tail, rank, world);
 }
-// reduced tail -> rows int32 [world*n], grads [world*n, Ue] in rank order (every rank passed the same n)
+// reduced tail -> rows int32 [world*n], grads [world*n, Ue] (and grads2) in rank order (every rank passed the same n)
 __global__ void dp_unpack_kernel(const float* __restrict__ tail, int n, int B, int Ue, int world, int32_t* __restrict__ rows,
-                                 float* __restrict__ g) {
-  const int S = B * (1 + Ue);
+                                 float* __restrict__ g, float* __restrict__ g2) {
+  const int ntab = g2 ? 2 : 1, S = B * (1 + ntab * Ue);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= world * n * (1 + Ue)) return;
-  const int per = n * (1 + Ue);
+  const int per = n * (1 + ntab * Ue);
+  if (i >= world * per) return;
   const int k = i / per, e = i - k * per;
   const float* slot = tail + (size_t)k * S;
   if (e < n) rows[k * n + e] = (int32_t)(slot[e] + 0.5f);
-  else g[(size_t)k * n * Ue + (e - n)] = slot[B + (e - n)];
+  else {
+    const int x = e - n, tab = x / (n * Ue), r = x - tab * (n * Ue);
+    (tab ? g2 : g)[(size_t)k * n * Ue + r] = slot[B + tab * (B * Ue) + r];
+  }
 }
-void launch_dp_unpack(const float* tail, int n, int B, int Ue, int world, int32_t* rows, float* g, hipStream_t s) {
-  const int total = world * n * (1 + Ue);
-  if (total) hipLaunchKernelGGL(dp_unpack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, tail, n, B, Ue, world, rows, g);
+void launch_dp_unpack(const float* tail, int n, int B, int Ue, int world, int32_t* rows, float* g, float* g2, hipStream_t s) {
+  const int total = world * n * (1 + (g2 ? 2 : 1) * Ue);
+  if (total) hipLaunchKernelGGL(dp_unpack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, tail, n, B, Ue, world, rows, g, g2);
 }
 
 __global__ void slot_clear_kernel(const int32_t* __restrict__ rows, int n, int32_t* __restrict__ slot) {

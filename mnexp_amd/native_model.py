@@ -534,8 +534,6 @@ class NativeModel:
                      self.stats.data_ptr(), s), 'lstur_forward_backward')
         self.optimizer.iterations += 1
         t = self.optimizer.iterations
-        if (self.world > 1 or self.force_collectives) and self.arch in ('iigru', 'iicgru'):
-            raise _lib.LsturError('iigru (two user tables) is single-GPU only: the data-parallel exchange carries one table')
         if self.world > 1 or self.force_collectives:
             rows, grads = self._allreduce_grads(n)
             check(lib.lstur_adam_step(self._ctx, self.optimizer.lr, t, rows.data_ptr(), grads.data_ptr(),
@@ -566,6 +564,9 @@ class NativeModel:
             Ue = self.sizes.user_emb_dim
             return (self._peek_ptr(rows.value, world * n, torch.int32),
                     self._peek_ptr(grads.value, world * n * Ue, torch.float32).view(world * n, Ue))
+        if self.arch in ('iigru', 'iicgru'):
+            raise _lib.LsturError('iigru (two user tables): the data-parallel exchange needs the one-collective path '
+                                  '(world <= 8, n_users < 2^24)')
         # general fallback: all-reduce of the bucket + all-gather of rows and gradients
         D.allreduce_bucket(self.dense_grad, self.dist_group, prescaled=True)
         rows, grads, cnt = C.c_void_p(), C.c_void_p(), C.c_int32()

@@ -198,9 +198,11 @@ def test_click_entry_point(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), 'logx.txt'))
 
 
-def test_dp_call_sequence_on_one_rank_nccl():
-    """The data-parallel step (RCCL all-reduce of the flat bucket + all-gather of the sparse user rows +
-    Adam over the gathered rows) with a 1-rank 'nccl' group must equal the plain single-GPU step."""
+@pytest.mark.parametrize('arch', ['igru', 'iigru'])
+def test_dp_call_sequence_on_one_rank_nccl(arch):
+    """The data-parallel step (RCCL all-reduce of the flat bucket with the sparse user rows in its tail + Adam over the
+    exchanged rows) with a 1-rank 'nccl' group must equal the plain single-GPU step; iigru: the tail carries the row
+    gradients of BOTH user tables."""
     _need_gpu()
     import torch.distributed as dist
     from conftest import make_batch
@@ -214,7 +216,7 @@ def test_dp_call_sequence_on_one_rank_nccl():
         dims, B, W, T, K1 = MID, 16, 6, 9, 5
         outs = []
         for force in (False, True):
-            O, p, model, rng = build('igru', dims, B, W, T, K1, 0.2)
+            O, p, model, rng = build(arch, dims, B, W, T, K1, 0.2)
             model.force_collectives = force
             for step in range(2):
                 user, hist, cands = make_batch(rng, B, W, T, K1, dims['V'], dims['N_u'])
@@ -225,9 +227,63 @@ def test_dp_call_sequence_on_one_rank_nccl():
             outs.append(model.get_weights())
         for n in outs[0]:
             assert np.array_equal(outs[0][n], outs[1][n]), n
+        assert ('user_emb2' in outs[0]) == (arch == 'iigru')
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_dp_tail_of_two_tables_concatenates_over_ranks():
+    """lstur_dp_stage / lstur_dp_unpack for iigru: two 'ranks' (two contexts on this GPU) stage their rows and both tables'
+    row gradients into their slot of the tail; the SUM of the two tails (what the all-reduce delivers) unpacks to the
+    concatenation in rank order, and one Adam step over it equals the oracle's dense update of both tables."""
+    _need_gpu()
+    from conftest import make_batch
+    from test_gpu_model import build, MID, rel_close
+    from mnexp_amd._lib import lib, check
+    import ctypes as C
+    dims, B, W, T, K1 = MID, 12, 5, 9, 5
+    world = 2
+    models, tails, refs = [], [], []
+    O = None
+    for r in range(world):
+        O, p, model, rng = build('iigru', dims, B, W, T, K1, 0.0, seed=5)      # identical replicas
+        rb = np.random.default_rng(100 + r)
+        user, hist, cands = make_batch(rb, B, W, T, K1, dims['V'], dims['N_u'])
+        user[1] = user[0]
+        u, h, c = model._dev_i32(user), model._dev_i32(hist), model._dev_i32(cands)
+        check(lib.lstur_forward_backward(model._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), B, 0, 1.0 / world,
+                                         model.stats.data_ptr(), model._stream()))
+        n_tail = int(lib.lstur_dp_tail_floats(C.byref(model.cfg), world))
+        assert n_tail == world * B * (1 + 2 * dims['U'])
+        tail = torch.zeros(n_tail, dtype=torch.float32, device='cuda')
+        check(lib.lstur_dp_stage(model._ctx, tail.data_ptr(), r, world, model._stream()))
+        models.append(model)
+        tails.append(tail)
+        refs.append(O.forward_backward(p, 'iigru', user, hist, cands))
+        refs[-1]['user'] = user
+    torch.cuda.synchronize()
+    total = tails[0] + tails[1]                                                # the all-reduce
+    m = models[0]
+    rows, grads = C.c_void_p(), C.c_void_p()
+    check(lib.lstur_dp_unpack(m._ctx, total.data_ptr(), world, B, C.byref(rows), C.byref(grads), m._stream()))
+    got_rows = m._peek_ptr(rows.value, world * B, torch.int32).cpu().numpy()
+    got_g1 = m._peek_ptr(grads.value, world * B * dims['U'], torch.float32).cpu().numpy().reshape(world * B, -1)
+    assert np.array_equal(got_rows, np.concatenate([r['user'] for r in refs]))
+    want_g1 = np.concatenate([r['user_row_grads'] for r in refs]) / world
+    rel_close(got_g1, want_g1, 2e-3, 'table 1 rows')
+    # one Adam step over the exchanged rows: both tables move like the oracle's dense update of the summed gradients
+    before2 = m.user_emb2.clone()
+    check(lib.lstur_adam_step(m._ctx, 1e-3, 1, rows.value, grads.value, world * B, m._stream()))
+    torch.cuda.synchronize()
+    want_g2 = np.concatenate([r['user_row_grads2'] for r in refs]) / world
+    dense2 = O.densify_user_grad(dims['N_u'], dims['U'], got_rows, want_g2, np.float64)
+    moved = (m.user_emb2 - before2).cpu().numpy().reshape(dims['N_u'], dims['U'])
+    touched = np.abs(dense2).sum(1) > 0
+    # first Adam step: delta = -lr_t * g / (|g| + eps') ~ -lr * sign(g) for the rows with a gradient, 0 elsewhere
+    assert np.abs(moved[~touched]).max() == 0.0
+    big = np.abs(dense2) > 1e-9
+    assert np.array_equal(np.sign(moved[big]), -np.sign(dense2[big]))
 
 
 def test_save_load_round_trip(tmp_path):
