@@ -563,9 +563,11 @@ hipStream_t wgrad_stream(lstur_ctx* c) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     static const bool flat = getenv("LSTUR_WG_PRIORITY") && !strcmp(getenv("LSTUR_WG_PRIORITY"), "0");
+    static const bool two = getenv("LSTUR_WG_STREAMS") && !strcmp(getenv("LSTUR_WG_STREAMS"), "2");
+    if (two && (hipStreamCreateWithPriority(&c->side_w2, hipStreamNonBlocking, flat ? lo : hi) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_w4, hipEventDisableTiming) != hipSuccess))
+      c->side_w2 = nullptr;
     if (hipStreamCreateWithPriority(&c->side_w, hipStreamNonBlocking, flat ? lo : hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->side_w2, hipStreamNonBlocking, flat ? lo : hi) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_w4, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w3, hipEventDisableTiming) != hipSuccess) {
@@ -585,6 +587,23 @@ void use_set(lstur_ctx* c, int k) {
 }
 
 // enqueue the pending prefetch (if any) on the side stream, behind everything `s` holds so far; true: something was launched
+// ONE background stream for everything that hides under the recurrences: the next batch's staging, then the zero-gradient
+// half of the user-table sweep, later the batch's own table rows (side_p and side_t are the same queue).  Streams are not
+// free on this stack: a FIFTH one in use (measured: a second parameter-gradient stream) made every kernel of the step
+// ~45 % slower -- beyond the hardware queues streams get multiplexed -- and RCCL brings its own in data-parallel runs.
+bool background_stream(lstur_ctx* c) {
+  if (c->side_p) return true;
+  if (hipStreamCreateWithFlags(&c->side_p, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_p0, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_t0, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming) != hipSuccess) {
+    c->side_p = c->side_t = nullptr;
+    return false;
+  }
+  c->side_t = c->side_p;
+  return true;
+}
 bool fork_events(lstur_ctx* c) {
   if (c->ev_f0) return true;
   if (hipEventCreateWithFlags(&c->ev_f0, hipEventDisableTiming) != hipSuccess) c->ev_f0 = nullptr;
@@ -600,14 +619,9 @@ bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
   const Dims& d = c->d;
   Workspace& w = c->ws;
   if (!prefetch_wanted(c)) return false;
-  if (!c->side_p) {
-    if (hipStreamCreateWithFlags(&c->side_p, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_p0, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming) != hipSuccess) {
-      c->side_p = nullptr;
-      q.valid = false;
-      return false;
-    }
+  if (!background_stream(c)) {
+    q.valid = false;
+    return false;
   }
   const Workspace::StageSet& t = w.set[c->cur_set ^ 1];
   hipStream_t p = c->side_p;
@@ -694,16 +708,7 @@ void adam_user_tables(lstur_ctx* c, const int32_t* rows, const float* row_grads,
 // registers, beside the small GEMMs / attention backward it takes the bandwidth they are bound by: both were measured.)
 // The batch's own rows are marked first (their table reads of this forward see the old values) and finished behind the
 // recurrence's backward from their combined gradients.  Same arithmetic per element as the one-piece sweep.
-bool table_stream(lstur_ctx* c) {
-  if (c->side_t) return true;
-  if (hipStreamCreateWithFlags(&c->side_t, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_t0, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming) != hipSuccess) {
-    c->side_t = nullptr;
-    return false;
-  }
-  return true;
-}
+bool table_stream(lstur_ctx* c) { return background_stream(c); }
 // The recurrence beside it is a latency chain (its gate inputs and tape cross HBM every step): a sweep at full bandwidth
 // stretched it by most of what the sweep took (176 -> 216 us at 50 k users), and at 256 workgroups by more.  So the sweep
 // is launched THIN -- as many workgroups as finish it inside the two recurrences (~14 GB/s each at this load; 64 at 50 k
@@ -1507,19 +1512,15 @@ int lstur_destroy(lstur_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_done1);
     (void)hipStreamDestroy(ctx->side);
   }
-  if (ctx && ctx->side_p) {
+  if (ctx && ctx->side_p) {    // (side_t is the same stream)
     (void)hipStreamSynchronize(ctx->side_p);
     (void)hipEventDestroy(ctx->ev_p0);
     (void)hipEventDestroy(ctx->ev_p1);
+    (void)hipEventDestroy(ctx->ev_t0);
+    (void)hipEventDestroy(ctx->ev_t1);
     (void)hipStreamDestroy(ctx->side_p);
   }
   if (ctx && ctx->ev_f0) (void)hipEventDestroy(ctx->ev_f0);
-  if (ctx && ctx->side_t) {
-    (void)hipStreamSynchronize(ctx->side_t);
-    (void)hipEventDestroy(ctx->ev_t0);
-    (void)hipEventDestroy(ctx->ev_t1);
-    (void)hipStreamDestroy(ctx->side_t);
-  }
   if (ctx && ctx->side_w) {
     (void)hipStreamSynchronize(ctx->side_w);
     (void)hipEventDestroy(ctx->ev_w1);

@@ -630,7 +630,10 @@ __global__ __launch_bounds__(256) void adam_table_kernel(float* __restrict__ p, 
                                                          float* __restrict__ v, const int32_t* __restrict__ slot,
                                                          const float* __restrict__ gsum, size_t total, int dimv,
                                                          float lr_t, float b1, float b2, float eps) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  // a block sweeps ONE contiguous range of the table (256-element pieces, one after the other): a grid-strided sweep
+  // touched 6 streams x 8192 blocks of pages at once and fell to 4.1 TB/s on the 2.4 GB of a 1 M-row table
+  const size_t per = (total + gridDim.x - 1) / gridDim.x, lo = (size_t)blockIdx.x * per, hi = lo + per < total ? lo + per : total;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     size_t row = i / dimv;
     int c = (int)(i - row * dimv);
     int sl = slot[row];
