@@ -591,9 +591,13 @@ void use_set(lstur_ctx* c, int k) {
 // half of the user-table sweep, later the batch's own table rows (side_p and side_t are the same queue).  Streams are not
 // free on this stack: a FIFTH one in use (measured: a second parameter-gradient stream) made every kernel of the step
 // ~45 % slower -- beyond the hardware queues streams get multiplexed -- and RCCL brings its own in data-parallel runs.
+hipStream_t wgrad_stream(lstur_ctx* c);
 bool background_stream(lstur_ctx* c) {
   if (c->side_p) return true;
-  if (hipStreamCreateWithFlags(&c->side_p, hipStreamNonBlocking) != hipSuccess ||
+  static const bool share = getenv("LSTUR_ONE_SIDE") != nullptr;    // experiment: ONE side stream for everything
+  hipStream_t shared = share ? wgrad_stream(c) : nullptr;
+  if (shared) c->side_p = shared;
+  if ((!shared && hipStreamCreateWithFlags(&c->side_p, hipStreamNonBlocking) != hipSuccess) ||
       hipEventCreateWithFlags(&c->ev_p0, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_t0, hipEventDisableTiming) != hipSuccess ||
@@ -1518,7 +1522,7 @@ int lstur_destroy(lstur_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_p1);
     (void)hipEventDestroy(ctx->ev_t0);
     (void)hipEventDestroy(ctx->ev_t1);
-    (void)hipStreamDestroy(ctx->side_p);
+    if (ctx->side_p != ctx->side_w) (void)hipStreamDestroy(ctx->side_p);
   }
   if (ctx && ctx->ev_f0) (void)hipEventDestroy(ctx->ev_f0);
   if (ctx && ctx->side_w) {
