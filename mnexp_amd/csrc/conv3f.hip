@@ -44,6 +44,10 @@ size_t conv3_e3_elems(int n_titles, int T, int D, int ksize) {
   return (size_t)n_titles * (T + ksize - 1) * conv3_dp(D) * 3 + 3 * 256;
 }
 size_t conv3_w3_elems2(int D, int ksize, int F) { return (size_t)3 * f2_kp(D, ksize) * f2_np(F); }
+void conv3_w2_dims(int D, int ksize, int F, int* Kp, int* Np) {
+  *Kp = f2_kp(D, ksize);
+  *Np = f2_np(F);
+}
 
 // W [ksize * D, F] fp32 -> three bf16 parts [3][Kp][Np] in k' = tap * Dp + d order, zero padded
 __global__ void conv3_pack_w2_kernel(const float* __restrict__ W, int D, int Dp, int ksize, int F, int Kp, int Np,

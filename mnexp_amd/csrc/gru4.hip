@@ -185,6 +185,7 @@ int gru4_kq(int H) {
   const int q = cdiv(H, 4);
   return q <= 10 ? 10 : (q <= 32 ? 32 : 50);
 }
+int gru4_pack_kq(int H) { return gru4_kq(H); }
 size_t gru4_pack_floats(int H) {
   const int KQ = gru4_kq(H);
   return KQ ? (size_t)KQ * 4 * 6 * H : 0;

@@ -84,6 +84,20 @@ void launch_colsum(const float* x, int rows, int cols, int ld, float* out, float
 constexpr int kColsumSlices = 64;
 void launch_colsum2(const float* x, int rows, int cols, int ld, float* out, float scale, float* scratch,
                     hipStream_t s, ReduceJob* defer = nullptr);
+// Adam over the dense bucket + the weight images of the NEXT forward in the same launch: an updated conv_w element also
+// lands (split into three bf16 parts) in the conv kernels' W3 image, an updated gru_u element in the two resident-U images
+// that hold it.  The images' padding stays as the stand-alone pack kernels wrote it once.
+struct ImagePlan {
+  size_t conv_off = 0, conv_cnt = 0;   // conv_w slot of the bucket ([ksize * D, F]); 0: no W3 image
+  int D = 0, Dp = 0, F = 0, Np = 0;
+  unsigned short* w3 = nullptr;
+  size_t w3_part = 0;                  // elements of one part of W3 (Kp * Np)
+  size_t gru_off = 0;                  // gru_u slot ([H, 3H]); H == 0: no resident-U images
+  int H = 0, KQ = 0;
+  float* gimg = nullptr;
+};
+void launch_adam_flat_pack(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
+                           const ImagePlan& plan, hipStream_t s);
 void launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1,
                       float b2, float eps, hipStream_t s);
 // the same sweep + launch_user_grad_combine(rows, rg, ...) in one launch
@@ -172,6 +186,7 @@ void launch_conv3_fwd(const float* emb, const unsigned short* W3, const float* b
                       hipStream_t s);
 
 // ---- conv3f.hip: second generation of the bf16x3 forward (both operands pre-split; see the file header) --------
+void conv3_w2_dims(int D, int ksize, int F, int* Kp, int* Np);   // padded shape of the W3 image ([3][Kp][Np], k' = tap * Dp + d)
 int conv3_dp(int D);                                              // embedding row length of E3 (D rounded up to 8)
 size_t conv3_e3_elems(int n_titles, int T, int D, int ksize);   // bf16 elements of E3 incl. slack
 size_t conv3_w3_elems2(int D, int ksize, int F);                // bf16 elements of the k'-ordered split weight image
@@ -284,6 +299,7 @@ bool gru_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh);
 
 // gru4.hip (fast path: four sample rows per workgroup, U resident in VGPRs + LDS; H <= 200)
 bool gru4_supported(int H);
+int gru4_pack_kq(int H);            // k-quads per column of the resident-U images (0: the general kernels' layout is used)
 size_t gru4_pack_floats(int H);
 size_t gru4_tape_floats(int n, int W, int H);
 void gru4_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh);

@@ -614,6 +614,41 @@ void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size
     hipLaunchKernelGGL(adam_flat_combine_kernel, dim3(fb + cb), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps, fb, rows,
                        rg, n_rows, dim, gsum, slot);
 }
+__global__ void adam_flat_pack_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                      float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, ImagePlan P) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam1(pi, g[i], mi, vi, lr_t, b1, b2, eps);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    if (i - P.conv_off < P.conv_cnt) {            // conv_w[tap * D + d][f] -> W3[part][tap * Dp + d][f]  (conv3_pack_w2_kernel)
+      const size_t j = i - P.conv_off;
+      const int f = (int)(j % P.F), td = (int)(j / P.F), tap = td / P.D, d = td - tap * P.D;
+      const size_t idx = ((size_t)tap * P.Dp + d) * P.Np + f;
+      u16x4 h, mm, l;
+      split3(make_float4(pi, 0.f, 0.f, 0.f), h, mm, l);
+      P.w3[idx] = h[0];
+      P.w3[P.w3_part + idx] = mm[0];
+      P.w3[2 * P.w3_part + idx] = l[0];
+    }
+    if (P.H && i - P.gru_off < (size_t)3 * P.H * P.H) {   // gru_u[k][c]: the forward image and a transposed one (gru4_pack_kernel)
+      const size_t j = i - P.gru_off;
+      const int H = P.H, c = (int)(j % (3 * H)), k = (int)(j / (3 * H));
+      const size_t e = (size_t)P.KQ * 4 * H;
+      if (c < 2 * H) P.gimg[((size_t)(k >> 2) * 2 * H + c) * 4 + (k & 3)] = pi;                          // izr
+      else P.gimg[2 * e + ((size_t)(k >> 2) * H + (c - 2 * H)) * 4 + (k & 3)] = pi;                      // ih
+      const int which = 1 + c / H, kk = c - (which - 1) * H;                                             // itz | itr | ith
+      P.gimg[2 * e + (size_t)which * e + ((size_t)(kk >> 2) * H + k) * 4 + (kk & 3)] = pi;
+    }
+  }
+}
+void launch_adam_flat_pack(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
+                           const ImagePlan& plan, hipStream_t s) {
+  if (!n) return;
+  const int blocks = (int)std::min<size_t>(cdivz(n, 256), 4096);
+  hipLaunchKernelGGL(adam_flat_pack_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps, plan);
+}
 void launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                       float eps, hipStream_t s) {
   if (!n) return;
