@@ -329,13 +329,16 @@ __global__ __launch_bounds__(256) void conv3_fwd2_fix_kernel(const float* __rest
   constexpr int BM = 128, BCOLS = 448;
   const int count = vcount ? vcount[0] : M;
   const TailPlan tp = tail_plan(count, BM, ncu);
-  const int tile = tp.full + blockIdx.x;
-  if (tp.S <= 1 || tile * BM >= count) return;
+  if (tp.S <= 1) return;
+  // (the number of sliced tiles is a device-side value: a few workgroup columns walk over them -- a grid sized for the most
+  //  there can be, ncu / 2, spent ~5 us dispatching 8 000 workgroups that returned at once)
+  for (int bt = blockIdx.x; (tp.full + bt) * BM < count; bt += gridDim.x) {
+  const int tile = tp.full + bt;
   const int c4 = threadIdx.x & 127, lr = blockIdx.y * 2 + (threadIdx.x >> 7);   // 112 column quads (448 columns), 2 rows
   const int i = tile * BM + lr;
-  if (c4 >= BCOLS / 4 || i >= count) return;
+  if (c4 >= BCOLS / 4 || i >= count) continue;
   const int m = vidx ? vidx[i] : i;
-  const float* p = slabs + (size_t)blockIdx.x * tp.S * (BM * BCOLS) + (size_t)lr * BCOLS + c4 * 4;
+  const float* p = slabs + (size_t)bt * tp.S * (BM * BCOLS) + (size_t)lr * BCOLS + c4 * 4;
   float4 v[8];
 #pragma unroll
   for (int sl = 0; sl < 8; ++sl) v[sl] = *(const float4*)(p + (size_t)min(sl, tp.S - 1) * (BM * BCOLS));
@@ -351,6 +354,7 @@ __global__ __launch_bounds__(256) void conv3_fwd2_fix_kernel(const float* __rest
 #pragma unroll
   for (int e = 0; e < 4; ++e)
     if (col + e < F) C[(size_t)m * F + col + e] = fmaxf(o[e] + bias[col + e], 0.f) * keep;
+  }
 }
 
 bool conv3f_supported(int D, int ksize, int F) { return D % 4 == 0 && F >= 1 && F <= 448; }
@@ -392,7 +396,7 @@ void launch_conv3_fwd2(const unsigned short* e3, const unsigned short* W3, const
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), f2_lds(4, 2, 7), s, e3, e_bytes, W3, bias, ids, out, vidx, vcount, M, T, Tp,
                      Dp / 8, F, Kp, Np, ncu, (float*)scratch);
   if (ncu > 0)
-    hipLaunchKernelGGL(conv3_fwd2_fix_kernel, dim3(ncu / 2, 64), dim3(256), 0, s, (const float*)scratch, bias, ids, out, vidx,
+    hipLaunchKernelGGL(conv3_fwd2_fix_kernel, dim3(8, 64), dim3(256), 0, s, (const float*)scratch, bias, ids, out, vidx,
                        vcount, M, F, ncu);
 }
 
