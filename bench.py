@@ -250,6 +250,10 @@ def e2e_legs(wl, word, steps, dropout, device):
             nonpad = []
             # one batch of look-ahead, as NativeModel.fit_generator does: the next batch is uploaded and announced to the
             # library (lstur_prefetch_ids) before the current step is launched
+            # ... and, like Keras' fit_generator (workers=1, max_queue_size=10) and NativeModel.fit_generator, the generator
+            # runs in one background thread at most 10 batches ahead
+            from mnexp_amd.native_model import prefetched
+            feed = prefetched(feed, steps + 12, 10)
             X, _ = next(feed)
             staged = None
             for _ in range(10):
@@ -257,14 +261,17 @@ def e2e_legs(wl, word, steps, dropout, device):
                 staged = model.train_on_ids(*X, next_ids=Xn, staged=staged)
                 X = Xn
             torch.cuda.synchronize()
+            seen = []
             t0 = time.perf_counter()
             for _ in range(steps):
                 Xn, _ = next(feed)
                 staged = model.train_on_ids(*X, next_ids=Xn, staged=staged)
-                nonpad.append(int((h.docs.title_table[X[1]] != 0).sum() + (h.docs.title_table[X[2]] != 0).sum()))
+                seen.append(X)
                 X = Xn
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
+            next(feed, None)                     # (lets the worker finish its count)
+            nonpad = [int((h.docs.title_table[x[1]] != 0).sum() + (h.docs.title_table[x[2]] != 0).sum()) for x in seen]
             out[name] = dict(value=round(wl['B'] * steps / el, 1), unit='impressions/s wall (feed + H2D + step)',
                              ms_per_step=round(1e3 * el / steps, 4),
                              non_pad_token_fraction=round(float(np.mean(nonpad)) / (wl['B'] * (wl['W'] + wl['K1']) * wl['T']), 4))

@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <deque>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -552,6 +554,28 @@ struct ProfScope {
     stmt;                           \
   } while (0)
 
+// Side streams are shared by ALL contexts of the process on a device and live as long as the process: a stream is a queue,
+// the hardware has few of them, and a process that held two contexts (bench.py: the headline model + the end-to-end
+// model; the test suite) ran every kernel ~30 % slower once their private streams added up to more than the hardware
+// queues.  kind: 0 parameter gradients (high priority), 1 background (staging prefetch, table sweep), 2 second
+// parameter-gradient stream (experiment), 3 the two-lane step's lane.  Ordering between contexts that share a stream is
+// plain stream order (each context still forks / joins through its own events).
+hipStream_t pooled_stream(int kind, bool high_priority) {
+  struct Pool { hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr}; };
+  static std::mutex mu;
+  static std::map<int, Pool> pools;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  Pool& p = pools[dev];
+  if (!p.s[kind]) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&p.s[kind], hipStreamNonBlocking, high_priority ? hi : lo) != hipSuccess) p.s[kind] = nullptr;
+  }
+  return p.s[kind];
+}
+
 // the side stream of the parameter-gradient GEMMs (nullptr: keep them on the caller's stream)
 hipStream_t wgrad_stream(lstur_ctx* c) {
   const bool off = getenv("LSTUR_WG_STREAM") && !strcmp(getenv("LSTUR_WG_STREAM"), "0");
@@ -560,14 +584,11 @@ hipStream_t wgrad_stream(lstur_ctx* c) {
     // highest priority: its thin kernels are to slip in as soon as a workgroup of the main stream's kernel retires -- at
     // equal priority they waited behind the attention backward's 3520 workgroups and spilled into the conv kernel gradient,
     // which shares a CU with nothing (it then ran ~10 % slower and the step's reduction waited for the stragglers)
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     static const bool flat = getenv("LSTUR_WG_PRIORITY") && !strcmp(getenv("LSTUR_WG_PRIORITY"), "0");
     static const bool two = getenv("LSTUR_WG_STREAMS") && !strcmp(getenv("LSTUR_WG_STREAMS"), "2");
-    if (two && (hipStreamCreateWithPriority(&c->side_w2, hipStreamNonBlocking, flat ? lo : hi) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_w4, hipEventDisableTiming) != hipSuccess))
+    if (two && (!(c->side_w2 = pooled_stream(2, !flat)) || hipEventCreateWithFlags(&c->ev_w4, hipEventDisableTiming) != hipSuccess))
       c->side_w2 = nullptr;
-    if (hipStreamCreateWithPriority(&c->side_w, hipStreamNonBlocking, flat ? lo : hi) != hipSuccess ||
+    if (!(c->side_w = pooled_stream(0, !flat)) ||
         hipEventCreateWithFlags(&c->ev_w1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w3, hipEventDisableTiming) != hipSuccess) {
@@ -597,7 +618,7 @@ bool background_stream(lstur_ctx* c) {
   static const bool share = getenv("LSTUR_ONE_SIDE") != nullptr;    // experiment: ONE side stream for everything
   hipStream_t shared = share ? wgrad_stream(c) : nullptr;
   if (shared) c->side_p = shared;
-  if ((!shared && hipStreamCreateWithFlags(&c->side_p, hipStreamNonBlocking) != hipSuccess) ||
+  if ((!shared && !(c->side_p = pooled_stream(1, false))) ||
       hipEventCreateWithFlags(&c->ev_p0, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_t0, hipEventDisableTiming) != hipSuccess ||
@@ -1225,7 +1246,7 @@ int train_two_lanes(lstur_ctx* c, const int32_t* user, const int32_t* hist, cons
   if (nB < 1 || nB > c->d1.B) return fail(LSTUR_ERR_STATE, "two-lane step: lane 1 capacity");
   Workspace &w0 = c->ws, &w1 = c->ws1;
   if (!c->side) {
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+    if (!(c->side = pooled_stream(3, false)) ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_enc0, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_done1, hipEventDisableTiming) != hipSuccess)
@@ -1514,7 +1535,7 @@ int lstur_destroy(lstur_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_fork);
     (void)hipEventDestroy(ctx->ev_enc0);
     (void)hipEventDestroy(ctx->ev_done1);
-    (void)hipStreamDestroy(ctx->side);
+    // (pooled streams outlive the context)
   }
   if (ctx && ctx->side_p) {    // (side_t is the same stream)
     (void)hipStreamSynchronize(ctx->side_p);
@@ -1522,7 +1543,7 @@ int lstur_destroy(lstur_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_p1);
     (void)hipEventDestroy(ctx->ev_t0);
     (void)hipEventDestroy(ctx->ev_t1);
-    if (ctx->side_p != ctx->side_w) (void)hipStreamDestroy(ctx->side_p);
+
   }
   if (ctx && ctx->ev_f0) (void)hipEventDestroy(ctx->ev_f0);
   if (ctx && ctx->side_w) {
@@ -1530,11 +1551,7 @@ int lstur_destroy(lstur_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_w1);
     (void)hipEventDestroy(ctx->ev_w2);
     (void)hipEventDestroy(ctx->ev_w3);
-    (void)hipStreamDestroy(ctx->side_w);
-    if (ctx->side_w2) {
-      (void)hipStreamSynchronize(ctx->side_w2);
-      (void)hipStreamDestroy(ctx->side_w2);
-    }
+    if (ctx->side_w2) (void)hipStreamSynchronize(ctx->side_w2);
     if (ctx->ev_w4) (void)hipEventDestroy(ctx->ev_w4);
   }
   if (ctx)

@@ -19,6 +19,30 @@ from . import _lib
 from ._lib import lib, check
 
 
+def prefetched(generator, count, depth=10):
+    """The next ``count`` items of ``generator``, drawn by one background thread at most ``depth`` ahead (what Keras'
+    GeneratorEnqueuer does for fit_generator with workers=1); an exception in the generator is re-raised here."""
+    import queue
+    import threading
+    q = queue.Queue(max(1, int(depth)))
+
+    def work():
+        try:
+            for _ in range(count):
+                q.put((True, next(generator)))
+        except BaseException as e:          # noqa: B902 -- handed to the consumer
+            q.put((False, e))
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    for _ in range(count):
+        ok, item = q.get()
+        if not ok:
+            raise item
+        yield item
+    t.join()
+
+
 class History:
     def __init__(self):
         self.history = {}
@@ -603,11 +627,16 @@ class NativeModel:
         return nxt
 
     def fit_generator(self, generator, steps_per_epoch, epochs=1, initial_epoch=0, verbose=2, ids_form=False,
-                      **_ignored):
-        """One ``train_on_batch`` per generator item (Keras fit_generator semantics, main.py:73-78)."""
+                      workers=1, max_queue_size=10, **_ignored):
+        """One ``train_on_batch`` per generator item (Keras fit_generator semantics, main.py:73-78).  Like Keras (defaults
+        workers=1, max_queue_size=10: a GeneratorEnqueuer thread) the generator runs in ONE background thread, at most
+        ``max_queue_size`` batches ahead -- and here exactly ``steps_per_epoch`` draws per epoch, so the RNG streams the
+        generators consume advance as in a plain loop.  workers=0: the calling thread."""
         hist = History()
+        source = generator
         for epoch in range(initial_epoch, epochs):
             self.stats_acc.zero_()
+            generator = prefetched(source, steps_per_epoch, max_queue_size) if workers else source
             look = ids_form and not self.pointwise      # one batch of look-ahead: the next batch is staged under this step
             cur = next(generator) if look else None
             staged = None

@@ -25,3 +25,27 @@ if __name__ == '__main__':
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print('host enqueue %.1f us/step; wall incl. drain %.1f us/step' % ((t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
+    # + prefetch announcement and the H2D of id batches (what train_on_ids adds per step)
+    t0 = time.perf_counter()
+    for k in range(n):
+        u, h, c = dev[k % len(dev)]
+        _, h2, c2 = dev[(k + 1) % len(dev)]
+        model.prefetch_ids(h2, c2)
+        model._train_step(u, h, c, True)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print('with prefetch_ids: host enqueue %.1f us/step; wall incl. drain %.1f us/step' % ((t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
+    staged = None
+    t0 = time.perf_counter()
+    for k in range(n):
+        staged = model.train_on_ids(*batches[k % len(batches)], next_ids=batches[(k + 1) % len(batches)], staged=staged)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print('train_on_ids (numpy ids -> H2D -> step): host %.1f us/step; wall incl. drain %.1f us/step' % ((t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
+    t0 = time.perf_counter()
+    for k in range(n):
+        x = model._ids_to_dev(batches[k % len(batches)])
+    t1 = time.perf_counter()
+    print('_ids_to_dev alone: %.1f us/call' % ((t1 - t0) / n * 1e6))
