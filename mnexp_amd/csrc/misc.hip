@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float4* __restrict__
   // pieces of ITS chunk; they cross LDS once so that every store instruction writes 1 KB of consecutive bytes (lane-strided
   // 48-byte granules reached HBM as partial lines: 3.5 TB/s in the step, against the 4 + TB/s of whole-line stores).
   __shared__ uint4 xbuf[4][192];
-  constexpr int U = 4;      // four chunks (eight 16-byte table loads) in flight per thread
+  constexpr int U = 4;      // four chunks (eight 16-byte table loads) in flight per thread (1, 2, 8: the same or slower)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t b0 = blockIdx.x * blockDim.x; b0 < total8; b0 += U * stride) {     // block-uniform trip count
@@ -163,7 +163,11 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float4* __restrict__
       for (int q = 0; q < 3; ++q) {
         const int pc = q * 64 + lane;                               // piece pc belongs to chunk (= lane) pc / 3
         const uint4 v = xbuf[wv][pc];
-        if ((live >> (pc / 3)) & 1ull) o[pc] = v;
+        if ((live >> (pc / 3)) & 1ull) {
+          // streamed once, read much later (by the conv kernels of the next step): non-temporal, no cache allocation
+          typedef unsigned int u32x4nt __attribute__((ext_vector_type(4)));
+          __builtin_nontemporal_store(*(const u32x4nt*)&v, (u32x4nt*)(o + pc));
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }

@@ -136,3 +136,31 @@ def test_batches_past_the_32_bit_offset_reach_are_refused():
     for B in (1400, 2000, 40000):
         with pytest.raises(_lib.LsturError, match='4 GiB'):
             _lib.query_sizes(_lib.make_cfg(B, 50, 30, 5, 1000, 300, 400, 3, 200, 10))
+
+
+def test_prefetched_draws_exactly_count_items_in_order_and_reraises():
+    """native_model.prefetched: the background generator thread of fit_generator (Keras' GeneratorEnqueuer for workers=1)
+    takes exactly `count` items, in order, and hands an exception of the generator to the consumer."""
+    from mnexp_amd.native_model import prefetched
+    drawn = []
+
+    def gen():
+        i = 0
+        while True:
+            drawn.append(i)
+            yield i
+            i += 1
+
+    g = gen()
+    assert list(prefetched(g, 25, depth=3)) == list(range(25))
+    assert drawn == list(range(25))                 # not one draw beyond the count: the RNG streams behind it stay put
+    assert next(g) == 25
+
+    def bad():
+        yield 1
+        raise RuntimeError('feed broke')
+
+    it = prefetched(bad(), 5)
+    assert next(it) == 1
+    with pytest.raises(RuntimeError, match='feed broke'):
+        next(it)
