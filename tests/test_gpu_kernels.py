@@ -271,6 +271,47 @@ def test_full_step_at_baseline_shapes_small_batch(arch):
     rel_close(g['user_row_grads'], ref['user_row_grads'], 2e-3, 'user_row_grads')
 
 
+def test_fused_prefetched_steps_at_baseline_shapes_track_oracle():
+    """The product path as bench.py / fit_generator drive it, at D=300/T=30/F=400/U=200: doc-id batches through the resident
+    title table, every batch announced one step ahead (staging + keep bits prefetched under the recurrence), forward +
+    backward + Adam in ONE call (table sweep in two halves, weight images written by the Adam launch).  Three steps
+    against the oracle's train_step: per-step loss, final parameters, the touched and untouched rows of the user table."""
+    _need_gpu()
+    from test_gpu_model import build, rel_close
+    from mnexp_amd._lib import lib
+    dims = dict(V=2000, D=300, F=400, k=3, U=200, N_u=300)
+    B, W, T, K1, n_docs = 6, 10, 30, 5, 120
+    O, p, model, rng = build('igru', dims, B, W, T, K1, 0.2)
+    tt = rng.integers(1, dims['V'], size=(n_docs, T)).astype(np.int32)
+    tt[0] = 0
+    for d in range(1, n_docs):
+        tt[d, rng.integers(8, T + 1):] = 0
+    model.set_title_table(tt)
+    pf = {n: a.astype(np.float32) for n, a in p.items()}
+    opt = O.Adam(pf, O.dense_param_names('igru') + ['user_emb'], lr=1e-3)
+    batches = []
+    for _ in range(3):
+        user = rng.integers(0, dims['N_u'], size=B).astype(np.int32)
+        user[2] = user[0]
+        hist = rng.integers(0, n_docs, size=(B, W)).astype(np.int32)
+        hist[1, :4] = 0                                   # short history: padded slots in front
+        batches.append((user, hist, rng.integers(1, n_docs, size=(B, K1)).astype(np.int32)))
+    dev = [tuple(model._dev_i32(a) for a in b) for b in batches]
+    for i, (user, hist, cands) in enumerate(batches):
+        ref = O.train_step(pf, 'igru', opt, user, tt[hist], tt[cands], drop_p=0.2, seed=77, step=i)
+        if i + 1 < len(dev):
+            model.prefetch_ids(dev[i + 1][1], dev[i + 1][2])
+        model._train_step(*dev[i], True)
+        torch.cuda.synchronize()
+        assert abs(model.stats[0].item() - ref['loss']) <= 2e-3 * max(1.0, abs(ref['loss'])), i
+    assert lib.lstur_prefetch_hits(model._ctx) == 2
+    w = model.get_weights()
+    # (1e-2 of scale: with 6 samples many conv_w / word-side gradients are ~1e-7, where Adam's m / (sqrt(v) + eps) turns a
+    #  3e-8 gradient difference into a quarter of a learning-rate step)
+    for n in O.dense_param_names('igru') + ['user_emb']:
+        rel_close(w[n].reshape(-1), pf[n].reshape(-1), 1e-2, n)
+
+
 def test_config4_shapes_batch_512_one_million_users():
     """BASELINE.json configs[3] per GPU: B = 512, 1 M users (D=300/T=30/W=50/F=400/U=200).  Logits of the full batch
     against a forward-only oracle call (fp32), then two Adam steps over the 1 M-row table: rows touched by a step against
