@@ -626,7 +626,9 @@ bool background_stream(lstur_ctx* c) {
     c->side_p = c->side_t = nullptr;
     return false;
   }
-  c->side_t = c->side_p;
+  static const bool split_bg = getenv("LSTUR_SPLIT_BG") != nullptr;   // experiment: a stream of its own for the table sweep
+  c->side_t = split_bg ? pooled_stream(2, false) : c->side_p;
+  if (!c->side_t) c->side_t = c->side_p;
   return true;
 }
 bool fork_events(lstur_ctx* c) {
