@@ -1674,15 +1674,15 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
   const float lr_t = lr * (sqrtf(1.0f - powf(c.beta2, (float)t)) / (1.0f - powf(c.beta1, (float)t)));
   lazy_init(ctx, s);
   const bool no_user = !has_user_table(d);
+  // The next forward's weight images ride the dense Adam launch when they exist (packed whole once) and both fast kernels
+  // are in use: two 5-us launches less between the step's reduction and the next conv forward.
   bool packed = false;
-  if (no_user || skip_table) {
-    // the next forward's weight images ride the same launch when they exist (packed whole once) and both fast kernels are in
-    // use: two 5-us launches less between the step's reduction and the next conv forward
+  ImagePlan pl;
+  {
     static const bool conv_alt = getenv("LSTUR_CONV_F32") != nullptr || getenv("LSTUR_CONV_GEN1") != nullptr;
     static const bool no_fuse = getenv("LSTUR_ADAM_PACK") && !strcmp(getenv("LSTUR_ADAM_PACK"), "0");
     const int kq = gru4_supported(d.H) ? gru4_pack_kq(d.H) : 0;
     if (ctx->images_valid && !no_fuse && !conv_alt && d.enc != LSTUR_ENC_MHSA && ctx->ws.conv_w3 && kq > 0 && ctx->ws.gru_up) {
-      ImagePlan pl;
       int Kp = 0, Np = 0;
       conv3_w2_dims(d.D, d.k, d.F, &Kp, &Np);
       pl.conv_off = (size_t)(ctx->P("conv_w") - ctx->buf.dense_param);
@@ -1693,17 +1693,20 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
       pl.gru_off = (size_t)(ctx->P("gru_u") - ctx->buf.dense_param);
       pl.H = d.H; pl.KQ = kq;
       pl.gimg = ctx->ws.gru_up;
+      packed = true;
+    }
+  }
+  if (no_user || skip_table) {
+    if (packed)
       launch_adam_flat_pack(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v, ctx->dense_total,
                             lr_t, c.beta1, c.beta2, c.eps, pl, s);
-      packed = true;
-    } else {
+    else
       launch_adam_flat(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v, ctx->dense_total,
                        lr_t, c.beta1, c.beta2, c.eps, s);
-    }
-  } else {
+  } else {   // (the split / data-parallel sequence: + the duplicate-row combine of the row gradients in the same launch)
     launch_adam_flat_combine(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v,
                              ctx->dense_total, lr_t, c.beta1, c.beta2, c.eps, rows, row_grads, n_rows, d.Ue,
-                             ctx->ws.gsum, ctx->ws.slot, s);
+                             ctx->ws.gsum, ctx->ws.slot, s, packed ? &pl : nullptr);
   }
   // the next forward's weight images, behind the dense update (in front of the next conv forward they would be a bubble:
   // with the staging prefetched nothing else is left to hide them under)

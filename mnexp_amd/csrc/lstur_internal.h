@@ -84,6 +84,9 @@ void launch_colsum(const float* x, int rows, int cols, int ld, float* out, float
 constexpr int kColsumSlices = 64;
 void launch_colsum2(const float* x, int rows, int cols, int ld, float* out, float scale, float* scratch,
                     hipStream_t s, ReduceJob* defer = nullptr);
+
+void launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1,
+                      float b2, float eps, hipStream_t s);
 // Adam over the dense bucket + the weight images of the NEXT forward in the same launch: an updated conv_w element also
 // lands (split into three bf16 parts) in the conv kernels' W3 image, an updated gru_u element in the two resident-U images
 // that hold it.  The images' padding stays as the stand-alone pack kernels wrote it once.
@@ -98,12 +101,10 @@ struct ImagePlan {
 };
 void launch_adam_flat_pack(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
                            const ImagePlan& plan, hipStream_t s);
-void launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1,
-                      float b2, float eps, hipStream_t s);
 // the same sweep + launch_user_grad_combine(rows, rg, ...) in one launch
 void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                               float eps, const int32_t* rows, const float* rg, int n_rows, int dim, float* gsum,
-                              int32_t* slot, hipStream_t s);
+                              int32_t* slot, hipStream_t s, const ImagePlan* plan = nullptr);
 // dense Adam sweep of the user table; slot[row] = index into gsum or -1
 void launch_adam_table(float* p, float* m, float* v, const int32_t* slot, const float* gsum, int n_rows,
                        int dim, float lr_t, float b1, float b2, float eps, hipStream_t s);

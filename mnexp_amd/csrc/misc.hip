@@ -590,12 +590,14 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
 // launch: blocks [0, flat_blocks) sweep the bucket, the rest handle one sample row per wave.
 __device__ __forceinline__ void combine_row(const int32_t* __restrict__ rows, const float* __restrict__ g, int n, int dim,
                                             float* __restrict__ gsum, int32_t* __restrict__ slot, int i, int lane);
+__device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, float pi);
 __global__ __launch_bounds__(256) void adam_flat_combine_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                 float* __restrict__ m, float* __restrict__ v, size_t n,
                                                                 float lr_t, float b1, float b2, float eps,
                                                                 int flat_blocks, const int32_t* __restrict__ rows,
                                                                 const float* __restrict__ rg, int n_rows, int dim,
-                                                                float* __restrict__ gsum, int32_t* __restrict__ slot) {
+                                                                float* __restrict__ gsum, int32_t* __restrict__ slot,
+                                                                ImagePlan P) {
   if ((int)blockIdx.x >= flat_blocks) {
     const int i = (blockIdx.x - flat_blocks) * 4 + (threadIdx.x >> 6);
     if (i < n_rows) combine_row(rows, rg, n_rows, dim, gsum, slot, i, threadIdx.x & 63);
@@ -607,25 +609,20 @@ __global__ __launch_bounds__(256) void adam_flat_combine_kernel(float* __restric
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
+    image_scatter(P, i, pi);            // (an empty plan scatters nothing)
   }
 }
 void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                               float eps, const int32_t* rows, const float* rg, int n_rows, int dim, float* gsum,
-                              int32_t* slot, hipStream_t s) {
+                              int32_t* slot, hipStream_t s, const ImagePlan* plan) {
   const int fb = (int)std::min<size_t>(cdivz(n, 256), 4096);
   const int cb = cdiv(n_rows, 4);
   if (fb + cb)
     hipLaunchKernelGGL(adam_flat_combine_kernel, dim3(fb + cb), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps, fb, rows,
-                       rg, n_rows, dim, gsum, slot);
+                       rg, n_rows, dim, gsum, slot, plan ? *plan : ImagePlan());
 }
-__global__ void adam_flat_pack_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                      float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, ImagePlan P) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float pi = p[i], mi = m[i], vi = v[i];
-    adam1(pi, g[i], mi, vi, lr_t, b1, b2, eps);
-    p[i] = pi;
-    m[i] = mi;
-    v[i] = vi;
+// the updated element i of the bucket also goes into the weight images that hold it (ImagePlan, lstur_internal.h)
+__device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, float pi) {
     if (i - P.conv_off < P.conv_cnt) {            // conv_w[tap * D + d][f] -> W3[part][tap * Dp + d][f]  (conv3_pack_w2_kernel)
       const size_t j = i - P.conv_off;
       const int f = (int)(j % P.F), td = (int)(j / P.F), tap = td / P.D, d = td - tap * P.D;
@@ -645,6 +642,16 @@ __global__ void adam_flat_pack_kernel(float* __restrict__ p, const float* __rest
       const int which = 1 + c / H, kk = c - (which - 1) * H;                                             // itz | itr | ith
       P.gimg[2 * e + (size_t)which * e + ((size_t)(kk >> 2) * H + k) * 4 + (kk & 3)] = pi;
     }
+}
+__global__ void adam_flat_pack_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                      float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, ImagePlan P) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam1(pi, g[i], mi, vi, lr_t, b1, b2, eps);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    image_scatter(P, i, pi);
   }
 }
 void launch_adam_flat_pack(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
