@@ -316,6 +316,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prefetch', action='store_true', help='stage every batch inside its own step (no lstur_prefetch_ids)')
     ap.add_argument('--no-profile', action='store_true', help='skip the HIP-event brackets around kernels')
+    ap.add_argument('--fresh-users', action='store_true',
+                    help='draw every step\'s user ids uniformly from the whole table (default: the 32 synthetic batches cycle, '
+                         'i.e. 32 x B distinct users) -- the steady state of the lazy table update at 1 M users needs this')
     ap.add_argument('--force-dp', action='store_true', help='diagnostic: run the RCCL collectives of the data-parallel step even with one rank')
     args = ap.parse_args()
 
@@ -345,13 +348,23 @@ def main():
     dev = [(model._dev_i32(u), model._dev_i32(h), model._dev_i32(c)) for u, h, c in batches]
     torch.cuda.synchronize()
 
+    gen = torch.Generator(device='cuda:%d' % local).manual_seed(99 + rank)
+
+    def users_of(k):
+        if args.fresh_users:
+            return torch.randint(0, wl['N_u'], (wl['B'],), dtype=torch.int32, device='cuda:%d' % local, generator=gen)
+        return dev[k % len(dev)][0]
+
     def run(nsteps, offset):
+        u = users_of(offset)
         for i in range(nsteps):
-            u, h, c = dev[(offset + i) % len(dev)]
+            _, h, c = dev[(offset + i) % len(dev)]
+            u2 = users_of(offset + i + 1)
             if not args.no_prefetch and i + 1 < nsteps:      # announce the next batch: its staging overlaps this step
                 _, h2, c2 = dev[(offset + i + 1) % len(dev)]
-                model.prefetch_ids(h2, c2)
+                model.prefetch_ids(h2, c2, u2)
             model._train_step(u, h, c, True)
+            u = u2
 
     run(args.warmup, 0)
     torch.cuda.synchronize()

@@ -198,6 +198,9 @@ int lstur_forward_backward_ids(lstur_ctx* ctx, const int32_t* user, const int32_
  * Same kernels on the same data: results are bit-identical with and without the announcement.  No-op for configurations
  * that stage inline anyway (trainable word table, exact-fp32 conv path, pointwise heads, mhsa). */
 int lstur_prefetch_ids(lstur_ctx* ctx, const int32_t* hist_ids, const int32_t* cand_ids, int32_t n, uint32_t step);
+/* ... and the user ids of that next batch (call BEFORE lstur_prefetch_ids; optional): with a lazily updated table
+ * (lstur_flush_tables) the rows that batch will read are brought up to date under the current step's recurrence as well. */
+int lstur_prefetch_rows(lstur_ctx* ctx, const int32_t* user);
 /* how many training calls picked up a prefetched batch so far (diagnostics / tests) */
 int32_t lstur_prefetch_hits(lstur_ctx* ctx);
 
@@ -221,6 +224,17 @@ int lstur_dp_unpack(lstur_ctx* ctx, const float* tail, int32_t world, int32_t n,
  * rows (duplicates are summed in ascending order).  t = 1-based Adam iteration. */
 int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, const float* row_grads,
                     int32_t n_rows, lstur_stream stream);
+
+/* Large user tables (n_users >= 200 000; LSTUR_LAZY_ADAM=0 / 1 overrides) are updated LAZILY: TF-1 Keras densifies the
+ * embedding gradient, so every row takes an Adam update every step -- for a row outside the batch the zero-gradient one.
+ * Instead of sweeping the table every step (24 B of HBM traffic per element: 1.1 of 7 ms at 1 M users) a row takes its
+ * pending zero-gradient updates, in order and with each iteration's lr_t, when it is next read by a forward or updated with a
+ * gradient: the same fp32 operations per element, bit-identical values, computed later.  lstur_flush_tables brings every row
+ * of user_emb / user_m / user_v (and the second table) up to date -- call it before reading those buffers on the host.
+ * lstur_lazy_adam: 1 when the context updates lazily.  The Adam iteration t must advance by one per step (anything else
+ * flushes and re-bases). */
+int lstur_flush_tables(lstur_ctx* ctx, lstur_stream stream);
+int lstur_lazy_adam(lstur_ctx* ctx);
 
 /* The caller wrote parameters (dense_param, word_emb) from outside -- set_weights, a checkpoint load: the weight images
  * the library keeps for its MFMA kernels (packed behind every Adam step, for the NEXT forward) and a batch staged by

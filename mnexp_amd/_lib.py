@@ -59,9 +59,12 @@ SIGNATURES = {
     'lstur_forward_backward_ids': (_I, [_P, _P, _P, _P, _I, _U, _F, _P, _P]),
     'lstur_prefetch_ids': (_I, [_P, _P, _P, _I, _U]),
     'lstur_prefetch_hits': (_I, [_P]),
+    'lstur_prefetch_rows': (_I, [_P, _P]),
     'lstur_user_grad': (_I, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I)]),
     'lstur_adam_step': (_I, [_P, _F, _I, _P, _P, _I, _P]),
     'lstur_params_changed': (_I, [_P]),
+    'lstur_flush_tables': (_I, [_P, _P]),
+    'lstur_lazy_adam': (_I, [_P]),
     'lstur_train_step': (_I, [_P, _P, _P, _P, _P, _I, _U, _F, _I, _P, _P]),
     'lstur_train_step_ids': (_I, [_P, _P, _P, _P, _P, _I, _U, _F, _I, _P, _P]),
     'lstur_dp_tail_floats': (_Z, [C.POINTER(Cfg), _I]),

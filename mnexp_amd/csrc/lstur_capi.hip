@@ -36,7 +36,10 @@ struct Dims {
   int nt_max;   // titles per call
   int n_cap;    // per-sample buffers
   int rows_cap; // sparse user-grad rows per adam step
+  int lazy;     // lazy dense Adam of the user table(s) (large tables; misc.hip)
 };
+constexpr int kLazyLog = 1 << 16;        // logged lr_t values (a full flush at the latest every kLazyLog - 2 iterations)
+constexpr int kLazyMinRows = 200000;     // tables from this size on update lazily (LSTUR_LAZY_ADAM=0 / 1 overrides)
 
 // iigru / iicgru: a SECOND user table, gathered with the same rows (paper.py:614-621, 343-348)
 static inline bool two_tables(const Dims& d) { return d.arch == LSTUR_ARCH_IIGRU || d.arch == LSTUR_ARCH_IICGRU; }
@@ -174,6 +177,11 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
   int pred_rows = d->nt_max / (d->W + 1);
   d->n_cap = ceil16(std::max(d->B, pred_rows));   // GRU kernels process whole 16-sample row tiles
   d->rows_cap = d->B * 8;
+  {   // the dense sweep of a small table hides under the recurrences (fused step); a large one does not -- it goes lazy
+    const char* e = getenv("LSTUR_LAZY_ADAM");
+    const bool has_table = d->arch != LSTUR_ARCH_NIGRU && d->arch != LSTUR_ARCH_NIAVG && d->arch != LSTUR_ARCH_NIATT;
+    d->lazy = has_table && (e ? !strcmp(e, "1") : d->Nu >= kLazyMinRows);
+  }
   return true;
 }
 
@@ -189,7 +197,7 @@ bool lanes_supported(const Dims& d) {
   const bool off = !(getenv("LSTUR_PIPELINE") && !strcmp(getenv("LSTUR_PIPELINE"), "1"));   // (read per context)
   const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
   return !off && d.B >= kPipeMin && d.head == LSTUR_HEAD_SOFTMAX && d.enc == LSTUR_ENC_CNNATT && !d.word_trainable &&
-         has_gru && gru4_supported(d.H) && conv3f_supported(d.D, d.k, d.F) && d.k <= 8;
+         has_gru && gru4_supported(d.H) && conv3f_supported(d.D, d.k, d.F) && d.k <= 8 && !d.lazy;
 }
 Dims lane1_dims(const Dims& d) {
   Dims e = d;
@@ -198,6 +206,7 @@ Dims lane1_dims(const Dims& d) {
   e.n_cap = ceil16(e.B);
   e.rows_cap = 16;          // (the sparse-row scratch of the optimizer lives in lane 0)
   e.Nu = 1;                 // (so does the slot map)
+  e.lazy = 0;
   return e;
 }
 
@@ -260,7 +269,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* dp_rows; float* dp_grads; float* dp_grads2; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* conv_w3_v1; unsigned short* e3; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
+  int32_t* lazy_last; float* lazy_lrt; int32_t* lazy_first; int32_t* dp_rows; float* dp_grads; float* dp_grads2; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* conv_w3_v1; unsigned short* e3; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   // the staged form of a batch (token ids, their compacted list + offsets, the gathered embeddings) exists twice: while a
   // step runs on one set, the NEXT batch can be staged into the other (lstur_prefetch_ids); ids / e3 / vidx / ... above
@@ -359,6 +368,9 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->first = (int32_t*)take((size_t)d.rows_cap * 4);
   w->gsum = (float*)take((size_t)d.rows_cap * d.Ue * f4);
   w->slot = (int32_t*)take((size_t)d.Nu * 4);
+  w->lazy_last = d.lazy ? (int32_t*)take((size_t)d.Nu * 4) : nullptr;
+  w->lazy_lrt = d.lazy ? (float*)take((size_t)kLazyLog * f4) : nullptr;
+  w->lazy_first = d.lazy ? (int32_t*)take((size_t)std::max(d.n_cap, d.rows_cap) * 4) : nullptr;
   w->scat = (float*)take(nc * (d.Uu + d.U) * f4);
   w->spre = (float*)take(nc * d.U * f4);
   w->sds = (float*)take(nc * f4);
@@ -470,8 +482,10 @@ struct lstur_ctx {
   hipEvent_t ev_w1 = nullptr, ev_w2 = nullptr, ev_w3 = nullptr, ev_w4 = nullptr;
   // staging prefetch (lstur_prefetch_ids): the next batch's title expansion, compaction and embedding gather run on a
   // side stream under the current step's forward recurrence (HBM and 240 CUs idle there)
-  struct Pending { const int32_t* hist = nullptr; const int32_t* cands = nullptr; int n = 0; uint32_t step = 0;
+  struct Pending { const int32_t* hist = nullptr; const int32_t* cands = nullptr; const int32_t* users = nullptr; int n = 0;
+                   uint32_t step = 0;
                    bool valid = false, launched = false, kbits = false; } pend, ready;   // announced | staged in the other set
+  const int32_t* next_users = nullptr;  // lstur_prefetch_rows: the user ids of the batch the next lstur_prefetch_ids announces
   int prefetch_hits = 0;
   int cur_set = 0;
   bool staged_hit = false;              // this step's staging was prefetched: run_forward skips it
@@ -483,11 +497,14 @@ struct lstur_ctx {
   // sweep of the user table(s) needs only the recurrence's row gradients and runs on a stream of its own under the news
   // encoder's backward (HBM-bound beside MFMA-bound kernels); the weight images of the NEXT step are packed behind the
   // dense Adam instead of in front of the next conv forward
-  struct Fused { bool on = false, swept = false, table_done = false; float lr_t = 0.f; } fused;
+  struct Fused { bool on = false, swept = false, table_done = false; float lr_t = 0.f; int t = 0; } fused;
   hipStream_t side_t = nullptr;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_f0 = nullptr;           // the forward's one fork point (staging prefetch + table sweep)
   bool images_valid = false;            // conv / GRU weight images match dense_param (packed behind the last Adam)
+  bool lazy_prefetched = false;         // rows of the next batch were brought up on lazy_stream this step
+  int lazy_t = 0;                       // lazy Adam: iterations applied so far (rows are current for last[row] <= lazy_t)
+  int lazy_flushed_t = 0;               // ... and the iteration of the last full flush (the lr_t log is a ring)
   std::vector<ParamSlot> layout;
   size_t dense_total;
   const int32_t* title_table = nullptr;
@@ -607,6 +624,14 @@ void use_set(lstur_ctx* c, int k) {
   w.kbits = w.set[k].kbits;
 }
 
+void lazy_catchup_rows(lstur_ctx* c, const int32_t* rows, int n, hipStream_t s);
+hipStream_t wgrad_stream(lstur_ctx* c);
+// the stream a lazily updated table is worked on outside the caller's stream: the parameter-gradient stream (idle under
+// the recurrences), else the background stream
+hipStream_t lazy_stream(lstur_ctx* c) {
+  hipStream_t w = wgrad_stream(c);
+  return w ? w : c->side_p;
+}
 // enqueue the pending prefetch (if any) on the side stream, behind everything `s` holds so far; true: something was launched
 // ONE background stream for everything that hides under the recurrences: the next batch's staging, then the zero-gradient
 // half of the user-table sweep, later the batch's own table rows (side_p and side_t are the same queue).  Streams are not
@@ -665,6 +690,17 @@ bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
   }
   // the attention passes' dropout decisions for that batch (stream 1 of its step), behind the gather
   q.kbits = launch_attpool_keep_bits(t.live, t.kbits, nt, d.T, d.F, c->cfg.dropout, dropout_key(c->cfg.seed, q.step, 1), p);
+  // lazily updated table: the rows that batch will read take their pending zero-gradient updates here, under the
+  // recurrence (a row that waited 2 000 iterations is a 2 000-long chain per element: latency-bound work for idle CUs);
+  // the forward's own catch-up then finds one iteration left
+  // -- on the parameter-gradient stream, idle until BPTT is through and the one the batch's own rows are stepped on (a row
+  // of this batch AND the next must take its catch-up and its step in order), beside the gather on this one
+  if (d.lazy && q.users) {
+    hipStream_t ls = lazy_stream(c);
+    if (ls != p) (void)hipStreamWaitEvent(ls, forked, 0);
+    lazy_catchup_rows(c, q.users, q.n, ls);
+    c->lazy_prefetched = true;
+  }
   (void)hipEventRecord(c->ev_p1, p);
   q.launched = true;
   c->ready = q;                      // staged: the next training call may pick it up
@@ -709,6 +745,59 @@ bool has_user_table(const Dims& d) {
   return d.arch != LSTUR_ARCH_NIGRU && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
 }
 
+// ---- lazy dense Adam (large tables; kernels and rationale in misc.hip) ----
+void lazy_init(lstur_ctx* c, hipStream_t s);
+void lazy_flush_all(lstur_ctx* c, hipStream_t s) {   // every row current for iteration lazy_t
+  const Dims& d = c->d;
+  const lstur_cfg& cf = c->cfg;
+  if (!d.lazy || c->lazy_flushed_t == c->lazy_t) return;
+  lazy_init(c, s);
+  launch_lazy_flush(c->buf.user_emb, c->buf.user_m, c->buf.user_v, c->ws.lazy_last, c->ws.lazy_lrt, c->lazy_t, d.Nu, d.Ue,
+                    cf.beta1, cf.beta2, cf.eps, kLazyLog - 1, s);
+  if (two_tables(d))
+    launch_lazy_flush(c->buf.user_emb2, c->buf.user_m2, c->buf.user_v2, c->ws.lazy_last, c->ws.lazy_lrt, c->lazy_t, d.Nu, d.Ue,
+                      cf.beta1, cf.beta2, cf.eps, kLazyLog - 1, s);
+  launch_fill_i32(c->ws.lazy_last, c->lazy_t, d.Nu, s);
+  c->lazy_flushed_t = c->lazy_t;
+}
+// the caller is about to apply iteration t: iterations must come one after the other (a restart or a jump flushes and
+// re-bases), and no row may fall further behind than the lr_t ring reaches
+void lazy_begin_iteration(lstur_ctx* c, int t, hipStream_t s) {
+  if (!c->d.lazy) return;
+  lazy_init(c, s);
+  if (t != c->lazy_t + 1) {
+    lazy_flush_all(c, s);
+    c->lazy_t = c->lazy_flushed_t = t - 1;
+    launch_fill_i32(c->ws.lazy_last, t - 1, c->d.Nu, s);
+  } else if (t - c->lazy_flushed_t >= kLazyLog - 2) {
+    lazy_flush_all(c, s);
+  }
+}
+// the rows a forward is about to read, current for every iteration applied so far
+void lazy_catchup_rows(lstur_ctx* c, const int32_t* rows, int n, hipStream_t s) {
+  const Dims& d = c->d;
+  const lstur_cfg& cf = c->cfg;
+  if (!d.lazy || c->lazy_t == c->lazy_flushed_t) return;
+  const bool two = two_tables(d);
+  launch_lazy_catchup(c->buf.user_emb, c->buf.user_m, c->buf.user_v, two ? c->buf.user_emb2 : nullptr,
+                      two ? c->buf.user_m2 : nullptr, two ? c->buf.user_v2 : nullptr, rows, n, c->ws.lazy_first,
+                      c->ws.lazy_last, c->ws.lazy_lrt, c->lazy_t, d.Ue, cf.beta1, cf.beta2, cf.eps, kLazyLog - 1, s);
+}
+// iteration t for the rows with a gradient (gsum / slot from the row combine; second table: combined here)
+void lazy_rows_step(lstur_ctx* c, const int32_t* rows, const float* row_grads2, int n_rows, int t, float lr_t, hipStream_t s) {
+  const Dims& d = c->d;
+  const lstur_cfg& cf = c->cfg;
+  launch_lazy_rows_adam(c->buf.user_emb, c->buf.user_m, c->buf.user_v, rows, c->ws.slot, c->ws.gsum, n_rows, d.Ue,
+                        c->ws.lazy_last, c->ws.lazy_lrt, t, lr_t, cf.beta1, cf.beta2, cf.eps, kLazyLog - 1, s);
+  if (two_tables(d)) {
+    launch_user_grad_combine(rows, row_grads2 ? row_grads2 : c->ws.duser2, n_rows, d.Ue, c->ws.first, c->ws.gsum2, c->ws.slot, s);
+    launch_lazy_rows_adam(c->buf.user_emb2, c->buf.user_m2, c->buf.user_v2, rows, c->ws.slot, c->ws.gsum2, n_rows, d.Ue,
+                          c->ws.lazy_last, c->ws.lazy_lrt, t, lr_t, cf.beta1, cf.beta2, cf.eps, kLazyLog - 1, s);
+  }
+  launch_lazy_rows_mark(rows, c->ws.slot, n_rows, c->ws.lazy_last, c->ws.lazy_lrt, t, lr_t, kLazyLog - 1, s);
+  launch_user_slot_clear(rows, n_rows, c->ws.slot, s);
+}
+
 // Keras-Adam sweep of the user table(s) for the rows / row gradients of this batch (duplicates combined in sample order)
 void adam_user_tables(lstur_ctx* c, const int32_t* rows, const float* row_grads, int n_rows, float lr_t, bool combine_first,
                       hipStream_t s, const float* row_grads2 = nullptr) {
@@ -744,7 +833,7 @@ bool table_stream(lstur_ctx* c) { return background_stream(c); }
 // batch's embedding gather, which keeps the bandwidth it is measured on.
 bool early_table_sweep_wanted(const lstur_ctx* c) {
   const auto& f = c->fused;
-  return f.on && !f.swept && c->cur_lane == 0 && c->conv_cus == 0 && has_user_table(c->d);
+  return f.on && !f.swept && c->cur_lane == 0 && c->conv_cus == 0 && has_user_table(c->d) && !c->d.lazy;
 }
 void early_table_sweep(lstur_ctx* c, int n, hipEvent_t forked, bool recurrent, bool after_prefetch) {
   auto& f = c->fused;
@@ -774,8 +863,9 @@ void early_table_sweep(lstur_ctx* c, int n, hipEvent_t forked, bool recurrent, b
                                cf.beta2, cf.eps, sweep_blocks, st);
   f.swept = true;
 }
-bool finish_table_rows_wanted(const lstur_ctx* c) {
+bool finish_table_rows_wanted(lstur_ctx* c) {
   const auto& f = c->fused;
+  if (c->d.lazy) return f.on && !f.table_done && c->cur_lane == 0 && c->conv_cus == 0 && table_stream(c);
   return f.on && f.swept && !f.table_done && c->cur_lane == 0;
 }
 // behind the row gradients (and their row masks): `forked` was recorded there on the caller's stream
@@ -783,10 +873,16 @@ void finish_table_rows(lstur_ctx* c, int n, hipEvent_t forked) {
   auto& f = c->fused;
   const Dims& d = c->d;
   const lstur_cfg& cf = c->cfg;
-  hipStream_t st = c->side_t;
+  hipStream_t st = d.lazy ? lazy_stream(c) : c->side_t;
   const int32_t* rows = c->ws.user_rows;
   (void)hipStreamWaitEvent(st, forked, 0);
   launch_user_grad_combine(rows, c->ws.duser, n, d.Ue, c->ws.first, c->ws.gsum, c->ws.slot, st);
+  if (d.lazy) {   // no sweep at all: the batch's rows take iteration t now, every other row when it is next read / updated
+    lazy_rows_step(c, rows, nullptr, n, f.t, f.lr_t, st);
+    (void)hipEventRecord(c->ev_t1, st);
+    f.table_done = true;
+    return;
+  }
   launch_adam_rows(c->buf.user_emb, c->buf.user_m, c->buf.user_v, rows, c->ws.slot, c->ws.gsum, n, d.Ue, f.lr_t, cf.beta1,
                    cf.beta2, cf.eps, st);
   if (two_tables(d)) {
@@ -813,6 +909,10 @@ void lazy_init(lstur_ctx* c, hipStream_t s) {
   const Dims& d = c->d;
   (void)hipMemsetAsync(c->ws.emb + (size_t)d.nt_max * d.Tp * d.D, 0, kEmbSlack * sizeof(float), s);
   launch_fill_i32(c->ws.slot, -1, d.Nu, s);
+  if (d.lazy) {
+    launch_fill_i32(c->ws.lazy_last, 0, d.Nu, s);
+    (void)hipMemsetAsync(c->ws.lazy_lrt, 0, (size_t)kLazyLog * sizeof(float), s);
+  }
   // E3: the gather skips rows no window covers; the k tail of a window may still touch one (under a zero weight)
   if (c->ws.e3) (void)hipMemsetAsync(c->ws.e3, 0, conv3_e3_elems(d.nt_max, d.T, d.D, d.k) * 2, s);
   if (c->ws.set[1].e3 && c->ws.set[1].e3 != c->ws.set[0].e3)
@@ -897,6 +997,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
                                          drop, key1, s, w.live, (training && w.kbits_valid) ? w.kbits : nullptr));
   dense_gemm(w.pooled, d.F, c->P("dense_w"), d.U, false, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, w.gemm_scratch, s);
   // user encoder (paper.py:584-633)
+  if (d.lazy && c->cur_lane == 0) lazy_catchup_rows(c, user, n, s);   // (large tables: the rows read below, made current)
   launch_hist_mask(w.ids, w.docvec, w.hmask, w.gmask, nW, d.T, d.U, s, c->buf.user_emb, user, w.user_rows, w.uvec, n,
                    d.Ue);
   // whole-row dropout of the user embedding: dgru's Dropout(0.5, noise_shape=(None, 1)) (paper.py:610), or the id_keep
@@ -1589,9 +1690,17 @@ int lstur_prefetch_ids(lstur_ctx* ctx, const int32_t* hist_ids, const int32_t* c
   if (ctx->ws.set[1].ids == ctx->ws.set[0].ids) return LSTUR_OK;      // this configuration stages inline: a no-op
   ctx->pend.hist = hist_ids;
   ctx->pend.cands = cand_ids;
+  ctx->pend.users = ctx->next_users;     // (lstur_prefetch_rows, same batch)
+  ctx->next_users = nullptr;
   ctx->pend.n = n;
   ctx->pend.step = step;
   ctx->pend.valid = true;
+  return LSTUR_OK;
+}
+
+int lstur_prefetch_rows(lstur_ctx* ctx, const int32_t* user) {
+  if (!ctx) return fail(LSTUR_ERR_ARG, "ctx is NULL");
+  ctx->next_users = user;
   return LSTUR_OK;
 }
 
@@ -1673,6 +1782,8 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
   if (n_rows < 0 || n_rows > d.rows_cap) return fail(LSTUR_ERR_ARG, "too many sparse rows for one adam step");
   const float lr_t = lr * (sqrtf(1.0f - powf(c.beta2, (float)t)) / (1.0f - powf(c.beta1, (float)t)));
   lazy_init(ctx, s);
+  // (a prefetch-time catch-up of the next batch's rows ran on the parameter-gradient stream: the backward joined it)
+  lazy_begin_iteration(ctx, t, s);   // (large tables; a no-op when the fused step already did it)
   const bool no_user = !has_user_table(d);
   // The next forward's weight images ride the dense Adam launch when they exist (packed whole once) and both fast kernels
   // are in use: two 5-us launches less between the step's reduction and the next conv forward.
@@ -1715,9 +1826,12 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
   if (d.word_trainable)   // dense Keras-Adam sweep of the word table (TF-1 densifies the IndexedSlices gradient)
     launch_adam_flat(ctx->buf.word_emb, ctx->buf.word_grad, ctx->buf.word_m, ctx->buf.word_v, (size_t)d.V * d.D, lr_t,
                      c.beta1, c.beta2, c.eps, s);
-  if (!no_user && !skip_table)   // nigru / niavg: the user embedding is not part of the graph (paper.py:627-630)
-    adam_user_tables(ctx, rows, row_grads, n_rows, lr_t, false, s, row_grads2);
+  if (!no_user && !skip_table) {   // nigru / niavg: the user embedding is not part of the graph (paper.py:627-630)
+    if (d.lazy) lazy_rows_step(ctx, rows, row_grads2, n_rows, t, lr_t, s);
+    else adam_user_tables(ctx, rows, row_grads, n_rows, lr_t, false, s, row_grads2);
+  }
   if (skip_table) (void)hipStreamWaitEvent(s, ctx->ev_t1, 0);
+  if (d.lazy) ctx->lazy_t = t;
   return check_launch("adam_step");
 }
 
@@ -1726,6 +1840,13 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
   if (!ctx || t < 1) return fail(LSTUR_ERR_ARG, "bad adam step");
   return adam_impl(ctx, lr, t, rows, row_grads, n_rows, (hipStream_t)stream, false);
 }
+
+int lstur_flush_tables(lstur_ctx* ctx, lstur_stream stream) {
+  if (!ctx) return fail(LSTUR_ERR_ARG, "ctx is NULL");
+  lazy_flush_all(ctx, (hipStream_t)stream);
+  return check_launch("flush_tables");
+}
+int lstur_lazy_adam(lstur_ctx* ctx) { return (ctx && ctx->d.lazy) ? 1 : 0; }
 
 int lstur_params_changed(lstur_ctx* ctx) {
   if (!ctx) return fail(LSTUR_ERR_ARG, "ctx is NULL");
@@ -1744,6 +1865,8 @@ static int train_step_impl(lstur_ctx* ctx, const int32_t* user, const int32_t* h
   ctx->fused.on = !off;
   ctx->fused.swept = ctx->fused.table_done = false;
   ctx->fused.lr_t = lr * (sqrtf(1.0f - powf(c.beta2, (float)t)) / (1.0f - powf(c.beta1, (float)t)));
+  ctx->fused.t = t;
+  lazy_begin_iteration(ctx, t, s);
   int rc;
   if (ctx->d.head == LSTUR_HEAD_SOFTMAX)
     rc = train_impl(ctx, user, hist, cands, n, step, 1.f, stats, s, ids_form, true, true);

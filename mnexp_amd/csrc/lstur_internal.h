@@ -116,6 +116,18 @@ void launch_dp_stage(const int32_t* rows, const float* g, const float* g2, int n
                      int world, hipStream_t s);
 void launch_dp_unpack(const float* tail, int n, int B, int Ue, int world, int32_t* rows, float* g, float* g2, hipStream_t s);
 void launch_user_slot_clear(const int32_t* rows, int n, int32_t* slot, hipStream_t s);
+// lazy dense Adam of large user tables (misc.hip): a row takes its pending zero-gradient updates when it is next read or
+// updated; last[row] = the iteration it is current for, lrt[t] = the lr_t of iteration t
+void launch_lazy_catchup(float* p, float* m, float* v, float* p2, float* m2, float* v2, const int32_t* rows, int n,
+                         int32_t* first, int32_t* last, const float* lrt, int upto, int dim, float b1, float b2, float eps,
+                         int mask, hipStream_t s);    // (p2 != NULL: both tables; first: n int32 of scratch)
+void launch_lazy_rows_adam(float* p, float* m, float* v, const int32_t* rows, const int32_t* slot, const float* gsum, int n,
+                           int dim, const int32_t* last, const float* lrt, int t, float lr_t, float b1, float b2, float eps,
+                           int mask, hipStream_t s);
+void launch_lazy_rows_mark(const int32_t* rows, const int32_t* slot, int n, int32_t* last, float* lrt, int t, float lr_t,
+                           int mask, hipStream_t s);   // behind the row steps of every table
+void launch_lazy_flush(float* p, float* m, float* v, const int32_t* last, const float* lrt, int upto, int n_rows, int dim,
+                       float b1, float b2, float eps, int mask, hipStream_t s);   // (lrt is indexed t & mask)
 // the sweep in two halves (fused step): mark the batch's rows, move every OTHER row with its zero gradient (independent of
 // the step's backward), later finish the marked rows from their combined gradients (first occurrences, slot[row] == i)
 void launch_user_rows_mark(const int32_t* rows, int n, int32_t* slot, hipStream_t s);

@@ -766,6 +766,130 @@ void launch_adam_rows(float* p, float* m, float* v, const int32_t* rows, const i
   if (n) hipLaunchKernelGGL(adam_rows_kernel, dim3(n), dim3(64), 0, s, p, m, v, rows, slot, gsum, dim, lr_t, b1, b2, eps);
 }
 
+// ---------------------------------------------------------------------------------------------
+// LAZY dense Adam for large user tables.  TF-1 Keras densifies the embedding gradient, so every row takes an update every
+// step -- for a row outside the batch the zero-gradient one, which depends on nothing but the row's own (p, m, v) and the
+// step's lr_t.  Instead of sweeping N_u rows per step (24 B of HBM traffic per element: 4.8 GB at 1 M users, 1.1 ms), a row
+// remembers the last iteration it is current for (last[row]) and takes its pending zero-gradient updates, in order, with
+// the logged lr_t of each, when it is next READ (forward gather) or next UPDATED with a gradient: the same sequence of
+// fp32 operations per element as the dense sweep (same adam1, no FMA contraction), hence bit-identical values -- only the
+// time they are computed moves, and the work turns from HBM traffic into registers.  lstur_flush_tables brings every row
+// up to date (before the host reads the table).
+// ---------------------------------------------------------------------------------------------
+// One THREAD per (sample, column): a row that waited 2 000 iterations is a 2 000-long dependent chain of sqrt / divide per
+// element, so the parallelism has to come from the elements (a wave per row took 1.7 ms for 512 rows at 1 M users; this
+// form ~0.3 ms).  first[i] (smallest j with rows[j] == rows[i], lazy_first_kernel) picks one sample per distinct row; the
+// rows' `last` is advanced by lazy_mark_kernel once every table has been brought up.
+__global__ void lazy_first_kernel(const int32_t* __restrict__ rows, int n, int32_t* __restrict__ first) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r = rows[i];
+  int f = i;
+  for (int j = 0; j < i; ++j)
+    if (rows[j] == r) {
+      f = j;
+      break;
+    }
+  first[i] = f;
+}
+__global__ __launch_bounds__(256) void lazy_catchup_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                          const int32_t* __restrict__ rows, const int32_t* __restrict__ first,
+                                                          int n, const int32_t* __restrict__ last,
+                                                          const float* __restrict__ lrt, int upto, int dim, float b1, float b2,
+                                                          float eps, int mask) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * dim) return;
+  const int i = idx / dim, c = idx - i * dim;
+  if (first[i] != i) return;
+  const int r = rows[i], l = last[r];
+  if (l >= upto) return;
+  const size_t e = (size_t)r * dim + c;
+  float pp = p[e], mm = m[e], vv = v[e];
+  for (int tt = l + 1; tt <= upto; ++tt) adam1(pp, 0.f, mm, vv, lrt[tt & mask], b1, b2, eps);
+  p[e] = pp;
+  m[e] = mm;
+  v[e] = vv;
+}
+__global__ void lazy_mark_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ first, int n,
+                                 int32_t* __restrict__ last, int upto) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && first[i] == i && last[rows[i]] < upto) last[rows[i]] = upto;
+}
+// rows[0..n) current for iteration `upto` in table (p, m, v) and, when p2 != NULL, in the second table
+void launch_lazy_catchup(float* p, float* m, float* v, float* p2, float* m2, float* v2, const int32_t* rows, int n,
+                         int32_t* first, int32_t* last, const float* lrt, int upto, int dim, float b1, float b2, float eps,
+                         int mask, hipStream_t s) {
+  if (n <= 0 || upto <= 0) return;
+  hipLaunchKernelGGL(lazy_first_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, rows, n, first);
+  hipLaunchKernelGGL(lazy_catchup_kernel, dim3(cdiv(n * dim, 256)), dim3(256), 0, s, p, m, v, rows, (const int32_t*)first, n,
+                     (const int32_t*)last, lrt, upto, dim, b1, b2, eps, mask);
+  if (p2)
+    hipLaunchKernelGGL(lazy_catchup_kernel, dim3(cdiv(n * dim, 256)), dim3(256), 0, s, p2, m2, v2, rows, (const int32_t*)first,
+                       n, (const int32_t*)last, lrt, upto, dim, b1, b2, eps, mask);
+  hipLaunchKernelGGL(lazy_mark_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, rows, (const int32_t*)first, n, last, upto);
+}
+// iteration t for the batch's rows (first occurrences: slot[row] == i, set by the row combine): pending zero-gradient
+// updates up to t - 1, then the step with the combined gradient; one thread per (sample, column).  lazy_rows_mark_kernel
+// then advances `last` and logs lr_t for the catch-ups to come.
+__global__ __launch_bounds__(256) void lazy_rows_adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                            const int32_t* __restrict__ rows, const int32_t* __restrict__ slot,
+                                                            const float* __restrict__ gsum, int n, int dim,
+                                                            const int32_t* __restrict__ last, const float* __restrict__ lrt,
+                                                            int t, float lr_t, float b1, float b2, float eps, int mask) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * dim) return;
+  const int i = idx / dim, c = idx - i * dim, r = rows[i];
+  if (slot[r] != i) return;
+  const int l = last[r];
+  const size_t e = (size_t)r * dim + c;
+  float pp = p[e], mm = m[e], vv = v[e];
+  for (int tt = l + 1; tt < t; ++tt) adam1(pp, 0.f, mm, vv, lrt[tt & mask], b1, b2, eps);
+  adam1(pp, gsum[(size_t)i * dim + c], mm, vv, lr_t, b1, b2, eps);
+  p[e] = pp;
+  m[e] = mm;
+  v[e] = vv;
+}
+__global__ void lazy_rows_mark_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ slot, int n,
+                                      int32_t* __restrict__ last, float* __restrict__ lrt, int t, float lr_t, int mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) lrt[t & mask] = lr_t;
+  if (i < n && slot[rows[i]] == i) last[rows[i]] = t;
+}
+void launch_lazy_rows_adam(float* p, float* m, float* v, const int32_t* rows, const int32_t* slot, const float* gsum, int n,
+                           int dim, const int32_t* last, const float* lrt, int t, float lr_t, float b1, float b2, float eps,
+                           int mask, hipStream_t s) {
+  if (n > 0)
+    hipLaunchKernelGGL(lazy_rows_adam_kernel, dim3(cdiv(n * dim, 256)), dim3(256), 0, s, p, m, v, rows, slot, gsum, n, dim, last,
+                       lrt, t, lr_t, b1, b2, eps, mask);
+}
+void launch_lazy_rows_mark(const int32_t* rows, const int32_t* slot, int n, int32_t* last, float* lrt, int t, float lr_t,
+                           int mask, hipStream_t s) {
+  hipLaunchKernelGGL(lazy_rows_mark_kernel, dim3(std::max(1, cdiv(n, 256))), dim3(256), 0, s, rows, slot, n, last, lrt, t, lr_t,
+                     mask);
+}
+// every row up to iteration `upto` (before the host reads the table); the caller then sets last[] = upto
+__global__ __launch_bounds__(256) void lazy_flush_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                         const int32_t* __restrict__ last, const float* __restrict__ lrt,
+                                                         int upto, size_t total, int dim, float b1, float b2, float eps,
+                                                         int mask) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int l = last[e / dim];
+    if (l >= upto) continue;
+    float pp = p[e], mm = m[e], vv = v[e];
+    for (int tt = l + 1; tt <= upto; ++tt) adam1(pp, 0.f, mm, vv, lrt[tt & mask], b1, b2, eps);
+    p[e] = pp;
+    m[e] = mm;
+    v[e] = vv;
+  }
+}
+void launch_lazy_flush(float* p, float* m, float* v, const int32_t* last, const float* lrt, int upto, int n_rows, int dim,
+                       float b1, float b2, float eps, int mask, hipStream_t s) {
+  const size_t total = (size_t)n_rows * dim;
+  if (total && upto > 0)
+    hipLaunchKernelGGL(lazy_flush_kernel, dim3((unsigned)std::min<size_t>(cdivz(total, 256), 256 * 32)), dim3(256), 0, s, p, m,
+                       v, last, lrt, upto, total, dim, b1, b2, eps, mask);
+}
+
 // first[i] = smallest j with rows[j] == rows[i]
 __global__ void first_occurrence_kernel(const int32_t* __restrict__ rows, int n, int32_t* __restrict__ first) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

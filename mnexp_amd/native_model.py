@@ -328,8 +328,15 @@ class NativeModel:
     def param_names(self):
         return [n for n, _, _ in self.layout] + ['user_emb'] + (['user_emb2'] if self.arch in ('iigru', 'iicgru') else [])
 
+    def flush_tables(self):
+        """Large user tables are updated lazily (include/lstur.h: lstur_flush_tables): bring every row up to date before
+        the host reads or overwrites user_emb / user_m / user_v."""
+        if getattr(self, '_ctx', None):
+            check(lib.lstur_flush_tables(self._ctx, self._stream()), 'lstur_flush_tables')
+
     def set_weights(self, weights):
         """weights: dict name -> ndarray (any subset of param_names() + 'word_emb')."""
+        self.flush_tables()
         for name, arr in weights.items():
             a = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)).to(self.device)
             if name == 'user_emb':
@@ -361,6 +368,7 @@ class NativeModel:
         return flat[off:off + cnt].cpu().numpy().reshape(self.shapes[name])
 
     def get_weights(self):
+        self.flush_tables()
         return {n: self._get(self.dense_param, n) for n in self.param_names()}
 
     def get_grads(self):
@@ -522,12 +530,15 @@ class NativeModel:
             return a.to(device=self.device, dtype=torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.float32)).to(self.device, non_blocking=True)
 
-    def prefetch_ids(self, hist_ids, cand_ids):
+    def prefetch_ids(self, hist_ids, cand_ids, user=None):
         """Announce the NEXT training step's doc-id batch (device int32 tensors; kept alive here until that step): the
-        library stages it under the current step's GRU recurrence (include/lstur.h: lstur_prefetch_ids)."""
+        library stages it under the current step's GRU recurrence (include/lstur.h: lstur_prefetch_ids).  user: that
+        batch's user ids -- a lazily updated (large) user table brings those rows up to date there as well."""
         if self.pointwise:
             return
-        self._prefetched = (hist_ids, cand_ids)
+        self._prefetched = (hist_ids, cand_ids, user)
+        if user is not None and self.has_user:
+            check(lib.lstur_prefetch_rows(self._ctx, user.data_ptr()), 'lstur_prefetch_rows')
         check(lib.lstur_prefetch_ids(self._ctx, hist_ids.data_ptr(), cand_ids.data_ptr(), int(hist_ids.shape[0]),
                                      self.step + 1), 'lstur_prefetch_ids')
 
@@ -621,7 +632,7 @@ class NativeModel:
         nxt = None
         if next_ids is not None and not self.pointwise:
             nxt = self._ids_to_dev(next_ids)
-            self.prefetch_ids(nxt[1], nxt[2])
+            self.prefetch_ids(nxt[1], nxt[2], nxt[0])
         lab = self._dev_f32(np.asarray(labels).reshape(-1)) if self.pointwise else None
         self._train_step(dev[0], dev[1], dev[2], True, lab)
         return nxt

@@ -53,8 +53,11 @@ if world > 1:
 '''
 
 
-@pytest.mark.parametrize('arch,ranks', [('igru', 2), ('iigru', 2), ('igru', 4)])
-def test_two_process_data_parallel_equals_one_process_on_the_joint_batch(arch, ranks, tmp_path):
+@pytest.mark.parametrize('arch,ranks,lazy', [('igru', 2, None), ('iigru', 2, None), ('igru', 4, None), ('igru', 2, '1'),
+                                             ('iigru', 2, '1')])
+def test_two_process_data_parallel_equals_one_process_on_the_joint_batch(arch, ranks, lazy, tmp_path):
+    """lazy = '1': the lazily updated user table (large tables; forced here) -- rows another rank touched take their
+    pending zero-gradient updates inside the row step of the exchange."""
     if not torch.cuda.is_available():
         pytest.skip('needs an MI355X')
     code = _CHILD % (ROOT, os.path.join(ROOT, 'tests'))
@@ -65,6 +68,8 @@ def test_two_process_data_parallel_equals_one_process_on_the_joint_batch(arch, r
         procs = []
         for rank in range(world):
             env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+            if lazy:
+                env['LSTUR_LAZY_ADAM'] = lazy
             procs.append(subprocess.Popen([sys.executable, '-c', code, arch, out, port, str(ranks)], env=env, cwd=ROOT,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         for pr in procs:

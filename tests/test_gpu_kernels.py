@@ -345,7 +345,9 @@ def test_config4_shapes_batch_512_one_million_users():
     rows1, rg1 = g['user_rows'], g['user_row_grads'].astype(np.float64)
     assert np.array_equal(rows1, user)
     table0 = model.user_emb.view(-1, Ue)[torch.from_numpy(np.unique(rows1)).cuda().long()].cpu().numpy().astype(np.float64)
+    assert lib.lstur_lazy_adam(model._ctx) == 1          # a table of this size updates lazily: flush before reading it
     check(lib.lstur_adam_step(model._ctx, lr, 1, None, None, 0, model._stream()))
+    model.flush_tables()
     torch.cuda.synchronize()
     uniq = np.unique(rows1)
     gsum = np.zeros((len(uniq), Ue))
@@ -370,6 +372,12 @@ def test_config4_shapes_batch_512_one_million_users():
     check(lib.lstur_forward_backward(model._ctx, u2.data_ptr(), h.data_ptr(), c.data_ptr(), B, 1, 1.0,
                                      model.stats.data_ptr(), model._stream()))
     check(lib.lstur_adam_step(model._ctx, lr, 2, None, None, 0, model._stream()))
+    torch.cuda.synchronize()
+    # lazily, the rows of step 1 that step 2 did not touch are still at iteration 1 ...
+    io_ = torch.from_numpy(old_only).cuda().long()
+    stale = model.user_m.view(-1, Ue)[io_].cpu().numpy()
+    np.testing.assert_allclose(stale, m1[np.searchsorted(uniq, old_only)], rtol=2e-5, atol=1e-12)
+    model.flush_tables()                                 # ... and take their zero-gradient update of iteration 2 here
     torch.cuda.synchronize()
     sel = np.searchsorted(uniq, old_only)
     io = torch.from_numpy(old_only).cuda().long()
