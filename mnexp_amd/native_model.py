@@ -360,6 +360,8 @@ class NativeModel:
         raise KeyError(name)
 
     def _get(self, flat, name):
+        if name in ('user_emb', 'user_emb2'):
+            self.flush_tables()            # (a lazily updated table: every row current before the host reads it)
         if name == 'user_emb':
             return self.user_emb.cpu().numpy().reshape(self.shapes['user_emb'])
         if name == 'user_emb2':
