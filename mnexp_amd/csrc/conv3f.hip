@@ -393,11 +393,14 @@ void launch_conv3_fwd2(const unsigned short* e3, const unsigned short* W3, const
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f2_lds(4, 2, 7));
   // grid: every tile as a plain tile, or whole rounds + at most ncu slices (the device decides from the token count)
   const int grid = tiles + ncu;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), f2_lds(4, 2, 7), s, e3, e_bytes, W3, bias, ids, out, vidx, vcount, M, T, Tp,
-                     Dp / 8, F, Kp, Np, ncu, (float*)scratch);
-  if (ncu > 0)
-    hipLaunchKernelGGL(conv3_fwd2_fix_kernel, dim3(8, 64), dim3(256), 0, s, (const float*)scratch, bias, ids, out, vidx,
-                       vcount, M, F, ncu);
+  if (ncu <= 0) last_launch();
+  launch_k(kern, dim3(grid), dim3(512), f2_lds(4, 2, 7), s, e3, e_bytes, W3, bias, ids, out, vidx, vcount, M, T, Tp, Dp / 8, F,
+           Kp, Np, ncu, (float*)scratch);
+  if (ncu > 0) {
+    last_launch();
+    launch_k(conv3_fwd2_fix_kernel, dim3(8, 64), dim3(256), 0, s, (const float*)scratch, bias, ids, out, vidx, vcount, M, F,
+             ncu);
+  }
 }
 
 
@@ -625,7 +628,8 @@ int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, 
   const uint32_t e_bytes = (uint32_t)std::min(conv3_e3_elems(n_titles, T, D, ksize) * 2, (size_t)0xFFFFFFFFu);
   const uint32_t g_bytes = (uint32_t)std::min((size_t)M * F * 4, (size_t)0xFFFFFFFFu);
   const dim3 grid(cdiv(ns, 8) * 8 * mblocks * nblocks);
-  hipLaunchKernelGGL(conv3_wgrad2_kernel, grid, dim3(G2_THREADS), G2_LDS, s, e3, e_bytes, dout, g_bytes, (float*)scratch,
+  last_launch();
+  launch_k(conv3_wgrad2_kernel, grid, dim3(G2_THREADS), G2_LDS, s, e3, e_bytes, dout, g_bytes, (float*)scratch,
                      vcount, M, F, Kq, mblocks, nblocks, ns, offA, offB);
   for (int j = 0; j < ksize; ++j)
     jobs[j] = ReduceJob{(const float*)scratch + (size_t)j * Dp * F, dw + (size_t)j * D * F, D, F, F, ns, (size_t)Kq * F, alpha, 0.f};

@@ -527,6 +527,8 @@ struct lstur_ctx {
 };
 
 thread_local hipEvent_t lstur::g_stop_event = nullptr;
+thread_local hipEvent_t lstur::g_start_event = nullptr;
+thread_local hipEvent_t lstur::g_stop_pending = nullptr;
 
 namespace {
 
@@ -537,11 +539,14 @@ int check_launch(const char* what) {
 }
 
 // HIP-event bracket around one kernel family on the launch stream (only when profiling is enabled)
+// attach = true: the launcher below this scope goes through launch_k / last_launch (conv3f forward + fix-up, kernel
+// gradient, gather3): the two events ride the family's first and last kernel instead of being recorded around them
 struct ProfScope {
   lstur_ctx* c;
   ProfKernel* k = nullptr;
   hipStream_t s;
-  ProfScope(lstur_ctx* ctx, const char* name, hipStream_t st) : c(ctx), s(st) {
+  bool attached = false;
+  ProfScope(lstur_ctx* ctx, const char* name, hipStream_t st, bool attach = false) : c(ctx), s(st) {
     if (!c->prof_on) return;
     if (c->prof_roofline_only && strcmp(name, "gather") && strcmp(name, "conv_fwd") && strcmp(name, "conv_wgrad") &&
         strcmp(name, "qkv_proj") && strcmp(name, "qkv_wgrad"))
@@ -556,11 +561,23 @@ struct ProfScope {
       k->start.push_back(a);
       k->stop.push_back(b);
     }
-    (void)hipEventRecord(k->start[k->used], s);
+    static const bool no_attach = getenv("LSTUR_PROF_ATTACH") && !strcmp(getenv("LSTUR_PROF_ATTACH"), "0");
+    if (attach && !no_attach) {
+      arm_bracket(k->start[k->used], k->stop[k->used]);
+      attached = true;
+    } else {
+      (void)hipEventRecord(k->start[k->used], s);
+    }
   }
   ~ProfScope() {
     if (k) {
-      (void)hipEventRecord(k->stop[k->used], s);
+      if (!attached) (void)hipEventRecord(k->stop[k->used], s);
+      else if (g_start_event || g_stop_pending || g_stop_event) {   // nothing was launched (empty batch): record plainly
+        arm_bracket(nullptr, nullptr);
+        g_stop_event = nullptr;
+        (void)hipEventRecord(k->start[k->used], s);
+        (void)hipEventRecord(k->stop[k->used], s);
+      }
       k->used++;
     }
   }
@@ -683,7 +700,7 @@ bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
   launch_compact_write_offsets(t.ids, nt * d.T, t.vscratch, t.vidx, t.vcount, d.T, d.Tp, conv3_dp(d.D) / 8 * 3, d.F, t.offA,
                                t.offB, p, t.live);
   {
-    ProfScope _ps(c, "gather", p);
+    ProfScope _ps(c, "gather", p, true);
     static const int pf_blocks = getenv("LSTUR_PREFETCH_BLOCKS") ? atoi(getenv("LSTUR_PREFETCH_BLOCKS")) : 0;
     launch_gather3(c->buf.word_emb, t.ids, t.e3, nt, d.T, d.D, pl, d.k - 1 - pl, c->cfg.dropout,
                    dropout_key(c->cfg.seed, q.step, 0), true, p, pf_blocks);
@@ -975,7 +992,10 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   launch_compact_write_offsets(w.ids, nt * d.T, w.vscratch, w.vidx, w.vcount, d.T, d.Tp,
                                (use3 && !gen1) ? conv3_dp(d.D) / 8 * 3 : d.D, d.F, w.offA, w.offB, s, w.live);
   if (use3 && !gen1)   // Embedding + Dropout straight into the pre-split layout of the bf16x3 conv kernels (rows nobody reads skipped)
-    PROF("gather", launch_gather3(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, s));
+  {
+    ProfScope _ps(c, "gather", s, true);
+    launch_gather3(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, s);
+  }
   else
     PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
   }
@@ -987,8 +1007,9 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     PROF("conv_fwd", launch_conv3_fwd(w.emb, w.conv_w3_v1, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
                                       w.vcount, s));
   } else if (use3) {
-    PROF("conv_fwd", launch_conv3_fwd2(w.e3, w.conv_w3, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
-                                       w.vcount, 0, w.fwd2_scratch, s, c->conv_cus));
+    ProfScope _ps(c, "conv_fwd", s, true);
+    launch_conv3_fwd2(w.e3, w.conv_w3, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx, w.vcount, 0,
+                      w.fwd2_scratch, s, c->conv_cus);
   } else {
     PROF("conv_fwd", launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
                                      w.vcount, s));
@@ -1235,7 +1256,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     PROF("conv_wgrad", launch_conv3_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vidx,
                                           w.vcount, s, &jobs[nj++], w.offA, w.offB));
   else if (w.conv_w3 && !conv_f32) {   // fp32-grade bf16x3 contraction (conv3f.hip), like the forward; one reduce job per tap
-    ProfScope _ps(c, "conv_wgrad", s);
+    ProfScope _ps(c, "conv_wgrad", s, true);
     nj += launch_conv3_wgrad2(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, s, &jobs[nj],
                               w.offA, w.offB, 1.0f, c->conv_cus);
   } else

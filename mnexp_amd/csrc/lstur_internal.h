@@ -32,12 +32,27 @@ constexpr int kMaxReduceJobs = 24;
 extern thread_local hipEvent_t g_stop_event;
 inline void arm_stop_event(hipEvent_t e) { g_stop_event = e; }
 inline bool stop_event_pending() { return g_stop_event != nullptr; }
+// The same for timing brackets (bench.py's roofline kernels inside its timed region): arm_bracket(start, stop) attaches
+// `start` to the next launch_k launch and `stop` to the launch in front of which the launcher calls last_launch() -- a
+// family of kernels is bracketed from its first to its last launch without a single record packet (two records per
+// family cost the step 17-19 us over gather + conv forward + conv kernel gradient).
+extern thread_local hipEvent_t g_start_event, g_stop_pending;
+inline void arm_bracket(hipEvent_t start, hipEvent_t stop) {
+  g_start_event = start;
+  g_stop_pending = stop;
+}
+inline void last_launch() {
+  if (g_stop_pending) {
+    g_stop_event = g_stop_pending;
+    g_stop_pending = nullptr;
+  }
+}
 template <typename F, typename... Args>
 inline void launch_k(F kern, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
-  if (g_stop_event) {
-    hipEvent_t e = g_stop_event;
-    g_stop_event = nullptr;
-    hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, nullptr, e, 0, args...);
+  if (g_stop_event || g_start_event) {
+    hipEvent_t e0 = g_start_event, e1 = g_stop_event;
+    g_start_event = g_stop_event = nullptr;
+    hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, e0, e1, 0, args...);
   } else {
     hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
   }

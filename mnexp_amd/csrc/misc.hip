@@ -184,8 +184,9 @@ void launch_gather3(const float* table, const int32_t* ids, unsigned short* e3, 
   const uint32_t th = drop > 0.f ? dropout_thresh(drop) : 0u;
   const float sc = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
   auto go = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, (const float4*)table, ids, (uint4*)e3, (uint32_t)total8, T, Tp, D4,
-                       C8, pad_l, pad_r, th, key, sc);
+    last_launch();
+    launch_k(kern, dim3(blocks), dim3(256), 0, s, (const float4*)table, ids, (uint4*)e3, (uint32_t)total8, T, Tp, D4, C8, pad_l,
+             pad_r, th, key, sc);
   };
   if (drop > 0.f) skip_unread ? go(gather3_kernel<true, true>) : go(gather3_kernel<true, false>);
   else skip_unread ? go(gather3_kernel<false, true>) : go(gather3_kernel<false, false>);
