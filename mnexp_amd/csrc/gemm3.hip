@@ -16,7 +16,7 @@
 
 namespace lstur {
 
-constexpr int G3_T = 64, G3_K = 32, G3_NS = 8;        // tile, k-step, k-steps of loads in flight (even: LDS buffer = step & 1)
+constexpr int G3_T = 64, G3_K = 32;                    // tile, k-step
 constexpr int G3_SA = G3_K + 8;                        // [x][k] image row: 80 bytes (conflict-free 16-byte fragment reads)
 constexpr int G3_SB = tr_stride(G3_T);                 // [k][n] image row (transposed fragment reads)
 constexpr int G3_AIMG = G3_T * G3_SA;                  // elements of one part of an [x][k] tile
@@ -62,7 +62,10 @@ __device__ __forceinline__ void g3_store(unsigned short* img, int img_elems, int
 // A_KM: A is stored [K][M] (C = A^T . B: the parameter gradients, contraction over the rows of both operands); such
 // launches are split along K into gridDim.z slabs of k_per_split rows, written as C + z * M * N (ld N, no bias) and summed
 // in fixed order by the caller's reduction (bitwise reproducible).
-template <bool A_KM, bool B_NK>
+// NS: k-steps of operand loads in flight (even).  8 for the critical-path products (alone on the chip between the big
+// kernels: latency is all that matters); 2 for the parameter-gradient form, which has to squeeze in BESIDE the attention
+// backward on the side stream -- 96 registers instead of 188.
+template <bool A_KM, bool B_NK, int NS>
 __global__ __launch_bounds__(256) void gemm3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                     float* __restrict__ C, int ldc, const float* __restrict__ bias, int M,
                                                     int N, int Kfull, uint32_t bytesA, uint32_t bytesB, int k_per_split) {
@@ -76,29 +79,29 @@ __global__ __launch_bounds__(256) void gemm3_kernel(const float* __restrict__ A,
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, bytesA), rsB = make_rsrc(B, bytesB);
-  float4 ra[G3_NS][2], rb[G3_NS][2];
+  float4 ra[NS][2], rb[NS][2];
 #pragma unroll
-  for (int u = 0; u < G3_NS; ++u) {
+  for (int u = 0; u < NS; ++u) {
     g3_load<!A_KM>(rsA, lda, m0, kbeg + u * G3_K, tid, ra[u]);
     g3_load<B_NK>(rsB, ldb, n0, kbeg + u * G3_K, tid, rb[u]);
   }
   g3_store<!A_KM>(sm3, AIMG, tid, ra[0], kbeg, K);
   g3_store<B_NK>(sm3 + 3 * AIMG, G3_BIMG, tid, rb[0], kbeg, K);
-  g3_load<!A_KM>(rsA, lda, m0, kbeg + G3_NS * G3_K, tid, ra[0]);
-  g3_load<B_NK>(rsB, ldb, n0, kbeg + G3_NS * G3_K, tid, rb[0]);
+  g3_load<!A_KM>(rsA, lda, m0, kbeg + NS * G3_K, tid, ra[0]);
+  g3_load<B_NK>(rsB, ldb, n0, kbeg + NS * G3_K, tid, rb[0]);
   __syncthreads();
   for (int k0 = kbeg; k0 < K;) {
 #pragma unroll
-    for (int u = 0; u < G3_NS; ++u) {      // step k0 / G3_K == u (mod G3_NS); its tile is in LDS buffer u & 1
+    for (int u = 0; u < NS; ++u) {      // step k0 / G3_K == u (mod NS); its tile is in LDS buffer u & 1
       const int kn = k0 + G3_K;
-      {   // stage the next step (loaded G3_NS - 1 steps ago), unconditionally: past K it stores zeros nobody reads -- a
+      {   // stage the next step (loaded NS - 1 steps ago), unconditionally: past K it stores zeros nobody reads -- a
           // branch here makes the compiler wait for ALL outstanding loads
-        const int nx = (u + 1) % G3_NS;
+        const int nx = (u + 1) % NS;
         unsigned short* nb = sm3 + ((u + 1) & 1) * BUF;
         g3_store<!A_KM>(nb, AIMG, tid, ra[nx], kn, K);
         g3_store<B_NK>(nb + 3 * AIMG, G3_BIMG, tid, rb[nx], kn, K);
-        g3_load<!A_KM>(rsA, lda, m0, kn + G3_NS * G3_K, tid, ra[nx]);
-        g3_load<B_NK>(rsB, ldb, n0, kn + G3_NS * G3_K, tid, rb[nx]);
+        g3_load<!A_KM>(rsA, lda, m0, kn + NS * G3_K, tid, ra[nx]);
+        g3_load<B_NK>(rsB, ldb, n0, kn + NS * G3_K, tid, rb[nx]);
       }
       const unsigned short* as = sm3 + (u & 1) * BUF;
       const unsigned short* bs = as + 3 * AIMG;
@@ -150,9 +153,9 @@ static void g3_attrs() {
   static bool attr_set = false;
   if (attr_set) return;
   constexpr int lds = 2 * (6 * G3_BIMG) * (int)sizeof(unsigned short);   // the largest variant
-  (void)hipFuncSetAttribute((const void*)gemm3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  (void)hipFuncSetAttribute((const void*)gemm3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  (void)hipFuncSetAttribute((const void*)gemm3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)gemm3_kernel<false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)gemm3_kernel<false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)gemm3_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   attr_set = true;
 }
 // b_nk: B is [N][K] (C = A . B^T); else [K][N].  The caller checks gemm3_supported.
@@ -164,9 +167,9 @@ void launch_gemm3(const float* A, int lda, const float* B, int ldb, bool b_nk, f
   const uint32_t bytesB = (uint32_t)((b_nk ? (size_t)(N - 1) * ldb + K : (size_t)(K - 1) * ldb + N) * 4);
   const dim3 grid(cdiv(N, G3_T), cdiv(M, G3_T));
   if (b_nk)
-    launch_k(gemm3_kernel<false, true>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB, K);
+    launch_k(gemm3_kernel<false, true, 8>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB, K);
   else
-    launch_k(gemm3_kernel<false, false>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB, K);
+    launch_k(gemm3_kernel<false, false, 8>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB, K);
 }
 
 // C[M,N] = A^T . B with A [K][M], B [K][N] (parameter gradients: long K, small M x N), split along K into slabs in
@@ -188,7 +191,7 @@ void launch_gemm3_tn(const float* A, int lda, const float* B, int ldb, float* C,
   const int kps = cdiv(cdiv(K, ns), G3_K) * G3_K;
   ns = std::max(1, cdiv(K, kps));
   const uint32_t bytesA = (uint32_t)(((size_t)(K - 1) * lda + M) * 4), bytesB = (uint32_t)(((size_t)(K - 1) * ldb + N) * 4);
-  hipLaunchKernelGGL((gemm3_kernel<true, false>), dim3(cdiv(N, G3_T), cdiv(M, G3_T), ns), dim3(256), lds, s, A, lda, B, ldb,
+  hipLaunchKernelGGL((gemm3_kernel<true, false, 2>), dim3(cdiv(N, G3_T), cdiv(M, G3_T), ns), dim3(256), lds, s, A, lda, B, ldb,
                      (float*)scratch, N, (const float*)nullptr, M, N, K, bytesA, bytesB, kps);
   *job = ReduceJob{(const float*)scratch, C, M, N, ldc, ns, (size_t)M * N, alpha};
 }

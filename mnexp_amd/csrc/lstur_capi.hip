@@ -736,9 +736,11 @@ void dense_gemm(const float* A, int lda, const float* B, int ldb, bool b_nk, flo
 void wgrad_gemm(const float* A, int lda, const float* B, int ldb, float* G, int ldg, int M, int N, int K, void* scratch,
                 hipStream_t s, ReduceJob* job) {
   // These run on the side stream BESIDE the attention backward and have to fit into what its workgroups leave of a SIMD's
-  // registers: the fp32 MFMA kernel (68 VGPRs, 20 KB LDS) does, the bf16x3 kernel (188 VGPRs, 72 KB) waits for whole
-  // CUs to drain and then runs into the conv kernel gradient (measured: 59 us instead of 41 for dgru_u, and the last
-  // product finished BEHIND the conv kernel gradient).  LSTUR_WGRAD_BF16X3=1 selects it for A/B runs.
+  // registers: the fp32 MFMA kernel (68 VGPRs, 20 KB LDS) does; the bf16x3 kernel with eight k-steps in flight (188
+  // VGPRs, 72 KB) waited for whole CUs to drain and ran into the conv kernel gradient (59 us instead of 41 for dgru_u, the
+  // last product finished BEHIND the conv kernel gradient), and its thin form (two k-steps in flight, 92 VGPRs) still
+  // measures 6-9 us per step behind the fp32 kernel (same box, 1.143 / 1.147 against 1.138 / 1.138 ms).
+  // LSTUR_WGRAD_BF16X3=1 selects it for A/B runs.
   static const bool x3 = getenv("LSTUR_WGRAD_BF16X3") != nullptr;
   if (x3 && gemm3_tn_supported(lda, ldb, M, N, K)) launch_gemm3_tn(A, lda, B, ldb, G, ldg, M, N, K, 1.f, scratch, s, job);
   else launch_gemm(A, lda, 1, B, ldb, 0, G, ldg, nullptr, M, N, K, 1.f, scratch, s, job);
