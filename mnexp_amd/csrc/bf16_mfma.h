@@ -21,6 +21,9 @@ __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float
 __device__ __forceinline__ f32x16 mfma32b(u16x8 a, u16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4v mfma16b(u16x8 a, u16x8 b, f32x4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 // MFMA fragment (index x0 + (lane & 31), 8 consecutive k from k0 + 8 * (lane >> 5)) out of a row-major [k][x] bf16
 // tile: two transposed reads of a 4 x 16 block per 16-lane group.  EXEC must be full.
 __device__ __forceinline__ u16x8 tr_frag(const unsigned short* tile, int stride, int k0, int x0, int lane) {

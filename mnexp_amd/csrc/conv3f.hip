@@ -229,6 +229,26 @@ __global__ __launch_bounds__(RW* CW * 64, MT == 1 ? 2 : 1) void conv3_fwd2_kerne
           b[2] = tr_frag(bp + 2 * B_IMG, SB, 0, x0, lane);
         };
         auto six = [&](int j, const u16x8 (&b)[3]) {
+          if (OPT & 64) {   // timing-only probe (WRONG results): every 32x32x16 product as two 16x16x32 ones -- the same
+                            // FLOPs, cycles, operand registers and LDS reads; does the chip hold a higher clock on this shape?
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              f32x4v q[4];
+#pragma unroll
+              for (int x = 0; x < 4; ++x) q[x] = {acc[i][j][4 * x], acc[i][j][4 * x + 1], acc[i][j][4 * x + 2], acc[i][j][4 * x + 3]};
+              q[0] = mfma16b(al[i], b[0], q[0]); q[1] = mfma16b(al[i], b[0], q[1]);
+              q[2] = mfma16b(ah[i], b[2], q[2]); q[3] = mfma16b(ah[i], b[2], q[3]);
+              q[0] = mfma16b(am[i], b[1], q[0]); q[1] = mfma16b(am[i], b[1], q[1]);
+              q[2] = mfma16b(am[i], b[0], q[2]); q[3] = mfma16b(am[i], b[0], q[3]);
+              q[0] = mfma16b(ah[i], b[1], q[0]); q[1] = mfma16b(ah[i], b[1], q[1]);
+              q[2] = mfma16b(ah[i], b[0], q[2]); q[3] = mfma16b(ah[i], b[0], q[3]);
+#pragma unroll
+              for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[i][j][4 * x + y] = q[x][y];
+            }
+            return;
+          }
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
             f32x16 c = acc[i][j];
@@ -389,6 +409,7 @@ void launch_conv3_fwd2(const unsigned short* e3, const unsigned short* W3, const
   auto kern = variant == 10 ? conv3_fwd2_kernel<4, 2, 7, 1, 4> : variant == 11 ? conv3_fwd2_kernel<4, 2, 7, 1, 12> :
               variant == 12 ? conv3_fwd2_kernel<4, 2, 7, 1, 28> : variant == 13 ? conv3_fwd2_kernel<4, 2, 7, 1, 60> :
               variant == 14 ? conv3_fwd2_kernel<4, 2, 7, 1, 16> : variant == 15 ? conv3_fwd2_kernel<4, 2, 7, 1, 32> :
+              variant == 16 ? conv3_fwd2_kernel<4, 2, 7, 1, 64> :
                               conv3_fwd2_kernel<4, 2, 7, 1, 0>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f2_lds(4, 2, 7));
   // grid: every tile as a plain tile, or whole rounds + at most ncu slices (the device decides from the token count)

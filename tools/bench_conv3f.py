@@ -101,7 +101,7 @@ if __name__ == '__main__':
     arms = [('gather_f32', g1), ('gather_split3', g3), ('gather_split3 skip', g3s), ('conv3 v1', f1), ('conv3f', f2(0)), ('conv3f no-tail', f2(0, False)),
             ('wgrad v1 (+offsets, reduce)', w1), ('wgrad v2 (+offsets, reduce)', w2)]
     if '--ablate' in sys.argv:
-        arms += [('conv3f abl%d' % v, f2(v, False)) for v in range(10, 16)]
+        arms += [('conv3f abl%d' % v, f2(v, False)) for v in range(10, 17)]     # 16: MFMA shape probe (16x16x32)
     res = {n: [] for n, _ in arms}
     for f in [a[1] for a in arms]:
         for _ in range(3):
