@@ -331,11 +331,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)' % (args.gpus, args.gpus, world))
+    # LSTUR_BENCH_BACKEND=gloo: rehearsal of the N > 1 launch on a box with fewer GPUs than ranks (RCCL refuses two ranks on
+    # one device; gloo moves the bucket through the host): same code path, meaningless throughput
+    backend = os.environ.get('LSTUR_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1 or args.force_dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     rng = np.random.default_rng(1234 + rank)
@@ -470,7 +478,8 @@ def main():
                        'candidates': wl['K1'], 'word_dim': wl['D'], 'filters': wl['F'], 'user_dim': wl['U'],
                        'n_users': wl['N_u'], 'n_docs': wl['N_d'], 'vocab': wl['V'], 'dropout': args.dropout,
                        'news_encoder': wl.get('encoder', 'cnnatt'), 'heads': wl.get('heads', 0),
-                       'parallelism': 'dp%d' % world, 'optimizer': 'keras-adam (dense user-table sweep)',
+                       'parallelism': 'dp%d' % world, 'collective_backend': ('rccl' if backend == 'nccl' else backend) if world > 1 else None,
+                       'optimizer': 'keras-adam (dense user-table sweep)',
                        # the synthetic histories are 90 % full windows (62 % non-pad tokens): heavier than real click
                        # histories (the `e2e` legs run at ~49 % non-pad tokens)
                        'history_fill': 'synthetic: 90 %% of the samples have a full %d-slot history' % wl['W']},

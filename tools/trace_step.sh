@@ -1,9 +1,9 @@
 #!/bin/bash
-# kernel trace of a few bench steps; prints the timeline of the last step (start, duration, stream/queue, kernel)
+# kernel trace of a few bench steps (extra arguments go to bench.py, e.g. --force-dp); prints the timeline of the last step (start, duration, stream/queue, kernel)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/tr1
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tr1 -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-profile > $R/gpurun_out/trace_run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tr1 -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-profile "$@" > $R/gpurun_out/trace_run.log 2>&1
 python3 - <<'PY'
 import csv, glob, os
 R = os.environ['GRAFT_REPO_ROOT']
