@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liblstur_hip.so')
+# (LSTUR_LIB: another build of the same library, for same-box A/B runs of two kernel versions)
+LIB_PATH = os.environ.get('LSTUR_LIB') or os.path.join(_HERE, 'liblstur_hip.so')
 
 ARCH = {'igru': 0, 'gru': 1, 'hgru': 2, 'nigru': 3, 'ngru': 4, 'dgru': 5, 'pgru': 6, 'vo': 7, 'niavg': 8, 'niatt': 9, 'iigru': 10, 'iicgru': 11}
 SCORE = {'dot': 0, 'ddot': 1, 'dnn': 2}     # --score-model (paper.py:443-458)

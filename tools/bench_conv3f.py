@@ -50,6 +50,9 @@ if __name__ == '__main__':
     rounds = int(args[1]) if len(args) > 1 else 8
     frac = float(args[2]) if len(args) > 2 else 0.14
     D, T, F, k, V = 300, 30, 400, 3, 50000
+    for a in sys.argv[1:]:
+        if a.startswith('--F='):
+            F = int(a[4:])       # (column-tile experiments)
     rng = np.random.default_rng(0)
     ids = rng.integers(1, V, size=(N, T)).astype(np.int32)
     lens = np.clip(rng.integers(5, T + 6, size=N), 0, T)
