@@ -440,8 +440,12 @@ void launch_conv3_fwd2(const unsigned short* e3, const unsigned short* W3, const
 constexpr int G2_TM = 8, G2_TN = 7, G2_BK = 16, G2_THREADS = G2_TM * 64;
 constexpr int G2_BMR = G2_TM * 32, G2_BNC = G2_TN * 32;                       // 256 x 224
 constexpr int G2_SA = tr_stride(G2_BMR), G2_SB = tr_stride(G2_BNC);          // 288 / 224 elements
-constexpr int G2_A_IMG = G2_BK * G2_SA, G2_B_IMG = G2_BK * G2_SB;
-constexpr int G2_STAGE = 3 * G2_A_IMG + 3 * G2_B_IMG;
+// The three part images of A lie 48 bytes (mod 256) apart: the loader's 16-byte stores go out in w = chunk * 3 + part order, so
+// eight consecutive lanes then cover eight different 16-byte bank groups (with images a multiple of 256 bytes apart the three
+// parts of a chunk hit the same banks: a 3-way conflict on every A store)
+constexpr int G2_A_IMG = G2_BK * G2_SA + 24, G2_B_IMG = G2_BK * G2_SB;
+static_assert((G2_BK * G2_SA * 2) % 256 == 0, "part skew assumes image sizes of whole bank rows");
+constexpr int G2_STAGE = 3 * G2_A_IMG + 3 * G2_B_IMG + 64 * 4;          // + an 8-byte trash slot per lane
 constexpr size_t G2_LDS = 2 * G2_STAGE * sizeof(unsigned short);
 constexpr int G2_APC = G2_BK * (G2_BMR / 8) * 3 / G2_THREADS;                 // 3 sixteen-byte pieces per thread and step
 constexpr int G2_BPC = (G2_BK * (G2_BNC / 4) + G2_THREADS - 1) / G2_THREADS;  // 2 float4 per thread and step
@@ -462,6 +466,7 @@ size_t conv3_wgrad2_scratch_bytes(int n_titles, int T, int D, int ksize, int F) 
   return (size_t)g2_slabs(n_titles * T, ksize * conv3_dp(D), F) * ksize * conv3_dp(D) * F * sizeof(float);
 }
 
+template <int OPT = 0>   // OPT != 0: timing-only ablations (WRONG results; LSTUR_WGRAD_ABLATE, tools/bench_conv3f.py)
 __global__ __launch_bounds__(G2_THREADS, 2) void conv3_wgrad2_kernel(
     const unsigned short* __restrict__ E3, uint32_t e_bytes, const float* __restrict__ G, uint32_t g_bytes,
     float* __restrict__ slabs, const int32_t* __restrict__ vcount, int M, int F, int Kq, int mblocks, int nblocks, int nslabs,
@@ -489,49 +494,49 @@ __global__ __launch_bounds__(G2_THREADS, 2) void conv3_wgrad2_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // loader roles.  A: piece idx -> (token row, w) with w = chunk * 3 + part: the 96 pieces of a token row are 1536
-  // contiguous bytes of its window in E3; B: float4 (token row, 4 f)
-  int a_kr[G2_APC], a_lds[G2_APC], b_kr[G2_BPC], b_sg[G2_BPC];
-  uint32_t a_w16[G2_APC];
+  // loader roles: a thread serves ONE token row of the step (row = tid / 32), so a step costs it one index load per operand
+  // (offA / offB of its token) -- with pieces dealt out in idx order a thread's pieces lay in up to five different rows,
+  // five index loads per step: 4 % of the kernel's time (LSTUR_WGRAD_ABLATE=1).  A: pieces w = c + 32 p (p < 3) of the 96 of
+  // its row (w = chunk * 3 + part: 1536 contiguous bytes of the token's window in E3); B: float4 slots c + 32 p (p < 2) --
+  // 64 slots for the 56 of a 224-column tile; the other 8 load through the out-of-range offset and store to a trash slot
+  static_assert(G2_APC == 3 && G2_BPC == 2 && G2_THREADS == 32 * G2_BK, "row-per-32-threads loader grid");
+  const int l_row = tid >> 5, l_c = tid & 31;
+  int a_lds[G2_APC];
 #pragma unroll
   for (int p = 0; p < G2_APC; ++p) {
-    const int idx = tid + p * G2_THREADS;
-    a_kr[p] = idx / 96;
-    const int w = idx - a_kr[p] * 96, chunk = w / 3, part = w - chunk * 3;
-    a_w16[p] = (uint32_t)w * 16u + (uint32_t)kd0 * 6u;          // byte offset inside the window (kd0 / 8 chunks of 48 bytes)
-    a_lds[p] = part * G2_A_IMG + a_kr[p] * G2_SA + chunk * 8;
+    const int w = l_c + 32 * p, chunk = w / 3, part = w - chunk * 3;
+    a_lds[p] = part * G2_A_IMG + l_row * G2_SA + chunk * 8;
   }
+  const uint32_t a_w16 = (uint32_t)l_c * 16u + (uint32_t)kd0 * 6u;   // byte offset inside the window (kd0 / 8 chunks of 48 bytes)
+  int b_lds[G2_BPC];
 #pragma unroll
-  for (int p = 0; p < G2_BPC; ++p) {
-    int idx = tid + p * G2_THREADS;
-    if (idx >= G2_BK * (G2_BNC / 4)) idx = tid;   // past the tile: the thread repeats its first piece (same value, same place:
-    b_kr[p] = idx / (G2_BNC / 4);                 //  no exec-mask branch in the store phase)
-    b_sg[p] = idx - b_kr[p] * (G2_BNC / 4);
-  }
+  for (int p = 0; p < G2_BPC; ++p)
+    b_lds[p] = (l_c + 32 * p) * 4 < G2_BNC ? 3 * G2_A_IMG + l_row * G2_SB + (l_c + 32 * p) * 4 : G2_STAGE - 64 * 4 + (tid & 63) * 4;
   // Row offsets of a step's pieces come in two halves so that no wait sits between the prefetch loads: `fetch_rows`
   // only issues the index loads (clamped, branch-free), `make_offsets` turns them into byte offsets one step later.
   // A token past the slab's end contributes 0 through the out-of-range offset of G.
-  uint32_t a_off[G2_APC], b_off[G2_BPC];
-  int a_raw[G2_APC], b_raw[G2_BPC];
+  uint32_t a_off, b_off[G2_BPC];
+  int a_raw, b_raw;
   auto fetch_rows = [&](int t0) {
-#pragma unroll
-    for (int p = 0; p < G2_APC; ++p) a_raw[p] = offA[min(t0 + a_kr[p], count - 1)];
-#pragma unroll
-    for (int p = 0; p < G2_BPC; ++p) b_raw[p] = offB[min(t0 + b_kr[p], count - 1)];
+    if ((OPT & 1) && t0 > t_begin) return;          // ablation: the row offsets of the first step for every step
+    a_raw = offA[min(t0 + l_row, count - 1)];
+    b_raw = offB[min(t0 + l_row, count - 1)];
   };
   auto make_offsets = [&](int t0) {
-#pragma unroll
-    for (int p = 0; p < G2_APC; ++p) a_off[p] = (uint32_t)a_raw[p] * 16u + a_w16[p];     // offA: 16-byte pieces
+    a_off = (uint32_t)a_raw * 16u + a_w16;                                               // offA: 16-byte pieces
 #pragma unroll
     for (int p = 0; p < G2_BPC; ++p) {
-      const bool ok = t0 + b_kr[p] < t_end && f0 + b_sg[p] * 4 < F;
-      b_off[p] = ok ? ((uint32_t)b_raw[p] + (uint32_t)(f0 + b_sg[p] * 4)) * 4u : kBufOob;   // offB: floats
+      const int col = f0 + (l_c + 32 * p) * 4;
+      b_off[p] = (t0 + l_row < t_end && col < F && col < f0 + G2_BNC) ? ((uint32_t)b_raw + (uint32_t)col) * 4u : kBufOob;   // offB: floats
     }
   };
   float4 ra[G2_APC], rb[G2_BPC];
+  int loads_done = 0;
   auto load = [&]() {
+    if ((OPT & 4) && loads_done >= 2) return;       // ablation: no global loads inside the loop
+    ++loads_done;
 #pragma unroll
-    for (int p = 0; p < G2_APC; ++p) ra[p] = buf_load4(rsE, a_off[p], 0);
+    for (int p = 0; p < G2_APC; ++p) ra[p] = buf_load4(rsE, a_off, (uint32_t)(p * 512));
 #pragma unroll
     for (int p = 0; p < G2_BPC; ++p) rb[p] = buf_load4(rsG, b_off[p], 0);
   };
@@ -542,11 +547,18 @@ __global__ __launch_bounds__(G2_THREADS, 2) void conv3_wgrad2_kernel(
 #pragma unroll
     for (int p = 0; p < G2_BPC; ++p) {
       u16x4 h, m, l;
-      split3(rb[p], h, m, l);
-      unsigned short* d = st + 3 * G2_A_IMG + b_kr[p] * G2_SB + b_sg[p] * 4;
+      if (OPT & 2) {                                // ablation: no split arithmetic
+        h = __builtin_bit_cast(u16x4, make_float2(rb[p].x, rb[p].y));
+        m = __builtin_bit_cast(u16x4, make_float2(rb[p].z, rb[p].w));
+        l = __builtin_bit_cast(u16x4, make_float2(rb[p].y, rb[p].z));
+      } else {
+        split3(rb[p], h, m, l);
+      }
+      const bool in_tile = (l_c + 32 * p) * 4 < G2_BNC;
+      unsigned short* d = st + b_lds[p];
       *(u16x4*)d = h;
-      *(u16x4*)(d + G2_B_IMG) = m;
-      *(u16x4*)(d + 2 * G2_B_IMG) = l;
+      *(u16x4*)(d + (in_tile ? G2_B_IMG : 0)) = m;
+      *(u16x4*)(d + (in_tile ? 2 * G2_B_IMG : 0)) = l;
     }
   };
 
@@ -566,7 +578,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void conv3_wgrad2_kernel(
     constexpr int NA = decltype(na_tag)::value;
     for (int it = 0; it < nit; ++it) {
       if (it + 1 < nit) {
-        store((it & 1) ^ 1);                           // step it + 1 (its loads were issued a step ago)
+        if (!(OPT & 8) || it == 0) store((it & 1) ^ 1);   // step it + 1 (its loads were issued a step ago)
         make_offsets(t_begin + (it + 2) * G2_BK);      // from the rows fetched a step ago
         load();                                        // step it + 2
         fetch_rows(t_begin + (it + 3) * G2_BK);        // consumed in the next step
@@ -639,18 +651,18 @@ int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, 
     for (int j = 0; j < ksize; ++j) jobs[j].nslices = 0;
     return ksize;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv3_wgrad2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2_LDS);
-    attr_set = true;
-  }
+  static const int ablate = getenv("LSTUR_WGRAD_ABLATE") ? atoi(getenv("LSTUR_WGRAD_ABLATE")) : 0;
+  auto kern = ablate == 1 ? conv3_wgrad2_kernel<1> : ablate == 2 ? conv3_wgrad2_kernel<2> : ablate == 3 ? conv3_wgrad2_kernel<3> :
+              ablate == 4 ? conv3_wgrad2_kernel<4> : ablate == 7 ? conv3_wgrad2_kernel<7> : ablate == 15 ? conv3_wgrad2_kernel<15> :
+                            conv3_wgrad2_kernel<0>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2_LDS);
   // (the scratch is sized for the full-chip slab count; fewer CUs -> fewer slabs)
   const int mblocks = g2_mblocks(Kq), nblocks = g2_nblocks(F), ns = g2_slabs(M, Kq, F, cus > 0 ? std::min(cus, 256) : 256);
   const uint32_t e_bytes = (uint32_t)std::min(conv3_e3_elems(n_titles, T, D, ksize) * 2, (size_t)0xFFFFFFFFu);
   const uint32_t g_bytes = (uint32_t)std::min((size_t)M * F * 4, (size_t)0xFFFFFFFFu);
   const dim3 grid(cdiv(ns, 8) * 8 * mblocks * nblocks);
   last_launch();
-  launch_k(conv3_wgrad2_kernel, grid, dim3(G2_THREADS), G2_LDS, s, e3, e_bytes, dout, g_bytes, (float*)scratch,
+  launch_k(kern, grid, dim3(G2_THREADS), G2_LDS, s, e3, e_bytes, dout, g_bytes, (float*)scratch,
                      vcount, M, F, Kq, mblocks, nblocks, ns, offA, offB);
   for (int j = 0; j < ksize; ++j)
     jobs[j] = ReduceJob{(const float*)scratch + (size_t)j * Dp * F, dw + (size_t)j * D * F, D, F, F, ns, (size_t)Kq * F, alpha, 0.f};
