@@ -133,6 +133,7 @@ __global__ __launch_bounds__(128) void att_pool_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 constexpr int kTitleTok = 8;   // token rows per wave (4 waves)
 static bool title_path(int T, int F) { return T <= 4 * kTitleTok && F <= 512 && F % 4 == 0 && !getenv("LSTUR_ATT_STREAMING"); }
+bool attpool_title_path(int T, int F) { return title_path(T, F); }
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
@@ -352,11 +353,12 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
                                                             const float* __restrict__ dpooled, float* __restrict__ dc,
                                                             float* __restrict__ parts, int T, int F, uint32_t thresh,
                                                             uint32_t key, float scale, int ldp, int off_aw, int off_cb,
-                                                            int off_ab, int relu, const uint32_t* __restrict__ kbits) {
+                                                            int off_ab, int relu, const uint32_t* __restrict__ kbits,
+                                                            int title0) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // dw[32] | (unused)[32] | red[4][2][F]
   float* dwL = sm;
   float* red = sm + 64;
-  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), F4 = F / 4;
+  const int n = title0 + blockIdx.x, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), F4 = F / 4;
   const uint32_t lm = title_mask(live, ids, n, T, lane);
   float4 x[kTitleTok][2];
   bool nz[kTitleTok];
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
                         float drop, uint32_t key, hipStream_t s, int ldp, int off_aw, int off_cb, int off_ab, int relu,
-                        const uint32_t* live, const uint32_t* kbits) {
+                        const uint32_t* live, const uint32_t* kbits, int title0, int title_count) {
   if (ldp <= 0) {   // default layout of the public entry point: datt_w[F] | dconv_b[F] | datt_b
     ldp = 2 * F + 1;
     off_aw = 0;
@@ -632,10 +634,12 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
   float scale = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
   const int rows = n_titles * T;
   const int nparts = attpool_bwd_parts(n_titles);
-  if (title_path(T, F)) {
-    hipLaunchKernelGGL(att_bwd_title_kernel, dim3(n_titles), dim3(256), (64 + 8 * F) * sizeof(float), s, c, ids, live, att_w, a,
-                       w, dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu,
-                       thresh ? kbits : nullptr);
+  if (title_path(T, F)) {   // (title0, title_count: a sub-range of the titles -- this path only; all arrays stay title-indexed)
+    const int cnt = title_count >= 0 ? title_count : n_titles - title0;
+    if (cnt > 0)
+      hipLaunchKernelGGL(att_bwd_title_kernel, dim3(cnt), dim3(256), (64 + 8 * F) * sizeof(float), s, c, ids, live, att_w, a,
+                         w, dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu,
+                         thresh ? kbits : nullptr, title0);
     return;
   }
   if (F % 4 == 0) {

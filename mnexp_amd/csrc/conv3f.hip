@@ -462,26 +462,30 @@ static int g2_slabs(int M, int Kq, int F, int cus = 256) {
   const int want = cus >= 256 ? rounds * 256 / per / 8 * 8 : std::max(1, rounds * cus / per);
   return std::max(1, std::min(std::max(8, want), std::max(1, M / 512)));
 }
+// (twice the slab count of one launch: a step may give the candidate titles' tokens a launch of their own)
 size_t conv3_wgrad2_scratch_bytes(int n_titles, int T, int D, int ksize, int F) {
-  return (size_t)g2_slabs(n_titles * T, ksize * conv3_dp(D), F) * ksize * conv3_dp(D) * F * sizeof(float);
+  return (size_t)2 * g2_slabs(n_titles * T, ksize * conv3_dp(D), F) * ksize * conv3_dp(D) * F * sizeof(float);
 }
 
 template <int OPT = 0>   // OPT != 0: timing-only ablations (WRONG results; LSTUR_WGRAD_ABLATE, tools/bench_conv3f.py)
 __global__ __launch_bounds__(G2_THREADS, 2) void conv3_wgrad2_kernel(
     const unsigned short* __restrict__ E3, uint32_t e_bytes, const float* __restrict__ G, uint32_t g_bytes,
     float* __restrict__ slabs, const int32_t* __restrict__ vcount, int M, int F, int Kq, int mblocks, int nblocks, int nslabs,
-    const int32_t* __restrict__ offA, const int32_t* __restrict__ offB) {
+    const int32_t* __restrict__ offA, const int32_t* __restrict__ offB, int range_sel, int slab_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int count = vcount ? vcount[0] : M;
+  // tokens [lo, count) of the compacted list: all of it, or one side of the title boundary the compaction counted
+  // (vcount[1]: history | candidates) -- the candidates' share runs early, under the recurrence's backward
+  const int count = vcount ? (range_sel == 1 ? vcount[1] : vcount[0]) : M;
+  const int lo = (vcount && range_sel == 2) ? vcount[1] : 0;
   // block -> (slab, m-block, n-block); XCD-aware: workgroup ids go round-robin over the 8 XCDs, so the blocks of one slab
   // get ids 8 apart: they run on ONE XCD at about the same time and share the slab's tokens through its L2
   const int per = mblocks * nblocks;
   const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
   const int slab = (seq / per) * 8 + xcd, rem = seq - (seq / per) * per, mb = rem / nblocks, nb = rem - mb * nblocks;
   if (slab >= nslabs) return;
-  const int per_slab = (count + nslabs - 1) / nslabs, tpad = (per_slab + G2_BK - 1) / G2_BK * G2_BK;
-  const int t_begin = slab * tpad, t_end = min(count, t_begin + tpad);
+  const int per_slab = (count - lo + nslabs - 1) / nslabs, tpad = (per_slab + G2_BK - 1) / G2_BK * G2_BK;
+  const int t_begin = lo + slab * tpad, t_end = min(count, t_begin + tpad);
   const int kd0 = mb * G2_BMR, f0 = nb * G2_BNC;
   const __amdgpu_buffer_rsrc_t rsE = make_rsrc(E3, e_bytes), rsG = make_rsrc(G, g_bytes);
   // live work of this wave: its row tile must start inside k' < Kq; column tiles inside F
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void conv3_wgrad2_kernel(
 
   // slab [Kq, F] of this token range (zeros when the range is empty: the reduction reads every slab)
   const int hh = lane >> 5, c32 = lane & 31;
-  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(slabs + (size_t)slab * Kq * F, (uint32_t)((size_t)Kq * F * 4));
+  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(slabs + (size_t)(slab_base + slab) * Kq * F, (uint32_t)((size_t)Kq * F * 4));
 #pragma unroll
   for (int j = 0; j < G2_TN; ++j) {
     const int f = f0 + j * 32 + c32;
@@ -643,13 +647,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) void conv3_wgrad2_kernel(
 // dw [ksize * D, F] through jobs[0 .. ksize) (one per tap; slabs in `scratch`, conv3_wgrad2_scratch_bytes); dout rows of pad
 // tokens are not read.  offA: per-token window offset in 16-byte pieces of E3 ((title * Tp + t) * Dp / 8 * 3), offB: per-token
 // row offset in floats of dout (token * F) -- launch_compact_write_offsets with rowA = Dp / 8 * 3.  Returns the job count.
+// A step may cut the token list at a title boundary (range_sel 2: the tokens behind vcount[1], 1: those in front) and give
+// each part its own launch: the parts' slabs lie one after the other (slab_base = slabs of the launches before, plan_titles
+// = the titles of this part for the slab count) and the LAST launch writes the jobs over all of them (jobs == NULL: none).
 int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
                         int ksize, int F, const int32_t* vcount, hipStream_t s, ReduceJob* jobs, const int32_t* offA,
-                        const int32_t* offB, float alpha, int cus) {
+                        const int32_t* offB, float alpha, int cus, int range_sel, int slab_base, int plan_titles, int* slabs_out) {
   const int M = n_titles * T, Dp = conv3_dp(D), Kq = ksize * Dp;
+  if (slabs_out) *slabs_out = 0;
   if (M == 0) {
-    for (int j = 0; j < ksize; ++j) jobs[j].nslices = 0;
-    return ksize;
+    for (int j = 0; jobs && j < ksize; ++j) jobs[j].nslices = 0;
+    return jobs ? ksize : 0;
   }
   static const int ablate = getenv("LSTUR_WGRAD_ABLATE") ? atoi(getenv("LSTUR_WGRAD_ABLATE")) : 0;
   auto kern = ablate == 1 ? conv3_wgrad2_kernel<1> : ablate == 2 ? conv3_wgrad2_kernel<2> : ablate == 3 ? conv3_wgrad2_kernel<3> :
@@ -657,15 +665,18 @@ int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, 
                             conv3_wgrad2_kernel<0>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2_LDS);
   // (the scratch is sized for the full-chip slab count; fewer CUs -> fewer slabs)
-  const int mblocks = g2_mblocks(Kq), nblocks = g2_nblocks(F), ns = g2_slabs(M, Kq, F, cus > 0 ? std::min(cus, 256) : 256);
+  const int Mp = (plan_titles > 0 ? plan_titles : n_titles) * T;
+  const int mblocks = g2_mblocks(Kq), nblocks = g2_nblocks(F), ns = g2_slabs(Mp, Kq, F, cus > 0 ? std::min(cus, 256) : 256);
   const uint32_t e_bytes = (uint32_t)std::min(conv3_e3_elems(n_titles, T, D, ksize) * 2, (size_t)0xFFFFFFFFu);
   const uint32_t g_bytes = (uint32_t)std::min((size_t)M * F * 4, (size_t)0xFFFFFFFFu);
   const dim3 grid(cdiv(ns, 8) * 8 * mblocks * nblocks);
   last_launch();
   launch_k(kern, grid, dim3(G2_THREADS), G2_LDS, s, e3, e_bytes, dout, g_bytes, (float*)scratch,
-                     vcount, M, F, Kq, mblocks, nblocks, ns, offA, offB);
+                     vcount, M, F, Kq, mblocks, nblocks, ns, offA, offB, vcount ? range_sel : 0, slab_base);
+  if (slabs_out) *slabs_out = ns;
+  if (!jobs) return 0;
   for (int j = 0; j < ksize; ++j)
-    jobs[j] = ReduceJob{(const float*)scratch + (size_t)j * Dp * F, dw + (size_t)j * D * F, D, F, F, ns, (size_t)Kq * F, alpha, 0.f};
+    jobs[j] = ReduceJob{(const float*)scratch + (size_t)j * Dp * F, dw + (size_t)j * D * F, D, F, F, slab_base + ns, (size_t)Kq * F, alpha, 0.f};
   return ksize;
 }
 

@@ -480,6 +480,9 @@ struct lstur_ctx {
   // reduction, so they run beside the chain d(doc vectors) -> attention backward -> conv kernel gradient
   hipStream_t side_w = nullptr, side_w2 = nullptr;   // (second one: the Dense(U) parameter gradients, beside the GRU's)
   hipEvent_t ev_w1 = nullptr, ev_w2 = nullptr, ev_w3 = nullptr, ev_w4 = nullptr;
+  hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;   // candidate titles' encoder backward: fork behind the scorer, done
+  bool cand_forked = false;                       // ev_c0 rides on this step's scorer launch
+  bool lanes_active = false;                      // inside train_two_lanes (the lanes keep to one launch per kernel family)
   // staging prefetch (lstur_prefetch_ids): the next batch's title expansion, compaction and embedding gather run on a
   // side stream under the current step's forward recurrence (HBM and 240 CUs idle there)
   struct Pending { const int32_t* hist = nullptr; const int32_t* cands = nullptr; const int32_t* users = nullptr; int n = 0;
@@ -698,7 +701,7 @@ bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
   const int nW = q.n * d.W, nt = nW + q.n * d.K1, pl = (d.k - 1) / 2;
   launch_expand_count(c->title_table, q.hist, nW, q.cands, q.n * d.K1, d.T, t.ids, t.vscratch, p);
   launch_compact_write_offsets(t.ids, nt * d.T, t.vscratch, t.vidx, t.vcount, d.T, d.Tp, conv3_dp(d.D) / 8 * 3, d.F, t.offA,
-                               t.offB, p, t.live);
+                               t.offB, p, t.live, nW * d.T);
   {
     ProfScope _ps(c, "gather", p, true);
     static const int pf_blocks = getenv("LSTUR_PREFETCH_BLOCKS") ? atoi(getenv("LSTUR_PREFETCH_BLOCKS")) : 0;
@@ -992,7 +995,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   c->counted_flag() = false;
   // (offA: a token's window offset in the units of its path -- 16-byte pieces of E3, or floats of the fp32 layout)
   launch_compact_write_offsets(w.ids, nt * d.T, w.vscratch, w.vidx, w.vcount, d.T, d.Tp,
-                               (use3 && !gen1) ? conv3_dp(d.D) / 8 * 3 : d.D, d.F, w.offA, w.offB, s, w.live);
+                               (use3 && !gen1) ? conv3_dp(d.D) / 8 * 3 : d.D, d.F, w.offA, w.offB, s, w.live, nW * d.T);
   if (use3 && !gen1)   // Embedding + Dropout straight into the pre-split layout of the bf16x3 conv kernels (rows nobody reads skipped)
   {
     ProfScope _ps(c, "gather", s, true);
@@ -1128,6 +1131,30 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
       (void)hipStreamWaitEvent(s, c->ev_w4, 0);
     }
   };
+  // the candidate titles' encoder backward, under the recurrence's backward (cand_split_wanted)
+  const bool split = c->cand_forked && sw != s && !c->cfg.freeze_encoder;
+  c->cand_forked = false;
+  const int ncand = nt - nW;
+  int cand_slabs = 0;
+  if (split) {
+    const int off_cb = 0, off_aw = (int)(c->G("att_w") - c->G("conv_b")), off_ab = (int)(c->G("att_b") - c->G("conv_b"));
+    const int ldp = off_ab + 1;
+    (void)hipStreamWaitEvent(sw, c->ev_c0, 0);
+    forked = true;
+    dense_gemm(w.ddocvec + (size_t)nW * d.U, d.U, c->P("dense_w"), d.U, true, w.dpooled + (size_t)nW * d.F, d.F, nullptr, ncand,
+               d.F, d.U, nullptr, sw);
+    {
+      ProfScope _ps(c, "attpool_bwd", sw);
+      launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, w.att_ds, nt, d.T, d.F,
+                         drop, key1, sw, ldp, off_aw, off_cb, off_ab, 1, w.live, w.kbits_valid ? w.kbits : nullptr, nW, ncand);
+    }
+    {
+      ProfScope _ps(c, "conv_wgrad", sw, true);
+      (void)launch_conv3_wgrad2(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, sw, nullptr,
+                                w.offA, w.offB, 1.0f, 0, 2, 0, ncand, &cand_slabs);
+    }
+    (void)hipEventRecord(c->ev_c1, sw);
+  }
   // ONE event behind the recurrence serves both side streams (forks are merged wherever the dependencies allow), attached
   // to the recurrence kernel's own completion when nothing else sits between it and the fork
   const bool fork_t = finish_table_rows_wanted(c);
@@ -1214,7 +1241,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   }
   wgrad_gemm(w.pooled, d.F, w.ddocvec, d.U, c->G("dense_w"), d.U, d.F, d.U, nt, w.gemm_scratch_k[3], sw2, &jobs[nj++]);
   launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], sw2, &jobs[nj++]);
-  dense_gemm(w.ddocvec, d.U, c->P("dense_w"), d.U, true, w.dpooled, d.F, nullptr, nt, d.F, d.U, w.gemm_scratch, s);
+  dense_gemm(w.ddocvec, d.U, c->P("dense_w"), d.U, true, w.dpooled, d.F, nullptr, split ? nW : nt, d.F, d.U, w.gemm_scratch, s);
   // partial sums laid out like the bucket slice conv_b .. att_b -> one reduction straight into dense_grad
   if (d.enc == LSTUR_ENC_MHSA) {
     // partial sums: datt_w | datt_b like the bucket slice att_w .. att_b, the (unused) column sums of dconv behind them
@@ -1244,7 +1271,8 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   const int ldp = off_ab + 1;
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
                                          w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 1, w.live,
-                                         w.kbits_valid ? w.kbits : nullptr));
+                                         w.kbits_valid ? w.kbits : nullptr, 0, split ? nW : nt));
+  if (split) (void)hipStreamWaitEvent(s, c->ev_c1, 0);   // the candidate titles' partial sums, gradient rows and slabs
   // (on the side stream this one found no free CU beside the conv kernel gradient and finished behind it)
   launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch_k[2], s, &jobs[nj++]);
   if (d.word_trainable) {   // conv input gradient -> word-table gradient (embedding dropout mask = stream 0 of the step)
@@ -1260,7 +1288,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   else if (w.conv_w3 && !conv_f32) {   // fp32-grade bf16x3 contraction (conv3f.hip), like the forward; one reduce job per tap
     ProfScope _ps(c, "conv_wgrad", s, true);
     nj += launch_conv3_wgrad2(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, s, &jobs[nj],
-                              w.offA, w.offB, 1.0f, c->conv_cus);
+                              w.offA, w.offB, 1.0f, c->conv_cus, split ? 1 : 0, cand_slabs, split ? nW : 0);
   } else
     PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
                                          w.vidx, w.vcount, s, w.offA, w.offB,
@@ -1290,6 +1318,29 @@ int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n,
   return LSTUR_OK;
 }
 
+// The candidate titles' share of the news-encoder backward (d(pooled) -> attention backward -> conv kernel gradient, 9 % of
+// the titles at 5 candidates against 50 history slots) needs nothing from the recurrence: d(candidate doc vectors) comes
+// out of the scorer.  It runs on the parameter-gradient stream UNDER the recurrence's backward (240 idle CUs) instead of
+// behind it; the history titles follow on the caller's stream as before.  Same kernels on title / token sub-ranges (the
+// compaction counts the tokens in front of the first candidate title), the kernel gradient's slabs of both launches are
+// reduced together in fixed order.  LSTUR_CAND_SPLIT=0: one launch each over all titles.
+bool cand_split_wanted(lstur_ctx* c, int n) {
+  static const bool off = getenv("LSTUR_CAND_SPLIT") && !strcmp(getenv("LSTUR_CAND_SPLIT"), "0");
+  static const bool other_conv = getenv("LSTUR_CONV_F32") != nullptr || getenv("LSTUR_CONV_GEN1") != nullptr;
+  const Dims& d = c->d;
+  const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
+  if (off || other_conv || !has_gru || c->lanes_active || c->cur != &c->ws || c->cur_lane != 0 || c->conv_cus != 0) return false;
+  if (d.enc != LSTUR_ENC_CNNATT || !c->ws.conv_w3 || d.word_trainable || c->cfg.freeze_encoder) return false;
+  if (d.head != LSTUR_HEAD_SOFTMAX || d.score != LSTUR_SCORE_DOT || !attpool_title_path(d.T, d.F)) return false;
+  if (!gemm3_supported(d.U, d.U, n * d.K1, d.F, d.U) || !wgrad_stream(c)) return false;
+  if (!c->ev_c0 && (hipEventCreateWithFlags(&c->ev_c0, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) != hipSuccess)) {
+    c->ev_c0 = c->ev_c1 = nullptr;
+    return false;
+  }
+  return true;
+}
+
 // Listwise score model on (uservec [n, Uu], candidate doc vectors [n*k1, U]) (paper.py:443-464).
 //   scores != NULL: test model, sigmoid(score) for k1 == 1 (paper.py:661-665)
 //   else: logits / probs / loss (+ `backward`: du, d(candidate doc vectors) and the score model's parameter gradients)
@@ -1301,9 +1352,17 @@ void run_listwise_score(lstur_ctx* c, int n, int k1, float inv_n, bool backward,
   float* ddvec = w.ddocvec + (size_t)nW * d.U;
   if (d.score == LSTUR_SCORE_DOT) {
     if (scores) launch_predict_score(w.uservec, dvec, scores, n, d.U, s);
-    else
+    else {
+      const bool fork_c = backward && k1 == d.K1 && cand_split_wanted(c, n);   // the candidates' encoder backward forks here
+      if (fork_c) arm_stop_event(c->ev_c0);
       launch_score(w.uservec, dvec, w.logits, w.probs, w.loss_i, w.correct_i, backward ? w.du : nullptr,
                    backward ? ddvec : nullptr, n, k1, d.U, inv_n, s);
+      if (fork_c && stop_event_pending()) {   // (the general scorer took the launch: record the classic way)
+        arm_stop_event(nullptr);
+        (void)hipEventRecord(c->ev_c0, s);
+      }
+      c->cand_forked = fork_c;
+    }
     return;
   }
   if (d.score == LSTUR_SCORE_DDOT) {   // tanh-Dense on both sides, then dot (paper.py:452-455)
@@ -1370,6 +1429,11 @@ int train_two_lanes(lstur_ctx* c, const int32_t* user, const int32_t* hist, cons
   const Dims& d = c->d;
   const int nA = lane0_share(n), nB = n - nA;
   if (nB < 1 || nB > c->d1.B) return fail(LSTUR_ERR_STATE, "two-lane step: lane 1 capacity");
+  struct Active {
+    lstur_ctx* c;
+    explicit Active(lstur_ctx* x) : c(x) { c->lanes_active = true; }
+    ~Active() { c->lanes_active = false; }
+  } active(c);
   Workspace &w0 = c->ws, &w1 = c->ws1;
   if (!c->side) {
     if (!(c->side = pooled_stream(3, false)) ||
@@ -1679,6 +1743,8 @@ int lstur_destroy(lstur_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_w3);
     if (ctx->side_w2) (void)hipStreamSynchronize(ctx->side_w2);
     if (ctx->ev_w4) (void)hipEventDestroy(ctx->ev_w4);
+    if (ctx->ev_c0) (void)hipEventDestroy(ctx->ev_c0);
+    if (ctx->ev_c1) (void)hipEventDestroy(ctx->ev_c1);
   }
   if (ctx)
     for (auto& k : ctx->prof)

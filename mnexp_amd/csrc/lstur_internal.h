@@ -89,7 +89,7 @@ void launch_expand_count(const int32_t* table, const int32_t* hist_ids, int n_hi
 void launch_compact_count(const int32_t* ids, int n, int32_t* block_counts, hipStream_t s);
 void launch_compact_write_offsets(const int32_t* ids, int n, const int32_t* block_counts, int32_t* vidx, int32_t* count,
                                   int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s,
-                                  uint32_t* live = nullptr);   // live != NULL: + the titles' non-pad bit masks
+                                  uint32_t* live = nullptr, int split_at = -1);   // count[1] = non-pad tokens in front of token split_at   // live != NULL: + the titles' non-pad bit masks
 size_t pack_b_floats(int K, int N);
 void launch_pack_b(const float* B, int ldb, int K, int N, float* packed, hipStream_t s);
 void launch_pack_b_t(const float* Bt, int ldb, int K, int N, float* packed, hipStream_t s);
@@ -232,7 +232,8 @@ void launch_conv3_fwd2(const unsigned short* e3, const unsigned short* W3, const
 size_t conv3_wgrad2_scratch_bytes(int n_titles, int T, int D, int ksize, int F);
 int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
                         int ksize, int F, const int32_t* vcount, hipStream_t s, ReduceJob* jobs, const int32_t* offA,
-                        const int32_t* offB, float alpha = 1.0f, int cus = 0);
+                        const int32_t* offB, float alpha = 1.0f, int cus = 0, int range_sel = 0, int slab_base = 0,
+                        int plan_titles = 0, int* slabs_out = nullptr);
 
 // ---- gemm3.hip: C = A[M,K] . op(B) + bias, fp32-grade on the bf16 matrix cores (bf16x3), for the dense layers on the
 // step's critical path.  b_nk: B is [N][K] (C = A . B^T), else [K][N].  Check gemm3_supported first.
@@ -263,7 +264,9 @@ int attpool_bwd_parts(int n_titles);
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
                         float drop, uint32_t key, hipStream_t s, int ldp = 0, int off_aw = 0, int off_cb = 0,
-                        int off_ab = 0, int relu = 1, const uint32_t* live = nullptr, const uint32_t* kbits = nullptr);
+                        int off_ab = 0, int relu = 1, const uint32_t* live = nullptr, const uint32_t* kbits = nullptr,
+                        int title0 = 0, int title_count = -1);
+bool attpool_title_path(int T, int F);   // the title-resident kernels (the only ones that take a title sub-range)
 
 // ---- mhsa.hip (build-defined multi-head self-attention token stage; T <= 32, F/heads in {16, 32, 64}) -------
 bool mhsa_supported(int T, int F, int heads);

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void compact_write_offsets_kernel(const int32_
                                                                     int32_t* __restrict__ count_out, int T, int Tp, int D,
                                                                     int F, int32_t* __restrict__ offA,
                                                                     int32_t* __restrict__ offB, int nblk,
-                                                                    uint32_t* __restrict__ live) {
+                                                                    uint32_t* __restrict__ live, int split_at) {
   if ((int)blockIdx.x >= nblk) {   // trailing blocks: bit t of live[title] = token t is not a pad (t < 32): the attention
     const int title = ((int)blockIdx.x - nblk) * 256 + threadIdx.x;   // kernels read ONE scalar per title instead of ids
     if (title * T < n) {
@@ -346,6 +346,14 @@ __global__ __launch_bounds__(256) void compact_write_offsets_kernel(const int32_
   }
   int total;
   int pos = base + block_exclusive_scan_256(c, &total);
+  // count_out[1]: the non-pad tokens in front of token `split_at` (a title boundary: history | candidates) -- the compacted
+  // list is ascending, so [0, count_out[1]) and [count_out[1], count_out[0]) are the two title ranges' tokens
+  if (i0 <= split_at && split_at < i0 + 4) {
+    int before = pos;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) before += (i0 + k < split_at && v[k]) ? 1 : 0;
+    count_out[1] = before;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if (v[k]) {
@@ -358,16 +366,19 @@ __global__ __launch_bounds__(256) void compact_write_offsets_kernel(const int32_
       }
       ++pos;
     }
-  if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) count_out[0] = base + total;
+  if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) {
+    count_out[0] = base + total;
+    if (split_at >= nblk * kCompactBlock || split_at < 0) count_out[1] = base + total;   // (no thread owns that index)
+  }
 }
 size_t compact_scratch_ints(int n) { return (size_t)cdiv(n, kCompactBlock); }
 void launch_compact_write_offsets(const int32_t* ids, int n, const int32_t* block_counts, int32_t* vidx, int32_t* count,
                                   int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s,
-                                  uint32_t* live) {
+                                  uint32_t* live, int split_at) {
   if (n <= 0) return;
   const int nblk = cdiv(n, kCompactBlock), lblk = live ? cdiv(n / T, 256) : 0;
   hipLaunchKernelGGL(compact_write_offsets_kernel, dim3(nblk + lblk), dim3(256), 0, s, ids, n, block_counts, vidx, count, T,
-                     Tp, D, F, offA, offB, nblk, live);
+                     Tp, D, F, offA, offB, nblk, live, split_at < 0 ? n : split_at);
 }
 void launch_compact_count(const int32_t* ids, int n, int32_t* block_counts, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(compact_count_kernel, dim3(cdiv(n, kCompactBlock)), dim3(256), 0, s, ids, n, block_counts);
@@ -1368,9 +1379,9 @@ __global__ __launch_bounds__(256) void score_fast_kernel(const float* __restrict
 void launch_score(const float* u, const float* d, float* logits, float* probs, float* loss_i, float* correct_i,
                   float* du, float* dd, int n, int K1, int U, float inv_n, hipStream_t s) {
   if (!n) return;
-  if (K1 <= 8 && U <= 256)
-    hipLaunchKernelGGL((score_fast_kernel<8, 4>), dim3(cdiv(n, 4)), dim3(256), 0, s, u, d, logits, probs, loss_i, correct_i, du,
-                       dd, n, K1, U, inv_n);
+  if (K1 <= 8 && U <= 256)   // (launch_k: a fork event armed by the step rides on this launch's completion)
+    launch_k((score_fast_kernel<8, 4>), dim3(cdiv(n, 4)), dim3(256), 0, s, u, d, logits, probs, loss_i, correct_i, du, dd, n, K1, U,
+             inv_n);
   else
     hipLaunchKernelGGL(score_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, u, d, logits, probs, loss_i, correct_i, du, dd, n, K1, U, inv_n);
 }
