@@ -235,6 +235,14 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
  * flushes and re-bases). */
 int lstur_flush_tables(lstur_ctx* ctx, lstur_stream stream);
 int lstur_lazy_adam(lstur_ctx* ctx);
+/* 1 when the step keeps the history titles in SLOT-major order inside the workspace (title = slot * n + sample instead of
+ * the reference's sample * W + slot; the candidate titles follow in both): the per-title arrays lstur_peek hands out
+ * ("doc_vec", "pooled", "dgates", ...) are in that order.  Inputs, outputs and dropout masks are unaffected (the library
+ * reads the caller's arrays in the reference's order and draws dropout at the reference position of every element).
+ * The layout lets a range of history slots be a contiguous range of titles, tokens and GRU rows -- what the backward
+ * pass needs to start the news encoder's backward of the LATE slots while the recurrence's backward still walks the
+ * early ones.  LSTUR_SLOT_MAJOR=0 keeps the reference's order. */
+int lstur_slot_major(lstur_ctx* ctx);
 
 /* The caller wrote parameters (dense_param, word_emb) from outside -- set_weights, a checkpoint load: the weight images
  * the library keeps for its MFMA kernels (packed behind every Adam step, for the NEXT forward) and a batch staged by

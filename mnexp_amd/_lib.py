@@ -66,6 +66,7 @@ SIGNATURES = {
     'lstur_params_changed': (_I, [_P]),
     'lstur_flush_tables': (_I, [_P, _P]),
     'lstur_lazy_adam': (_I, [_P]),
+    'lstur_slot_major': (_I, [_P]),
     'lstur_train_step': (_I, [_P, _P, _P, _P, _P, _I, _U, _F, _I, _P, _P]),
     'lstur_train_step_ids': (_I, [_P, _P, _P, _P, _P, _I, _U, _F, _I, _P, _P]),
     'lstur_dp_tail_floats': (_Z, [C.POINTER(Cfg), _I]),

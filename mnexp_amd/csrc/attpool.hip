@@ -164,7 +164,8 @@ __device__ __forceinline__ float keep_scaled(float v, uint32_t bits, int pos, fl
 template <bool NZ = true>
 __device__ __forceinline__ void title_load(const float* __restrict__ c, uint32_t lm, int n, int T, int F, int wv, int lane,
                                            uint32_t thresh, uint32_t key, float scale, float4 (&x)[kTitleTok][2],
-                                           bool (&nz)[kTitleTok], const uint32_t* __restrict__ kbits = nullptr) {
+                                           bool (&nz)[kTitleTok], const uint32_t* __restrict__ kbits = nullptr,
+                                           int hn = -1) {   // hn: the title's index in the reference's order (hash position)
   const int F4 = F / 4;
   uint32_t kb[2] = {0u, 0u};
   if (kbits) {
@@ -187,7 +188,7 @@ __device__ __forceinline__ void title_load(const float* __restrict__ c, uint32_t
 #pragma unroll
   for (int i = 0; i < kTitleTok; ++i) {
     const int t = wv + 4 * i;
-    const uint32_t row = (uint32_t)n * (uint32_t)T + (uint32_t)t;
+    const uint32_t row = (uint32_t)(hn >= 0 ? hn : n) * (uint32_t)T + (uint32_t)t;
     bool any = false;
     if (kbits) {            // (dead rows were loaded as zeros and stay zero: no branch)
 #pragma unroll
@@ -236,15 +237,16 @@ __device__ __forceinline__ float rows8_sum(const float (&p)[kTitleTok], int lane
 
 // keep bits of the conv-output dropout in the title kernels' thread layout (see title_load); dead rows and columns past F: 0
 __global__ __launch_bounds__(256) void att_keep_bits_kernel(const uint32_t* __restrict__ live, uint32_t* __restrict__ kbits,
-                                                            int T, int F, uint32_t thresh, uint32_t key) {
+                                                            int T, int F, uint32_t thresh, uint32_t key, TitleOrder ord) {
   const int n = blockIdx.x, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), F4 = F / 4;
+  const int hn = ref_title(ord, n);
   const uint32_t lm = title_mask(live, nullptr, n, T, lane);
   uint32_t kb[2] = {0u, 0u};
 #pragma unroll
   for (int i = 0; i < kTitleTok; ++i) {
     const int t = wv + 4 * i;
     if (!((lm >> t) & 1u)) continue;
-    const uint32_t row = (uint32_t)n * (uint32_t)T + (uint32_t)t;
+    const uint32_t row = (uint32_t)hn * (uint32_t)T + (uint32_t)t;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (lane + 64 * h >= F4) continue;
@@ -258,9 +260,9 @@ __global__ __launch_bounds__(256) void att_keep_bits_kernel(const uint32_t* __re
 }
 size_t attpool_keep_bits_words(int n_titles) { return (size_t)n_titles * 512; }
 bool launch_attpool_keep_bits(const uint32_t* live, uint32_t* kbits, int n_titles, int T, int F, float drop, uint32_t key,
-                              hipStream_t s) {
+                              hipStream_t s, TitleOrder ord) {
   if (!n_titles || !live || !kbits || !(drop > 0.f) || !title_path(T, F)) return false;
-  hipLaunchKernelGGL(att_keep_bits_kernel, dim3(n_titles), dim3(256), 0, s, live, kbits, T, F, dropout_thresh(drop), key);
+  hipLaunchKernelGGL(att_keep_bits_kernel, dim3(n_titles), dim3(256), 0, s, live, kbits, T, F, dropout_thresh(drop), key, ord);
   return true;
 }
 
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void att_fwd_title_kernel(const float* __restr
                                                             const float* __restrict__ att_b, float* __restrict__ a_out,
                                                             float* __restrict__ w_out, float* __restrict__ pooled, int T,
                                                             int F, uint32_t thresh, uint32_t key, float scale,
-                                                            const uint32_t* __restrict__ kbits) {
+                                                            const uint32_t* __restrict__ kbits, TitleOrder ord) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // e[32] | part[4][F]
   float* eL = sm;
   float* part = sm + 32;
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void att_fwd_title_kernel(const float* __restr
   const uint32_t lm = title_mask(live, ids, n, T, lane);
   float4 x[kTitleTok][2];
   bool nz[kTitleTok];
-  title_load(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz, kbits);
+  title_load(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz, kbits, ref_title(ord, n));
   float4 kf[2];
   const __amdgpu_buffer_rsrc_t rs_aw = make_rsrc(att_w, (uint32_t)F * 4u);
 #pragma unroll
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
                                                             float* __restrict__ parts, int T, int F, uint32_t thresh,
                                                             uint32_t key, float scale, int ldp, int off_aw, int off_cb,
                                                             int off_ab, int relu, const uint32_t* __restrict__ kbits,
-                                                            int title0) {
+                                                            int title0, TitleOrder ord) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // dw[32] | (unused)[32] | red[4][2][F]
   float* dwL = sm;
   float* red = sm + 64;
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
   const uint32_t lm = title_mask(live, ids, n, T, lane);
   float4 x[kTitleTok][2];
   bool nz[kTitleTok];
-  title_load<false>(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz, kbits);
+  title_load<false>(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz, kbits, ref_title(ord, n));
   float4 dp[2], kf[2];
   const __amdgpu_buffer_rsrc_t rs_aw = make_rsrc(att_w, (uint32_t)F * 4u);
   const __amdgpu_buffer_rsrc_t rs_dp = make_rsrc(dpooled + (size_t)n * F, (uint32_t)F * 4u);
@@ -440,14 +442,14 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
 
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
                         float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s,
-                        const uint32_t* live, const uint32_t* kbits) {
+                        const uint32_t* live, const uint32_t* kbits, TitleOrder ord) {
   if (!n_titles) return;
   uint32_t thresh = drop > 0.f ? dropout_thresh(drop) : 0u;
   float scale = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
   int rows = n_titles * T;
   if (title_path(T, F)) {
     hipLaunchKernelGGL(att_fwd_title_kernel, dim3(n_titles), dim3(256), (32 + 4 * F) * sizeof(float), s, c, ids, live, att_w,
-                       att_b, a, w, pooled, T, F, thresh, key, scale, thresh ? kbits : nullptr);
+                       att_b, a, w, pooled, T, F, thresh, key, scale, thresh ? kbits : nullptr, ord);
     return;
   }
   if (F % 4 == 0) {
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
                         float drop, uint32_t key, hipStream_t s, int ldp, int off_aw, int off_cb, int off_ab, int relu,
-                        const uint32_t* live, const uint32_t* kbits, int title0, int title_count) {
+                        const uint32_t* live, const uint32_t* kbits, int title0, int title_count, TitleOrder ord) {
   if (ldp <= 0) {   // default layout of the public entry point: datt_w[F] | dconv_b[F] | datt_b
     ldp = 2 * F + 1;
     off_aw = 0;
@@ -639,7 +641,7 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
     if (cnt > 0)
       hipLaunchKernelGGL(att_bwd_title_kernel, dim3(cnt), dim3(256), (64 + 8 * F) * sizeof(float), s, c, ids, live, att_w, a,
                          w, dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu,
-                         thresh ? kbits : nullptr, title0);
+                         thresh ? kbits : nullptr, title0, ord);
     return;
   }
   if (F % 4 == 0) {

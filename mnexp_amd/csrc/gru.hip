@@ -648,16 +648,19 @@ void launch_gru_pack(const float* U, int H, float* packed, hipStream_t s) {
   generic_pack(U, H, packed, packed + 2 * sixth, packed + 3 * sixth, packed + 4 * sixth, s);
 }
 void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
-                    float* hlast, int n, int W, int H, hipStream_t s) {
+                    float* hlast, int n, int W, int H, hipStream_t s, bool slot_major) {
   if (!n) return;
-  if (gru4_supported(H)) return launch_gru4_fwd(xw, gmask, h0, packed, tape, hlast, n, W, H, s);
+  if (gru4_supported(H)) return launch_gru4_fwd(xw, gmask, h0, packed, tape, hlast, n, W, H, s, slot_major);
   const size_t sixth = generic_pack_floats(H) / 6;
   generic_fwd(xw, gmask, h0, packed, packed + 2 * sixth, tape, hlast, n, W, H, s);
 }
 void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* packed, float* dgates,
-                    float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s) {
+                    float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s, bool slot_major, int t_hi,
+                    int t_lo) {
   if (!n) return;
-  if (gru4_supported(H)) return launch_gru4_bwd(dh_last, gmask, tape, packed, dgates, rh, hprev, dh0, n, W, H, s);
+  if (gru4_supported(H))
+    return launch_gru4_bwd(dh_last, gmask, tape, packed, dgates, rh, hprev, dh0, n, W, H, s, slot_major, t_hi, t_lo);
+  // (the general kernels know the sample-major layout and the whole recurrence only: callers ask gru4_supported first)
   const size_t sixth = generic_pack_floats(H) / 6;
   generic_bwd(dh_last, gmask, tape, packed + 4 * sixth, packed + 3 * sixth, dgates, rh, hprev, dh0, n, W, H, s);
 }

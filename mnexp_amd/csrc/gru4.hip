@@ -153,11 +153,11 @@ struct RowMasks {
   int chunk;
   const uint8_t* gm;
   uint32_t rbase[4];
-  int W, lane;
-  __device__ __forceinline__ void init(const uint8_t* gmask, int b0, int n, int W_, int lane_) {
-    gm = gmask; W = W_; lane = lane_; chunk = -1;
+  int W, lane, st;
+  __device__ __forceinline__ void init(const uint8_t* gmask, int b0, int n, int W_, int lane_, int sb_, int st_) {
+    gm = gmask; W = W_; lane = lane_; chunk = -1; st = st_;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rbase[j] = (uint32_t)min(b0 + j, n - 1) * (uint32_t)W_;
+    for (int j = 0; j < 4; ++j) rbase[j] = (uint32_t)min(b0 + j, n - 1) * (uint32_t)sb_;
   }
   __device__ __forceinline__ void seek(int t) {   // wave-uniform t
     if ((t >> 6) == chunk) return;
@@ -165,7 +165,7 @@ struct RowMasks {
     const int tt = chunk * 64 + lane;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint8_t v = tt < W ? gm[rbase[j] + tt] : (uint8_t)0;
+      const uint8_t v = tt < W ? gm[rbase[j] + (uint32_t)(tt * st)] : (uint8_t)0;
       bits[j] = __ballot(v != 0);
     }
   }
@@ -227,6 +227,7 @@ struct Gru4Fwd {
   const float* xw; const uint8_t* gmask; const float* h0; const float* izr; const float* ih;
   float* zr; float* hh; float* hp; float* rh; float* hlast;
   int n, W, H, dbg;   // dbg: measurement knobs (LSTUR_GRU4_DEBUG): 1 no global stores, 8 per-segment cycle stamps
+  int sb, st;         // row of (sample b, step t) in xw / gmask / the tape = b * sb + t * st: (W, 1) sample-major, (1, n) slot-major
 };
 
 // Strip plan of the forward kernel (host + device).  [z|r] strip s and s+4 are resident on wave s.  A wave whose
@@ -287,10 +288,11 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     rok[j] = b0 + j < n && !(g.dbg & 1);
-    rb[j] = (uint32_t)min(b0 + j, n - 1) * (uint32_t)W;
+    rb[j] = (uint32_t)min(b0 + j, n - 1) * (uint32_t)g.sb;
   }
+  const uint32_t ST = (uint32_t)g.st;
   RowMasks rm;
-  if (P2 != M_NONE) rm.init(g.gmask, b0, n, W, lane);
+  if (P2 != M_NONE) rm.init(g.gmask, b0, n, W, lane, g.sb, g.st);
   // measurement build only (dbg bit 3): per-segment shader cycles of this wave, summed over the steps
   const bool stamp = g.dbg & 8;
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, last = 0;
@@ -310,7 +312,7 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
 #pragma unroll
       for (int s = 0; s < NP1; ++s)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x1[s][j] = buf_load1(rxw, o1[s], (rb[j] + t) * H3 * 4);
+        for (int j = 0; j < 4; ++j) x1[s][j] = buf_load1(rxw, o1[s], (rb[j] + (uint32_t)t * ST) * H3 * 4);
       float hv[2][4];   // h at this lane's r columns (read before the stream: one LDS round trip less in the epilogue)
 #pragma unroll
       for (int s = 0; s < NP1; ++s)
@@ -333,15 +335,15 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
           dst1[s][j * 4] = val;
           k1[s][j] = gt;
           k1r[s][j] = val;
-          buf_store1(k1[s][j], rzr, rok[j] ? o1[s] : kBufOob, (rb[j] + t) * H2 * 4);
-          buf_store1(k1r[s][j], rrh, rok[j] ? o1r[s] : kBufOob, (rb[j] + t) * H * 4);
+          buf_store1(k1[s][j], rzr, rok[j] ? o1[s] : kBufOob, (rb[j] + (uint32_t)t * ST) * H2 * 4);
+          buf_store1(k1r[s][j], rrh, rok[j] ? o1r[s] : kBufOob, (rb[j] + (uint32_t)t * ST) * H * 4);
         }
     }
     float x2[4];
     if (P2 != M_NONE) {   // candidate inputs fly over the barrier and the candidate product
       rm.seek(t);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x2[j] = buf_load1(rxw, o2x, (rb[j] + t) * H3 * 4);
+      for (int j = 0; j < 4; ++j) x2[j] = buf_load1(rxw, o2x, (rb[j] + (uint32_t)t * ST) * H3 * 4);
     }
     LSTUR_STAMP(1)
     __syncthreads();
@@ -365,8 +367,8 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
         hdst2[j * 4] = rm.at(j, t) ? hn : hp[j];   // K.rnn: a masked step carries the previous state/output
         k2h[j] = hhv;
         k2p[j] = hp[j];
-        buf_store1(k2h[j], rhh, rok[j] ? o2 : kBufOob, (rb[j] + t) * H * 4);
-        buf_store1(k2p[j], rhp, rok[j] ? o2 : kBufOob, (rb[j] + t) * H * 4);
+        buf_store1(k2h[j], rhh, rok[j] ? o2 : kBufOob, (rb[j] + (uint32_t)t * ST) * H * 4);
+        buf_store1(k2p[j], rhp, rok[j] ? o2 : kBufOob, (rb[j] + (uint32_t)t * ST) * H * 4);
       }
     }
     if (NP1 > 0) {   // this step's z / r / r*h stores were issued a whole candidate product ago
@@ -474,7 +476,9 @@ struct Gru4Bwd {
   const float* itz; const float* itr; const float* ith;
   float* dgates; float* dh0;
   int n, W, H, dbg;
-};
+  int sb, st;         // row of (sample b, step t) = b * sb + t * st (like Gru4Fwd)
+  int t_hi, t_lo;     // this launch walks steps t_hi .. t_lo (W - 1 .. 0: the whole recurrence); dh_last = dh behind step t_hi,
+};                    // dh0 = dh in front of step t_lo
 static size_t gru4_bwd_lds(int H, int KQ) {
   const int G2 = cdiv(H, 64);
   const int w2 = G2 >= 3 ? std::min(64, H - 128) : 0, w3 = G2 >= 4 ? H - 192 : 0;
@@ -524,10 +528,11 @@ __device__ __forceinline__ void gru4_bwd_loop(const Gru4Bwd& g, const BwdLds& L,
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     rok[j] = b0 + j < n && !(g.dbg & 1);
-    rb[j] = (uint32_t)min(b0 + j, n - 1) * (uint32_t)W;
+    rb[j] = (uint32_t)min(b0 + j, n - 1) * (uint32_t)g.sb;
   }
+  const uint32_t ST = (uint32_t)g.st;
   RowMasks rm;
-  if (MB != M_NONE) rm.init(g.gmask, b0, n, W, lane);
+  if (MB != M_NONE) rm.init(g.gmask, b0, n, W, lane, g.sb, g.st);
 
   // element-wise head of step t for the (row, column) elements this lane owns in stage 2
   float n1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -546,25 +551,25 @@ __device__ __forceinline__ void gru4_bwd_loop(const Gru4Bwd& g, const BwdLds& L,
       dpzd[j * 4] = dpz;
       kz[j] = dpz;
       kh[j] = dph;
-      buf_store1(kz[j], rdg, rok[j] ? ob : kBufOob, (rb[j] + t) * H3 * 4);
-      buf_store1(kh[j], rdg, rok[j] ? obh : kBufOob, (rb[j] + t) * H3 * 4);
+      buf_store1(kz[j], rdg, rok[j] ? ob : kBufOob, (rb[j] + (uint32_t)t * ST) * H3 * 4);
+      buf_store1(kh[j], rdg, rok[j] ? obh : kBufOob, (rb[j] + (uint32_t)t * ST) * H3 * 4);
     }
   };
   if (MB != M_NONE) {
     float dh[4], z[4], hh[4], hp[4];
-    const int t = W - 1;
+    const int t = g.t_hi;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       dh[j] = (b0 + j < n && vb) ? g.dh_last[(size_t)(b0 + j) * H + cb] : 0.f;
-      z[j] = buf_load1(rzr, ob, (rb[j] + t) * H2 * 4);
-      hh[j] = buf_load1(rhh, ob, (rb[j] + t) * H * 4);
-      hp[j] = buf_load1(rhp, ob, (rb[j] + t) * H * 4);
+      z[j] = buf_load1(rzr, ob, (rb[j] + (uint32_t)t * ST) * H2 * 4);
+      hh[j] = buf_load1(rhh, ob, (rb[j] + (uint32_t)t * ST) * H * 4);
+      hp[j] = buf_load1(rhp, ob, (rb[j] + (uint32_t)t * ST) * H * 4);
     }
     head(t, dh, z, hh, hp);
   }
   __syncthreads();
 
-  for (int t = W - 1; t >= 0; --t) {
+  for (int t = g.t_hi; t >= g.t_lo; --t) {
     // ---- stage 1 ----
     if (NA > 0) {
       float r[2][4], hp[2][4];
@@ -573,8 +578,8 @@ __device__ __forceinline__ void gru4_bwd_loop(const Gru4Bwd& g, const BwdLds& L,
         for (int s = 0; s < 2; ++s)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            r[s][j] = buf_load1(rzr, oar[s], (rb[j] + t) * H2 * 4);
-            hp[s][j] = buf_load1(rhp, oa[s], (rb[j] + t) * H * 4);
+            r[s][j] = buf_load1(rzr, oar[s], (rb[j] + (uint32_t)t * ST) * H2 * 4);
+            hp[s][j] = buf_load1(rhp, oa[s], (rb[j] + (uint32_t)t * ST) * H * 4);
           }
         __builtin_amdgcn_sched_barrier(0);   // keep the loads in front of the MFMA stream
       }
@@ -595,7 +600,7 @@ __device__ __forceinline__ void gru4_bwd_loop(const Gru4Bwd& g, const BwdLds& L,
             dsta[s][j * 4] = dpr;
             dstn[s][j * 4] = drh * r[s][j];
             kr[s][j] = dpr;
-            buf_store1(kr[s][j], rdg, rok[j] ? oar[s] : kBufOob, (rb[j] + t) * H3 * 4);
+            buf_store1(kr[s][j], rdg, rok[j] ? oar[s] : kBufOob, (rb[j] + (uint32_t)t * ST) * H3 * 4);
           } else {
             dstn[s][j * 4] = acc[s][j];
           }
@@ -609,12 +614,12 @@ __device__ __forceinline__ void gru4_bwd_loop(const Gru4Bwd& g, const BwdLds& L,
     // ---- stage 2 (+ the element-wise head of step t-1) ----
     if (MB != M_NONE) {
       float z[4], hh[4], hp[4];
-      const int tp = max(t - 1, 0);
+      const int tp = max(t - 1, g.t_lo);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        z[j] = buf_load1(rzr, ob, (rb[j] + tp) * H2 * 4);
-        hh[j] = buf_load1(rhh, ob, (rb[j] + tp) * H * 4);
-        hp[j] = buf_load1(rhp, ob, (rb[j] + tp) * H * 4);
+        z[j] = buf_load1(rzr, ob, (rb[j] + (uint32_t)tp * ST) * H2 * 4);
+        hh[j] = buf_load1(rhh, ob, (rb[j] + (uint32_t)tp * ST) * H * 4);
+        hp[j] = buf_load1(rhp, ob, (rb[j] + (uint32_t)tp * ST) * H * 4);
       }
       __builtin_amdgcn_sched_barrier(0);
       f32x4 acc, unused;
@@ -622,7 +627,7 @@ __device__ __forceinline__ void gru4_bwd_loop(const Gru4Bwd& g, const BwdLds& L,
       float dh[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) dh[j] = n1[j] + n2s[j * 4] + n3s[j * 4] + acc[j];
-      if (t > 0) {
+      if (t > g.t_lo) {
         head(t - 1, dh, z, hh, hp);
       } else if (vb) {
 #pragma unroll
@@ -750,10 +755,11 @@ void gru4_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh)
 }
 
 void launch_gru4_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* img, float* tape, float* hlast,
-                     int n, int W, int H, hipStream_t s) {
+                     int n, int W, int H, hipStream_t s, bool slot_major) {
   const int KQ = gru4_kq(H);
   const size_t e = (size_t)n * W * H, ie = (size_t)KQ * 4 * H;
-  Gru4Fwd a{xw, gmask, h0, img, img + 2 * ie, tape, tape + 2 * e, tape + 3 * e, tape + 4 * e, hlast, n, W, H, gru4_dbg()};
+  Gru4Fwd a{xw, gmask, h0, img, img + 2 * ie, tape, tape + 2 * e, tape + 3 * e, tape + 4 * e, hlast, n, W, H, gru4_dbg(),
+            slot_major ? 1 : W, slot_major ? n : 1};
   const size_t lds = gru4_fwd_lds(H, KQ);
   const dim3 grid(cdiv(n, 4)), block(G4_THREADS);
 #define LSTUR_G4F(Q)                                              \
@@ -766,11 +772,12 @@ void launch_gru4_fwd(const float* xw, const uint8_t* gmask, const float* h0, con
 }
 
 void launch_gru4_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* img, float* dgates, float* rh,
-                     float* hprev, float* dh0, int n, int W, int H, hipStream_t s) {
+                     float* hprev, float* dh0, int n, int W, int H, hipStream_t s, bool slot_major, int t_hi, int t_lo) {
   const int KQ = gru4_kq(H);
   const size_t e = (size_t)n * W * H, ie = (size_t)KQ * 4 * H;
+  if (t_hi < 0) t_hi = W - 1;
   Gru4Bwd a{dh_last, gmask, tape, tape + 2 * e, tape + 3 * e, img + 3 * ie, img + 4 * ie, img + 5 * ie, dgates, dh0,
-            n, W, H, gru4_dbg()};
+            n, W, H, gru4_dbg(), slot_major ? 1 : W, slot_major ? n : 1, t_hi, t_lo};
   const size_t lds = gru4_bwd_lds(H, KQ);
   const dim3 grid(cdiv(n, 4)), block(G4_THREADS);
 #define LSTUR_G4B(Q)                                              \

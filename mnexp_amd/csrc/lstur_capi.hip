@@ -37,6 +37,8 @@ struct Dims {
   int n_cap;    // per-sample buffers
   int rows_cap; // sparse user-grad rows per adam step
   int lazy;     // lazy dense Adam of the user table(s) (large tables; misc.hip)
+  int slot;     // history titles in slot-major order inside the step (title = slot * n + sample): a range of history
+                // slots is then a contiguous range of titles, tokens and GRU rows (slot_major_wanted below)
 };
 constexpr int kLazyLog = 1 << 16;        // logged lr_t values (a full flush at the latest every kLazyLog - 2 iterations)
 constexpr int kLazyMinRows = 200000;     // tables from this size on update lazily (LSTUR_LAZY_ADAM=0 / 1 overrides)
@@ -182,6 +184,7 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     const bool has_table = d->arch != LSTUR_ARCH_NIGRU && d->arch != LSTUR_ARCH_NIAVG && d->arch != LSTUR_ARCH_NIATT;
     d->lazy = has_table && (e ? !strcmp(e, "1") : d->Nu >= kLazyMinRows);
   }
+  d->slot = 0;   // (decided per context: slot_major_wanted)
   return true;
 }
 
@@ -199,6 +202,17 @@ bool lanes_supported(const Dims& d) {
   return !off && d.B >= kPipeMin && d.head == LSTUR_HEAD_SOFTMAX && d.enc == LSTUR_ENC_CNNATT && !d.word_trainable &&
          has_gru && gru4_supported(d.H) && conv3f_supported(d.D, d.k, d.F) && d.k <= 8 && !d.lazy;
 }
+// Slot-major history titles: with the fast recurrence kernels on the pre-split cnnatt path (the kernels that draw dropout
+// there know the reference's order: TitleOrder).  LSTUR_SLOT_MAJOR=0: the reference's sample-major order.
+bool slot_major_wanted(const Dims& d) {
+  const bool off = getenv("LSTUR_SLOT_MAJOR") && !strcmp(getenv("LSTUR_SLOT_MAJOR"), "0");
+  const bool other_conv = getenv("LSTUR_CONV_F32") != nullptr || getenv("LSTUR_CONV_GEN1") != nullptr;
+  const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
+  return !off && !other_conv && has_gru && gru4_supported(d.H) && d.enc == LSTUR_ENC_CNNATT && conv3f_supported(d.D, d.k, d.F) &&
+         d.k <= 8 && attpool_title_path(d.T, d.F) && !lanes_supported(d) &&
+         !d.word_trainable;   // (the word-table gradient draws the embedding's dropout at physical token positions)
+}
+inline TitleOrder title_order(const Dims& d, int n) { return d.slot ? TitleOrder{n, d.W, n * d.W} : TitleOrder{0, 0, 0}; }
 Dims lane1_dims(const Dims& d) {
   Dims e = d;
   e.B = lane1_cap(d.B);
@@ -207,6 +221,7 @@ Dims lane1_dims(const Dims& d) {
   e.rows_cap = 16;          // (the sparse-row scratch of the optimizer lives in lane 0)
   e.Nu = 1;                 // (so does the slot map)
   e.lazy = 0;
+  e.slot = 0;
   return e;
 }
 
@@ -699,17 +714,18 @@ bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
   hipStream_t p = c->side_p;
   (void)hipStreamWaitEvent(p, forked, 0);
   const int nW = q.n * d.W, nt = nW + q.n * d.K1, pl = (d.k - 1) / 2;
-  launch_expand_count(c->title_table, q.hist, nW, q.cands, q.n * d.K1, d.T, t.ids, t.vscratch, p);
+  const TitleOrder ord = title_order(d, q.n);
+  launch_expand_count(c->title_table, q.hist, nW, q.cands, q.n * d.K1, d.T, t.ids, t.vscratch, p, ord);
   launch_compact_write_offsets(t.ids, nt * d.T, t.vscratch, t.vidx, t.vcount, d.T, d.Tp, conv3_dp(d.D) / 8 * 3, d.F, t.offA,
                                t.offB, p, t.live, nW * d.T);
   {
     ProfScope _ps(c, "gather", p, true);
     static const int pf_blocks = getenv("LSTUR_PREFETCH_BLOCKS") ? atoi(getenv("LSTUR_PREFETCH_BLOCKS")) : 0;
     launch_gather3(c->buf.word_emb, t.ids, t.e3, nt, d.T, d.D, pl, d.k - 1 - pl, c->cfg.dropout,
-                   dropout_key(c->cfg.seed, q.step, 0), true, p, pf_blocks);
+                   dropout_key(c->cfg.seed, q.step, 0), true, p, pf_blocks, ord);
   }
   // the attention passes' dropout decisions for that batch (stream 1 of its step), behind the gather
-  q.kbits = launch_attpool_keep_bits(t.live, t.kbits, nt, d.T, d.F, c->cfg.dropout, dropout_key(c->cfg.seed, q.step, 1), p);
+  q.kbits = launch_attpool_keep_bits(t.live, t.kbits, nt, d.T, d.F, c->cfg.dropout, dropout_key(c->cfg.seed, q.step, 1), p, ord);
   // lazily updated table: the rows that batch will read take their pending zero-gradient updates here, under the
   // recurrence (a row that waited 2 000 iterations is a 2 000-long chain per element: latency-bound work for idle CUs);
   // the forward's own catch-up then finds one iteration left
@@ -999,7 +1015,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   if (use3 && !gen1)   // Embedding + Dropout straight into the pre-split layout of the bf16x3 conv kernels (rows nobody reads skipped)
   {
     ProfScope _ps(c, "gather", s, true);
-    launch_gather3(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, s);
+    launch_gather3(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, s, 0, title_order(d, n));
   }
   else
     PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
@@ -1020,7 +1036,8 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
                                      w.vcount, s));
   }
   PROF("attpool_fwd", launch_attpool_fwd(w.conv, w.ids, c->P("att_w"), c->P("att_b"), w.pooled, w.att_a, w.att_wt, nt, d.T, d.F,
-                                         drop, key1, s, w.live, (training && w.kbits_valid) ? w.kbits : nullptr));
+                                         drop, key1, s, w.live, (training && w.kbits_valid) ? w.kbits : nullptr,
+                                         title_order(d, n)));
   dense_gemm(w.pooled, d.F, c->P("dense_w"), d.U, false, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, w.gemm_scratch, s);
   // user encoder (paper.py:584-633)
   if (d.lazy && c->cur_lane == 0) lazy_catchup_rows(c, user, n, s);   // (large tables: the rows read below, made current)
@@ -1059,7 +1076,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
     const bool init_user = d.arch == LSTUR_ARCH_IGRU || two_tables(d);   // initial_state = user_vec
     PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, init_user ? w.uvec : nullptr, w.gru_up,
-                                   w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s));
+                                   w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s, d.slot != 0));
     if (d.arch == LSTUR_ARCH_PGRU) {        // GRU(U)(x) + user_vec (paper.py:624-626)
       launch_add2(w.hlast, w.uvec, w.uservec, (size_t)n * d.U, s);
     } else if (!direct) {
@@ -1146,7 +1163,8 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     {
       ProfScope _ps(c, "attpool_bwd", sw);
       launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, w.att_ds, nt, d.T, d.F,
-                         drop, key1, sw, ldp, off_aw, off_cb, off_ab, 1, w.live, w.kbits_valid ? w.kbits : nullptr, nW, ncand);
+                         drop, key1, sw, ldp, off_aw, off_cb, off_ab, 1, w.live, w.kbits_valid ? w.kbits : nullptr, nW, ncand,
+                         title_order(d, n));
     }
     {
       ProfScope _ps(c, "conv_wgrad", sw, true);
@@ -1168,7 +1186,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     if (attach) arm_stop_event(fe);
     PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
                                    (d.arch == LSTUR_ARCH_IGRU || two_tables(d)) ? w.duser : w.dh0, n, d.W,
-                                   d.H, s));
+                                   d.H, s, d.slot != 0));
     fe_recorded = attach && !stop_event_pending();
     arm_stop_event(nullptr);
   }
@@ -1271,7 +1289,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   const int ldp = off_ab + 1;
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
                                          w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 1, w.live,
-                                         w.kbits_valid ? w.kbits : nullptr, 0, split ? nW : nt));
+                                         w.kbits_valid ? w.kbits : nullptr, 0, split ? nW : nt, title_order(d, n)));
   if (split) (void)hipStreamWaitEvent(s, c->ev_c1, 0);   // the candidate titles' partial sums, gradient rows and slabs
   // (on the side stream this one found no free CU beside the conv kernel gradient and finished behind it)
   launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch_k[2], s, &jobs[nj++]);
@@ -1309,10 +1327,11 @@ int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n,
   const size_t nW = (size_t)n * d.W;
   if (ids_form) {
     if (!c->title_table) return fail(LSTUR_ERR_STATE, "no title table bound (lstur_set_title_table)");
-    launch_expand_count(c->title_table, hist, (int)nW, cands, n * k1, d.T, w.ids, w.vscratch, s);
+    launch_expand_count(c->title_table, hist, (int)nW, cands, n * k1, d.T, w.ids, w.vscratch, s, title_order(d, n));
     c->counted_flag() = true;
   } else {
-    (void)hipMemcpyAsync(w.ids, hist, nW * d.T * 4, hipMemcpyDeviceToDevice, s);
+    if (d.slot) launch_permute_titles(hist, w.ids, (int)nW, d.T, title_order(d, n), s);
+    else (void)hipMemcpyAsync(w.ids, hist, nW * d.T * 4, hipMemcpyDeviceToDevice, s);
     (void)hipMemcpyAsync(w.ids + nW * d.T, cands, (size_t)n * k1 * d.T * 4, hipMemcpyDeviceToDevice, s);
   }
   return LSTUR_OK;
@@ -1699,6 +1718,7 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
   carve(d, buf->workspace, &c->ws);
   size_t need = c->ws.bytes;
   c->pipe_ok = lanes_supported(d);
+  c->d.slot = slot_major_wanted(d) ? 1 : 0;
   if (c->pipe_ok) {
     c->d1 = lane1_dims(d);
     carve(c->d1, (char*)buf->workspace + need, &c->ws1);
@@ -1936,6 +1956,7 @@ int lstur_flush_tables(lstur_ctx* ctx, lstur_stream stream) {
   return check_launch("flush_tables");
 }
 int lstur_lazy_adam(lstur_ctx* ctx) { return (ctx && ctx->d.lazy) ? 1 : 0; }
+int lstur_slot_major(lstur_ctx* ctx) { return (ctx && ctx->d.slot) ? 1 : 0; }
 
 int lstur_params_changed(lstur_ctx* ctx) {
   if (!ctx) return fail(LSTUR_ERR_ARG, "ctx is NULL");

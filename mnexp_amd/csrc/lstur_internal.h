@@ -62,6 +62,15 @@ void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s);
 
 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// Slot-major history titles (the step's layout when the fast recurrence kernels run): physical title n = slot * nb + sample
+// for n < nW, the reference's order is sample * W + slot (candidate titles behind the history are the same in both).  A
+// dropout decision is drawn at the REFERENCE position of an element, so every kernel that hashes maps its title first.
+struct TitleOrder {
+  int nb, W, nW;   // nb == 0: physical order = reference order
+};
+__host__ __device__ inline int ref_title(const TitleOrder& o, int n) {
+  return (o.nb > 0 && n < o.nW) ? (n % o.nb) * o.W + n / o.nb : n;
+}
 __host__ __device__ static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 __host__ __device__ static inline int ceil16(int a) { return (a + 15) & ~15; }
 
@@ -75,7 +84,8 @@ void launch_gather(const float* table, const int32_t* ids, float* out, int n_tit
 // the gather in the pre-split "E3" form of the bf16x3 conv kernels (layout: conv3f.hip); e3 = conv3_e3_elems() bf16
 // skip_unread: rows no window of a non-pad token covers are neither read nor written (the buffer must hold finite values)
 void launch_gather3(const float* table, const int32_t* ids, unsigned short* e3, int n_titles, int T, int D, int pad_l,
-                    int pad_r, float drop, uint32_t key, bool skip_unread, hipStream_t s, int max_blocks = 0);
+                    int pad_r, float drop, uint32_t key, bool skip_unread, hipStream_t s, int max_blocks = 0,
+                    TitleOrder ord = TitleOrder{0, 0, 0});
 void launch_expand_titles(const int32_t* table, const int32_t* doc_ids, int32_t* out, int n, int T,
                           hipStream_t s);
 // stable list of non-pad tokens: vidx[0..*count) ; scratch = compact_scratch_ints(n) int32
@@ -85,7 +95,9 @@ void launch_compact_valid(const int32_t* ids, int n, int32_t* vidx, int32_t* cou
 // title expansion) or launch_compact_count; launch_compact_write_offsets then writes vidx, the count and (offA != NULL)
 // the conv kernel gradient's per-token row offsets
 void launch_expand_count(const int32_t* table, const int32_t* hist_ids, int n_hist, const int32_t* cand_ids, int n_cand,
-                         int T, int32_t* out, int32_t* block_counts, hipStream_t s);
+                         int T, int32_t* out, int32_t* block_counts, hipStream_t s, TitleOrder ord = TitleOrder{0, 0, 0});
+// token ids given per title in the reference's order -> the step's (slot-major) title order
+void launch_permute_titles(const int32_t* src, int32_t* dst, int n_titles, int T, TitleOrder ord, hipStream_t s);
 void launch_compact_count(const int32_t* ids, int n, int32_t* block_counts, hipStream_t s);
 void launch_compact_write_offsets(const int32_t* ids, int n, const int32_t* block_counts, int32_t* vidx, int32_t* count,
                                   int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s,
@@ -253,19 +265,19 @@ void launch_gemm3_tn(const float* A, int lda, const float* B, int ldb, float* C,
 // bit masks of launch_compact_write_offsets for the same ids -- one scalar per title instead of an ids read per row
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
                         float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s,
-                        const uint32_t* live = nullptr, const uint32_t* kbits = nullptr);
+                        const uint32_t* live = nullptr, const uint32_t* kbits = nullptr, TitleOrder ord = TitleOrder{0, 0, 0});
 // kbits: the dropout keep decisions of (key, drop) for these titles in the title kernels' thread layout, made ahead of time
 // (attpool_keep_bits_words(n_titles) words; false: not applicable to this shape / drop == 0 -- pass NULL to the passes)
 size_t attpool_keep_bits_words(int n_titles);
 bool launch_attpool_keep_bits(const uint32_t* live, uint32_t* kbits, int n_titles, int T, int F, float drop, uint32_t key,
-                              hipStream_t s);
+                              hipStream_t s, TitleOrder ord = TitleOrder{0, 0, 0});
 int attpool_bwd_parts(int n_titles);
 // row_scratch: n_titles*T floats (dw -> ds)
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
                         float drop, uint32_t key, hipStream_t s, int ldp = 0, int off_aw = 0, int off_cb = 0,
                         int off_ab = 0, int relu = 1, const uint32_t* live = nullptr, const uint32_t* kbits = nullptr,
-                        int title0 = 0, int title_count = -1);
+                        int title0 = 0, int title_count = -1, TitleOrder ord = TitleOrder{0, 0, 0});
 bool attpool_title_path(int T, int F);   // the title-resident kernels (the only ones that take a title sub-range)
 
 // ---- mhsa.hip (build-defined multi-head self-attention token stage; T <= 32, F/heads in {16, 32, 64}) -------
@@ -320,10 +332,15 @@ void launch_gru_pack(const float* U, int H, float* packed, hipStream_t s);
 // tape: gru_tape_floats(n, W, H) floats of scratch shared by forward and BPTT (layout private to the kernels).
 // xw [n*W,3H] row-major; hlast [n,H]; dgates [n*W,3H], rh / hprev [n*W,H] row-major.  Requires H <= 256.
 size_t gru_tape_floats(int n, int W, int H);
+// slot_major (fast path only: gru4_supported): the rows of xw / gmask / dgates / rh / hprev are ordered (step, sample) --
+// row = t * n + b -- instead of (sample, step): the history titles of one slot are then a contiguous row range.
+// t_hi / t_lo (fast path only): the BPTT launch walks steps t_hi .. t_lo (default: W - 1 .. 0); dh_last is the state gradient
+// behind step t_hi, dh0 the one in front of step t_lo -- a recurrence cut into two launches hands dh over through memory.
 void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
-                    float* hlast, int n, int W, int H, hipStream_t s);
+                    float* hlast, int n, int W, int H, hipStream_t s, bool slot_major = false);
 void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* packed, float* dgates,
-                    float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s);
+                    float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s, bool slot_major = false,
+                    int t_hi = -1, int t_lo = 0);
 // On the fast path the forward already leaves hprev and r*hprev row-major inside the tape: returns true and the two
 // pointers (pass them to launch_gru_bwd to skip its copies); false on the general path.
 bool gru_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh);
@@ -336,8 +353,9 @@ size_t gru4_tape_floats(int n, int W, int H);
 void gru4_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh);
 void launch_gru4_pack(const float* U, int H, float* img, hipStream_t s);
 void launch_gru4_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* img, float* tape, float* hlast,
-                     int n, int W, int H, hipStream_t s);
+                     int n, int W, int H, hipStream_t s, bool slot_major = false);
 void launch_gru4_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* img, float* dgates, float* rh,
-                     float* hprev, float* dh0, int n, int W, int H, hipStream_t s);
+                     float* hprev, float* dh0, int n, int W, int H, hipStream_t s, bool slot_major = false, int t_hi = -1,
+                     int t_lo = 0);
 
 }  // namespace lstur

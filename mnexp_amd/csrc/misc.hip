@@ -91,7 +91,7 @@ template <bool DROP, bool SKIP>
 __global__ __launch_bounds__(256) void gather3_kernel(const float4* __restrict__ table, const int32_t* __restrict__ ids,
                                                       uint4* __restrict__ out, uint32_t total8, int T, int Tp, int D4,
                                                       int C8, int pad_l, int pad_r, uint32_t thresh, uint32_t key,
-                                                      float scale) {
+                                                      float scale, TitleOrder ord) {
   // A wave owns 64 consecutive chunks = 192 consecutive 16-byte pieces (3 KB) of the output.  Each lane produces the three
   // pieces of ITS chunk; they cross LDS once so that every store instruction writes 1 KB of consecutive bytes (lane-strided
   // 48-byte granules reached HBM as partial lines: 3.5 TB/s in the step, against the 4 + TB/s of whole-line stores).
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float4* __restrict__
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t b0 = blockIdx.x * blockDim.x; b0 < total8; b0 += U * stride) {     // block-uniform trip count
     const uint32_t i0 = b0 + threadIdx.x;
-    uint32_t c8[U], tok[U];
+    uint32_t c8[U], tok[U], htok[U];   // htok: the token's position in the reference's title order (dropout is drawn there)
     bool inr[U], real[U];
     int id[U];
 #pragma unroll
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float4* __restrict__
       const int t = (int)(row - n * (uint32_t)Tp) - pad_l;
       real[u] = t >= 0 && t < T;
       tok[u] = n * (uint32_t)T + (uint32_t)min(max(t, 0), T - 1);
+      htok[u] = DROP ? (uint32_t)ref_title(ord, (int)n) * (uint32_t)T + (uint32_t)min(max(t, 0), T - 1) : tok[u];
       id[u] = ids[tok[u]];
       if (SKIP) {
         bool need = false;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float4* __restrict__
       for (int hf = 0; hf < 2; ++hf) {
         const uint32_t c4 = 2u * c8[u] + hf;
         if (DROP) {
-          const uint32_t e = (tok[u] * (uint32_t)D4 + c4) * 4u;
+          const uint32_t e = (htok[u] * (uint32_t)D4 + c4) * 4u;
           bool k[4];
           keep_quad(key, e, thresh, k);
           w[hf].x = k[0] ? w[hf].x * scale : 0.f;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float4* __restrict__
 }
 
 void launch_gather3(const float* table, const int32_t* ids, unsigned short* e3, int n_titles, int T, int D, int pad_l,
-                    int pad_r, float drop, uint32_t key, bool skip_unread, hipStream_t s, int max_blocks) {
+                    int pad_r, float drop, uint32_t key, bool skip_unread, hipStream_t s, int max_blocks, TitleOrder ord) {
   const int Tp = T + pad_l + pad_r, D4 = D / 4, C8 = (D + 7) / 8;
   const size_t total8 = (size_t)n_titles * Tp * C8;
   if (total8 == 0) return;
@@ -186,7 +187,7 @@ void launch_gather3(const float* table, const int32_t* ids, unsigned short* e3, 
   auto go = [&](auto kern) {
     last_launch();
     launch_k(kern, dim3(blocks), dim3(256), 0, s, (const float4*)table, ids, (uint4*)e3, (uint32_t)total8, T, Tp, D4, C8, pad_l,
-             pad_r, th, key, sc);
+             pad_r, th, key, sc, ord);
   };
   if (drop > 0.f) skip_unread ? go(gather3_kernel<true, true>) : go(gather3_kernel<true, false>);
   else skip_unread ? go(gather3_kernel<false, true>) : go(gather3_kernel<false, false>);
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(256) void compact_write_kernel(const int32_t* __res
 __global__ __launch_bounds__(256) void expand_count_kernel(const int32_t* __restrict__ table,
                                                            const int32_t* __restrict__ hist_ids, int n_hist,
                                                            const int32_t* __restrict__ cand_ids, int n_total, int T,
-                                                           int32_t* __restrict__ out, int32_t* __restrict__ block_counts) {
+                                                           int32_t* __restrict__ out, int32_t* __restrict__ block_counts,
+                                                           TitleOrder ord) {
   const int n = n_total * T;
   const int i0 = blockIdx.x * kCompactBlock + threadIdx.x * 4;
   int c = 0;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256) void expand_count_kernel(const int32_t* __rest
     const int i = i0 + k;
     if (i < n) {
       const int title = i / T, t = i - title * T;
-      const int doc = title < n_hist ? hist_ids[title] : cand_ids[title - n_hist];
+      const int doc = title < n_hist ? hist_ids[ref_title(ord, title)] : cand_ids[title - n_hist];   // (the caller's arrays: reference order)
       const int id = table[(size_t)doc * T + t];
       out[i] = id;
       c += id != 0;
@@ -302,11 +304,22 @@ __global__ __launch_bounds__(256) void expand_count_kernel(const int32_t* __rest
   if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
 }
 void launch_expand_count(const int32_t* table, const int32_t* hist_ids, int n_hist, const int32_t* cand_ids, int n_cand,
-                         int T, int32_t* out, int32_t* block_counts, hipStream_t s) {
+                         int T, int32_t* out, int32_t* block_counts, hipStream_t s, TitleOrder ord) {
   const int n = (n_hist + n_cand) * T;
   if (n > 0)
     hipLaunchKernelGGL(expand_count_kernel, dim3(cdiv(n, kCompactBlock)), dim3(256), 0, s, table, hist_ids, n_hist,
-                       cand_ids, n_hist + n_cand, T, out, block_counts);
+                       cand_ids, n_hist + n_cand, T, out, block_counts, ord);
+}
+__global__ void permute_titles_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int total, int T,
+                                      TitleOrder ord) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int title = i / T, t = i - title * T;
+  dst[i] = src[(size_t)ref_title(ord, title) * T + t];
+}
+void launch_permute_titles(const int32_t* src, int32_t* dst, int n_titles, int T, TitleOrder ord, hipStream_t s) {
+  const int total = n_titles * T;
+  if (total) hipLaunchKernelGGL(permute_titles_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, src, dst, total, T, ord);
 }
 // Second half of the compaction with the block prefix computed in place (<= a few hundred block counts, each block
 // sums its predecessors) and the conv kernel-gradient's per-token row offsets written along: offA = row of the padded
