@@ -462,10 +462,15 @@ static int g2_slabs(int M, int Kq, int F, int cus = 256) {
   const int want = cus >= 256 ? rounds * 256 / per / 8 * 8 : std::max(1, rounds * cus / per);
   return std::max(1, std::min(std::max(8, want), std::max(1, M / 512)));
 }
-// (twice the slab count of one launch: a step may give the candidate titles' tokens a launch of their own)
+// (three times the slab count of one launch + one: a step may give the candidate titles' and the late history slots' tokens
+//  launches of their own and reduce their slabs into one ahead of time)
 size_t conv3_wgrad2_scratch_bytes(int n_titles, int T, int D, int ksize, int F) {
-  return (size_t)2 * g2_slabs(n_titles * T, ksize * conv3_dp(D), F) * ksize * conv3_dp(D) * F * sizeof(float);
+  return (size_t)(3 * g2_slabs(n_titles * T, ksize * conv3_dp(D), F) + 1) * ksize * conv3_dp(D) * F * sizeof(float);
 }
+int conv3_wgrad2_slabs(int plan_titles, int T, int D, int ksize, int F, int cus) {
+  return g2_slabs(plan_titles * T, ksize * conv3_dp(D), F, cus > 0 ? std::min(cus, 256) : 256);
+}
+size_t conv3_wgrad2_slab_floats(int D, int ksize, int F) { return (size_t)ksize * conv3_dp(D) * F; }
 
 template <int OPT = 0>   // OPT != 0: timing-only ablations (WRONG results; LSTUR_WGRAD_ABLATE, tools/bench_conv3f.py)
 __global__ __launch_bounds__(G2_THREADS, 2) void conv3_wgrad2_kernel(
@@ -474,10 +479,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) void conv3_wgrad2_kernel(
     const int32_t* __restrict__ offA, const int32_t* __restrict__ offB, int range_sel, int slab_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // tokens [lo, count) of the compacted list: all of it, or one side of the title boundary the compaction counted
-  // (vcount[1]: history | candidates) -- the candidates' share runs early, under the recurrence's backward
-  const int count = vcount ? (range_sel == 1 ? vcount[1] : vcount[0]) : M;
-  const int lo = (vcount && range_sel == 2) ? vcount[1] : 0;
+  // tokens [lo, count) of the compacted list: all of it, or a title range between the boundaries the compaction counted
+  // (vcount[0] total, [1] history | candidates, [2] early | late history slots of a slot-major step).  range_sel: 0 all,
+  // 1 history, 2 candidates, 3 early slots, 4 late slots -- what the recurrence's backward has not reached yet runs later
+  const int count = vcount ? vcount[range_sel == 1 || range_sel == 4 ? 1 : range_sel == 3 ? 2 : 0] : M;
+  const int lo = !vcount ? 0 : range_sel == 2 ? vcount[1] : range_sel == 4 ? vcount[2] : 0;
   // block -> (slab, m-block, n-block); XCD-aware: workgroup ids go round-robin over the 8 XCDs, so the blocks of one slab
   // get ids 8 apart: they run on ONE XCD at about the same time and share the slab's tokens through its L2
   const int per = mblocks * nblocks;

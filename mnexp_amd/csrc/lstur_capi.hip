@@ -39,6 +39,7 @@ struct Dims {
   int lazy;     // lazy dense Adam of the user table(s) (large tables; misc.hip)
   int slot;     // history titles in slot-major order inside the step (title = slot * n + sample): a range of history
                 // slots is then a contiguous range of titles, tokens and GRU rows (slot_major_wanted below)
+  int late;     // history slots whose encoder backward starts behind the first part of a recurrence backward cut in two
 };
 constexpr int kLazyLog = 1 << 16;        // logged lr_t values (a full flush at the latest every kLazyLog - 2 iterations)
 constexpr int kLazyMinRows = 200000;     // tables from this size on update lazily (LSTUR_LAZY_ADAM=0 / 1 overrides)
@@ -184,7 +185,7 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     const bool has_table = d->arch != LSTUR_ARCH_NIGRU && d->arch != LSTUR_ARCH_NIAVG && d->arch != LSTUR_ARCH_NIATT;
     d->lazy = has_table && (e ? !strcmp(e, "1") : d->Nu >= kLazyMinRows);
   }
-  d->slot = 0;   // (decided per context: slot_major_wanted)
+  d->slot = d->late = 0;   // (decided per context: slot_major_wanted)
   return true;
 }
 
@@ -202,10 +203,14 @@ bool lanes_supported(const Dims& d) {
   return !off && d.B >= kPipeMin && d.head == LSTUR_HEAD_SOFTMAX && d.enc == LSTUR_ENC_CNNATT && !d.word_trainable &&
          has_gru && gru4_supported(d.H) && conv3f_supported(d.D, d.k, d.F) && d.k <= 8 && !d.lazy;
 }
-// Slot-major history titles: with the fast recurrence kernels on the pre-split cnnatt path (the kernels that draw dropout
-// there know the reference's order: TitleOrder).  LSTUR_SLOT_MAJOR=0: the reference's sample-major order.
+// Slot-major history titles: possible with the fast recurrence kernels on the pre-split cnnatt path (the kernels that draw
+// dropout there know the reference's order: TitleOrder).  OPT-IN (LSTUR_LATE_SLOTS=n > 0 or LSTUR_SLOT_MAJOR=1): the layout
+// alone measures like the reference's order, and what it was built for -- the late slots' encoder backward under the rest
+// of the recurrence's backward (late_slots) -- LOSES 30-45 us per step at the config-2 shapes.
 bool slot_major_wanted(const Dims& d) {
-  const bool off = getenv("LSTUR_SLOT_MAJOR") && !strcmp(getenv("LSTUR_SLOT_MAJOR"), "0");
+  const char* ls = getenv("LSTUR_LATE_SLOTS");
+  const bool on = (ls && atoi(ls) > 0) || (getenv("LSTUR_SLOT_MAJOR") && !strcmp(getenv("LSTUR_SLOT_MAJOR"), "1"));
+  const bool off = !on;
   const bool other_conv = getenv("LSTUR_CONV_F32") != nullptr || getenv("LSTUR_CONV_GEN1") != nullptr;
   const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
   return !off && !other_conv && has_gru && gru4_supported(d.H) && d.enc == LSTUR_ENC_CNNATT && conv3f_supported(d.D, d.k, d.F) &&
@@ -213,6 +218,7 @@ bool slot_major_wanted(const Dims& d) {
          !d.word_trainable;   // (the word-table gradient draws the embedding's dropout at physical token positions)
 }
 inline TitleOrder title_order(const Dims& d, int n) { return d.slot ? TitleOrder{n, d.W, n * d.W} : TitleOrder{0, 0, 0}; }
+int late_slots(const Dims& d);
 Dims lane1_dims(const Dims& d) {
   Dims e = d;
   e.B = lane1_cap(d.B);
@@ -221,7 +227,7 @@ Dims lane1_dims(const Dims& d) {
   e.rows_cap = 16;          // (the sparse-row scratch of the optimizer lives in lane 0)
   e.Nu = 1;                 // (so does the slot map)
   e.lazy = 0;
-  e.slot = 0;
+  e.slot = e.late = 0;
   return e;
 }
 
@@ -279,7 +285,7 @@ std::vector<ParamSlot> param_layout(const Dims& d, size_t* total) {
 struct Workspace {
   int32_t* ids; float* emb; float* conv; float* dconv; float* att_a; float* att_wt; float* pooled; float* dpooled;
   float* docvec; float* ddocvec; uint8_t* hmask; uint8_t* gmask; float* uvec; float* xw; float* gru_tape;
-  float* dgates; float* rh; float* hprev; float* dh0; float* hlast; float* dhlast;
+  float* dgates; float* rh; float* hprev; float* dh0; float* dh_mid; float* hlast; float* dhlast;
   float* cat; float* dcat; float* uservec; float* duser; float* du; float* logits; float* probs; float* loss_i;
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
@@ -355,6 +361,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->rh = (float*)take(nW * d.H * f4);
   w->hprev = (float*)take(nW * d.H * f4);
   w->dh0 = (float*)take(nc * d.H * f4);
+  w->dh_mid = (float*)take(nc * d.H * f4);   // dh between the two launches of a recurrence backward cut at a slot
   w->hlast = (float*)take(nc * d.H * f4);
   w->dhlast = (float*)take(nc * d.H * f4);
   w->cat = (float*)take(nc * (d.H + d.Ue) * f4);
@@ -496,6 +503,7 @@ struct lstur_ctx {
   hipStream_t side_w = nullptr, side_w2 = nullptr;   // (second one: the Dense(U) parameter gradients, beside the GRU's)
   hipEvent_t ev_w1 = nullptr, ev_w2 = nullptr, ev_w3 = nullptr, ev_w4 = nullptr;
   hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;   // candidate titles' encoder backward: fork behind the scorer, done
+  hipEvent_t ev_l0 = nullptr;                     // late history slots: fork behind the first launch of the recurrence's backward
   bool cand_forked = false;                       // ev_c0 rides on this step's scorer launch
   bool lanes_active = false;                      // inside train_two_lanes (the lanes keep to one launch per kernel family)
   // staging prefetch (lstur_prefetch_ids): the next batch's title expansion, compaction and embedding gather run on a
@@ -717,7 +725,7 @@ bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
   const TitleOrder ord = title_order(d, q.n);
   launch_expand_count(c->title_table, q.hist, nW, q.cands, q.n * d.K1, d.T, t.ids, t.vscratch, p, ord);
   launch_compact_write_offsets(t.ids, nt * d.T, t.vscratch, t.vidx, t.vcount, d.T, d.Tp, conv3_dp(d.D) / 8 * 3, d.F, t.offA,
-                               t.offB, p, t.live, nW * d.T);
+                               t.offB, p, t.live, nW * d.T, (d.W - late_slots(d)) * q.n * d.T);
   {
     ProfScope _ps(c, "gather", p, true);
     static const int pf_blocks = getenv("LSTUR_PREFETCH_BLOCKS") ? atoi(getenv("LSTUR_PREFETCH_BLOCKS")) : 0;
@@ -1011,7 +1019,8 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   c->counted_flag() = false;
   // (offA: a token's window offset in the units of its path -- 16-byte pieces of E3, or floats of the fp32 layout)
   launch_compact_write_offsets(w.ids, nt * d.T, w.vscratch, w.vidx, w.vcount, d.T, d.Tp,
-                               (use3 && !gen1) ? conv3_dp(d.D) / 8 * 3 : d.D, d.F, w.offA, w.offB, s, w.live, nW * d.T);
+                               (use3 && !gen1) ? conv3_dp(d.D) / 8 * 3 : d.D, d.F, w.offA, w.offB, s, w.live, nW * d.T,
+                               (d.W - late_slots(d)) * n * d.T);
   if (use3 && !gen1)   // Embedding + Dropout straight into the pre-split layout of the bf16x3 conv kernels (rows nobody reads skipped)
   {
     ProfScope _ps(c, "gather", s, true);
@@ -1148,30 +1157,44 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
       (void)hipStreamWaitEvent(s, c->ev_w4, 0);
     }
   };
-  // the candidate titles' encoder backward, under the recurrence's backward (cand_split_wanted)
+  // the candidate titles' encoder backward, under the recurrence's backward (cand_split_wanted), and the late history
+  // slots' behind the first part of a recurrence backward cut in two (late_slots)
   const bool split = c->cand_forked && sw != s && !c->cfg.freeze_encoder;
   c->cand_forked = false;
   const int ncand = nt - nW;
-  int cand_slabs = 0;
-  if (split) {
+  const int Wl = split ? late_slots(d) : 0, Wh = d.W - Wl, nE = Wh * n, nL = nW - nE;   // early | late history titles
+  const bool late = Wl > 0 && has_gru && gemm3_supported(3 * d.H, 3 * d.H, nL, d.U, 3 * d.H) && gemm3_supported(d.U, d.U, nL, d.F, d.U);
+  // kernel-gradient slabs: [0] the side launches' slabs reduced ahead of time | the main launch's | the side launches'
+  const size_t slab_f = w.conv_w3 ? conv3_wgrad2_slab_floats(d.D, d.k, d.F) : 0;
+  const int main_slabs = split ? conv3_wgrad2_slabs(late ? nE : nW, d.T, d.D, d.k, d.F, c->conv_cus) : 0;
+  const int side_base = 1 + main_slabs;
+  int cand_slabs = 0, late_slabs = 0;
+  auto side_attention_and_kernel_gradient = [&](int title0, int count, int range_sel, int slab_base, int cus, int* slabs) {
     const int off_cb = 0, off_aw = (int)(c->G("att_w") - c->G("conv_b")), off_ab = (int)(c->G("att_b") - c->G("conv_b"));
     const int ldp = off_ab + 1;
+    {
+      ProfScope _ps(c, "attpool_bwd", sw);
+      launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, w.att_ds, nt, d.T, d.F,
+                         drop, key1, sw, ldp, off_aw, off_cb, off_ab, 1, w.live, w.kbits_valid ? w.kbits : nullptr, title0, count,
+                         title_order(d, n));
+    }
+    ProfScope _ps(c, "conv_wgrad", sw, true);
+    (void)launch_conv3_wgrad2(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, sw, nullptr, w.offA,
+                              w.offB, 1.0f, cus, range_sel, slab_base, count, slabs);
+  };
+  auto side_done = [&]() {   // the side launches' slabs -> slab 0 (off the critical path), then the join event
+    ReduceJob pre{(const float*)w.wgrad_scratch + (size_t)side_base * slab_f, (float*)w.wgrad_scratch, d.k * conv3_dp(d.D), d.F, d.F,
+                  cand_slabs + late_slabs, slab_f, 1.0f, 0.f};
+    launch_multi_reduce(&pre, 1, sw);
+    (void)hipEventRecord(c->ev_c1, sw);
+  };
+  if (split) {
     (void)hipStreamWaitEvent(sw, c->ev_c0, 0);
     forked = true;
     dense_gemm(w.ddocvec + (size_t)nW * d.U, d.U, c->P("dense_w"), d.U, true, w.dpooled + (size_t)nW * d.F, d.F, nullptr, ncand,
                d.F, d.U, nullptr, sw);
-    {
-      ProfScope _ps(c, "attpool_bwd", sw);
-      launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, w.att_ds, nt, d.T, d.F,
-                         drop, key1, sw, ldp, off_aw, off_cb, off_ab, 1, w.live, w.kbits_valid ? w.kbits : nullptr, nW, ncand,
-                         title_order(d, n));
-    }
-    {
-      ProfScope _ps(c, "conv_wgrad", sw, true);
-      (void)launch_conv3_wgrad2(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, sw, nullptr,
-                                w.offA, w.offB, 1.0f, 0, 2, 0, ncand, &cand_slabs);
-    }
-    (void)hipEventRecord(c->ev_c1, sw);
+    side_attention_and_kernel_gradient(nW, ncand, 2, side_base, 0, &cand_slabs);
+    if (!late) side_done();
   }
   // ONE event behind the recurrence serves both side streams (forks are merged wherever the dependencies allow), attached
   // to the recurrence kernel's own completion when nothing else sits between it and the fork
@@ -1183,10 +1206,27 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     float *hprev = w.hprev, *rh = w.rh;   // fast path: both already sit row-major in the tape (no copies)
     gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
     const bool attach = fork_b && !(user_row_drop(c) > 0.f) && !(c->prof_on && !c->prof_roofline_only);   // (a bracketed launch records behind it anyway)
+    if (late) {   // slots W - 1 .. Wh first; the late slots' encoder backward forks behind them
+      const bool attach_l = !(c->prof_on && !c->prof_roofline_only);
+      if (attach_l) arm_stop_event(c->ev_l0);
+      PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev, w.dh_mid, n, d.W, d.H, s, true,
+                                     d.W - 1, Wh));
+      if (!attach_l || stop_event_pending()) {
+        arm_stop_event(nullptr);
+        (void)hipEventRecord(c->ev_l0, s);
+      }
+      (void)hipStreamWaitEvent(sw, c->ev_l0, 0);
+      dense_gemm(w.dgates + (size_t)nE * 3 * d.H, 3 * d.H, c->P("gru_w"), 3 * d.H, true, w.ddocvec + (size_t)nE * d.U, d.U, nullptr,
+                 nL, d.U, 3 * d.H, nullptr, sw);
+      dense_gemm(w.ddocvec + (size_t)nE * d.U, d.U, c->P("dense_w"), d.U, true, w.dpooled + (size_t)nE * d.F, d.F, nullptr, nL, d.F,
+                 d.U, nullptr, sw);
+      side_attention_and_kernel_gradient(nE, nL, 4, side_base + cand_slabs, 240, &late_slabs);   // (16 CUs hold the recurrence)
+      side_done();
+    }
     if (attach) arm_stop_event(fe);
-    PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
+    PROF("gru_bwd", launch_gru_bwd(late ? w.dh_mid : dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
                                    (d.arch == LSTUR_ARCH_IGRU || two_tables(d)) ? w.duser : w.dh0, n, d.W,
-                                   d.H, s, d.slot != 0));
+                                   d.H, s, d.slot != 0, late ? Wh - 1 : -1, 0));
     fe_recorded = attach && !stop_event_pending();
     arm_stop_event(nullptr);
   }
@@ -1232,7 +1272,8 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   bool w2_recorded = false;
   if (has_gru) {
     if (sw != s) arm_stop_event(c->ev_w2);   // the Dense(U) parameter gradients fork behind this product
-    dense_gemm(w.dgates, 3 * d.H, c->P("gru_w"), 3 * d.H, true, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, w.gemm_scratch, s);
+    dense_gemm(w.dgates, 3 * d.H, c->P("gru_w"), 3 * d.H, true, w.ddocvec, d.U, nullptr, late ? nE : nW, d.U, 3 * d.H,
+               w.gemm_scratch, s);
     w2_recorded = sw != s && !stop_event_pending();
     arm_stop_event(nullptr);
   }
@@ -1259,7 +1300,8 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   }
   wgrad_gemm(w.pooled, d.F, w.ddocvec, d.U, c->G("dense_w"), d.U, d.F, d.U, nt, w.gemm_scratch_k[3], sw2, &jobs[nj++]);
   launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], sw2, &jobs[nj++]);
-  dense_gemm(w.ddocvec, d.U, c->P("dense_w"), d.U, true, w.dpooled, d.F, nullptr, split ? nW : nt, d.F, d.U, w.gemm_scratch, s);
+  dense_gemm(w.ddocvec, d.U, c->P("dense_w"), d.U, true, w.dpooled, d.F, nullptr, late ? nE : split ? nW : nt, d.F, d.U,
+             w.gemm_scratch, s);
   // partial sums laid out like the bucket slice conv_b .. att_b -> one reduction straight into dense_grad
   if (d.enc == LSTUR_ENC_MHSA) {
     // partial sums: datt_w | datt_b like the bucket slice att_w .. att_b, the (unused) column sums of dconv behind them
@@ -1289,7 +1331,8 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   const int ldp = off_ab + 1;
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
                                          w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 1, w.live,
-                                         w.kbits_valid ? w.kbits : nullptr, 0, split ? nW : nt, title_order(d, n)));
+                                         w.kbits_valid ? w.kbits : nullptr, 0, late ? nE : split ? nW : nt,
+                                         title_order(d, n)));
   if (split) (void)hipStreamWaitEvent(s, c->ev_c1, 0);   // the candidate titles' partial sums, gradient rows and slabs
   // (on the side stream this one found no free CU beside the conv kernel gradient and finished behind it)
   launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch_k[2], s, &jobs[nj++]);
@@ -1306,7 +1349,8 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   else if (w.conv_w3 && !conv_f32) {   // fp32-grade bf16x3 contraction (conv3f.hip), like the forward; one reduce job per tap
     ProfScope _ps(c, "conv_wgrad", s, true);
     nj += launch_conv3_wgrad2(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, s, &jobs[nj],
-                              w.offA, w.offB, 1.0f, c->conv_cus, split ? 1 : 0, cand_slabs, split ? nW : 0);
+                              w.offA, w.offB, 1.0f, c->conv_cus, late ? 3 : split ? 1 : 0, split ? 1 : 0,
+                              late ? nE : split ? nW : 0);
   } else
     PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
                                          w.vidx, w.vcount, s, w.offA, w.offB,
@@ -1353,12 +1397,22 @@ bool cand_split_wanted(lstur_ctx* c, int n) {
   if (d.head != LSTUR_HEAD_SOFTMAX || d.score != LSTUR_SCORE_DOT || !attpool_title_path(d.T, d.F)) return false;
   if (!gemm3_supported(d.U, d.U, n * d.K1, d.F, d.U) || !wgrad_stream(c)) return false;
   if (!c->ev_c0 && (hipEventCreateWithFlags(&c->ev_c0, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) != hipSuccess)) {
-    c->ev_c0 = c->ev_c1 = nullptr;
+                    hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&c->ev_l0, hipEventDisableTiming) != hipSuccess)) {
+    c->ev_c0 = c->ev_c1 = c->ev_l0 = nullptr;
     return false;
   }
   return true;
 }
+// The LATE history slots' share of the encoder backward (opt-in: LSTUR_LATE_SLOTS=n).  The recurrence's backward walks the
+// slots from the last to the first, so d(gate inputs) of the late slots are final long before it ends: with slot-major
+// titles (Dims::slot) they are a contiguous range of GRU rows, titles and tokens.  The launch is cut at slot W - n: behind
+// its first part the late slots' d(doc vectors) -> d(pooled) -> attention backward -> conv kernel gradient run on the
+// parameter-gradient stream while the second part walks the early slots on 16 CUs.  Measured at the config-2 shapes
+// (same box): n = 6 / 9 / 12 / 15 / 18 slots cost 30 / 40 / 39 / 45 / 42 us per step MORE than n = 0 -- the recurrence
+// stretches by 15-40 % beside the attention backward and the kernel gradient, a kernel gradient over a third of the tokens
+// takes 1.6 x its share, and what spills past the recurrence starves the main stream's products (trace in DESIGN.md 4c).
+int late_slots(const Dims& d) { return d.late; }
 
 // Listwise score model on (uservec [n, Uu], candidate doc vectors [n*k1, U]) (paper.py:443-464).
 //   scores != NULL: test model, sigmoid(score) for k1 == 1 (paper.py:661-665)
@@ -1719,6 +1773,11 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
   size_t need = c->ws.bytes;
   c->pipe_ok = lanes_supported(d);
   c->d.slot = slot_major_wanted(d) ? 1 : 0;
+  {
+    const char* ls = getenv("LSTUR_LATE_SLOTS");
+    const int want = ls ? atoi(ls) : 0;
+    c->d.late = (c->d.slot && want >= 1 && want < d.W) ? want : 0;
+  }
   if (c->pipe_ok) {
     c->d1 = lane1_dims(d);
     carve(c->d1, (char*)buf->workspace + need, &c->ws1);
@@ -1765,6 +1824,7 @@ int lstur_destroy(lstur_ctx* ctx) {
     if (ctx->ev_w4) (void)hipEventDestroy(ctx->ev_w4);
     if (ctx->ev_c0) (void)hipEventDestroy(ctx->ev_c0);
     if (ctx->ev_c1) (void)hipEventDestroy(ctx->ev_c1);
+    if (ctx->ev_l0) (void)hipEventDestroy(ctx->ev_l0);
   }
   if (ctx)
     for (auto& k : ctx->prof)

@@ -101,7 +101,8 @@ void launch_permute_titles(const int32_t* src, int32_t* dst, int n_titles, int T
 void launch_compact_count(const int32_t* ids, int n, int32_t* block_counts, hipStream_t s);
 void launch_compact_write_offsets(const int32_t* ids, int n, const int32_t* block_counts, int32_t* vidx, int32_t* count,
                                   int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s,
-                                  uint32_t* live = nullptr, int split_at = -1);   // count[1] = non-pad tokens in front of token split_at   // live != NULL: + the titles' non-pad bit masks
+                                  uint32_t* live = nullptr, int split_at = -1,   // count[1] = non-pad tokens in front of token split_at
+                                  int split_at2 = -1);                            // count[2]: the same for a second boundary   // live != NULL: + the titles' non-pad bit masks
 size_t pack_b_floats(int K, int N);
 void launch_pack_b(const float* B, int ldb, int K, int N, float* packed, hipStream_t s);
 void launch_pack_b_t(const float* Bt, int ldb, int K, int N, float* packed, hipStream_t s);
@@ -242,6 +243,8 @@ void launch_conv3_fwd2(const unsigned short* e3, const unsigned short* W3, const
 // kernel gradient on the pre-split embeddings (same file): dw through ksize reduce jobs (one per tap); returns the job
 // count.  offA: per-token window offsets in 16-byte pieces of E3, offB: per-token row offsets in floats of dout.
 size_t conv3_wgrad2_scratch_bytes(int n_titles, int T, int D, int ksize, int F);
+int conv3_wgrad2_slabs(int plan_titles, int T, int D, int ksize, int F, int cus = 0);   // slabs a launch planned for these titles writes
+size_t conv3_wgrad2_slab_floats(int D, int ksize, int F);                              // floats of one slab ([k * Dp, F])
 int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
                         int ksize, int F, const int32_t* vcount, hipStream_t s, ReduceJob* jobs, const int32_t* offA,
                         const int32_t* offB, float alpha = 1.0f, int cus = 0, int range_sel = 0, int slab_base = 0,

@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void compact_write_offsets_kernel(const int32_
                                                                     int32_t* __restrict__ count_out, int T, int Tp, int D,
                                                                     int F, int32_t* __restrict__ offA,
                                                                     int32_t* __restrict__ offB, int nblk,
-                                                                    uint32_t* __restrict__ live, int split_at) {
+                                                                    uint32_t* __restrict__ live, int split_at,
+                                                                    int split_at2) {
   if ((int)blockIdx.x >= nblk) {   // trailing blocks: bit t of live[title] = token t is not a pad (t < 32): the attention
     const int title = ((int)blockIdx.x - nblk) * 256 + threadIdx.x;   // kernels read ONE scalar per title instead of ids
     if (title * T < n) {
@@ -361,11 +362,18 @@ __global__ __launch_bounds__(256) void compact_write_offsets_kernel(const int32_
   int pos = base + block_exclusive_scan_256(c, &total);
   // count_out[1]: the non-pad tokens in front of token `split_at` (a title boundary: history | candidates) -- the compacted
   // list is ascending, so [0, count_out[1]) and [count_out[1], count_out[0]) are the two title ranges' tokens
+  // (count_out[2]: the same for a second boundary in front of it -- early | late history slots of a slot-major step)
   if (i0 <= split_at && split_at < i0 + 4) {
     int before = pos;
 #pragma unroll
     for (int k = 0; k < 4; ++k) before += (i0 + k < split_at && v[k]) ? 1 : 0;
     count_out[1] = before;
+  }
+  if (i0 <= split_at2 && split_at2 < i0 + 4) {
+    int before = pos;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) before += (i0 + k < split_at2 && v[k]) ? 1 : 0;
+    count_out[2] = before;
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k)
@@ -382,16 +390,17 @@ __global__ __launch_bounds__(256) void compact_write_offsets_kernel(const int32_
   if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) {
     count_out[0] = base + total;
     if (split_at >= nblk * kCompactBlock || split_at < 0) count_out[1] = base + total;   // (no thread owns that index)
+    if (split_at2 >= nblk * kCompactBlock || split_at2 < 0) count_out[2] = base + total;
   }
 }
 size_t compact_scratch_ints(int n) { return (size_t)cdiv(n, kCompactBlock); }
 void launch_compact_write_offsets(const int32_t* ids, int n, const int32_t* block_counts, int32_t* vidx, int32_t* count,
                                   int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s,
-                                  uint32_t* live, int split_at) {
+                                  uint32_t* live, int split_at, int split_at2) {
   if (n <= 0) return;
   const int nblk = cdiv(n, kCompactBlock), lblk = live ? cdiv(n / T, 256) : 0;
   hipLaunchKernelGGL(compact_write_offsets_kernel, dim3(nblk + lblk), dim3(256), 0, s, ids, n, block_counts, vidx, count, T,
-                     Tp, D, F, offA, offB, nblk, live, split_at < 0 ? n : split_at);
+                     Tp, D, F, offA, offB, nblk, live, split_at < 0 ? n : split_at, split_at2 < 0 ? n : split_at2);
 }
 void launch_compact_count(const int32_t* ids, int n, int32_t* block_counts, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(compact_count_kernel, dim3(cdiv(n, kCompactBlock)), dim3(256), 0, s, ids, n, block_counts);
