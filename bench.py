@@ -434,20 +434,35 @@ def main():
                             flop_per_launch=flop, operand_dtype=model.mhsa_proj_dtype)
         if prof and not mhsa:
             dom = max(('conv_fwd', 'conv_wgrad'), key=lambda k: kern[k]['avg_us'])
-            ach = conv_flop / (kern[dom]['avg_us'] * 1e-6) / 1e12
+            dom_flop = conv_flop
+            side = None
+            if dom == 'conv_wgrad' or 'conv_wgrad_side' in kern:
+                # the kernel gradient is two launches when the candidate titles' share runs beside the recurrence
+                # (family conv_wgrad_side, off the critical path): each is priced on the tokens it contracts over
+                hist_tok = float(np.mean([(titles[h] != 0).sum() for _, h, c in batches]))
+                if 'conv_wgrad_side' in kern:
+                    side_flop = conv_flop * (real_tok - hist_tok) / real_tok
+                    side = dict(kernel='conv_wgrad_side', avg_us=round(kern['conv_wgrad_side']['avg_us'], 1), flop_per_launch=side_flop,
+                                frac=round(side_flop / (kern['conv_wgrad_side']['avg_us'] * 1e-6) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4),
+                                note='candidate titles\' tokens: a launch of its own on the side stream under the recurrence\'s backward')
+                    if dom == 'conv_wgrad':
+                        dom_flop = conv_flop * hist_tok / real_tok
+            ach = dom_flop / (kern[dom]['avg_us'] * 1e-6) / 1e12
             bf16x3 = model.conv_scheme == 'bf16x3'
             # bf16x3 (conv3.hip): every fp32-grade product is SIX bf16 MFMA products, so the kernel's roofline is the
             # dense bf16 matrix peak / 6; the exact-fp32 MFMA kernels (LSTUR_CONV_F32=1) are priced against the fp32 peak
             peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if bf16x3 else PEAK_F32_MFMA_TFLOPS
             roofline = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s',
                             frac=round(ach / peak, 4), traffic=traffic(dom),
-                            avg_us=round(kern[dom]['avg_us'], 1), flop_per_launch=conv_flop,
+                            avg_us=round(kern[dom]['avg_us'], 1), flop_per_launch=dom_flop,
                             non_pad_token_fraction=round(real_tok / n_tok, 4),
-                            effective_algorithmic=round(conv_flop_full / (kern[dom]['avg_us'] * 1e-6) / 1e12, 2),
+                            effective_algorithmic=round(conv_flop_full * dom_flop / conv_flop / (kern[dom]['avg_us'] * 1e-6) / 1e12, 2),
                             scheme=('bf16x3: 3-way bf16 split of both fp32 operands, 6 MFMA products, fp32 accumulate '
                                     '(fp32-grade; peak = 2500 TFLOP/s dense bf16 / 6)') if bf16x3 else 'fp32 MFMA 16x16x4',
                             mfma_executed_tflops=round(ach * (6.0 if bf16x3 else 1.0), 1),
                             frac_vs_fp32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 4))
+            if side:
+                roofline['side_launch'] = side
         if prof:
             gb = gather_bytes / (kern['gather']['avg_us'] * 1e-6) / 1e9
             roofline_gather = dict(kernel='gather', bound='hbm', achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit='GB/s',

@@ -472,7 +472,10 @@ int conv3_wgrad2_slabs(int plan_titles, int T, int D, int ksize, int F, int cus)
 }
 size_t conv3_wgrad2_slab_floats(int D, int ksize, int F) { return (size_t)ksize * conv3_dp(D) * F; }
 
-template <int OPT = 0>   // OPT != 0: timing-only ablations (WRONG results; LSTUR_WGRAD_ABLATE, tools/bench_conv3f.py)
+// OPT != 0: timing-only ablations (WRONG results; LSTUR_WGRAD_ABLATE, tools/bench_conv3f.py).  SIDE: the same kernel under
+// another name -- the launches over a title sub-range that a step runs beside the recurrence show up as their own line in
+// rocprof summaries and PMC passes
+template <int OPT = 0, bool SIDE = false>
 __global__ __launch_bounds__(G2_THREADS, 2) void conv3_wgrad2_kernel(
     const unsigned short* __restrict__ E3, uint32_t e_bytes, const float* __restrict__ G, uint32_t g_bytes,
     float* __restrict__ slabs, const int32_t* __restrict__ vcount, int M, int F, int Kq, int mblocks, int nblocks, int nslabs,
@@ -668,7 +671,7 @@ int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, 
   static const int ablate = getenv("LSTUR_WGRAD_ABLATE") ? atoi(getenv("LSTUR_WGRAD_ABLATE")) : 0;
   auto kern = ablate == 1 ? conv3_wgrad2_kernel<1> : ablate == 2 ? conv3_wgrad2_kernel<2> : ablate == 3 ? conv3_wgrad2_kernel<3> :
               ablate == 4 ? conv3_wgrad2_kernel<4> : ablate == 7 ? conv3_wgrad2_kernel<7> : ablate == 15 ? conv3_wgrad2_kernel<15> :
-                            conv3_wgrad2_kernel<0>;
+              (vcount && (range_sel == 2 || range_sel == 4)) ? conv3_wgrad2_kernel<0, true> : conv3_wgrad2_kernel<0, false>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2_LDS);
   // (the scratch is sized for the full-chip slab count; fewer CUs -> fewer slabs)
   const int Mp = (plan_titles > 0 ? plan_titles : n_titles) * T;

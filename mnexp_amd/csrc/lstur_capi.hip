@@ -575,7 +575,7 @@ struct ProfScope {
   ProfScope(lstur_ctx* ctx, const char* name, hipStream_t st, bool attach = false) : c(ctx), s(st) {
     if (!c->prof_on) return;
     if (c->prof_roofline_only && strcmp(name, "gather") && strcmp(name, "conv_fwd") && strcmp(name, "conv_wgrad") &&
-        strcmp(name, "qkv_proj") && strcmp(name, "qkv_wgrad"))
+        strcmp(name, "conv_wgrad_side") && strcmp(name, "qkv_proj") && strcmp(name, "qkv_wgrad"))
       return;
     k = c->prof_slot(name);
     if (k->used == k->start.size()) {
@@ -1172,13 +1172,13 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   auto side_attention_and_kernel_gradient = [&](int title0, int count, int range_sel, int slab_base, int cus, int* slabs) {
     const int off_cb = 0, off_aw = (int)(c->G("att_w") - c->G("conv_b")), off_ab = (int)(c->G("att_b") - c->G("conv_b"));
     const int ldp = off_ab + 1;
-    {
-      ProfScope _ps(c, "attpool_bwd", sw);
+    {   // (families of their own in the profile: these launches run beside the recurrence, off the critical path)
+      ProfScope _ps(c, "attpool_bwd_side", sw);
       launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, w.att_ds, nt, d.T, d.F,
                          drop, key1, sw, ldp, off_aw, off_cb, off_ab, 1, w.live, w.kbits_valid ? w.kbits : nullptr, title0, count,
                          title_order(d, n));
     }
-    ProfScope _ps(c, "conv_wgrad", sw, true);
+    ProfScope _ps(c, "conv_wgrad_side", sw, true);
     (void)launch_conv3_wgrad2(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, sw, nullptr, w.offA,
                               w.offB, 1.0f, cus, range_sel, slab_base, count, slabs);
   };
