@@ -341,8 +341,10 @@ int lstur_conv3_relu_mask_fwd(const float* emb_padded, const uint16_t* w3, const
  * the three bf16 parts of every element into "E3" ([title][title_len + ksize - 1][ceil8(dim) / 8][part][8] bf16,
  * lstur_conv3_e3_elems() elements incl. slack; Embedding + Dropout of task/paper.py:132-147 like lstur_gather_f32;
  * skip_unread != 0: rows that no window of a non-pad token covers are left untouched -- e3 must then hold finite values), the
- * weight image w3 = lstur_conv3_pack_w2(conv_w) holds lstur_conv3_w3_elems2() elements.  variant 0 (10 .. 15 are timing-only
- * ablation builds with WRONG results, tools/bench_conv3f.py).  scratch: lstur_conv3_fwd2_scratch() bytes for the k-sliced
+ * weight image w3 = lstur_conv3_pack_w2(conv_w) holds lstur_conv3_w3_elems2() elements.  variant 0; 2 = the tap-sharing
+ * kernel (ksize 3, ceil8(dim) % 16 == 0, else the same as 0: each embedding row staged once per workgroup for the three
+ * taps -- a third of the fetch, measured 13 % slower); 10 .. 16 are timing-only ablation builds with WRONG results
+ * (tools/bench_conv3f.py).  scratch: lstur_conv3_fwd2_scratch() bytes for the k-sliced
  * tiles of the last partial round of workgroups, or NULL (every tile runs whole). */
 size_t lstur_conv3_e3_elems(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize);
 int lstur_gather_split3(const float* table, const int32_t* ids, uint16_t* e3, int32_t n_titles, int32_t title_len,

@@ -340,6 +340,301 @@ __global__ __launch_bounds__(RW* CW * 64, MT == 1 ? 2 : 1) void conv3_fwd2_kerne
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// A third take on the forward, for ksize == 3 and Dp % 16 == 0 (the reference's Conv1D(400, 3) on 300-d embeddings) -- OPT-IN
+// (variant 2 / LSTUR_CONV_FWD3=1: measured slower, see the end of this comment): the TAPS SHARE the embedding rows on chip.  A token's window is the three padded rows g, g + 1, g + 2 of its title;
+// conv3_fwd2 fetches the window of every token on its own, so a row that three neighbouring tokens cover is fetched three
+// times, ~19 k-steps apart -- from L2 / the Infinity Cache at best (PMC: 407 MB fetched for 133 MB of embeddings).  Here
+// the contraction runs chunk-major: for each 16-wide slice c of the embedding dimension the DISTINCT rows of the tile
+// (128 tokens in 5-8 titles: ~140 rows; 384 when every token stands alone) are staged ONCE as an LDS image
+// [part][row][16], and the three taps read it at rows lrow, lrow + 1, lrow + 2 (lrow: rank of the token's row g among the
+// tile's rows -- the rows a token needs are consecutive in E3 and therefore consecutive in the image).  The weight slice
+// of step (c, tap) is rows tap * Dp + 16 c .. + 16 of the same W3 image as before.  A fetch: 1/3 .. 1/2.7 of before, and
+// as many fewer 16-byte LDS stores.  The image is single-buffered (384 rows x 3 parts = 36 KB; the weight stages stay
+// double-buffered: 92 KB): the next slice's rows wait in registers and are stored behind a barrier of their own when
+// the last tap of a slice is through -- 19 extra barriers per tile.
+// Everything else (tile plan, k-slices of the tail tiles, column groups, epilogue) is conv3_fwd2's.
+// Measured (tools/bench_conv3f.py, same box): 249 us against 221 us for conv3_fwd2 (a first form that kept a whole slice's
+// pieces in registers and stored them behind an extra barrier: 223-226 us).  Both forms sit at the 256-register limit and
+// the compiler gives up the counted LDS waits of the B-fragment double buffer (lgkmcnt(0) in front of most MFMA groups):
+// the kernel is bound by MFMA issue, not by the bytes the sharing saves.
+// ---------------------------------------------------------------------------------------------
+constexpr int F3_AROWS = 384;                                 // rows of the shared A image: 128 tokens x 3 taps at most
+constexpr int F3_AIMG = F3_AROWS * F2_BK;
+// one weight stage: three images [16][SB] + a 16-byte trash slot per lane (pieces past a tile image: no exec-mask branches)
+__host__ __device__ constexpr int f3_stage_b(int CW, int NTW) { return 3 * F2_BK * f2_sb(CW, NTW) + 64 * 8; }
+__host__ __device__ constexpr size_t f3_lds(int CW, int NTW) {
+  return (3 * F3_AIMG + 2 * f3_stage_b(CW, NTW)) * sizeof(unsigned short) + (3 * 128 + F3_AROWS) * sizeof(int32_t);
+}
+
+template <int CW, int NTW>
+__global__ __launch_bounds__(4 * CW * 64, 2) void conv3_fwd3_kernel(
+    const unsigned short* __restrict__ E3, uint32_t e_bytes, const unsigned short* __restrict__ W3,
+    const float* __restrict__ bias, const int32_t* __restrict__ ids, float* __restrict__ C,
+    const int32_t* __restrict__ vidx, const int32_t* __restrict__ vcount, int M, int T, int Tp, int Dp8, int F, int Kp,
+    int Np, int ncu, float* __restrict__ slabs) {
+  constexpr int RW = 4, BM = 128, NTH = RW * CW * 64, SB = f2_sb(CW, NTW), BCOLS = CW * NTW * 32;
+  constexpr int B_IMG = F2_BK * SB, STAGE_B = f3_stage_b(CW, NTW);
+  constexpr int A_SUB = (F3_AROWS * 6 + 3 * NTH - 1) / (3 * NTH);     // 16-byte pieces (row, k-half, part) per thread and STEP:
+                                                                      // a slice's pieces go out in three sub-batches
+  constexpr int B_CH = 3 * F2_BK * (BCOLS / 8), B_PER = (B_CH + NTH - 1) / NTH;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short* aimg = smem;                                        // [3][F3_AROWS][16]
+  unsigned short* bst = smem + 3 * F3_AIMG;                           // two weight stages
+  int32_t* rowm = (int32_t*)(bst + 2 * STAGE_B);                      // output row of each tile row (-1: none)
+  float* rowkeep = (float*)(rowm + BM);                               // 1 / 0: id != 0
+  int32_t* lrow = (int32_t*)(rowkeep + BM);                           // image row of the token's first tap
+  int32_t* grow = lrow + BM;                                          // E3 row of every image row
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int trash_b = STAGE_B - 64 * 8 + lane * 8;                    // inside a weight stage
+  const int trash = 3 * F3_AIMG + trash_b;                            // (the A loader borrows stage 0's)
+  const int count = vcount ? vcount[0] : M;
+  const TailPlan tp = tail_plan(count, BM, ncu);
+  int tile = blockIdx.x, ks = 0;
+  if (tile >= tp.full) {
+    const int r = tile - tp.full;
+    tile = tp.full + r / tp.S;
+    ks = r - (r / tp.S) * tp.S;
+  }
+  const int m0 = tile * BM;
+  if (m0 >= count) return;
+  const bool sliced = tile >= tp.full && tp.S > 1;
+  const int NT = Np / 32;
+  const int wm = wv % RW, wn = wv / RW;
+  const int nt_lo = wn * NTW;
+  const int my_nt = max(0, min(NTW, NT - nt_lo));                     // scalar (wave-uniform by construction)
+  const int Dp = Dp8 * 8;
+
+  // ---- the tile's tokens, their E3 rows and the image rows they map to
+  if (tid < BM) {
+    const int i = min(m0 + tid, count - 1);
+    const int m = vidx ? vidx[i] : i;
+    const int title = m / T, t = m - title * T;
+    rowm[tid] = (m0 + tid < count) ? m : -1;
+    rowkeep[tid] = ids[m] != 0 ? 1.f : 0.f;
+    grow[tid] = title * Tp + t;                                        // (scratch: the tokens' rows g, overwritten below)
+  }
+  __syncthreads();
+  int my_l = 0, my_g = 0;
+  if (tid < BM) {
+    my_g = grow[tid];
+    int dlt = tid == 0 ? 0 : min(3, my_g - grow[tid - 1]);            // new image rows this token brings (0 past the count)
+    // inclusive scan over the 128 tokens: inside each wave by shuffles, wave 1 adds wave 0's total
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(dlt, o, 64);
+      if (lane >= o) dlt += v;
+    }
+    my_l = dlt;
+    if (tid == 63) lrow[0] = dlt;                                      // (scratch: wave 0's total)
+  }
+  __syncthreads();
+  if (tid >= 64 && tid < BM) my_l += lrow[0];
+  __syncthreads();
+  if (tid < BM) {
+    lrow[tid] = my_l;
+    grow[my_l] = my_g;                                                 // consecutive E3 rows: every image row is written
+    grow[my_l + 1] = my_g + 1;                                         // with the same value by every token that covers it
+    grow[my_l + 2] = my_g + 2;
+  }
+  __syncthreads();
+  const int R = lrow[BM - 1] + 3;                                      // image rows of this tile (<= 384)
+  // A loader role: piece idx = row * 6 + q, q = k-half * 3 + part: the six pieces of a row and slice are 96 contiguous bytes.
+  // Sub-batch b (one per step of the slice before) carries pieces idx = tid + (b * A_SUB + u) * NTH.
+  uint32_t a_off[3][A_SUB];
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int u = 0; u < A_SUB; ++u) {
+      const int idx = tid + (b * A_SUB + u) * NTH, arow = idx / 6, q = idx - arow * 6;
+      a_off[b][u] = arow < R ? ((uint32_t)grow[min(arow, F3_AROWS - 1)] * (uint32_t)Dp8 * 3u + (uint32_t)q) * 16u : kBufOob;
+    }
+  // A tile with at most half the image's rows (the usual case: ~140) keeps TWO slices in it, rows [0, 192) and [192, 384):
+  // the next slice is stored beside the one in use, a sub-batch per step, with no barrier of its own.  A tile with more rows
+  // (tokens scattered over many tiny titles) loads each slice in the open behind its last tap: correct, slow, rare.
+  const bool dbl = R <= F3_AROWS / 2;
+  constexpr int A_HALF = F3_AROWS / 2 * F2_BK;
+  auto a_dst = [&](int b, int u, int base) {     // LDS element of piece (b, u); past the tile's rows: the trash slot
+    const int idx = tid + (b * A_SUB + u) * NTH, arow = idx / 6, q = idx - arow * 6, seg = q / 3, part = q - seg * 3;
+    return arow < R ? base + part * F3_AIMG + arow * F2_BK + ((seg ^ ((arow >> 3) & 1)) << 3) : trash;
+  };
+  // B loader role: pieces of 16 bytes (8 columns) of the 3 x [16][BCOLS] window of the weight parts
+  uint32_t b_goff[B_PER];
+  int b_loff[B_PER];
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int idx = tid + i * NTH;
+    constexpr int C8 = BCOLS / 8;
+    const int img = idx / (F2_BK * C8), rem = idx - img * (F2_BK * C8), krow = rem / C8, ch = rem - krow * C8;
+    const bool use = idx < B_CH && ch * 8 < Np;
+    b_goff[i] = use ? (((uint32_t)img * (uint32_t)Kp + (uint32_t)krow) * (uint32_t)Np + (uint32_t)(ch * 8)) * 2u : kBufOob;
+    b_loff[i] = use ? img * B_IMG + krow * SB + ch * 8 : trash_b;
+  }
+  const __amdgpu_buffer_rsrc_t rsE = make_rsrc(E3, e_bytes);
+  const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W3, (uint32_t)((size_t)3 * Kp * Np * 2));
+
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float4 ra[A_SUB];
+  float4 rb[B_PER];
+  // step s = 3 c + tap: slice c of the embedding dimension (16 wide), weight rows tap * Dp + 16 c
+  auto load_a = [&](int c, auto b_tag) {
+    constexpr int b = decltype(b_tag)::value;
+#pragma unroll
+    for (int u = 0; u < A_SUB; ++u) ra[u] = buf_load4(rsE, a_off[b][u], (uint32_t)c * 96u);
+  };
+  auto store_a = [&](int c, auto b_tag) {
+    constexpr int b = decltype(b_tag)::value;
+    const int base = (dbl && (c & 1)) ? A_HALF : 0;
+#pragma unroll
+    for (int u = 0; u < A_SUB; ++u) *(float4*)(smem + a_dst(b, u, base)) = ra[u];
+  };
+  typedef std::integral_constant<int, 0> B0;
+  typedef std::integral_constant<int, 1> B1;
+  typedef std::integral_constant<int, 2> B2;
+  auto fill_a = [&](int c) {            // a whole slice in the open (the first one; every one of a tile with > 192 rows)
+    load_a(c, B0()); store_a(c, B0());
+    load_a(c, B1()); store_a(c, B1());
+    load_a(c, B2()); store_a(c, B2());
+  };
+  auto load_b = [&](int s) {
+    const int c = s / 3, tap = s - c * 3;
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) rb[i] = buf_load4(rsW, b_goff[i], (uint32_t)(tap * Dp + c * F2_BK) * (uint32_t)Np * 2u);
+  };
+  auto store_b = [&](int buf) {
+    unsigned short* st = bst + buf * STAGE_B;
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) *(float4*)(st + b_loff[i]) = rb[i];
+  };
+
+  // k-slices of the tail tiles are cut at slice boundaries (whole triples of steps)
+  const int nch = Kp / (3 * F2_BK);                                    // Dp / 16 slices
+  const int c0 = sliced ? ks * nch / tp.S : 0, c1 = sliced ? (ks + 1) * nch / tp.S : nch;
+  const int s0 = 3 * c0, s1 = 3 * c1;
+  if (c0 < c1) {
+    fill_a(c0);
+    load_b(s0);
+    store_b(s0 & 1);
+    load_b(s0 + 1);
+    if (dbl && c0 + 1 < c1) load_a(c0 + 1, B0());
+  }
+  __syncthreads();
+
+  const int tok_row = 32 * wm + (lane & 31), hh = lane >> 5;
+  const int lr = lrow[tok_row];
+  auto kloop = [&](auto na_tag) {
+    constexpr int NA = decltype(na_tag)::value;
+    auto step = [&](int c, auto tap_tag) {
+      constexpr int tap = decltype(tap_tag)::value;
+      const int s = 3 * c + tap;
+      const bool more = c + 1 < c1;                // another slice follows: its sub-batch `tap` is in ra (dbl)
+      if (s + 1 < s1) {
+        store_b((s + 1) & 1);
+        if (s + 2 < s1) load_b(s + 2);
+      }
+      if (dbl && more) {
+        store_a(c + 1, tap_tag);
+        if (tap == 0) load_a(c + 1, B1());
+        if (tap == 1) load_a(c + 1, B2());
+        if (tap == 2 && c + 2 < c1) load_a(c + 2, B0());
+      }
+      if constexpr (NA > 0) {
+        const int rho = lr + tap;
+        const unsigned short* ap = aimg + ((dbl && (c & 1)) ? A_HALF : 0) + rho * F2_BK + ((hh ^ ((rho >> 3) & 1)) << 3);
+        const u16x8 ah = *(const u16x8*)ap, am = *(const u16x8*)(ap + F3_AIMG), al = *(const u16x8*)(ap + 2 * F3_AIMG);
+        const unsigned short* bp = bst + (s & 1) * STAGE_B;
+        auto frags = [&](int j, u16x8 (&b)[3]) {
+          const int x0 = (wn * NTW + j) * 32;
+          b[0] = tr_frag(bp, SB, 0, x0, lane);
+          b[1] = tr_frag(bp + B_IMG, SB, 0, x0, lane);
+          b[2] = tr_frag(bp + 2 * B_IMG, SB, 0, x0, lane);
+        };
+        auto six = [&](int j, const u16x8 (&b)[3]) {
+          f32x16 cc = acc[j];
+          cc = mfma32b(al, b[0], cc);       // small terms first
+          cc = mfma32b(ah, b[2], cc);
+          cc = mfma32b(am, b[1], cc);
+          cc = mfma32b(am, b[0], cc);
+          cc = mfma32b(ah, b[1], cc);
+          cc = mfma32b(ah, b[0], cc);
+          acc[j] = cc;
+        };
+        u16x8 bA[3], bB[3];
+        frags(0, bA);
+#pragma unroll
+        for (int j = 0; j < NA; j += 2) {
+          if (j + 1 < NA) frags(j + 1, bB);
+          six(j, bA);
+          if (j + 2 < NA) frags(j + 2, bA);
+          if (j + 1 < NA) six(j + 1, bB);
+        }
+      }
+      __syncthreads();
+    };
+    for (int c = c0; c < c1; ++c) {
+      step(c, B0());
+      step(c, B1());
+      step(c, B2());
+      if (!dbl && c + 1 < c1) {          // (block-uniform) the image makes room for the next slice
+        fill_a(c + 1);
+        __syncthreads();
+      }
+    }
+  };
+  static_assert(NTW <= 7, "one k-loop instance per live tile count");
+  switch (my_nt) {
+    case 7: if constexpr (NTW >= 7) kloop(std::integral_constant<int, 7>()); break;
+    case 6: if constexpr (NTW >= 6) kloop(std::integral_constant<int, 6>()); break;
+    case 5: if constexpr (NTW >= 5) kloop(std::integral_constant<int, 5>()); break;
+    case 4: if constexpr (NTW >= 4) kloop(std::integral_constant<int, 4>()); break;
+    case 3: if constexpr (NTW >= 3) kloop(std::integral_constant<int, 3>()); break;
+    case 2: if constexpr (NTW >= 2) kloop(std::integral_constant<int, 2>()); break;
+    case 1: kloop(std::integral_constant<int, 1>()); break;
+    default: kloop(std::integral_constant<int, 0>()); break;
+  }
+
+  const int c32 = lane & 31;
+  if (sliced) {
+    float* slab = slabs + ((size_t)(tile - tp.full) * tp.S + ks) * (size_t)(BM * BCOLS);
+    const __amdgpu_buffer_rsrc_t rsS = make_rsrc(slab, (uint32_t)(BM * BCOLS * 4));
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int col = (wn * NTW + j) * 32 + c32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr2 = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        buf_store1(acc[j][r], rsS, j < my_nt ? (uint32_t)(lr2 * BCOLS + col) * 4u : kBufOob, 0);
+      }
+    }
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(C, (uint32_t)std::min((size_t)M * F * 4, (size_t)0xFFFFFFFFu));
+  const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias, (uint32_t)F * 4u);
+  int orow[16];
+  float okeep[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int lr2 = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    orow[r] = rowm[lr2];
+    okeep[r] = rowkeep[lr2];
+  }
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int col = (nt_lo + j) * 32 + c32;
+    const bool cok = j < my_nt && col < F;
+    const float bv = buf_load1(rsBias, cok ? (uint32_t)col * 4u : kBufOob, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      buf_store1(fmaxf(acc[j][r] + bv, 0.f) * okeep[r], rsC,
+                 (cok && orow[r] >= 0) ? ((uint32_t)orow[r] * (uint32_t)F + (uint32_t)col) * 4u : kBufOob, 0);
+  }
+}
+
 // Epilogue of the k-sliced tiles: out[token] = relu(bias + sum over slices, in slice order) x (id != 0).
 // grid (ncu / 2 tiles at most, 64 row pairs); one thread = one column quad of one row, all slice loads in flight at once
 __global__ __launch_bounds__(256) void conv3_fwd2_fix_kernel(const float* __restrict__ slabs, const float* __restrict__ bias,
@@ -411,12 +706,22 @@ void launch_conv3_fwd2(const unsigned short* e3, const unsigned short* W3, const
               variant == 14 ? conv3_fwd2_kernel<4, 2, 7, 1, 16> : variant == 15 ? conv3_fwd2_kernel<4, 2, 7, 1, 32> :
               variant == 16 ? conv3_fwd2_kernel<4, 2, 7, 1, 64> :
                               conv3_fwd2_kernel<4, 2, 7, 1, 0>;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f2_lds(4, 2, 7));
   // grid: every tile as a plain tile, or whole rounds + at most ncu slices (the device decides from the token count)
   const int grid = tiles + ncu;
   if (ncu <= 0) last_launch();
-  launch_k(kern, dim3(grid), dim3(512), f2_lds(4, 2, 7), s, e3, e_bytes, W3, bias, ids, out, vidx, vcount, M, T, Tp, Dp / 8, F,
-           Kp, Np, ncu, (float*)scratch);
+  // variant 2 (or LSTUR_CONV_FWD3=1 for variant 0): the tap-sharing kernel where it applies -- opt-in: it fetches a third
+  // of the embedding bytes and takes 13 % longer
+  static const bool want3 = getenv("LSTUR_CONV_FWD3") != nullptr;
+  if ((variant == 2 || (variant == 0 && want3)) && ksize == 3 && Dp % 16 == 0) {
+    auto k3 = conv3_fwd3_kernel<2, 7>;
+    (void)hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f3_lds(2, 7));
+    launch_k(k3, dim3(grid), dim3(512), f3_lds(2, 7), s, e3, e_bytes, W3, bias, ids, out, vidx, vcount, M, T, Tp, Dp / 8, F, Kp, Np,
+             ncu, (float*)scratch);
+  } else {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f2_lds(4, 2, 7));
+    launch_k(kern, dim3(grid), dim3(512), f2_lds(4, 2, 7), s, e3, e_bytes, W3, bias, ids, out, vidx, vcount, M, T, Tp, Dp / 8, F,
+             Kp, Np, ncu, (float*)scratch);
+  }
   if (ncu > 0) {
     last_launch();
     launch_k(conv3_fwd2_fix_kernel, dim3(8, 64), dim3(256), 0, s, (const float*)scratch, bias, ids, out, vidx, vcount, M, F,

@@ -2232,7 +2232,8 @@ int lstur_conv3_relu_mask_fwd2(const uint16_t* e3, const uint16_t* w3, const flo
   if (!e3 || !w3 || !bias || !ids || !out) return fail(LSTUR_ERR_ARG, "conv3_fwd2: NULL");
   if (!conv3f_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
   if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "conv3_fwd2: vidx and vcount go together");
-  if (variant != 0 && (variant < 10 || variant > 16)) return fail(LSTUR_ERR_ARG, "conv3_fwd2: variant 0 (10 .. 16: ablations)");
+  if (variant != 0 && variant != 2 && (variant < 10 || variant > 16))
+    return fail(LSTUR_ERR_ARG, "conv3_fwd2: variant 0 (2: the tap-sharing kernel, 10 .. 16: ablations)");
   if (conv3_e3_elems(n_titles, title_len, dim, ksize) * 2 >= ((size_t)1 << 32) ||
       (size_t)n_titles * title_len * filters * 4 >= ((size_t)1 << 32))
     return fail(LSTUR_ERR_ARG, "conv3_fwd2: more than 4 GiB of embeddings / outputs per call");

@@ -577,6 +577,13 @@ def test_conv3_fwd2_presplit_is_fp32_grade(N, D, T, F, k, sliced):
     else:
         assert torch.equal(out2[valid], out[valid])
     assert (out2[~valid] == -7.0).all()
+    # the opt-in tap-sharing kernel (variant 2; taken for ksize == 3 and Dp % 16 == 0, else the call falls back): same bounds
+    out3 = torch.full((N * T, F), -7.0, dtype=torch.float32, device='cuda')
+    check(lib.lstur_conv3_relu_mask_fwd2(e3.data_ptr(), w3.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(), out3.data_ptr(),
+                                         N, T, D, k, F, vidx.data_ptr(), vcount.data_ptr(), 2, scr_p, stream()))
+    assert (out3[valid].double() - ref.reshape(N * T, F)[valid]).abs().max().item() < 2e-5 * scale
+    assert (out3[valid] - out[valid]).abs().max().item() < 4e-6 * scale
+    assert (out3[~valid] == -7.0).all()
     if not sliced:
         return
     # ---- kernel gradient on the same E3: against fp64, and over the compacted list with NaN in the rows it must not read
