@@ -290,7 +290,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* lazy_last; float* lazy_lrt; int32_t* lazy_first; int32_t* dp_rows; float* dp_grads; float* dp_grads2; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* conv_w3_v1; unsigned short* e3; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
+  int32_t* lazy_last; float* lazy_lrt; int32_t* lazy_first; int32_t* dp_rows; int32_t* pend_rows; float* dp_grads; float* dp_grads2; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* conv_w3_v1; unsigned short* e3; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   // the staged form of a batch (token ids, their compacted list + offsets, the gathered embeddings) exists twice: while a
   // step runs on one set, the NEXT batch can be staged into the other (lstur_prefetch_ids); ids / e3 / vidx / ... above
@@ -428,6 +428,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->dqkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;
   w->mh_scratch = mh ? take(proj_wgrad_scratch_bytes(d.D, 3 * d.F, (int)(nt * d.T))) : nullptr;
   w->dp_rows = (int32_t*)take((size_t)d.rows_cap * 4);
+  w->pend_rows = (int32_t*)take((size_t)d.rows_cap * 4);   // rows of a deferred table sweep (marked until it has run)
   w->dp_grads = (float*)take((size_t)d.rows_cap * d.Ue * f4);
   w->dp_grads2 = ii ? (float*)take((size_t)d.rows_cap * d.Ue * f4) : nullptr;
   w->user_rows = (int32_t*)take(nc * 4);
@@ -506,6 +507,13 @@ struct lstur_ctx {
   hipEvent_t ev_l0 = nullptr;                     // late history slots: fork behind the first launch of the recurrence's backward
   bool cand_forked = false;                       // ev_c0 rides on this step's scorer launch
   bool lanes_active = false;                      // inside train_two_lanes (the lanes keep to one launch per kernel family)
+  // data-parallel step: the zero-gradient half of the dense table sweep of iteration t, deferred to the next forward
+  struct Deferred {
+    bool valid = false;      // rows [pend_rows, n_rows) are updated and MARKED; every other row still owes iteration t
+    bool inflight = false;   // the sweep runs on the background stream: ev_t1 tells when the marks are gone
+    float lr_t = 0.f;
+    int n_rows = 0;
+  } defer;
   // staging prefetch (lstur_prefetch_ids): the next batch's title expansion, compaction and embedding gather run on a
   // side stream under the current step's forward recurrence (HBM and 240 CUs idle there)
   struct Pending { const int32_t* hist = nullptr; const int32_t* cands = nullptr; const int32_t* users = nullptr; int n = 0;
@@ -941,6 +949,69 @@ void finish_table_rows(lstur_ctx* c, int n, hipEvent_t forked) {
   f.table_done = true;
 }
 
+// ---- data-parallel step: the dense table sweep's zero-gradient half, one forward later -----------------------------
+// lstur_adam_step with exchanged rows (every rank's batch) cannot hide the dense sweep of the user table(s) the way the
+// fused step does (the ranks' rows are known only behind the all-reduce): it was 38 us on the critical path at 50 k users.
+// A row outside the union of the batches takes the zero-gradient update, which depends on nothing but the row and lr_t --
+// so that half waits: the union's rows are updated at once and stay MARKED, the next forward first brings ITS rows up to
+// date (launch_defer_rows: marks them too), and the sweep of every unmarked row runs thin on the background stream under
+// that forward's recurrence, clearing the marks behind it.  Same operations per element in the same order, hence the same
+// tables on every rank (tests/test_gpu_dp_two_ranks.py).  Anything else that reads the tables (evaluation, lstur_flush_tables,
+// a step without exchanged rows) runs the pending sweep first, in the open.  LSTUR_DP_DEFER=0: the sweep inside lstur_adam_step.
+bool defer_wanted(lstur_ctx* c) {
+  static const bool off = getenv("LSTUR_DP_DEFER") && !strcmp(getenv("LSTUR_DP_DEFER"), "0");
+  return !off && !c->d.lazy && has_user_table(c->d) && c->cur_lane == 0 && !c->lanes_active && background_stream(c);
+}
+void defer_join(lstur_ctx* c, hipStream_t s) {
+  if (c->defer.inflight) (void)hipStreamWaitEvent(s, c->ev_t1, 0);
+  c->defer.inflight = false;
+}
+void defer_sweep_launch(lstur_ctx* c, int blocks, hipStream_t st) {   // every unmarked row of the table(s), then the marks
+  const Dims& d = c->d;
+  const lstur_cfg& cf = c->cfg;
+  {
+    ProfScope _ps(c, "adam_user_table", st);
+    launch_adam_table_unmarked(c->buf.user_emb, c->buf.user_m, c->buf.user_v, c->ws.slot, d.Nu, d.Ue, c->defer.lr_t, cf.beta1,
+                               cf.beta2, cf.eps, blocks, st);
+  }
+  if (two_tables(d))
+    launch_adam_table_unmarked(c->buf.user_emb2, c->buf.user_m2, c->buf.user_v2, c->ws.slot, d.Nu, d.Ue, c->defer.lr_t, cf.beta1,
+                               cf.beta2, cf.eps, blocks, st);
+  launch_user_slot_clear(c->ws.pend_rows, c->defer.n_rows, c->ws.slot, st);
+}
+void defer_flush(lstur_ctx* c, hipStream_t s) {   // in the open, at full width
+  defer_join(c, s);
+  if (!c->defer.valid) return;
+  defer_sweep_launch(c, 0, s);
+  c->defer.valid = false;
+}
+// this forward's rows first (on the caller's stream, in front of the row gather) ...
+void defer_rows_now(lstur_ctx* c, const int32_t* user, int n, hipStream_t s) {
+  const Dims& d = c->d;
+  const lstur_cfg& cf = c->cfg;
+  const bool two = two_tables(d);
+  launch_defer_rows(c->buf.user_emb, c->buf.user_m, c->buf.user_v, two ? c->buf.user_emb2 : nullptr, two ? c->buf.user_m2 : nullptr,
+                    two ? c->buf.user_v2 : nullptr, user, n, c->ws.slot, d.Ue, c->defer.lr_t, cf.beta1, cf.beta2, cf.eps, s);
+}
+// ... then everything else under the recurrence (`forked`: recorded on the caller's stream behind the row gather)
+void defer_sweep_background(lstur_ctx* c, int n, hipEvent_t forked, bool recurrent, bool after_prefetch) {
+  const Dims& d = c->d;
+  hipStream_t st = c->side_t;
+  (void)hipStreamWaitEvent(st, forked, 0);
+  if (after_prefetch) (void)hipStreamWaitEvent(st, c->ev_p1, 0);
+  int blocks = 0;   // 0: full width
+  if (recurrent) {  // (the thin sweep of early_table_sweep: as many workgroups as finish inside the two recurrences)
+    const double bytes = (double)d.Nu * d.Ue * 4.0 * 6.0 * (two_tables(d) ? 2.0 : 1.0);
+    const double need = bytes / (d.W * 3.4e-6 * 2.0 * 0.8 * 14e9);
+    if (need <= 128.0) blocks = need < 32.0 ? 32 : (int)need;
+  }
+  defer_sweep_launch(c, blocks, st);
+  launch_user_slot_clear(c->ws.user_rows, n, c->ws.slot, st);   // this forward's rows (marked by defer_rows_now)
+  (void)hipEventRecord(c->ev_t1, st);
+  c->defer.valid = false;
+  c->defer.inflight = true;
+}
+
 // whole-row dropout probability of the user embedding in training (0: none)
 float user_row_drop(const lstur_ctx* c) {
   const int a = c->d.arch;
@@ -1050,6 +1121,18 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   dense_gemm(w.pooled, d.F, c->P("dense_w"), d.U, false, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, w.gemm_scratch, s);
   // user encoder (paper.py:584-633)
   if (d.lazy && c->cur_lane == 0) lazy_catchup_rows(c, user, n, s);   // (large tables: the rows read below, made current)
+  bool want_df = false;   // a deferred table sweep (data-parallel step) is pending: this batch's rows now, the rest under the recurrence
+  if (c->defer.valid || c->defer.inflight) {
+    defer_join(c, s);
+    if (c->defer.valid) {
+      if (training && c->cur_lane == 0 && defer_wanted(c) && fork_events(c)) {
+        defer_rows_now(c, user, n, s);
+        want_df = true;
+      } else {
+        defer_flush(c, s);
+      }
+    }
+  }
   launch_hist_mask(w.ids, w.docvec, w.hmask, w.gmask, nW, d.T, d.U, s, c->buf.user_emb, user, w.user_rows, w.uvec, n,
                    d.Ue);
   // whole-row dropout of the user embedding: dgru's Dropout(0.5, noise_shape=(None, 1)) (paper.py:610), or the id_keep
@@ -1061,7 +1144,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   // user-table sweep.  ONE fork point for both side streams, attached to the input projection's completion.
   const bool want_pf = training && recurrent && use3 && !gen1 && prefetch_wanted(c);
   const bool want_sw = training && early_table_sweep_wanted(c);
-  const bool fork_f = (want_pf || want_sw) && fork_events(c);
+  const bool fork_f = (want_pf || want_sw || want_df) && fork_events(c);
   if (fork_f) arm_stop_event(c->ev_f0);
   dense_gemm(w.docvec, d.U, c->P("gru_w"), 3 * d.H, false, w.xw, 3 * d.H, c->P("gru_b"), nW, 3 * d.H, d.U, w.gemm_scratch, s);
   if (stop_event_pending()) {   // (the fp32 kernel took the launch: record the classic way)
@@ -1072,6 +1155,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   if (fork_f) {
     const bool pf = want_pf && launch_prefetch(c, c->ev_f0);
     early_table_sweep(c, n, c->ev_f0, recurrent, pf);
+    if (want_df) defer_sweep_background(c, n, c->ev_f0, recurrent, pf);
   }
   if (d.arch == LSTUR_ARCH_VO) {          // the user embedding alone (paper.py:622-623)
     (void)hipMemcpyAsync(w.uservec, w.uvec, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
@@ -1941,6 +2025,7 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
   const Dims& d = ctx->d;
   const lstur_cfg& c = ctx->cfg;
   const float* row_grads2 = nullptr;   // second table (iigru / iicgru): own rows -> ws.duser2, exchanged rows -> ws.dp_grads2
+  const bool exchanged = rows != nullptr;   // the data-parallel step: rows and gradients of every rank's batch
   if (rows && two_tables(d)) {
     if (rows != ctx->ws.dp_rows || row_grads != ctx->ws.dp_grads)
       return fail(LSTUR_ERR_ARG, "iigru: external user rows must come from lstur_dp_unpack (it carries both tables' gradients)");
@@ -1953,6 +2038,7 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
   }
   if (n_rows < 0 || n_rows > d.rows_cap) return fail(LSTUR_ERR_ARG, "too many sparse rows for one adam step");
   const float lr_t = lr * (sqrtf(1.0f - powf(c.beta2, (float)t)) / (1.0f - powf(c.beta1, (float)t)));
+  defer_flush(ctx, s);   // (a deferred sweep no forward picked up, or still in flight: the slot map must be clear)
   lazy_init(ctx, s);
   // (a prefetch-time catch-up of the next batch's rows ran on the parameter-gradient stream: the backward joined it)
   lazy_begin_iteration(ctx, t, s);   // (large tables; a no-op when the fused step already did it)
@@ -2000,7 +2086,21 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
                      c.beta1, c.beta2, c.eps, s);
   if (!no_user && !skip_table) {   // nigru / niavg: the user embedding is not part of the graph (paper.py:627-630)
     if (d.lazy) lazy_rows_step(ctx, rows, row_grads2, n_rows, t, lr_t, s);
-    else adam_user_tables(ctx, rows, row_grads, n_rows, lr_t, false, s, row_grads2);
+    else if (exchanged && n_rows > 0 && defer_wanted(ctx)) {
+      // the union's rows now (combined gradients: gsum / slot from the launch above), every other row one forward later
+      launch_adam_rows(ctx->buf.user_emb, ctx->buf.user_m, ctx->buf.user_v, rows, ctx->ws.slot, ctx->ws.gsum, n_rows, d.Ue, lr_t,
+                       c.beta1, c.beta2, c.eps, s);
+      if (two_tables(d)) {
+        launch_user_grad_combine(rows, row_grads2 ? row_grads2 : ctx->ws.duser2, n_rows, d.Ue, ctx->ws.first, ctx->ws.gsum2,
+                                 ctx->ws.slot, s);
+        launch_adam_rows(ctx->buf.user_emb2, ctx->buf.user_m2, ctx->buf.user_v2, rows, ctx->ws.slot, ctx->ws.gsum2, n_rows, d.Ue,
+                         lr_t, c.beta1, c.beta2, c.eps, s);
+      }
+      (void)hipMemcpyAsync(ctx->ws.pend_rows, rows, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+      ctx->defer.valid = true;
+      ctx->defer.lr_t = lr_t;
+      ctx->defer.n_rows = n_rows;
+    } else adam_user_tables(ctx, rows, row_grads, n_rows, lr_t, false, s, row_grads2);
   }
   if (skip_table) (void)hipStreamWaitEvent(s, ctx->ev_t1, 0);
   if (d.lazy) ctx->lazy_t = t;
@@ -2016,6 +2116,7 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
 int lstur_flush_tables(lstur_ctx* ctx, lstur_stream stream) {
   if (!ctx) return fail(LSTUR_ERR_ARG, "ctx is NULL");
   lazy_flush_all(ctx, (hipStream_t)stream);
+  defer_flush(ctx, (hipStream_t)stream);
   return check_launch("flush_tables");
 }
 int lstur_lazy_adam(lstur_ctx* ctx) { return (ctx && ctx->d.lazy) ? 1 : 0; }
@@ -2039,6 +2140,7 @@ static int train_step_impl(lstur_ctx* ctx, const int32_t* user, const int32_t* h
   ctx->fused.swept = ctx->fused.table_done = false;
   ctx->fused.lr_t = lr * (sqrtf(1.0f - powf(c.beta2, (float)t)) / (1.0f - powf(c.beta1, (float)t)));
   ctx->fused.t = t;
+  defer_flush(ctx, s);
   lazy_begin_iteration(ctx, t, s);
   int rc;
   if (ctx->d.head == LSTUR_HEAD_SOFTMAX)

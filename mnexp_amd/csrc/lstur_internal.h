@@ -163,6 +163,8 @@ void launch_adam_table_unmarked(float* p, float* m, float* v, const int32_t* slo
                                 float b1, float b2, float eps, int max_blocks, hipStream_t s);
 void launch_adam_rows(float* p, float* m, float* v, const int32_t* rows, const int32_t* slot, const float* gsum, int n,
                       int dim, float lr_t, float b1, float b2, float eps, hipStream_t s);
+void launch_defer_rows(float* p, float* m, float* v, float* p2, float* m2, float* v2, const int32_t* rows, int n, int32_t* slot,
+                       int dim, float lr_t, float b1, float b2, float eps, hipStream_t s);
 void launch_fill_i32(int32_t* p, int32_t v, size_t n, hipStream_t s);
 // history mask (ComputeMasking) applied to doc vectors + GRU step mask:  hv[b,w,:] *= any(ids != 0);
 // gmask[b,w] = any(hv != 0)

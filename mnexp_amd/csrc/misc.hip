@@ -799,6 +799,34 @@ void launch_adam_rows(float* p, float* m, float* v, const int32_t* rows, const i
                       int dim, float lr_t, float b1, float b2, float eps, hipStream_t s) {
   if (n) hipLaunchKernelGGL(adam_rows_kernel, dim3(n), dim3(64), 0, s, p, m, v, rows, slot, gsum, dim, lr_t, b1, b2, eps);
 }
+// Deferred zero-gradient sweep (data-parallel step, lstur_capi.hip): the rows a forward is about to read that the pending
+// sweep has not reached take their zero-gradient update here and are marked, so that the sweep skips them.  One wave per
+// sample; of several samples with the same row one claims it.
+__global__ __launch_bounds__(64) void defer_rows_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                        float* __restrict__ p2, float* __restrict__ m2, float* __restrict__ v2,
+                                                        const int32_t* __restrict__ rows, int32_t* __restrict__ slot, int dim,
+                                                        float lr_t, float b1, float b2, float eps) {
+  const int i = blockIdx.x, r = rows[i];
+  int old = 0;
+  if (threadIdx.x == 0) old = atomicCAS(&slot[r], -1, 0x40000000 + i);
+  old = __shfl(old, 0, 64);
+  if (old != -1) return;                    // swept with its gradient already (the step's union), or claimed by another sample
+  for (int c = threadIdx.x; c < dim; c += 64) {
+    const size_t e = (size_t)r * dim + c;
+    float pp = p[e], mm = m[e], vv = v[e];
+    adam1(pp, 0.f, mm, vv, lr_t, b1, b2, eps);
+    p[e] = pp; m[e] = mm; v[e] = vv;
+    if (p2) {
+      pp = p2[e]; mm = m2[e]; vv = v2[e];
+      adam1(pp, 0.f, mm, vv, lr_t, b1, b2, eps);
+      p2[e] = pp; m2[e] = mm; v2[e] = vv;
+    }
+  }
+}
+void launch_defer_rows(float* p, float* m, float* v, float* p2, float* m2, float* v2, const int32_t* rows, int n, int32_t* slot,
+                       int dim, float lr_t, float b1, float b2, float eps, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(defer_rows_kernel, dim3(n), dim3(64), 0, s, p, m, v, p2, m2, v2, rows, slot, dim, lr_t, b1, b2, eps);
+}
 
 // ---------------------------------------------------------------------------------------------
 // LAZY dense Adam for large user tables.  TF-1 Keras densifies the embedding gradient, so every row takes an update every
