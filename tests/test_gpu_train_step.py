@@ -115,3 +115,53 @@ def test_set_weights_between_steps_invalidates_the_weight_images():
     want = fresh.predict([u.cpu().numpy(), model.title_table[h.long()].cpu().numpy(),
                           model.title_table[c[:, 0].long()].cpu().numpy()])
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('arch', ['igru', 'iigru'])
+def test_deferred_table_sweep_of_the_exchanged_row_step_is_bit_identical(arch):
+    """lstur_adam_step with EXTERNAL rows (the data-parallel step: rows and gradients of every rank's batch) updates those
+    rows at once and lets the zero-gradient sweep of every other row wait for the next forward, under whose recurrence it
+    runs.  Six steps with overlapping users, an evaluation in between (the pending sweep then runs in
+    the open) and a final flush against the same steps with the sweep inside lstur_adam_step (rows = NULL: no deferral):
+    tables, moments, parameters, losses and predictions bit-identical."""
+    _need_gpu()
+    import ctypes as C
+    from mnexp_amd._lib import lib, check
+    B, W, T, K1 = 24, 7, 11, 5
+    outs = []
+    for mode in ('external', 'plain'):
+        O, p, model, rng = build(arch, MID, B, W, T, K1, 0.2)
+        steps = _batches(model, B, W, K1, T, 6, MID['N_u'])
+        losses, preds = [], []
+        for i, (u, h, c) in enumerate(steps):
+            s = model._stream()
+            check(lib.lstur_forward_backward_ids(model._ctx, u.data_ptr(), h.data_ptr(), c.data_ptr(), B, i, 1.0,
+                                                 model.stats.data_ptr(), s), 'fb')
+            if mode == 'external':
+                rows, grads, cnt = C.c_void_p(), C.c_void_p(), C.c_int32()
+                if arch == 'iigru':      # both tables' gradients travel through the exchange buffers
+                    world = 1
+                    used = int(lib.lstur_dp_tail_floats(C.byref(model.cfg), world))
+                    tail = model._bucket[model.sizes.dense:model.sizes.dense + used]
+                    check(lib.lstur_dp_stage(model._ctx, tail.data_ptr(), 0, world, s), 'stage')
+                    check(lib.lstur_dp_unpack(model._ctx, tail.data_ptr(), world, B, C.byref(rows), C.byref(grads), s), 'unpack')
+                    n_rows = B
+                else:
+                    check(lib.lstur_user_grad(model._ctx, C.byref(rows), C.byref(grads), C.byref(cnt)), 'user_grad')
+                    n_rows = cnt.value
+                check(lib.lstur_adam_step(model._ctx, 1e-3, i + 1, rows, grads, n_rows, s), 'adam')
+            else:
+                check(lib.lstur_adam_step(model._ctx, 1e-3, i + 1, None, None, 0, s), 'adam')
+            losses.append(model.stats[0].item())
+            if i == 2:
+                preds.append(model.predict_ids(*steps[0]))     # reads the tables: a pending sweep runs first, in the open
+        model.flush_tables()
+        torch.cuda.synchronize()
+        st = _state(model)
+        st['loss'] = np.array(losses)
+        st['pred_mid'] = preds[0]
+        st['pred'] = model.predict_ids(*steps[0])
+        outs.append(st)
+        del model
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
