@@ -463,6 +463,19 @@ def main():
                             frac_vs_fp32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 4))
             if side:
                 roofline['side_launch'] = side
+            if bf16x3:
+                # what the kernel has to move at least: every embedding row some non-pad token's window covers once (three
+                # bf16 parts), the split weight once, and its own output / input gradient rows (fp32) once
+                def rows_covered(mask):
+                    T_ = mask.shape[-1]
+                    q = np.pad(mask, [(0, 0)] * (mask.ndim - 1) + [(2, 2)])
+                    return int((q[..., 0:T_ + 2] | q[..., 1:T_ + 3] | q[..., 2:T_ + 4]).sum())
+                e_rows = sum(rows_covered(titles[x] != 0) for b_ in batches for x in (b_[1], b_[2])) / float(len(batches))
+                dp = (wl['D'] + 7) // 8 * 8
+                alg = e_rows * dp * 6 + 3 * wl['k'] * dp * ((wl['F'] + 31) // 32 * 32) * 2 + real_tok * wl['F'] * 4
+                roofline['traffic_algorithmic'] = int(alg * (dom_flop / conv_flop))
+                if roofline['traffic']:
+                    roofline['traffic_over_algorithmic'] = round(roofline['traffic'] / roofline['traffic_algorithmic'], 2)
         if prof:
             gb = gather_bytes / (kern['gather']['avg_us'] * 1e-6) / 1e9
             roofline_gather = dict(kernel='gather', bound='hbm', achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit='GB/s',
