@@ -1,8 +1,9 @@
 """Micro-benchmark + check of the bf16 projection GEMMs of the mhsa encoder (lstur_proj_fwd_bf16 / _wgrad_bf16)
 at the config-2 token count (HIP events); for kernel tuning.   python tools/bench_proj.py [M] [D] [N]"""
+import os
 import sys
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mnexp_amd._lib import lib, check
 
 
