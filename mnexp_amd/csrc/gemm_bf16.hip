@@ -19,16 +19,18 @@ namespace lstur {
 // A_KM = false: A is [M][K] (k contiguous), fp32.   A_KM = true: A is [K][M] fp32, and ONES_ROW appends the row
 // m == M of ones (bias gradient).  B is [K][N], fp32 (TB = float) or bf16 (TB = unsigned short).
 // OUT_BF16: C bf16 [M][ldc] = acc + bias;  else C = fp32 slabs [gridDim.z][Mo][N] (Mo = M + ONES_ROW).
-template <int TM, int TN, int WM, int WN, int BK, bool A_KM, bool ONES_ROW, typename TB, bool OUT_BF16>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const float* __restrict__ A, int lda,
+// TA: A's element type in HBM -- float (rounded to bf16 on the way into LDS) or unsigned short (bf16 already: 16-byte copies).
+template <int TM, int TN, int WM, int WN, int BK, bool A_KM, bool ONES_ROW, typename TB, bool OUT_BF16, typename TA = float>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const TA* __restrict__ A, int lda,
                                                                 const TB* __restrict__ B, int ldb, void* __restrict__ C,
                                                                 int ldc, const float* __restrict__ bias, int M, int N, int K,
                                                                 int k_per_split, int tiles_n, int groups) {
   constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int SA = A_KM ? tr_stride(BM) : BK + 8, SB = tr_stride(BN);   // [m][k] rows: 80 / 144 bytes, conflict-free b128
   constexpr int A_ELEMS = A_KM ? BK * SA : BM * SA, B_ELEMS = BK * SB;
-  constexpr int KF4 = BK / 4;                                                  // float4 per k-row of an [m][k] tile
-  constexpr int A_F4 = BM * BK / 4, A_PER = (A_F4 + NT - 1) / NT;            // float4 per thread for the A tile
+  constexpr int A_VEC = sizeof(TA) == 4 ? 4 : 8;                               // elements per 16-byte load of A
+  constexpr int KF4 = BK / A_VEC;                                              // 16-byte pieces per k-row of an [m][k] tile
+  constexpr int A_F4 = BM * BK / A_VEC, A_PER = (A_F4 + NT - 1) / NT;        // 16-byte pieces per thread for the A tile
   constexpr int B_VEC = sizeof(TB) == 4 ? 4 : 8;                               // elements per 16-byte load of B
   constexpr int B_CH = BK * BN / B_VEC, B_PER = (B_CH + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const float* __r
   float4 ra[A_PER];
   uint4 rb[B_PER];
   const __amdgpu_buffer_rsrc_t rsA =
-      make_rsrc(A, (uint32_t)(A_KM ? (size_t)kend * lda * 4 : std::min((size_t)M * lda * 4, (size_t)0xFFFFFFFFu)));
+      make_rsrc(A, (uint32_t)(A_KM ? (size_t)kend * lda * sizeof(TA) : std::min((size_t)M * lda * sizeof(TA), (size_t)0xFFFFFFFFu)));
   const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (uint32_t)((size_t)kend * ldb * sizeof(TB)));
   auto load = [&](int k0) {
 #pragma unroll
@@ -70,10 +72,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const float* __r
       uint32_t off;
       if (!A_KM) {
         const int row = idx / KF4, seg = idx - row * KF4;        // k >= K meets zero rows of B
-        off = ((uint32_t)(m0 + row) * (uint32_t)lda + (uint32_t)(k0 + seg * 4)) * 4u;
+        off = ((uint32_t)(m0 + row) * (uint32_t)lda + (uint32_t)(k0 + seg * A_VEC)) * (uint32_t)sizeof(TA);
       } else {
-        const int krow = idx / (BM / 4), seg = idx - krow * (BM / 4);
-        off = ((uint32_t)(k0 + krow) * (uint32_t)lda + (uint32_t)(m0 + seg * 4)) * 4u;
+        const int krow = idx / (BM / A_VEC), seg = idx - krow * (BM / A_VEC);
+        off = ((uint32_t)(k0 + krow) * (uint32_t)lda + (uint32_t)(m0 + seg * A_VEC)) * (uint32_t)sizeof(TA);
       }
       ra[i] = buf_load4(rsA, (A_F4 % NT == 0 || idx < A_F4) ? off : kBufOob, 0);
     }
@@ -95,8 +97,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const float* __r
       if (A_F4 % NT == 0 || idx < A_F4) {
         if (!A_KM) {
           const int row = idx / KF4, seg = idx - row * KF4;
-          *(u16x4*)(as + row * SA + seg * 4) = cvt4(ra[i]);
-        } else {
+          if (sizeof(TA) == 4) *(u16x4*)(as + row * SA + seg * 4) = cvt4(ra[i]);
+          else *(float4*)(as + row * SA + seg * 8) = ra[i];
+        } else if (sizeof(TA) == 4) {
           const int krow = idx / (BM / 4), seg = idx - krow * (BM / 4);
           u16x4 v = cvt4(ra[i]);
           if (ONES_ROW && m0 + seg * 4 == M) {     // M % 4 == 0: the row of ones (bias gradient) starts a float4
@@ -104,6 +107,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const float* __r
             v[1] = v[2] = v[3] = 0;
           }
           *(u16x4*)(as + krow * SA + seg * 4) = v;
+        } else {
+          const int krow = idx / (BM / 8), seg = idx - krow * (BM / 8);
+          u16x8 v = __builtin_bit_cast(u16x8, ra[i]);
+          const int mrel = M - (m0 + seg * 8);     // M % 4 == 0: the row of ones sits at element 0 or 4 of a piece
+          if (ONES_ROW && mrel >= 0 && mrel < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (e >= mrel) v[e] = (e == mrel && kcur + krow < kend) ? (unsigned short)0x3F80 : (unsigned short)0;
+          }
+          *(u16x8*)(as + krow * SA + seg * 8) = v;
         }
       }
     }
@@ -218,12 +231,42 @@ void launch_proj_fwd_bf16(const float* E, const float* W, const float* bias, uns
                      N, K, cdiv(K, BK) * BK, tiles_n, groups);
 }
 
+// The same with both operands already bf16 in HBM (the step's path: the embedding gather writes bf16 rows for this encoder,
+// the weight is rounded once per step): half the operand bytes per k-tile.
+void launch_proj_fwd_bf16e(const unsigned short* E16, const unsigned short* W16, const float* bias, unsigned short* out, int M,
+                           int N, int K, hipStream_t s) {
+  if (M == 0) return;
+  constexpr int TM = 2, TN = 4, WM = 4, WN = 2, BK = 32, BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t lds = (2 * (BM * (BK + 8)) + 2 * (BK * tr_stride(BN))) * sizeof(unsigned short);
+  auto kern = gemm_bf16_kernel<TM, TN, WM, WN, BK, false, false, unsigned short, true, unsigned short>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int tiles_n = cdiv(N, BN), groups = cdiv(M, BM);
+  hipLaunchKernelGGL(kern, dim3(cdiv(groups, 8) * 8 * tiles_n), dim3(WM * WN * 64), lds, s, E16, K, W16, N, (void*)out, N, bias,
+                     M, N, K, cdiv(K, BK) * BK, tiles_n, groups);
+}
+__global__ void round_bf16_kernel(const float4* __restrict__ src, u16x4* __restrict__ dst, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) dst[i] = cvt4(src[i]);
+}
+void launch_round_bf16(const float* src, unsigned short* dst, size_t n, hipStream_t s) {   // n % 4 == 0
+  if (n) hipLaunchKernelGGL(round_bf16_kernel, dim3((unsigned)cdivz(n / 4, 256)), dim3(256), 0, s, (const float4*)src, (u16x4*)dst, n / 4);
+}
+
 // ---- weight (+ bias) gradient: 320 x 128 workgroup tile (all of D), 2 x 4 waves of 160 x 32, token slabs ----------
 static int wgrad_splits(int N, int K) {
   const int tiles = cdiv(N, 128);
-  return std::max(1, std::min(cdiv(256, tiles), K / 512));
+  // one workgroup per CU (128 KiB of LDS each) and NOT ONE MORE: 43 slabs x 6 column tiles = 258 workgroups ran as two
+  // rounds on 256 CUs -- the last two alone in the second -- and the launch took twice as long as 42 x 6 = 252 do
+  return std::max(1, std::min(256 / tiles, K / 512));
 }
-size_t proj_wgrad_scratch_bytes(int D, int N, int K) { return (size_t)wgrad_splits(N, K) * (D + 1) * N * sizeof(float); }
+size_t proj_wgrad_scratch_bytes(int D, int N, int K) {
+  const int most = std::max(wgrad_splits(N, K), std::max(1, std::min(256 / cdiv(N, 256), K / 512)));   // (either tile width)
+  return (size_t)most * (D + 1) * N * sizeof(float);
+}
 
 // dW [D+1, N] (row D = bias gradient; the caller's dW and db must be contiguous) through *defer (slabs in `scratch`)
 void launch_proj_wgrad_bf16(const float* E, const unsigned short* dqkv, float* dW, void* scratch, int D, int N, int K,
@@ -243,6 +286,31 @@ void launch_proj_wgrad_bf16(const float* E, const unsigned short* dqkv, float* d
   hipLaunchKernelGGL(kern, dim3(cdiv(ns, 8) * 8 * tiles_n), dim3(WM * WN * 64), lds, s, E, D, dqkv, N, scratch, N,
                      (const float*)nullptr, D, N, K, kps, tiles_n, ns);
   *defer = ReduceJob{(const float*)scratch, dW, D + 1, N, N, ns, (size_t)(D + 1) * N, 1.0f};
+}
+
+template <int TN, int BK>
+static void proj_wgrad16_launch(const unsigned short* E16, const unsigned short* dqkv, float* dW, void* scratch, int D, int N,
+                                int K, hipStream_t s, ReduceJob* defer) {
+  constexpr int TM = 5, WM = 2, WN = 4, BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t lds = (2 * (BK * tr_stride(BM)) + 2 * (BK * tr_stride(BN))) * sizeof(unsigned short);
+  const int tiles_n = cdiv(N, BN);
+  int ns = std::max(1, std::min(256 / tiles_n, K / 512));   // one workgroup per CU
+  const int kps = cdiv(cdiv(K, ns), BK) * BK;
+  ns = std::max(1, cdiv(K, kps));
+  auto kern = gemm_bf16_kernel<TM, TN, WM, WN, BK, true, true, unsigned short, false, unsigned short>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(cdiv(ns, 8) * 8 * tiles_n), dim3(WM * WN * 64), lds, s, E16, D, dqkv, N, scratch, N,
+                     (const float*)nullptr, D, N, K, kps, tiles_n, ns);
+  *defer = ReduceJob{(const float*)scratch, dW, D + 1, N, N, ns, (size_t)(D + 1) * N, 1.0f};
+}
+void launch_proj_wgrad_bf16e(const unsigned short* E16, const unsigned short* dqkv, float* dW, void* scratch, int D, int N, int K,
+                             hipStream_t s, ReduceJob* defer) {
+  // 320 x 256 workgroup tile (2 x 4 waves of 160 x 64), k-tiles of 32 tokens: every column tile re-reads the slab's
+  // embedding rows, and the launch is bound by what goes through L2 (3 TB/s at this access pattern) -- three column tiles
+  // instead of six took it from 177 to 124 us.  (LSTUR_WGRAD_NARROW=1: the 320 x 128 tile, for A/B runs.)
+  static const bool narrow = getenv("LSTUR_WGRAD_NARROW") != nullptr;
+  if (narrow) proj_wgrad16_launch<1, 64>(E16, dqkv, dW, scratch, D, N, K, s, defer);
+  else proj_wgrad16_launch<2, 32>(E16, dqkv, dW, scratch, D, N, K, s, defer);
 }
 
 }  // namespace lstur

@@ -290,7 +290,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* lazy_last; float* lazy_lrt; int32_t* lazy_first; int32_t* dp_rows; int32_t* pend_rows; float* dp_grads; float* dp_grads2; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* conv_w3_v1; unsigned short* e3; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; void* mh_scratch;
+  int32_t* lazy_last; float* lazy_lrt; int32_t* lazy_first; int32_t* dp_rows; int32_t* pend_rows; float* dp_grads; float* dp_grads2; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* conv_w3_v1; unsigned short* e3; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; unsigned short* qkv_w16; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   // the staged form of a batch (token ids, their compacted list + offsets, the gathered embeddings) exists twice: while a
   // step runs on one set, the NEXT batch can be staged into the other (lstur_prefetch_ids); ids / e3 / vidx / ... above
@@ -426,6 +426,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->fwd2_scratch = c3 ? take(conv3_fwd2_scratch_bytes()) : nullptr;
   w->qkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;     // bf16 Q | K | V rows
   w->dqkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;
+  w->qkv_w16 = mh ? (unsigned short*)take((size_t)d.D * 3 * d.F * 2) : nullptr;   // the projection weight rounded to bf16, once per step
   w->mh_scratch = mh ? take(proj_wgrad_scratch_bytes(d.D, 3 * d.F, (int)(nt * d.T))) : nullptr;
   w->dp_rows = (int32_t*)take((size_t)d.rows_cap * 4);
   w->pend_rows = (int32_t*)take((size_t)d.rows_cap * 4);   // rows of a deferred table sweep (marked until it has run)
@@ -792,6 +793,7 @@ void pack_weight_images(lstur_ctx* c, hipStream_t sp) {
   if (use3 && gen1) launch_conv3_pack_w(c->P("conv_w"), d.KD, d.F, w.conv_w3_v1, sp);
   else if (use3) launch_conv3_pack_w2(c->P("conv_w"), d.D, d.k, d.F, w.conv_w3, sp);
   else if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, sp);
+  else launch_round_bf16(c->P("qkv_w"), w.qkv_w16, (size_t)d.D * 3 * d.F, sp);   // (D % 4 == 0: mhsa_supported)
   launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, sp);
 }
 
@@ -1098,11 +1100,16 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     launch_gather3(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, s, 0, title_order(d, n));
   }
   else
-    PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
+  {
+    if (mhsa)   // bf16 rows for the projections (they rounded the fp32 rows the same way on their way into LDS)
+      PROF("gather", launch_gather_bf16(c->buf.word_emb, w.ids, (unsigned short*)w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
+    else
+      PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
+  }
   }
   if (packs_forked) (void)hipStreamWaitEvent(s, c->ev_w3, 0);   // the weight images are ready
   if (mhsa) {   // token stage = multi-head self-attention (build-defined, include/lstur.h: LSTUR_ENC_MHSA)
-    PROF("qkv_proj", launch_proj_fwd_bf16(w.emb, c->P("qkv_w"), c->P("qkv_b"), w.qkv, nt * d.T, 3 * d.F, d.D, s));
+    PROF("qkv_proj", launch_proj_fwd_bf16e((const unsigned short*)w.emb, w.qkv_w16, c->P("qkv_b"), w.qkv, nt * d.T, 3 * d.F, d.D, s));
     PROF("mhsa_fwd", launch_mhsa_fwd_bf16(w.qkv, w.ids, w.conv, nt, d.T, d.F, d.heads, s));
   } else if (use3 && gen1) {
     PROF("conv_fwd", launch_conv3_fwd(w.emb, w.conv_w3_v1, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
@@ -1399,7 +1406,7 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     PROF("mhsa_bwd", launch_mhsa_bwd_bf16(w.qkv, w.dconv, w.ids, w.dqkv, nt, d.T, d.F, d.heads, s));
     // weight AND bias gradient in one product: the bucket keeps qkv_b right behind qkv_w (D * 3F is a multiple of the
     // slot alignment), so row D of [E | 1]^T . dQKV lands on it
-    PROF("qkv_wgrad", launch_proj_wgrad_bf16(w.emb, w.dqkv, c->G("qkv_w"), w.mh_scratch, d.D, 3 * d.F, nt * d.T, s,
+    PROF("qkv_wgrad", launch_proj_wgrad_bf16e((const unsigned short*)w.emb, w.dqkv, c->G("qkv_w"), w.mh_scratch, d.D, 3 * d.F, nt * d.T, s,
                                              &jobs[nj++]));
     if (stats) {
       jobs[nj++] = ReduceJob{w.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
@@ -2232,6 +2239,8 @@ int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* coun
                                  "run with LSTUR_PIPELINE=0 to inspect them");
   if (!strcmp(name, "emb") && ctx->last_use3)
     return fail(LSTUR_ERR_STATE, "emb: the bf16x3 conv path keeps the embeddings pre-split (E3); run with LSTUR_CONV_F32=1");
+  if (!strcmp(name, "emb") && d.enc == LSTUR_ENC_MHSA)
+    return fail(LSTUR_ERR_STATE, "emb: the mhsa encoder keeps the gathered embeddings as bf16 rows");
   for (auto& e : tab)
     if (!strcmp(e.nm, name)) {
       *ptr = e.p;

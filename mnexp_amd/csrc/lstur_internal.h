@@ -81,6 +81,9 @@ constexpr int kEmbSlack = 256;
 // ---- misc.hip ----------------------------------------------------------------------------------
 void launch_gather(const float* table, const int32_t* ids, float* out, int n_titles, int T, int D,
                    int pad_l, int pad_r, float drop, uint32_t key, hipStream_t s);
+// the same rows rounded to bf16 (the mhsa projections' A operand)
+void launch_gather_bf16(const float* table, const int32_t* ids, unsigned short* out, int n_titles, int T, int D, int pad_l,
+                        int pad_r, float drop, uint32_t key, hipStream_t s);
 // the gather in the pre-split "E3" form of the bf16x3 conv kernels (layout: conv3f.hip); e3 = conv3_e3_elems() bf16
 // skip_unread: rows no window of a non-pad token covers are neither read nor written (the buffer must hold finite values)
 void launch_gather3(const float* table, const int32_t* ids, unsigned short* e3, int n_titles, int T, int D, int pad_l,
@@ -309,6 +312,12 @@ size_t proj_wgrad_scratch_bytes(int D, int N, int K);
 // dW [D + 1, N] = [E | 1]^T . dqkv (row D = bias gradient; dW and db contiguous in the bucket), K = tokens
 void launch_proj_wgrad_bf16(const float* E, const unsigned short* dqkv, float* dW, void* scratch, int D, int N, int K,
                             hipStream_t s, ReduceJob* defer);
+// both operands bf16 in HBM already (launch_gather_bf16 rows, launch_round_bf16 weight): what the step runs
+void launch_proj_fwd_bf16e(const unsigned short* E16, const unsigned short* W16, const float* bias, unsigned short* out, int M,
+                           int N, int K, hipStream_t s);
+void launch_proj_wgrad_bf16e(const unsigned short* E16, const unsigned short* dqkv, float* dW, void* scratch, int D, int N, int K,
+                             hipStream_t s, ReduceJob* defer);
+void launch_round_bf16(const float* src, unsigned short* dst, size_t n, hipStream_t s);
 
 // ---- pointwise head (misc.hip) --------------------------------------------------------------------
 // point_dot: s = u . d; point_mlp: s = relu(pre) . w2 + b2 (pre = [u|d] W1 + b1 computed by the caller).

@@ -15,7 +15,9 @@ namespace lstur {
 // load): the four id loads, then the four row loads are in flight together, and the dropout hash of one piece
 // overlaps the loads of the others -- a guarded load per grid-stride step left ONE dependent id -> row chain in flight
 // per thread.
-template <bool DROP>
+// BF16: the same gather with the result rounded to bf16 (round-to-nearest-even, bf16_mfma.h: cvt4 -- what the mhsa
+// projections' loaders did with the fp32 rows on their way into LDS): half the bytes written here and read there
+template <bool DROP, bool BF16 = false>
 __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ table,
                                                      const int32_t* __restrict__ ids,
                                                      float4* __restrict__ out, uint32_t total4, int T, int Tp,
@@ -55,11 +57,27 @@ __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ 
         w.w = k[3] ? w.w * scale : 0.f;
       }
       if (!real[u]) w = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (inr[u]) out[i0 + u * stride] = w;
+      if (inr[u]) {
+        if (BF16) ((u16x4*)out)[i0 + u * stride] = cvt4(w);
+        else out[i0 + u * stride] = w;
+      }
     }
   }
 }
 
+void launch_gather_bf16(const float* table, const int32_t* ids, unsigned short* out, int n_titles, int T, int D, int pad_l,
+                        int pad_r, float drop, uint32_t key, hipStream_t s) {
+  int Tp = T + pad_l + pad_r, D4 = D / 4;
+  size_t total4 = (size_t)n_titles * Tp * D4;
+  if (total4 == 0) return;
+  int blocks = (int)std::min<size_t>(cdivz(total4, 256 * 4), 256 * 16);
+  if (drop > 0.f)
+    hipLaunchKernelGGL((gather_kernel<true, true>), dim3(blocks), dim3(256), 0, s, (const float4*)table, ids, (float4*)out,
+                       (uint32_t)total4, T, Tp, D4, pad_l, dropout_thresh(drop), key, 1.0f / (1.0f - drop));
+  else
+    hipLaunchKernelGGL((gather_kernel<false, true>), dim3(blocks), dim3(256), 0, s, (const float4*)table, ids, (float4*)out,
+                       (uint32_t)total4, T, Tp, D4, pad_l, 0u, 0u, 1.0f);
+}
 void launch_gather(const float* table, const int32_t* ids, float* out, int n_titles, int T, int D, int pad_l,
                    int pad_r, float drop, uint32_t key, hipStream_t s) {
   int Tp = T + pad_l + pad_r, D4 = D / 4;
