@@ -1209,10 +1209,16 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   const uint32_t key1 = dropout_key(c->cfg.seed, step, lane_stream + 1);
   // user encoder head
   const float* dhl = w.du;
+  // LSTUR-con's Dense over [h | user_vec]: its parameter gradients feed nothing but the optimizer -- they go to the side stream
+  // together with the candidate titles' encoder backward (the fork behind the scorer), off the path to the recurrence
+  const bool con_side = (d.arch == LSTUR_ARCH_GRU || d.arch == LSTUR_ARCH_IIGRU) && c->cand_forked && wgrad_stream(c) &&
+                        wgrad_stream(c) != s && !c->cfg.freeze_encoder;
   if (d.arch == LSTUR_ARCH_GRU || d.arch == LSTUR_ARCH_IIGRU) {
-    launch_gemm(w.cat, d.H + d.Ue, 1, w.du, d.U, 0, c->G("con_w"), d.U, nullptr, d.H + d.Ue, d.U, n, 1.f,
-                w.gemm_scratch, s);
-    launch_colsum2(w.du, n, d.U, d.U, c->G("con_b"), 1.f, w.colsum_scratch, s);
+    if (!con_side) {
+      launch_gemm(w.cat, d.H + d.Ue, 1, w.du, d.U, 0, c->G("con_w"), d.U, nullptr, d.H + d.Ue, d.U, n, 1.f,
+                  w.gemm_scratch, s);
+      launch_colsum2(w.du, n, d.U, d.U, c->G("con_b"), 1.f, w.colsum_scratch, s);
+    }
     launch_gemm(w.du, d.U, 0, c->P("con_w"), d.U, 1, w.dcat, d.H + d.Ue, nullptr, n, d.H + d.Ue, d.U, 1.f,
                 w.gemm_scratch, s);
     launch_split2(w.dcat, d.H, d.Ue, w.dhlast, d.arch == LSTUR_ARCH_IIGRU ? w.duser2 : w.duser, n, s);
@@ -1282,6 +1288,10 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   if (split) {
     (void)hipStreamWaitEvent(sw, c->ev_c0, 0);
     forked = true;
+    if (con_side) {   // (scratch of their own: the main stream's products use gemm_scratch / colsum_scratch meanwhile)
+      launch_gemm(w.cat, d.H + d.Ue, 1, w.du, d.U, 0, c->G("con_w"), d.U, nullptr, d.H + d.Ue, d.U, n, 1.f, w.gemm_scratch_k[3], sw);
+      launch_colsum2(w.du, n, d.U, d.U, c->G("con_b"), 1.f, w.colsum_scratch_k[1], sw);
+    }
     dense_gemm(w.ddocvec + (size_t)nW * d.U, d.U, c->P("dense_w"), d.U, true, w.dpooled + (size_t)nW * d.F, d.F, nullptr, ncand,
                d.F, d.U, nullptr, sw);
     side_attention_and_kernel_gradient(nW, ncand, 2, side_base, 0, &cand_slabs);
