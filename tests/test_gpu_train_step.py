@@ -165,3 +165,45 @@ def test_deferred_table_sweep_of_the_exchanged_row_step_is_bit_identical(arch):
         del model
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+_SPLIT_CHILD = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+from test_gpu_model import MID, build
+from test_gpu_train_step import _batches, _state
+B, W, T, K1 = 24, 7, 11, 5
+O, p, model, rng = build(sys.argv[2], MID, B, W, T, K1, 0.2)
+steps = _batches(model, B, W, K1, T, 4, MID['N_u'])
+for u, h, c in steps:
+    model._train_step(u, h, c, True)
+torch.cuda.synchronize()
+model.flush_tables()
+st = _state(model)
+st['pred'] = model.predict_ids(*steps[0])
+np.savez(sys.argv[1], **st)
+'''
+
+
+@pytest.mark.parametrize('arch', ['igru', 'gru'])
+def test_candidate_split_of_the_encoder_backward_changes_only_the_summation_order(arch, tmp_path):
+    """The candidate titles' encoder backward on the side stream under BPTT (DESIGN.md section 4c; default) against one launch per
+    kernel over all titles (LSTUR_CAND_SPLIT=0): the same products, reduced in a different slab order -- parameters, moments,
+    tables and predictions after four steps agree to 2e-4 of scale (1e-2 for the Adam moments of near-zero gradients)."""
+    _need_gpu()
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, env in (('split', {}), ('whole', {'LSTUR_CAND_SPLIT': '0'})):
+        f = str(tmp_path / (tag + '.npz'))
+        subprocess.check_call([sys.executable, '-c', _SPLIT_CHILD % (root, os.path.join(root, 'tests')), f, arch],
+                              env=dict(os.environ, **env), cwd=root)
+        outs.append(np.load(f))
+    for k in outs[0].files:
+        a, b = outs[0][k].astype(np.float64), outs[1][k].astype(np.float64)
+        scale = max(np.abs(b).max(), 1e-6)
+        tol = 1e-2 if k.endswith('_m') or k.endswith('_v') or k in ('dense_m', 'dense_v') else 2e-4
+        assert np.abs(a - b).max() <= tol * scale + 1e-7, (k, np.abs(a - b).max(), scale)
