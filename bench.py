@@ -61,6 +61,14 @@ def synth_inputs(wl, rng, n_batches):
     return titles, word, batches
 
 
+def rows_covered(mask):
+    """padded embedding rows tp = 0 .. T + 1 of a title that the 3-row window of some non-pad token covers (what the
+    split-layout gather writes and the conv kernels read); mask [..., T] = token is not a pad"""
+    T_ = mask.shape[-1]
+    q = np.pad(mask, [(0, 0)] * (mask.ndim - 1) + [(2, 2)])
+    return int((q[..., 0:T_ + 2] | q[..., 1:T_ + 3] | q[..., 2:T_ + 4]).sum())
+
+
 def pmc_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/;
     FETCH_SIZE doubled per the gfx950 correction) -- None when no file matches the workload."""
@@ -283,7 +291,7 @@ def e2e_legs(wl, word, steps, dropout, device):
 
 def parity_check(model, wl, titles, batch):
     """Outside the timed region: logits of one bench batch (dropout off) from the HIP path against the fp64 CPU oracle with
-    the model's CURRENT (trained) weights -- the number that shows the bf16x3 conv kernels are fp32-grade at the bench
+    the model's CURRENT (trained) weights -- the number that shows the split-operand conv kernels are fp32-grade at the bench
     shapes (BASELINE.json: fp32 logits within 1e-3 relative)."""
     import torch
     from oracle import lstur_oracle as O
@@ -443,58 +451,66 @@ def main():
                 if 'conv_wgrad_side' in kern:
                     side_flop = conv_flop * (real_tok - hist_tok) / real_tok
                     side = dict(kernel='conv_wgrad_side', avg_us=round(kern['conv_wgrad_side']['avg_us'], 1), flop_per_launch=side_flop,
-                                frac=round(side_flop / (kern['conv_wgrad_side']['avg_us'] * 1e-6) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4),
                                 note='candidate titles\' tokens: a launch of its own on the side stream under the recurrence\'s backward')
                     if dom == 'conv_wgrad':
                         dom_flop = conv_flop * hist_tok / real_tok
             ach = dom_flop / (kern[dom]['avg_us'] * 1e-6) / 1e12
-            bf16x3 = model.conv_scheme == 'bf16x3'
-            # bf16x3 (conv3.hip): every fp32-grade product is SIX bf16 MFMA products, so the kernel's roofline is the
-            # dense bf16 matrix peak / 6; the exact-fp32 MFMA kernels (LSTUR_CONV_F32=1) are priced against the fp32 peak
-            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if bf16x3 else PEAK_F32_MFMA_TFLOPS
+            # split-operand kernels (convx.hip): every fp32-grade product is THREE fp16 (f16x2) or SIX bf16 (bf16x3) MFMA
+            # products, so the kernel's roofline is the dense 16-bit matrix peak / 3 or / 6; the exact-fp32 MFMA kernels
+            # (LSTUR_CONV_F32=1) are priced against the fp32 peak
+            parts = {'f16x2': 2, 'bf16x3': 3}.get(model.conv_scheme)
+            products = {'f16x2': 3.0, 'bf16x3': 6.0}.get(model.conv_scheme, 1.0)
+            peak = PEAK_BF16_MFMA_TFLOPS / products if parts else PEAK_F32_MFMA_TFLOPS
+            scheme = {'f16x2': 'f16x2: both fp32 operands as two fp16 parts of the power-of-two scaled value, 3 MFMA products, '
+                               'fp32 accumulate (fp32-grade; peak = 2500 TFLOP/s dense fp16 / 3)',
+                      'bf16x3': 'bf16x3: 3-way bf16 split of both fp32 operands, 6 MFMA products, fp32 accumulate '
+                                '(fp32-grade; peak = 2500 TFLOP/s dense bf16 / 6)'}.get(model.conv_scheme, 'fp32 MFMA 16x16x4')
             roofline = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s',
                             frac=round(ach / peak, 4), traffic=traffic(dom),
                             avg_us=round(kern[dom]['avg_us'], 1), flop_per_launch=dom_flop,
                             non_pad_token_fraction=round(real_tok / n_tok, 4),
                             effective_algorithmic=round(conv_flop_full * dom_flop / conv_flop / (kern[dom]['avg_us'] * 1e-6) / 1e12, 2),
-                            scheme=('bf16x3: 3-way bf16 split of both fp32 operands, 6 MFMA products, fp32 accumulate '
-                                    '(fp32-grade; peak = 2500 TFLOP/s dense bf16 / 6)') if bf16x3 else 'fp32 MFMA 16x16x4',
-                            mfma_executed_tflops=round(ach * (6.0 if bf16x3 else 1.0), 1),
+                            scheme=scheme, mfma_executed_tflops=round(ach * products, 1),
                             frac_vs_fp32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 4))
             if side:
+                side['frac'] = round(side['flop_per_launch'] / (side['avg_us'] * 1e-6) / 1e12 / peak, 4)
                 roofline['side_launch'] = side
-            if bf16x3:
-                # what the kernel has to move at least: every embedding row some non-pad token's window covers once (three
-                # bf16 parts), the split weight once, and its own output / input gradient rows (fp32) once
-                def rows_covered(mask):
-                    T_ = mask.shape[-1]
-                    q = np.pad(mask, [(0, 0)] * (mask.ndim - 1) + [(2, 2)])
-                    return int((q[..., 0:T_ + 2] | q[..., 1:T_ + 3] | q[..., 2:T_ + 4]).sum())
+            if parts:
+                # what the kernel has to move at least: every embedding row some non-pad token's window covers once (its
+                # 16-bit parts), the split weight once, and its own output / input gradient rows (fp32) once
                 e_rows = sum(rows_covered(titles[x] != 0) for b_ in batches for x in (b_[1], b_[2])) / float(len(batches))
                 dp = (wl['D'] + 7) // 8 * 8
-                alg = e_rows * dp * 6 + 3 * wl['k'] * dp * ((wl['F'] + 31) // 32 * 32) * 2 + real_tok * wl['F'] * 4
+                alg = e_rows * dp * 2 * parts + parts * wl['k'] * dp * ((wl['F'] + 31) // 32 * 32) * 2 + real_tok * wl['F'] * 4
                 roofline['traffic_algorithmic'] = int(alg * (dom_flop / conv_flop))
                 if roofline['traffic']:
                     roofline['traffic_over_algorithmic'] = round(roofline['traffic'] / roofline['traffic_algorithmic'], 2)
         if prof:
-            gb = gather_bytes / (kern['gather']['avg_us'] * 1e-6) / 1e9
+            # The gather is priced on the bytes the SELECTED kernel moves (ids + table rows read + rows written in its layout):
+            # `achieved` / `frac` can therefore not exceed the HBM peak.  The SURVEY's stand-alone figure (2404 B/token: id +
+            # fp32 row in + fp32 row out for EVERY token, pads included) over the same launch time is kept as `effective_*`:
+            # rows the kernel skips, or writes in fewer bytes, count there as moved.
+            us = kern['gather']['avg_us']
+            n_titles = wl['B'] * (wl['W'] + wl['K1'])
+            if model.conv_scheme in ('f16x2', 'bf16x3'):
+                parts = {'f16x2': 2, 'bf16x3': 3}[model.conv_scheme]
+                rows = sum(rows_covered(titles[x] != 0) for b in batches for x in (b[1], b[2])) / float(len(batches))
+                moved = rows * (4 * wl['D'] + 2 * parts * ((wl['D'] + 7) // 8 * 8)) + n_tok * 4
+                layout = 'Ex: %d x 16-bit parts per element (%d B), padded rows no window of a non-pad token covers skipped' % (parts, 2 * parts)
+            elif mhsa:
+                moved = n_tok * (4 + 4 * wl['D'] + 2 * wl['D'])
+                layout = 'bf16 rows [N_tok, D] for the projections: fp32 row in, bf16 row out, every token'
+            else:
+                moved = n_titles * (wl['T'] + wl['k'] - 1) * 4 * wl['D'] + n_tok * (4 + 4 * wl['D'])
+                layout = 'fp32 padded rows [N_t, T + k - 1, D]: every row written, every token\'s table row read'
+            gb = moved / (us * 1e-6) / 1e9
+            eff = gather_bytes / (us * 1e-6) / 1e9
             roofline_gather = dict(kernel='gather', bound='hbm', achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                                   frac=round(gb / PEAK_HBM_GBS, 4), traffic=traffic('gather'),
-                                   avg_us=round(kern['gather']['avg_us'], 1), bytes_per_launch=gather_bytes)
-            if model.conv_scheme == 'bf16x3':
-                # the gather feeds the bf16x3 conv kernels: it writes three bf16 parts per element (6 B instead of 4) but
-                # only the padded rows some non-pad token's window covers; `achieved` stays the SURVEY's 2404 B/token
-                # over the launch time ("effective": rows skipped count as moved), `moved` is what the kernel moves
-                def rows_written(mask):      # padded rows tp = 0 .. T+1 covered by the window of a non-pad token tp-2 .. tp
-                    T_ = mask.shape[-1]
-                    q = np.pad(mask, [(0, 0)] * (mask.ndim - 1) + [(2, 2)])
-                    return int((q[..., 0:T_ + 2] | q[..., 1:T_ + 3] | q[..., 2:T_ + 4]).sum())
-                rows = sum(rows_written(titles[x] != 0) for b in batches for x in (b[1], b[2])) / float(len(batches))
-                moved = rows * (4 * wl['D'] + 6 * ((wl['D'] + 7) // 8 * 8)) + n_tok * 4
-                roofline_gather.update(layout='E3: 3 x bf16 parts per element, rows no window covers skipped',
-                                       moved_bytes_per_launch=int(moved),
-                                       moved_gbs=round(moved / (kern['gather']['avg_us'] * 1e-6) / 1e9, 1),
-                                       moved_frac=round(moved / (kern['gather']['avg_us'] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4))
+                                   frac=round(gb / PEAK_HBM_GBS, 4), traffic=traffic('gather'), avg_us=round(us, 1),
+                                   bytes_per_launch=int(moved), layout=layout,
+                                   effective_bytes_per_launch=gather_bytes, effective_gbs=round(eff, 1),
+                                   effective_frac=round(eff / PEAK_HBM_GBS, 4),
+                                   effective_note='SURVEY 8d: 2404 B/token stand-alone (id + fp32 row read + fp32 row write, pads '
+                                                  'included) over the same launch time')
         out = {
             'metric': 'training impressions/sec', 'value': round(world * wl['B'] * args.steps / el, 1),
             'unit': 'impressions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -507,7 +523,10 @@ def main():
                        'n_users': wl['N_u'], 'n_docs': wl['N_d'], 'vocab': wl['V'], 'dropout': args.dropout,
                        'news_encoder': wl.get('encoder', 'cnnatt'), 'heads': wl.get('heads', 0),
                        'parallelism': 'dp%d' % world, 'collective_backend': ('rccl' if backend == 'nccl' else backend) if world > 1 else None,
-                       'optimizer': 'keras-adam (dense user-table sweep)',
+                       'optimizer': 'keras-adam (dense user-table update, applied lazily per row: bit-identical)' if model.lazy_table
+                                    else 'keras-adam (dense user-table sweep)',
+                       'lazy_table': bool(model.lazy_table), 'fresh_users': bool(args.fresh_users),
+                       'prefetch': not args.no_prefetch,
                        # the synthetic histories are 90 % full windows (62 % non-pad tokens): heavier than real click
                        # histories (the `e2e` legs run at ~49 % non-pad tokens)
                        'history_fill': 'synthetic: 90 %% of the samples have a full %d-slot history' % wl['W']},

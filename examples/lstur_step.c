@@ -55,10 +55,11 @@ static int upload_f(float* dev, size_t n, float amp) {
 int main(void) {
   lstur_cfg cfg;
   memset(&cfg, 0, sizeof(cfg));
+  cfg.struct_size = sizeof(cfg);   /* ABI guard: the library refuses a lstur_cfg of another size */
   cfg.max_batch = 16; cfg.window = 10; cfg.title_len = 12; cfg.cands = 5; cfg.vocab = 2000; cfg.word_dim = 64;
   cfg.filters = 96; cfg.kernel = 3; cfg.user_dim = 48; cfg.n_users = 300; cfg.arch = LSTUR_ARCH_IGRU;
   cfg.dropout = 0.2f; cfg.seed = 1; cfg.beta1 = 0.9f; cfg.beta2 = 0.999f; cfg.eps = 1e-7f;
-  cfg.head = LSTUR_HEAD_SOFTMAX; cfg.gain = 1.0f; cfg.loss_negatives = 4;
+  cfg.head = LSTUR_HEAD_SOFTMAX; cfg.gain = 1.0f; cfg.loss_negatives = 4; cfg.id_keep = 1.0f;
 
   lstur_sizes sz;
   LSTUR(lstur_query_sizes(&cfg, &sz));

@@ -85,7 +85,14 @@ enum lstur_encoder {         /* token stage of the news encoder (--news-encoder)
                                 ignored; parameters qkv_w [D, 3F], qkv_b [3F] replace conv_w / conv_b          */
 };
 
+/* ABI guard: the caller writes sizeof(lstur_cfg) of ITS build into cfg.struct_size (first field).  Every entry point that
+ * takes a lstur_cfg refuses a value that differs from the library's own sizeof(lstur_cfg) with LSTUR_ERR_ARG instead of
+ * reading past a shorter struct; lstur_abi_version() (LSTUR_ABI_VERSION of the library build) lets a binding check the
+ * rest of this header before it calls anything else. */
+#define LSTUR_ABI_VERSION 3
+
 typedef struct lstur_cfg {
+  uint32_t struct_size;      /* = sizeof(lstur_cfg) of the caller's build (see above)                  */
   int32_t max_batch;         /* largest n passed to train_step (-b)                                    */
   int32_t window;            /* W  history length (-w / window_size)                                   */
   int32_t title_len;         /* T  (--title-shape)                                                     */
@@ -150,6 +157,7 @@ typedef struct lstur_buffers {
 
 const char* lstur_last_error(void);
 const char* lstur_version(void);
+int lstur_abi_version(void);              /* LSTUR_ABI_VERSION the library was built from */
 
 /* Sizes for a configuration (no GPU needed). */
 int lstur_query_sizes(const lstur_cfg* cfg, lstur_sizes* out);
@@ -235,15 +243,6 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
  * flushes and re-bases). */
 int lstur_flush_tables(lstur_ctx* ctx, lstur_stream stream);
 int lstur_lazy_adam(lstur_ctx* ctx);
-/* 1 when the step keeps the history titles in SLOT-major order inside the workspace (title = slot * n + sample instead of
- * the reference's sample * W + slot; the candidate titles follow in both): the per-title arrays lstur_peek hands out
- * ("doc_vec", "pooled", "dgates", ...) are in that order.  Inputs, outputs and dropout masks are unaffected (the library
- * reads the caller's arrays in the reference's order and draws dropout at the reference position of every element).
- * The layout lets a range of history slots be a contiguous range of titles, tokens and GRU rows -- what the backward
- * pass needs to start the news encoder's backward of the LATE slots while the recurrence's backward still walks the
- * early ones.  LSTUR_SLOT_MAJOR=0 keeps the reference's order. */
-int lstur_slot_major(lstur_ctx* ctx);
-
 /* The caller wrote parameters (dense_param, word_emb) from outside -- set_weights, a checkpoint load: the weight images
  * the library keeps for its MFMA kernels (packed behind every Adam step, for the NEXT forward) and a batch staged by
  * lstur_prefetch_ids are stale.  Not needed after lstur_adam_step / lstur_train_step. */
@@ -297,9 +296,11 @@ int lstur_point_evaluate(lstur_ctx* ctx, const int32_t* user, const int32_t* his
 int lstur_profile(lstur_ctx* ctx, int enable);
 int lstur_profile_read(lstur_ctx* ctx, int index, const char** name, float* total_ms, int32_t* launches);
 
-/* How the Conv1D contractions of this context run: 0 = none (mhsa encoder), 1 = "bf16x3" (fp32-grade 3-way bf16 split on
- * the bf16 matrix cores, mnexp_amd/csrc/conv3f.hip), 2 = exact fp32 MFMA (mnexp_amd/csrc/conv.hip: filters > 448, kernel
- * > 8, or LSTUR_CONV_F32 set in the environment).  Negative: error. */
+/* How the Conv1D contractions of this context run: 0 = none (mhsa encoder); 3 = "f16x2" (the default: both operands as two
+ * fp16 parts of the power-of-two scaled value, three fp16 MFMA products per fp32-grade product); 1 = "bf16x3" (three bf16
+ * parts, six products: trainable word table, or LSTUR_CONV_SCHEME=bf16x3) -- both in mnexp_amd/csrc/convx.hip, both
+ * fp32-grade (error of the order of an fp32 FMA chain in another order), not reduced-precision kernels; 2 = exact fp32 MFMA
+ * (mnexp_amd/csrc/conv.hip: filters > 448, kernel > 8, or LSTUR_CONV_F32 set in the environment).  Negative: error. */
 int lstur_conv_scheme(lstur_ctx* ctx);
 
 /* Debug/inspection: device pointers to intermediates of the last call (valid until the next call).
@@ -328,47 +329,44 @@ int lstur_conv1d_relu_mask_fwd(const float* emb_padded, const float* w_packed, c
                                const int32_t* ids, float* out, int32_t n_titles, int32_t title_len,
                                int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx,
                                const int32_t* vcount, lstur_stream stream);
-/* The same Conv1D forward as an fp32-GRADE contraction on the bf16 matrix cores ("bf16x3": both operands split into
- * three bf16 parts, six products accumulated in fp32; error ~2^-23 of |a||b| per product, the level of an fp32 FMA
- * chain in another order -- not a reduced-precision kernel).  This is the kernel the training step uses (filters <= 448);
- * w3 = lstur_conv3_pack_w(conv_w [k*D, F]) holds lstur_conv3_w3_elems() bf16 elements.  Same arguments otherwise. */
-size_t lstur_conv3_w3_elems(int32_t dim, int32_t ksize, int32_t filters);
-int lstur_conv3_pack_w(const float* w, int32_t dim, int32_t ksize, int32_t filters, uint16_t* w3, lstur_stream stream);
-int lstur_conv3_relu_mask_fwd(const float* emb_padded, const uint16_t* w3, const float* bias, const int32_t* ids, float* out,
-                              int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters,
-                              const int32_t* vidx, const int32_t* vcount, lstur_stream stream);
-/* Second generation of the bf16x3 forward (mnexp_amd/csrc/conv3f.hip): BOTH operands pre-split.  The embedding gather writes
- * the three bf16 parts of every element into "E3" ([title][title_len + ksize - 1][ceil8(dim) / 8][part][8] bf16,
- * lstur_conv3_e3_elems() elements incl. slack; Embedding + Dropout of task/paper.py:132-147 like lstur_gather_f32;
- * skip_unread != 0: rows that no window of a non-pad token covers are left untouched -- e3 must then hold finite values), the
- * weight image w3 = lstur_conv3_pack_w2(conv_w) holds lstur_conv3_w3_elems2() elements.  variant 0; 2 = the tap-sharing
- * kernel (ksize 3, ceil8(dim) % 16 == 0, else the same as 0: each embedding row staged once per workgroup for the three
- * taps -- a third of the fetch, measured 13 % slower); 10 .. 16 are timing-only ablation builds with WRONG results
- * (tools/bench_conv3f.py).  scratch: lstur_conv3_fwd2_scratch() bytes for the k-sliced
- * tiles of the last partial round of workgroups, or NULL (every tile runs whole). */
-size_t lstur_conv3_e3_elems(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize);
-int lstur_gather_split3(const float* table, const int32_t* ids, uint16_t* e3, int32_t n_titles, int32_t title_len,
-                        int32_t dim, int32_t pad_left, int32_t pad_right, float drop, uint32_t key, int32_t skip_unread,
-                        lstur_stream stream);
-size_t lstur_conv3_w3_elems2(int32_t dim, int32_t ksize, int32_t filters);
-int lstur_conv3_pack_w2(const float* w, int32_t dim, int32_t ksize, int32_t filters, uint16_t* w3, lstur_stream stream);
-int lstur_conv3_relu_mask_fwd2(const uint16_t* e3, const uint16_t* w3, const float* bias, const int32_t* ids, float* out,
-                               int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters,
-                               const int32_t* vidx, const int32_t* vcount, int32_t variant, void* scratch,
-                               lstur_stream stream);
-size_t lstur_conv3_fwd2_scratch(void);
-/* ... and its kernel gradient on the same pre-split embeddings (dout fp32 [n_titles * title_len, filters]; rows of pad tokens
- * are not read when the compacted list is given).  scratch: lstur_conv3_wgrad2_scratch() bytes; offsets: 2 * n_titles *
- * title_len int32 of scratch (per-token window / row offsets, filled by the call). */
-size_t lstur_conv3_wgrad2_scratch(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters);
-int lstur_conv3_wgrad2(const uint16_t* e3, const float* dout, float* dw, void* scratch, int32_t* offsets, int32_t n_titles,
-                       int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx,
-                       const int32_t* vcount, lstur_stream stream);
-/* ... and the kernel gradient in the same scheme (what the training step uses); scratch: lstur_conv3_wgrad_scratch bytes. */
-size_t lstur_conv3_wgrad_scratch(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters);
-int lstur_conv3_wgrad(const float* emb_padded, const float* dout, float* dw, void* scratch, int32_t n_titles,
+/* ---- The Conv1D contractions the training step uses: fp32-GRADE products on the 16-bit matrix cores with BOTH operands
+ * pre-split into `parts` 16-bit pieces (mnexp_amd/csrc/convx.hip; Embedding + Dropout + Conv1D of task/paper.py:132-155):
+ *   parts = 2 "f16x2":  x s = h + l, two fp16 values of the power-of-two scaled element; products hh + hl + lh; the scales
+ *                       (embeddings: from max |word table|, weight: from max |conv_w|, gradient: from max |dout|) live in a
+ *                       device block of lstur_convx_scales_bytes() bytes that the calls below read and maintain;
+ *   parts = 3 "bf16x3": x = h + m + l, three bf16 values; six products; `scales` may be NULL.
+ * Error ~2^-22 of |a||b| per product, random in sign -- below what the fp32 accumulation of a k*D-long dot product rounds
+ * away; tests/test_gpu_kernels.py holds both to the bound of the exact-fp32 MFMA kernel against fp64.
+ * Layouts: "Ex" = [title][title_len + ksize - 1][ceil8(dim) / 8][part][8] 16-bit (lstur_convx_e_elems elements incl. slack;
+ * written by lstur_convx_gather: out = table[ids] (x dropout mask / (1 - drop)) (x scale), zero rows left and right;
+ * skip_unread != 0: rows that no window of a non-pad token covers are left untouched -- ex must then hold finite values);
+ * weight image wx = lstur_convx_pack_w(conv_w [ksize * dim, filters]) of lstur_convx_w_elems elements.
+ * Call order for parts = 2: lstur_convx_scales_init, lstur_convx_embedding_scale(table), lstur_convx_pack_w, then gather /
+ * forward / kernel gradient in any order. */
+size_t lstur_convx_scales_bytes(void);
+int lstur_convx_scales_init(float* scales, lstur_stream stream);
+int lstur_convx_embedding_scale(const float* table, size_t count, float drop, float* scales, lstur_stream stream);
+size_t lstur_convx_e_elems(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t parts);
+int lstur_convx_gather(const float* table, const int32_t* ids, uint16_t* ex, int32_t n_titles, int32_t title_len, int32_t dim,
+                       int32_t pad_left, int32_t pad_right, float drop, uint32_t key, int32_t skip_unread, int32_t parts,
+                       const float* scales, lstur_stream stream);
+size_t lstur_convx_w_elems(int32_t dim, int32_t ksize, int32_t filters, int32_t parts);
+int lstur_convx_pack_w(const float* w, int32_t dim, int32_t ksize, int32_t filters, uint16_t* wx, int32_t parts, float* scales,
+                       lstur_stream stream);
+/* Conv1D('same', relu) * (id != 0) on Ex; vidx / vcount as in lstur_conv1d_relu_mask_fwd.  scratch: lstur_convx_fwd_scratch()
+ * bytes for the k-sliced tiles of the last partial round of workgroups, or NULL (every tile runs whole). */
+size_t lstur_convx_fwd_scratch(void);
+int lstur_convx_fwd(const uint16_t* ex, const uint16_t* wx, const float* bias, const int32_t* ids, float* out, int32_t n_titles,
+                    int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx, const int32_t* vcount,
+                    int32_t parts, const float* scales, void* scratch, lstur_stream stream);
+/* ... and its kernel gradient dw [ksize * dim, filters] = im2col(E)^T . dout on the same pre-split embeddings (dout fp32
+ * [n_titles * title_len, filters]; rows of pad tokens are not read when the compacted list is given; for parts = 2 this
+ * stand-alone call first takes max |dout| over the rows it reads).  scratch: lstur_convx_wgrad_scratch() bytes;
+ * offsets: 2 * n_titles * title_len int32 of scratch (per-token window / row offsets, filled by the call). */
+size_t lstur_convx_wgrad_scratch(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters);
+int lstur_convx_wgrad(const uint16_t* ex, const float* dout, float* dw, void* scratch, int32_t* offsets, int32_t n_titles,
                       int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx,
-                      const int32_t* vcount, lstur_stream stream);
+                      const int32_t* vcount, int32_t parts, float* scales, lstur_stream stream);
 /* Conv1D kernel gradient: dW[k*D,F] = im2col(emb)^T . dOut ; scratch >= lstur_conv1d_wgrad_scratch() bytes. */
 size_t lstur_conv1d_wgrad_scratch(int32_t dim, int32_t ksize, int32_t filters);
 int lstur_conv1d_wgrad(const float* emb_padded, const float* dout, float* dw, void* scratch,

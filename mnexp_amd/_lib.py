@@ -22,8 +22,11 @@ class LsturError(RuntimeError):
     pass
 
 
+ABI_VERSION = 3     # include/lstur.h: LSTUR_ABI_VERSION this binding was written against
+
+
 class Cfg(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ('max_batch', 'window', 'title_len', 'cands', 'vocab', 'word_dim',
+    _fields_ = [('struct_size', C.c_uint32)] + [(n, C.c_int32) for n in ('max_batch', 'window', 'title_len', 'cands', 'vocab', 'word_dim',
                                          'filters', 'kernel', 'user_dim', 'n_users', 'arch')] + [
         ('dropout', C.c_float), ('seed', C.c_uint32), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
         ('head', C.c_int32), ('gain', C.c_float), ('loss_negatives', C.c_int32), ('word_trainable', C.c_int32),
@@ -50,6 +53,7 @@ _P, _I, _U, _F, _Z = C.c_void_p, C.c_int32, C.c_uint32, C.c_float, C.c_size_t
 SIGNATURES = {
     'lstur_last_error': (C.c_char_p, []),
     'lstur_version': (C.c_char_p, []),
+    'lstur_abi_version': (_I, []),
     'lstur_query_sizes': (_I, [C.POINTER(Cfg), C.POINTER(Sizes)]),
     'lstur_param': (_I, [C.POINTER(Cfg), C.c_char_p, C.POINTER(_Z), C.POINTER(_Z)]),
     'lstur_param_name': (C.c_char_p, [C.POINTER(Cfg), _I]),
@@ -66,7 +70,6 @@ SIGNATURES = {
     'lstur_params_changed': (_I, [_P]),
     'lstur_flush_tables': (_I, [_P, _P]),
     'lstur_lazy_adam': (_I, [_P]),
-    'lstur_slot_major': (_I, [_P]),
     'lstur_train_step': (_I, [_P, _P, _P, _P, _P, _I, _U, _F, _I, _P, _P]),
     'lstur_train_step_ids': (_I, [_P, _P, _P, _P, _P, _I, _U, _F, _I, _P, _P]),
     'lstur_dp_tail_floats': (_Z, [C.POINTER(Cfg), _I]),
@@ -86,19 +89,17 @@ SIGNATURES = {
     'lstur_valid_tokens_scratch': (_Z, [_I]),
     'lstur_valid_tokens': (_I, [_P, _I, _P, _P, _P, _P]),
     'lstur_conv1d_relu_mask_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    'lstur_conv3_w3_elems': (_Z, [_I, _I, _I]),
-    'lstur_conv3_pack_w': (_I, [_P, _I, _I, _I, _P, _P]),
-    'lstur_conv3_relu_mask_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    'lstur_conv3_e3_elems': (_Z, [_I, _I, _I, _I]),
-    'lstur_gather_split3': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _I, _P]),
-    'lstur_conv3_w3_elems2': (_Z, [_I, _I, _I]),
-    'lstur_conv3_pack_w2': (_I, [_P, _I, _I, _I, _P, _P]),
-    'lstur_conv3_relu_mask_fwd2': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
-    'lstur_conv3_fwd2_scratch': (_Z, []),
-    'lstur_conv3_wgrad2_scratch': (_Z, [_I, _I, _I, _I, _I]),
-    'lstur_conv3_wgrad2': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    'lstur_conv3_wgrad_scratch': (_Z, [_I, _I, _I, _I, _I]),
-    'lstur_conv3_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'lstur_convx_scales_bytes': (_Z, []),
+    'lstur_convx_scales_init': (_I, [_P, _P]),
+    'lstur_convx_embedding_scale': (_I, [_P, _Z, _F, _P, _P]),
+    'lstur_convx_e_elems': (_Z, [_I, _I, _I, _I, _I]),
+    'lstur_convx_gather': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _I, _I, _P, _P]),
+    'lstur_convx_w_elems': (_Z, [_I, _I, _I, _I]),
+    'lstur_convx_pack_w': (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
+    'lstur_convx_fwd_scratch': (_Z, []),
+    'lstur_convx_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    'lstur_convx_wgrad_scratch': (_Z, [_I, _I, _I, _I, _I]),
+    'lstur_convx_wgrad': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     'lstur_conv1d_wgrad_scratch': (_Z, [_I, _I, _I]),
     'lstur_conv1d_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'lstur_pack_b_floats': (_Z, [_I, _I]),
@@ -145,6 +146,9 @@ def _load():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.lstur_abi_version() != ABI_VERSION:
+        raise LsturError('{} was built from ABI version {}, this binding is written against {}: rebuild the library '
+                         '(make -C mnexp_amd/csrc)'.format(LIB_PATH, lib.lstur_abi_version(), ABI_VERSION))
     return lib
 
 
@@ -169,7 +173,7 @@ def make_cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kern
     if news_encoder not in ENCODER:
         raise LsturError('news encoder {!r} is not supported by the native path (have {})'.format(
             news_encoder, sorted(ENCODER)))
-    return Cfg(max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
+    return Cfg(C.sizeof(Cfg), max_batch, window, title_len, cands, vocab, word_dim, filters, kernel, user_dim, n_users,
                ARCH[arch], dropout, seed, beta1, beta2, eps, HEAD[head], gain, loss_negatives,
                int(bool(word_trainable)), int(bool(freeze_encoder)), ENCODER[news_encoder], int(heads),
                SCORE[score_model], float(id_keep))

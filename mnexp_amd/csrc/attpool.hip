@@ -237,9 +237,9 @@ __device__ __forceinline__ float rows8_sum(const float (&p)[kTitleTok], int lane
 
 // keep bits of the conv-output dropout in the title kernels' thread layout (see title_load); dead rows and columns past F: 0
 __global__ __launch_bounds__(256) void att_keep_bits_kernel(const uint32_t* __restrict__ live, uint32_t* __restrict__ kbits,
-                                                            int T, int F, uint32_t thresh, uint32_t key, TitleOrder ord) {
+                                                            int T, int F, uint32_t thresh, uint32_t key) {
   const int n = blockIdx.x, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), F4 = F / 4;
-  const int hn = ref_title(ord, n);
+  const int hn = n;
   const uint32_t lm = title_mask(live, nullptr, n, T, lane);
   uint32_t kb[2] = {0u, 0u};
 #pragma unroll
@@ -260,9 +260,9 @@ __global__ __launch_bounds__(256) void att_keep_bits_kernel(const uint32_t* __re
 }
 size_t attpool_keep_bits_words(int n_titles) { return (size_t)n_titles * 512; }
 bool launch_attpool_keep_bits(const uint32_t* live, uint32_t* kbits, int n_titles, int T, int F, float drop, uint32_t key,
-                              hipStream_t s, TitleOrder ord) {
+                              hipStream_t s) {
   if (!n_titles || !live || !kbits || !(drop > 0.f) || !title_path(T, F)) return false;
-  hipLaunchKernelGGL(att_keep_bits_kernel, dim3(n_titles), dim3(256), 0, s, live, kbits, T, F, dropout_thresh(drop), key, ord);
+  hipLaunchKernelGGL(att_keep_bits_kernel, dim3(n_titles), dim3(256), 0, s, live, kbits, T, F, dropout_thresh(drop), key);
   return true;
 }
 
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void att_fwd_title_kernel(const float* __restr
                                                             const float* __restrict__ att_b, float* __restrict__ a_out,
                                                             float* __restrict__ w_out, float* __restrict__ pooled, int T,
                                                             int F, uint32_t thresh, uint32_t key, float scale,
-                                                            const uint32_t* __restrict__ kbits, TitleOrder ord) {
+                                                            const uint32_t* __restrict__ kbits) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // e[32] | part[4][F]
   float* eL = sm;
   float* part = sm + 32;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void att_fwd_title_kernel(const float* __restr
   const uint32_t lm = title_mask(live, ids, n, T, lane);
   float4 x[kTitleTok][2];
   bool nz[kTitleTok];
-  title_load(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz, kbits, ref_title(ord, n));
+  title_load(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz, kbits, n);
   float4 kf[2];
   const __amdgpu_buffer_rsrc_t rs_aw = make_rsrc(att_w, (uint32_t)F * 4u);
 #pragma unroll
@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
                                                             float* __restrict__ parts, int T, int F, uint32_t thresh,
                                                             uint32_t key, float scale, int ldp, int off_aw, int off_cb,
                                                             int off_ab, int relu, const uint32_t* __restrict__ kbits,
-                                                            int title0, TitleOrder ord) {
+                                                            int title0, uint32_t* __restrict__ gmax,
+                                                            uint32_t* __restrict__ gzero) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // dw[32] | (unused)[32] | red[4][2][F]
   float* dwL = sm;
   float* red = sm + 64;
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
   const uint32_t lm = title_mask(live, ids, n, T, lane);
   float4 x[kTitleTok][2];
   bool nz[kTitleTok];
-  title_load<false>(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz, kbits, ref_title(ord, n));
+  title_load<false>(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz, kbits, n);
   float4 dp[2], kf[2];
   const __amdgpu_buffer_rsrc_t rs_aw = make_rsrc(att_w, (uint32_t)F * 4u);
   const __amdgpu_buffer_rsrc_t rs_dp = make_rsrc(dpooled + (size_t)n * F, (uint32_t)F * 4u);
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
   const float ds_t = (dw_t - sum) * w_t * (1.0f - a_t * a_t);
   const __amdgpu_buffer_rsrc_t rs_dc = make_rsrc(dc + (size_t)n * T * F, (uint32_t)T * (uint32_t)F * 4u);
   float4 gaw[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, gcb[2] = {gaw[0], gaw[0]};
+  float gm = 0.f;                                      // max |dc| of this thread's elements (the kernel gradient's fp16 scale)
 #pragma unroll
   for (int i = 0; i < kTitleTok; ++i) {
     const int t = wv + 4 * i;
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
         gcb[h].y += o.y;
         gcb[h].z += o.z;
         gcb[h].w += o.w;
+        gm = fmaxf(fmaxf(gm, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
       }
       buf_store4(o, rs_dc, (lane + 64 * h < F4) ? ((uint32_t)t * (uint32_t)F + (uint32_t)(lane + 64 * h) * 4u) * 4u : kBufOob, 0);
     }
@@ -438,18 +441,23 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
     for (int t = 0; t < T; ++t) gab += lane_value(ds_t, t);
     if (lane == 0) pr[off_ab] = gab;
   }
+  if (gmax) {      // (a NaN gradient compares false everywhere: it does not raise the maximum, it shows in the loss)
+    gm = wave_max(gm);
+    if (lane == 0 && gm > 0.f) atomicMax(gmax, __float_as_uint(gm));
+  }
+  if (gzero && blockIdx.x == 0 && threadIdx.x == 0) gzero[0] = gzero[1] = 0u;
 }
 
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
                         float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s,
-                        const uint32_t* live, const uint32_t* kbits, TitleOrder ord) {
+                        const uint32_t* live, const uint32_t* kbits) {
   if (!n_titles) return;
   uint32_t thresh = drop > 0.f ? dropout_thresh(drop) : 0u;
   float scale = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
   int rows = n_titles * T;
   if (title_path(T, F)) {
     hipLaunchKernelGGL(att_fwd_title_kernel, dim3(n_titles), dim3(256), (32 + 4 * F) * sizeof(float), s, c, ids, live, att_w,
-                       att_b, a, w, pooled, T, F, thresh, key, scale, thresh ? kbits : nullptr, ord);
+                       att_b, a, w, pooled, T, F, thresh, key, scale, thresh ? kbits : nullptr);
     return;
   }
   if (F % 4 == 0) {
@@ -530,8 +538,10 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
     const float* __restrict__ c, const int32_t* __restrict__ ids, const float* __restrict__ att_w,
     const float* __restrict__ w, const float* __restrict__ ds, const float* __restrict__ dpooled,
     float* __restrict__ dc, float* __restrict__ parts, int rows, int T, int F, uint32_t thresh, uint32_t key,
-    float scale, int ldp, int off_aw, int off_cb, int off_ab, int relu) {
+    float scale, int ldp, int off_aw, int off_cb, int off_ab, int relu, uint32_t* __restrict__ gmax,
+    uint32_t* __restrict__ gzero) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [2][F] partials of sub-stream 1
+  float gm = 0.f;
   const int cols = VEC == 4 ? F / 4 : F;
   const int per = (rows + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
@@ -566,6 +576,7 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
           gcb.y += o.y;
           gcb.z += o.z;
           gcb.w += o.w;
+          gm = fmaxf(fmaxf(gm, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
         ((float4*)(dc + (size_t)row * F))[j] = o;
       }
@@ -599,6 +610,7 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
           gaw += dst * x;
           o = grad_gate(x, relu) ? (dpooled[(size_t)n * F + j] * wt + dst * kf) * scale : 0.f;
           gcb += o;
+          gm = fmaxf(gm, fabsf(o));
         }
         dc[(size_t)row * F + j] = o;
       }
@@ -619,12 +631,18 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
     for (int row = r0; row < r1; ++row) gab += ds[row];   // ds is 0 on masked / pad rows
     pr[off_ab] = gab;
   }
+  if (gmax) {
+    gm = wave_max(gm);
+    if ((threadIdx.x & 63) == 0 && gm > 0.f) atomicMax(gmax, __float_as_uint(gm));
+  }
+  if (gzero && blockIdx.x == 0 && threadIdx.x == 0) gzero[0] = gzero[1] = 0u;
 }
 
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
                         float drop, uint32_t key, hipStream_t s, int ldp, int off_aw, int off_cb, int off_ab, int relu,
-                        const uint32_t* live, const uint32_t* kbits, int title0, int title_count, TitleOrder ord) {
+                        const uint32_t* live, const uint32_t* kbits, int title0, int title_count, uint32_t* gmax,
+                        uint32_t* gzero) {
   if (ldp <= 0) {   // default layout of the public entry point: datt_w[F] | dconv_b[F] | datt_b
     ldp = 2 * F + 1;
     off_aw = 0;
@@ -641,7 +659,7 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
     if (cnt > 0)
       hipLaunchKernelGGL(att_bwd_title_kernel, dim3(cnt), dim3(256), (64 + 8 * F) * sizeof(float), s, c, ids, live, att_w, a,
                          w, dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu,
-                         thresh ? kbits : nullptr, title0, ord);
+                         thresh ? kbits : nullptr, title0, gmax, gzero);
     return;
   }
   if (F % 4 == 0) {
@@ -649,13 +667,13 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
                        thresh, key, scale);
     hipLaunchKernelGGL(att_bwd_ds_kernel, dim3(cdiv(n_titles, 128)), dim3(128), 0, s, row_scratch, w, a, n_titles, T);
     hipLaunchKernelGGL(att_bwd_dc_kernel<4>, dim3(nparts), dim3(128 * kDcRsub), 2 * F * sizeof(float), s, c, ids, att_w, w, row_scratch, dpooled, dc,
-                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu);
+                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu, gmax, gzero);
   } else {
     hipLaunchKernelGGL(att_bwd_dw_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, s, c, w, dpooled, row_scratch, rows, T, F,
                        thresh, key, scale);
     hipLaunchKernelGGL(att_bwd_ds_kernel, dim3(cdiv(n_titles, 128)), dim3(128), 0, s, row_scratch, w, a, n_titles, T);
     hipLaunchKernelGGL(att_bwd_dc_kernel<1>, dim3(nparts), dim3(128 * kDcRsub), 2 * F * sizeof(float), s, c, ids, att_w, w, row_scratch, dpooled, dc,
-                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu);
+                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu, gmax, gzero);
   }
 }
 

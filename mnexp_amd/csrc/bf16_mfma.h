@@ -1,4 +1,4 @@
-// bf16 MFMA helpers shared by gemm_bf16.hip and conv3.hip (gfx950).
+// 16-bit MFMA helpers (bf16 and fp16 operands, fp32 accumulation) shared by the conv / GEMM / projection kernels (gfx950).
 #pragma once
 #include "lstur_device.h"
 
@@ -54,5 +54,38 @@ __device__ __forceinline__ void split3(float4 v, u16x4& h, u16x4& m, u16x4& l) {
   const float4 r2 = make_float4(r1.x - bf2f(m[0]), r1.y - bf2f(m[1]), r1.z - bf2f(m[2]), r1.w - bf2f(m[3]));
   l = cvt4(r2);
 }
+
+
+// ---- fp16 pairs ("f16x2"): x * s = h + l with h = fp16(x s), l = fp16(x s - h), s a power of two that puts the tensor's
+// largest magnitude at 2^12 .. 2^15.  h carries 11 significant bits, l the next 11 (l is a normal fp16 down to |x s| = 2^-3;
+// below that its absolute error is 2^-25, i.e. < 2^-37 of the tensor's maximum), so h + l = x s to 2^-22 relative, and the
+// three products hh + hl + lh of two such pairs reproduce the fp32 product to ~2^-21 relative (the dropped ll term is
+// below 2^-22).  A dot product of K such products carries a random-sign error of ~sqrt(K) 2^-23 |a||b| -- below what the
+// fp32 accumulation of the same K terms rounds away -- at HALF the matrix-core work of the bf16 triple (3 instead of 6
+// products) and 4 instead of 6 bytes per staged element.  Products of fp16 values are exact in the MFMA's fp32 accumulate;
+// the scale is undone once per accumulator (exact: a power of two).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma32h(u16x8 a, u16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// v must already carry the tensor's scale and lie inside +-65504 (fp16 range)
+__device__ __forceinline__ void split2(float4 v, u16x4& h, u16x4& l) {
+  const f32x4v f = {v.x, v.y, v.z, v.w};
+  const f16x4 hh = __builtin_convertvector(f, f16x4);                       // round-to-nearest-even
+  const f32x4v r = f - __builtin_convertvector(hh, f32x4v);                 // exact in fp32
+  h = __builtin_bit_cast(u16x4, hh);
+  l = __builtin_bit_cast(u16x4, __builtin_convertvector(r, f16x4));
+}
+// power of two s with max * s in [2^target, 2^(target + 1)), from the bits of max = |largest element| (1 for max = 0 or a
+// subnormal maximum: such a tensor is zero at fp16-pair resolution).  s and 1 / s are normal floats.
+__host__ __device__ __forceinline__ uint32_t pow2_scale_bits(uint32_t max_bits, int target) {
+  const int ef = (int)((max_bits >> 23) & 0xFFu);
+  if (ef == 0) return 0x3F800000u;
+  int f = 127 + target - (ef - 127);
+  f = f < 1 ? 1 : (f > 253 ? 253 : f);
+  return (uint32_t)f << 23;
+}
+__device__ __forceinline__ float pow2_scale(uint32_t max_bits, int target) { return __uint_as_float(pow2_scale_bits(max_bits, target)); }
 
 }  // namespace lstur

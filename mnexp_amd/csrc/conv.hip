@@ -637,24 +637,16 @@ void launch_conv_wgrad(const float* emb, const float* dout, float* dw, void* scr
   constexpr int TK = 16;
   int nsplit = std::min(g.nsplit, std::max(1, cdiv(M, TK)));   // splits beyond the token list write zero slabs
   float* part = (float*)scratch;
-  static const bool no_glds = getenv("LSTUR_WGRAD_NO_GLDS") != nullptr;   // A/B switch for measurements
-  if (g.big && offA && offB && zeros && vcount && !no_glds) {
+  if (g.big && offA && offB && zeros && vcount) {
     constexpr int WK = 3, WN = 5, CT = 5;
     size_t lds = 2 * TK * (64 * WK + 16 * CT * WN) * sizeof(float);
     static bool attr_set2 = false;
     if (!attr_set2) {
       (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<WK, WN, CT, TK, false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<WK, WN, CT, TK, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set2 = true;
     }
-    static const bool asm_dma = getenv("LSTUR_WGRAD_ASMDMA") != nullptr;   // measured equal once the row offsets are prefetched
-    if (asm_dma)
-      hipLaunchKernelGGL((conv_wgrad_glds_kernel<WK, WN, CT, TK, true>), dim3(g.kblocks, nsplit, 1), dim3(WK * WN * 64),
-                         lds, s, emb, dout, part, KD, F, offA, offB, vcount, zeros);
-    else
-      hipLaunchKernelGGL((conv_wgrad_glds_kernel<WK, WN, CT, TK, false>), dim3(g.kblocks, nsplit, 1),
+    hipLaunchKernelGGL((conv_wgrad_glds_kernel<WK, WN, CT, TK, false>), dim3(g.kblocks, nsplit, 1),
                          dim3(WK * WN * 64), lds, s, emb, dout, part, KD, F, offA, offB, vcount, zeros);
   } else if (g.big) {
     constexpr int WK = 3, WN = 5, CT = 5;

@@ -307,10 +307,8 @@ void launch_proj_wgrad_bf16e(const unsigned short* E16, const unsigned short* dq
                              hipStream_t s, ReduceJob* defer) {
   // 320 x 256 workgroup tile (2 x 4 waves of 160 x 64), k-tiles of 32 tokens: every column tile re-reads the slab's
   // embedding rows, and the launch is bound by what goes through L2 (3 TB/s at this access pattern) -- three column tiles
-  // instead of six took it from 177 to 124 us.  (LSTUR_WGRAD_NARROW=1: the 320 x 128 tile, for A/B runs.)
-  static const bool narrow = getenv("LSTUR_WGRAD_NARROW") != nullptr;
-  if (narrow) proj_wgrad16_launch<1, 64>(E16, dqkv, dW, scratch, D, N, K, s, defer);
-  else proj_wgrad16_launch<2, 32>(E16, dqkv, dW, scratch, D, N, K, s, defer);
+  // instead of six took it from 177 to 124 us.
+  proj_wgrad16_launch<2, 32>(E16, dqkv, dW, scratch, D, N, K, s, defer);
 }
 
 }  // namespace lstur

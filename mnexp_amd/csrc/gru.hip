@@ -614,7 +614,11 @@ static void generic_fwd(const float* xw, const uint8_t* gmask, const float* h0, 
   size_t lds = (size_t)3 * 16 * LDH * sizeof(float);
   static size_t cur = 0;
   set_lds_attr((const void*)gru_fwd_kernel, lds, &cur);
-  static const int dbg = getenv("LSTUR_GRU_DEBUG") ? atoi(getenv("LSTUR_GRU_DEBUG")) : 0;  // measurement knobs
+#ifdef LSTUR_ABLATE
+  static const int dbg = getenv("LSTUR_GRU_DEBUG") ? atoi(getenv("LSTUR_GRU_DEBUG")) : 0;  // measurement knobs (bench-only library)
+#else
+  constexpr int dbg = 0;
+#endif
   const size_t S = tape_section(n, W, H);
   hipLaunchKernelGGL(gru_xw_to_tape_kernel, dim3((unsigned)cdivz(3 * S / 4, 256)), dim3(256), 0, s, xw, tape, n, W, H, S);
   GruFwdArgs a{gmask, h0, u_zr_packed, u_h_packed, tape, hlast, n, W, H, dbg};
@@ -648,18 +652,17 @@ void launch_gru_pack(const float* U, int H, float* packed, hipStream_t s) {
   generic_pack(U, H, packed, packed + 2 * sixth, packed + 3 * sixth, packed + 4 * sixth, s);
 }
 void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
-                    float* hlast, int n, int W, int H, hipStream_t s, bool slot_major) {
+                    float* hlast, int n, int W, int H, hipStream_t s) {
   if (!n) return;
-  if (gru4_supported(H)) return launch_gru4_fwd(xw, gmask, h0, packed, tape, hlast, n, W, H, s, slot_major);
+  if (gru4_supported(H)) return launch_gru4_fwd(xw, gmask, h0, packed, tape, hlast, n, W, H, s);
   const size_t sixth = generic_pack_floats(H) / 6;
   generic_fwd(xw, gmask, h0, packed, packed + 2 * sixth, tape, hlast, n, W, H, s);
 }
 void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* packed, float* dgates,
-                    float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s, bool slot_major, int t_hi,
-                    int t_lo) {
+                    float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s) {
   if (!n) return;
   if (gru4_supported(H))
-    return launch_gru4_bwd(dh_last, gmask, tape, packed, dgates, rh, hprev, dh0, n, W, H, s, slot_major, t_hi, t_lo);
+    return launch_gru4_bwd(dh_last, gmask, tape, packed, dgates, rh, hprev, dh0, n, W, H, s);
   // (the general kernels know the sample-major layout and the whole recurrence only: callers ask gru4_supported first)
   const size_t sixth = generic_pack_floats(H) / 6;
   generic_bwd(dh_last, gmask, tape, packed + 4 * sixth, packed + 3 * sixth, dgates, rh, hprev, dh0, n, W, H, s);

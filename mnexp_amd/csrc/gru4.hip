@@ -730,9 +730,14 @@ __global__ __launch_bounds__(G4_THREADS) void gru4_bwd_kernel(Gru4Bwd g) {
 #undef LSTUR_ROLE
 }
 
+// measurement knobs (wrong results: no stores / cycle stamps) exist in the bench-only library alone (-DLSTUR_ABLATE)
 static int gru4_dbg() {
+#ifdef LSTUR_ABLATE
   const char* e = getenv("LSTUR_GRU4_DEBUG");
   return e ? atoi(e) : 0;
+#else
+  return 0;
+#endif
 }
 
 // ---- launchers -------------------------------------------------------------------------------------
@@ -755,11 +760,11 @@ void gru4_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh)
 }
 
 void launch_gru4_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* img, float* tape, float* hlast,
-                     int n, int W, int H, hipStream_t s, bool slot_major) {
+                     int n, int W, int H, hipStream_t s) {
   const int KQ = gru4_kq(H);
   const size_t e = (size_t)n * W * H, ie = (size_t)KQ * 4 * H;
   Gru4Fwd a{xw, gmask, h0, img, img + 2 * ie, tape, tape + 2 * e, tape + 3 * e, tape + 4 * e, hlast, n, W, H, gru4_dbg(),
-            slot_major ? 1 : W, slot_major ? n : 1};
+            W, 1};
   const size_t lds = gru4_fwd_lds(H, KQ);
   const dim3 grid(cdiv(n, 4)), block(G4_THREADS);
 #define LSTUR_G4F(Q)                                              \
@@ -772,12 +777,11 @@ void launch_gru4_fwd(const float* xw, const uint8_t* gmask, const float* h0, con
 }
 
 void launch_gru4_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* img, float* dgates, float* rh,
-                     float* hprev, float* dh0, int n, int W, int H, hipStream_t s, bool slot_major, int t_hi, int t_lo) {
+                     float* hprev, float* dh0, int n, int W, int H, hipStream_t s) {
   const int KQ = gru4_kq(H);
   const size_t e = (size_t)n * W * H, ie = (size_t)KQ * 4 * H;
-  if (t_hi < 0) t_hi = W - 1;
   Gru4Bwd a{dh_last, gmask, tape, tape + 2 * e, tape + 3 * e, img + 3 * ie, img + 4 * ie, img + 5 * ie, dgates, dh0,
-            n, W, H, gru4_dbg(), slot_major ? 1 : W, slot_major ? n : 1, t_hi, t_lo};
+            n, W, H, gru4_dbg(), W, 1, W - 1, 0};
   const size_t lds = gru4_bwd_lds(H, KQ);
   const dim3 grid(cdiv(n, 4)), block(G4_THREADS);
 #define LSTUR_G4B(Q)                                              \

@@ -37,9 +37,9 @@ struct Dims {
   int n_cap;    // per-sample buffers
   int rows_cap; // sparse user-grad rows per adam step
   int lazy;     // lazy dense Adam of the user table(s) (large tables; misc.hip)
-  int slot;     // history titles in slot-major order inside the step (title = slot * n + sample): a range of history
-                // slots is then a contiguous range of titles, tokens and GRU rows (slot_major_wanted below)
-  int late;     // history slots whose encoder backward starts behind the first part of a recurrence backward cut in two
+  int np;       // split-operand conv kernels (convx.hip): 16-bit parts per element, 2 = f16x2 (default), 3 = bf16x3 (trainable
+                // word table: its maximum moves every step; LSTUR_CONV_SCHEME=bf16x3); 0: exact-fp32 MFMA kernels of conv.hip
+                // (filters > 448, kernel > 8, LSTUR_CONV_F32=1) or no conv at all (mhsa)
 };
 constexpr int kLazyLog = 1 << 16;        // logged lr_t values (a full flush at the latest every kLazyLog - 2 iterations)
 constexpr int kLazyMinRows = 200000;     // tables from this size on update lazily (LSTUR_LAZY_ADAM=0 / 1 overrides)
@@ -49,9 +49,56 @@ static inline bool two_tables(const Dims& d) { return d.arch == LSTUR_ARCH_IIGRU
 
 constexpr size_t kParamAlign = 64;  // floats
 
+// Environment switches of the step orchestration.  All of them select between variants that compute the SAME results (A/B
+// measurements, tests/): they are read once, when the context is created, so a step can never see two settings.
+struct Opts {
+  bool conv_f32;       // LSTUR_CONV_F32=1: exact-fp32 MFMA conv kernels (conv.hip) instead of the split-operand ones
+  bool conv_bf16x3;    // LSTUR_CONV_SCHEME=bf16x3: three bf16 parts / six products instead of two fp16 parts / three products
+  bool wg_stream;      // LSTUR_WG_STREAM=0: parameter-gradient GEMMs on the caller's stream
+  bool cand_split;     // LSTUR_CAND_SPLIT=0: one launch per kernel over all titles in the backward pass
+  bool fused_adam;     // LSTUR_FUSED_ADAM=0: lstur_train_step = forward_backward + adam_step, unscheduled
+  bool adam_pack;      // LSTUR_ADAM_PACK=0: weight images packed by their own launches behind the Adam
+  bool dp_defer;       // LSTUR_DP_DEFER=0: the data-parallel step sweeps the user table inside lstur_adam_step
+  bool prof_attach;    // LSTUR_PROF_ATTACH=0: timing brackets recorded around the kernels instead of riding them
+  bool wgrad_bf16x3;   // LSTUR_WGRAD_BF16X3=1: parameter-gradient GEMMs on the bf16x3 kernel
+  int sweep_blocks;    // LSTUR_SWEEP_BLOCKS=n: workgroups of the thin table sweep (-1: planned)
+  int prefetch_blocks; // LSTUR_PREFETCH_BLOCKS=n: workgroups of a prefetched gather (0: all)
+  int lazy_log;        // LSTUR_LAZY_LOG=n (power of two): entries of the lazy table's lr_t ring (tests: force wraps)
+  static bool is(const char* name, const char* v) {
+    const char* e = getenv(name);
+    return e && !strcmp(e, v);
+  }
+  static Opts read() {
+    Opts o;
+    o.conv_f32 = getenv("LSTUR_CONV_F32") != nullptr;
+    o.conv_bf16x3 = is("LSTUR_CONV_SCHEME", "bf16x3");
+    o.wg_stream = !is("LSTUR_WG_STREAM", "0");
+    o.cand_split = !is("LSTUR_CAND_SPLIT", "0");
+    o.fused_adam = !is("LSTUR_FUSED_ADAM", "0");
+    o.adam_pack = !is("LSTUR_ADAM_PACK", "0");
+    o.dp_defer = !is("LSTUR_DP_DEFER", "0");
+    o.prof_attach = !is("LSTUR_PROF_ATTACH", "0");
+    o.wgrad_bf16x3 = getenv("LSTUR_WGRAD_BF16X3") != nullptr;
+    o.sweep_blocks = getenv("LSTUR_SWEEP_BLOCKS") ? atoi(getenv("LSTUR_SWEEP_BLOCKS")) : -1;
+    o.prefetch_blocks = getenv("LSTUR_PREFETCH_BLOCKS") ? atoi(getenv("LSTUR_PREFETCH_BLOCKS")) : 0;
+    o.lazy_log = kLazyLog;
+    if (const char* e = getenv("LSTUR_LAZY_LOG")) {
+      const int v = atoi(e);
+      if (v >= 8 && v <= kLazyLog && (v & (v - 1)) == 0) o.lazy_log = v;
+    }
+    return o;
+  }
+};
+
+
 bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
   if (!c) {
     *why = "cfg is NULL";
+    return false;
+  }
+  if (c->struct_size != (uint32_t)sizeof(lstur_cfg)) {   // a caller built against another lstur.h: refuse, never read past it
+    *why = "lstur_cfg.struct_size is " + std::to_string(c->struct_size) + ", this library's sizeof(lstur_cfg) is " +
+           std::to_string(sizeof(lstur_cfg)) + " (ABI version " + std::to_string(LSTUR_ABI_VERSION) + "): rebuild the binding from include/lstur.h";
     return false;
   }
   d->B = c->max_batch; d->W = c->window; d->T = c->title_len; d->K1 = c->cands; d->V = c->vocab;
@@ -170,7 +217,7 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     // every kernel addresses a step's token-level tensors through 32-bit buffer offsets (descriptor size and per-lane
     // offset both wrap at 4 GiB): refuse such batches instead of dropping stores silently
     const size_t nt = (size_t)d->nt_max, lim = (size_t)1 << 32;
-    const size_t emb = (nt * d->Tp * (size_t)std::max(d->D, conv3_dp(d->D) * 3 / 2) + 1024) * 4;   // fp32 rows or E3 (6 B / element)
+    const size_t emb = (nt * d->Tp * (size_t)std::max(d->D, convx_dp(d->D) * 3 / 2) + 1024) * 4;   // fp32 rows or Ex (<= 6 B / element)
     if (emb >= lim || nt * d->T * d->F * 4 >= lim) {
       *why = "max_batch too large: a step's embeddings / conv outputs exceed 4 GiB (the kernels address them through 32-bit "
              "buffer offsets); split the batch";
@@ -185,50 +232,17 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     const bool has_table = d->arch != LSTUR_ARCH_NIGRU && d->arch != LSTUR_ARCH_NIAVG && d->arch != LSTUR_ARCH_NIATT;
     d->lazy = has_table && (e ? !strcmp(e, "1") : d->Nu >= kLazyMinRows);
   }
-  d->slot = d->late = 0;   // (decided per context: slot_major_wanted)
+  {
+    const bool cx = d->enc == LSTUR_ENC_CNNATT && convx_supported(d->D, d->k, d->F) && !getenv("LSTUR_CONV_F32");
+    d->np = !cx ? 0 : (d->word_trainable || Opts::is("LSTUR_CONV_SCHEME", "bf16x3")) ? 3 : 2;
+  }
+  // the backward pass hands its deferred reductions to ONE launch: 4 (GRU) + 2 (Dense) + 1 (conv_b / attention) + kernel (one
+  // per tap) + 4 (batch statistics) + 1 (mhsa) jobs
+  if (12 + d->k > kMaxReduceJobs) {
+    *why = "kernel (conv width) too large for the step's single reduction launch";
+    return false;
+  }
   return true;
-}
-
-// ---- two-lane step: sample ranges ---------------------------------------------------------------------
-constexpr int kPipeMin = 32;     // smallest batch that is cut into two lanes (each lane >= 16 samples)
-// samples of lane 0 (a multiple of 16: the aliased per-sample arrays of lane 1 start on a row-tile boundary)
-inline int lane0_share(int n) { return std::max(16, (n / 2) / 16 * 16); }
-inline int lane1_cap(int B) { return B / 2 + 16; }
-// does this configuration take the two-lane step?  (listwise head on the bf16x3 cnnatt path with the fast GRU kernels)
-bool lanes_supported(const Dims& d) {
-  // opt-in (LSTUR_PIPELINE=1): at B = 64 the step is no faster with two lanes yet -- the recurrences do hide, but the
-  // one-workgroup-per-CU conv kernels of a half batch lose what that wins
-  const bool off = !(getenv("LSTUR_PIPELINE") && !strcmp(getenv("LSTUR_PIPELINE"), "1"));   // (read per context)
-  const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
-  return !off && d.B >= kPipeMin && d.head == LSTUR_HEAD_SOFTMAX && d.enc == LSTUR_ENC_CNNATT && !d.word_trainable &&
-         has_gru && gru4_supported(d.H) && conv3f_supported(d.D, d.k, d.F) && d.k <= 8 && !d.lazy;
-}
-// Slot-major history titles: possible with the fast recurrence kernels on the pre-split cnnatt path (the kernels that draw
-// dropout there know the reference's order: TitleOrder).  OPT-IN (LSTUR_LATE_SLOTS=n > 0 or LSTUR_SLOT_MAJOR=1): the layout
-// alone measures like the reference's order, and what it was built for -- the late slots' encoder backward under the rest
-// of the recurrence's backward (late_slots) -- LOSES 30-45 us per step at the config-2 shapes.
-bool slot_major_wanted(const Dims& d) {
-  const char* ls = getenv("LSTUR_LATE_SLOTS");
-  const bool on = (ls && atoi(ls) > 0) || (getenv("LSTUR_SLOT_MAJOR") && !strcmp(getenv("LSTUR_SLOT_MAJOR"), "1"));
-  const bool off = !on;
-  const bool other_conv = getenv("LSTUR_CONV_F32") != nullptr || getenv("LSTUR_CONV_GEN1") != nullptr;
-  const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
-  return !off && !other_conv && has_gru && gru4_supported(d.H) && d.enc == LSTUR_ENC_CNNATT && conv3f_supported(d.D, d.k, d.F) &&
-         d.k <= 8 && attpool_title_path(d.T, d.F) && !lanes_supported(d) &&
-         !d.word_trainable;   // (the word-table gradient draws the embedding's dropout at physical token positions)
-}
-inline TitleOrder title_order(const Dims& d, int n) { return d.slot ? TitleOrder{n, d.W, n * d.W} : TitleOrder{0, 0, 0}; }
-int late_slots(const Dims& d);
-Dims lane1_dims(const Dims& d) {
-  Dims e = d;
-  e.B = lane1_cap(d.B);
-  e.nt_max = e.B * (e.W + e.K1);
-  e.n_cap = ceil16(e.B);
-  e.rows_cap = 16;          // (the sparse-row scratch of the optimizer lives in lane 0)
-  e.Nu = 1;                 // (so does the slot map)
-  e.lazy = 0;
-  e.slot = e.late = 0;
-  return e;
 }
 
 std::vector<ParamSlot> param_layout(const Dims& d, size_t* total) {
@@ -285,12 +299,12 @@ std::vector<ParamSlot> param_layout(const Dims& d, size_t* total) {
 struct Workspace {
   int32_t* ids; float* emb; float* conv; float* dconv; float* att_a; float* att_wt; float* pooled; float* dpooled;
   float* docvec; float* ddocvec; uint8_t* hmask; uint8_t* gmask; float* uvec; float* xw; float* gru_tape;
-  float* dgates; float* rh; float* hprev; float* dh0; float* dh_mid; float* hlast; float* dhlast;
+  float* dgates; float* rh; float* hprev; float* dh0; float* hlast; float* dhlast;
   float* cat; float* dcat; float* uservec; float* duser; float* du; float* logits; float* probs; float* loss_i;
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* lazy_last; float* lazy_lrt; int32_t* lazy_first; int32_t* dp_rows; int32_t* pend_rows; float* dp_grads; float* dp_grads2; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* conv_w3_v1; unsigned short* e3; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; unsigned short* qkv_w16; void* mh_scratch;
+  int32_t* lazy_last; float* lazy_lrt; int32_t* lazy_first; int32_t* dp_rows; int32_t* pend_rows; float* dp_grads; float* dp_grads2; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* e3; float* cs; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; unsigned short* qkv_w16; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   // the staged form of a batch (token ids, their compacted list + offsets, the gathered embeddings) exists twice: while a
   // step runs on one set, the NEXT batch can be staged into the other (lstur_prefetch_ids); ids / e3 / vidx / ... above
@@ -361,7 +375,6 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->rh = (float*)take(nW * d.H * f4);
   w->hprev = (float*)take(nW * d.H * f4);
   w->dh0 = (float*)take(nc * d.H * f4);
-  w->dh_mid = (float*)take(nc * d.H * f4);   // dh between the two launches of a recurrence backward cut at a slot
   w->hlast = (float*)take(nc * d.H * f4);
   w->dhlast = (float*)take(nc * d.H * f4);
   w->cat = (float*)take(nc * (d.H + d.Ue) * f4);
@@ -377,8 +390,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->conv_wp = (float*)take(pack_b_floats(d.KD, d.F) * f4);
   w->gru_up = (float*)take(gru_pack_floats(d.H) * f4);
   w->wgrad_scratch = take(std::max(conv_wgrad_scratch_bytes(d.D, d.k, d.F),
-                                   conv3f_supported(d.D, d.k, d.F) ? std::max(conv3_wgrad2_scratch_bytes((int)nt, d.T, d.D, d.k, d.F),
-                                                                                 conv3_wgrad_scratch_bytes((int)nt, d.T, d.D, d.k, d.F)) : 0));
+                                   d.np ? convx_wgrad_scratch_bytes((int)nt, d.T, d.D, d.k, d.F) : 0));
   w->gemm_scratch_bytes = max_gemm_scratch(d);
   w->gemm_scratch = take(w->gemm_scratch_bytes);
   // weight-gradient GEMMs of the backward pass keep their split-K slabs until the step's single reduction launch
@@ -391,7 +403,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->gsum = (float*)take((size_t)d.rows_cap * d.Ue * f4);
   w->slot = (int32_t*)take((size_t)d.Nu * 4);
   w->lazy_last = d.lazy ? (int32_t*)take((size_t)d.Nu * 4) : nullptr;
-  w->lazy_lrt = d.lazy ? (float*)take((size_t)kLazyLog * f4) : nullptr;
+  w->lazy_lrt = d.lazy ? (float*)take((size_t)kLazyLog * f4) : nullptr;   // (LSTUR_LAZY_LOG uses a prefix of it)
   w->lazy_first = d.lazy ? (int32_t*)take((size_t)std::max(d.n_cap, d.rows_cap) * 4) : nullptr;
   w->scat = (float*)take(nc * (d.Uu + d.U) * f4);
   w->spre = (float*)take(nc * d.U * f4);
@@ -418,12 +430,13 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->duser2 = ii ? (float*)take(nc * d.Ue * f4) : nullptr;
   w->gsum2 = ii ? (float*)take((size_t)d.rows_cap * d.Ue * f4) : nullptr;
   const bool mh = d.enc == LSTUR_ENC_MHSA;
-  // bf16x3 conv path (conv3f.hip): split weight image, pre-split embeddings E3, slabs of the k-sliced tail tiles
-  const bool c3 = !mh && conv3f_supported(d.D, d.k, d.F) && d.k <= 8;
-  w->conv_w3 = c3 ? (unsigned short*)take(conv3_w3_elems2(d.D, d.k, d.F) * 2) : nullptr;
-  w->conv_w3_v1 = c3 ? (unsigned short*)take(conv3_w3_elems(d.D, d.k, d.F) * 2) : nullptr;   // A/B switch LSTUR_CONV_GEN1
-  w->e3 = c3 ? (unsigned short*)take(conv3_e3_elems((int)nt, d.T, d.D, d.k) * 2) : nullptr;
-  w->fwd2_scratch = c3 ? take(conv3_fwd2_scratch_bytes()) : nullptr;
+  // split-operand conv path (convx.hip): split weight image Wx, pre-split embeddings Ex, the scale block, slabs of the
+  // k-sliced tail tiles
+  const bool c3 = d.np != 0;
+  w->conv_w3 = c3 ? (unsigned short*)take(convx_w_elems(d.D, d.k, d.F, d.np) * 2) : nullptr;
+  w->e3 = c3 ? (unsigned short*)take(convx_e_elems((int)nt, d.T, d.D, d.k, d.np) * 2) : nullptr;
+  w->cs = c3 ? (float*)take(kCsWords * sizeof(float)) : nullptr;
+  w->fwd2_scratch = c3 ? take(convx_fwd_scratch_bytes()) : nullptr;
   w->qkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;     // bf16 Q | K | V rows
   w->dqkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;
   w->qkv_w16 = mh ? (unsigned short*)take((size_t)d.D * 3 * d.F * 2) : nullptr;   // the projection weight rounded to bf16, once per step
@@ -449,7 +462,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->set[1] = w->set[0];
   if (c3 && d.head == LSTUR_HEAD_SOFTMAX && !d.word_trainable) {   // second staging set (prefetch of the next batch)
     w->set[1].ids = (int32_t*)take(nt * d.T * 4);
-    w->set[1].e3 = (unsigned short*)take(conv3_e3_elems((int)nt, d.T, d.D, d.k) * 2);
+    w->set[1].e3 = (unsigned short*)take(convx_e_elems((int)nt, d.T, d.D, d.k, d.np) * 2);
     w->set[1].vidx = (int32_t*)take(nt * d.T * 4);
     w->set[1].vcount = (int32_t*)take(256);
     w->set[1].offA = (int32_t*)take(nt * d.T * 4);
@@ -471,6 +484,7 @@ struct ProfKernel {
 };
 
 struct lstur_ctx {
+  Opts opt;
   bool prof_on = false;
   bool prof_roofline_only = false;   // lstur_profile(ctx, 2): brackets around gather / conv_fwd / conv_wgrad only
   std::deque<ProfKernel> prof;  // deque: nested ProfScopes hold pointers across push_back
@@ -485,29 +499,12 @@ struct lstur_ctx {
   Dims d;
   lstur_buffers buf;
   Workspace ws;
-  // ---- two-lane step (see train_impl): a batch of >= kPipeMin samples is cut into two sample ranges that run out of
-  // step on two streams, so that one lane's recurrence (a latency chain on a few CUs) runs beside the other's encoder.
-  // Lane 0 lives in `ws` (full size), lane 1 in `ws1` (about half a batch) with its own gradient bucket `grad1`; the
-  // kernel-sequence functions below work on the CURRENT lane (`cur`, `cur_grad`, `cur_lane`), set by the orchestrator.
-  Dims d1;
-  Workspace ws1;
-  float* grad1 = nullptr;
-  Workspace* cur = nullptr;
-  float* cur_grad = nullptr;
-  int cur_lane = 0;
-  bool counted1 = false;
-  hipEvent_t cur_ev_enc = nullptr;      // recorded behind the lane's encoder forward when set
-  int conv_cus = 0;                     // CUs the conv kernels plan for (0: all); the other lane's recurrence holds some
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_enc0 = nullptr, ev_done1 = nullptr;
   // weight-gradient side stream (run_backward): the GRU / Dense parameter-gradient GEMMs only feed the step's final
   // reduction, so they run beside the chain d(doc vectors) -> attention backward -> conv kernel gradient
-  hipStream_t side_w = nullptr, side_w2 = nullptr;   // (second one: the Dense(U) parameter gradients, beside the GRU's)
-  hipEvent_t ev_w1 = nullptr, ev_w2 = nullptr, ev_w3 = nullptr, ev_w4 = nullptr;
+  hipStream_t side_w = nullptr;
+  hipEvent_t ev_w1 = nullptr, ev_w2 = nullptr, ev_w3 = nullptr;
   hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;   // candidate titles' encoder backward: fork behind the scorer, done
-  hipEvent_t ev_l0 = nullptr;                     // late history slots: fork behind the first launch of the recurrence's backward
   bool cand_forked = false;                       // ev_c0 rides on this step's scorer launch
-  bool lanes_active = false;                      // inside train_two_lanes (the lanes keep to one launch per kernel family)
   // data-parallel step: the zero-gradient half of the dense table sweep of iteration t, deferred to the next forward
   struct Deferred {
     bool valid = false;      // rows [pend_rows, n_rows) are updated and MARKED; every other row still owes iteration t
@@ -526,8 +523,6 @@ struct lstur_ctx {
   bool staged_hit = false;              // this step's staging was prefetched: run_forward skips it
   hipStream_t side_p = nullptr;
   hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;
-  bool pipe_ok = false, last_piped = false;
-  int last_nA = 0;
   // fused training step (lstur_train_step*): the optimizer is part of the call, so the library schedules it -- the dense
   // sweep of the user table(s) needs only the recurrence's row gradients and runs on a stream of its own under the news
   // encoder's backward (HBM-bound beside MFMA-bound kernels); the weight images of the NEXT step are packed behind the
@@ -537,7 +532,9 @@ struct lstur_ctx {
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_f0 = nullptr;           // the forward's one fork point (staging prefetch + table sweep)
   bool images_valid = false;            // conv / GRU weight images match dense_param (packed behind the last Adam)
-  bool lazy_prefetched = false;         // rows of the next batch were brought up on lazy_stream this step
+  bool escale_valid = false;            // f16x2: the embedding scale matches the word table (lstur_params_changed clears it)
+  int pack_seq = 0;                     // f16x2: packs of the conv weight image so far (rotating maxima, convx.hip)
+  int bwd_seq = 0;                      // f16x2: backward passes so far (parity of the dC maxima the attention backward leaves)
   int lazy_t = 0;                       // lazy Adam: iterations applied so far (rows are current for last[row] <= lazy_t)
   int lazy_flushed_t = 0;               // ... and the iteration of the last full flush (the lr_t log is a ring)
   std::vector<ParamSlot> layout;
@@ -546,19 +543,18 @@ struct lstur_ctx {
   int32_t n_docs = 0;
   bool lazy_init_done = false;
   int last_n = 0, last_k1 = 0;
-  bool last_use3 = false;   // the last forward ran the bf16x3 conv path (E3 embeddings; the fp32 `emb` layout was not written)
+  bool last_usex = false;   // the last forward ran the split-operand conv path (Ex embeddings; the fp32 `emb` layout was not written)
   bool counted = false;   // stage_titles already left the per-block non-pad counts in ws.vscratch
   float* P(const char* name) const {
     for (auto& s : layout)
       if (!strcmp(s.name, name)) return buf.dense_param + s.offset;
     return nullptr;
   }
-  float* G(const char* name) const {      // in the CURRENT lane's gradient bucket
+  float* G(const char* name) const {
     for (auto& s : layout)
-      if (!strcmp(s.name, name)) return (cur_grad ? cur_grad : buf.dense_grad) + s.offset;
+      if (!strcmp(s.name, name)) return buf.dense_grad + s.offset;
     return nullptr;
   }
-  bool& counted_flag() { return cur_lane ? counted1 : counted; }
 };
 
 thread_local hipEvent_t lstur::g_stop_event = nullptr;
@@ -574,8 +570,8 @@ int check_launch(const char* what) {
 }
 
 // HIP-event bracket around one kernel family on the launch stream (only when profiling is enabled)
-// attach = true: the launcher below this scope goes through launch_k / last_launch (conv3f forward + fix-up, kernel
-// gradient, gather3): the two events ride the family's first and last kernel instead of being recorded around them
+// attach = true: the launcher below this scope goes through launch_k / last_launch (convx forward + fix-up, kernel
+// gradient, gather): the two events ride the family's first and last kernel instead of being recorded around them
 struct ProfScope {
   lstur_ctx* c;
   ProfKernel* k = nullptr;
@@ -596,8 +592,7 @@ struct ProfScope {
       k->start.push_back(a);
       k->stop.push_back(b);
     }
-    static const bool no_attach = getenv("LSTUR_PROF_ATTACH") && !strcmp(getenv("LSTUR_PROF_ATTACH"), "0");
-    if (attach && !no_attach) {
+    if (attach && c->opt.prof_attach) {
       arm_bracket(k->start[k->used], k->stop[k->used]);
       attached = true;
     } else {
@@ -626,11 +621,10 @@ struct ProfScope {
 // Side streams are shared by ALL contexts of the process on a device and live as long as the process: a stream is a queue,
 // the hardware has few of them, and a process that held two contexts (bench.py: the headline model + the end-to-end
 // model; the test suite) ran every kernel ~30 % slower once their private streams added up to more than the hardware
-// queues.  kind: 0 parameter gradients (high priority), 1 background (staging prefetch, table sweep), 2 second
-// parameter-gradient stream (experiment), 3 the two-lane step's lane.  Ordering between contexts that share a stream is
-// plain stream order (each context still forks / joins through its own events).
+// queues.  kind: 0 parameter gradients (high priority), 1 background (staging prefetch, table sweep).  Ordering between
+// contexts that share a stream is plain stream order (each context still forks / joins through its own events).
 hipStream_t pooled_stream(int kind, bool high_priority) {
-  struct Pool { hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr}; };
+  struct Pool { hipStream_t s[2] = {nullptr, nullptr}; };
   static std::mutex mu;
   static std::map<int, Pool> pools;
   int dev = 0;
@@ -647,17 +641,12 @@ hipStream_t pooled_stream(int kind, bool high_priority) {
 
 // the side stream of the parameter-gradient GEMMs (nullptr: keep them on the caller's stream)
 hipStream_t wgrad_stream(lstur_ctx* c) {
-  const bool off = getenv("LSTUR_WG_STREAM") && !strcmp(getenv("LSTUR_WG_STREAM"), "0");
-  if (off || c->cur_lane != 0 || c->conv_cus != 0) return nullptr;     // (the two-lane step has its own streams)
+  if (!c->opt.wg_stream) return nullptr;
   if (!c->side_w) {
     // highest priority: its thin kernels are to slip in as soon as a workgroup of the main stream's kernel retires -- at
     // equal priority they waited behind the attention backward's 3520 workgroups and spilled into the conv kernel gradient,
     // which shares a CU with nothing (it then ran ~10 % slower and the step's reduction waited for the stragglers)
-    static const bool flat = getenv("LSTUR_WG_PRIORITY") && !strcmp(getenv("LSTUR_WG_PRIORITY"), "0");
-    static const bool two = getenv("LSTUR_WG_STREAMS") && !strcmp(getenv("LSTUR_WG_STREAMS"), "2");
-    if (two && (!(c->side_w2 = pooled_stream(2, !flat)) || hipEventCreateWithFlags(&c->ev_w4, hipEventDisableTiming) != hipSuccess))
-      c->side_w2 = nullptr;
-    if (!(c->side_w = pooled_stream(0, !flat)) ||
+    if (!(c->side_w = pooled_stream(0, true)) ||
         hipEventCreateWithFlags(&c->ev_w1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w3, hipEventDisableTiming) != hipSuccess) {
@@ -689,13 +678,9 @@ hipStream_t lazy_stream(lstur_ctx* c) {
 // half of the user-table sweep, later the batch's own table rows (side_p and side_t are the same queue).  Streams are not
 // free on this stack: a FIFTH one in use (measured: a second parameter-gradient stream) made every kernel of the step
 // ~45 % slower -- beyond the hardware queues streams get multiplexed -- and RCCL brings its own in data-parallel runs.
-hipStream_t wgrad_stream(lstur_ctx* c);
 bool background_stream(lstur_ctx* c) {
   if (c->side_p) return true;
-  static const bool share = getenv("LSTUR_ONE_SIDE") != nullptr;    // experiment: ONE side stream for everything
-  hipStream_t shared = share ? wgrad_stream(c) : nullptr;
-  if (shared) c->side_p = shared;
-  if ((!shared && !(c->side_p = pooled_stream(1, false))) ||
+  if (!(c->side_p = pooled_stream(1, false)) ||
       hipEventCreateWithFlags(&c->ev_p0, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_t0, hipEventDisableTiming) != hipSuccess ||
@@ -703,9 +688,7 @@ bool background_stream(lstur_ctx* c) {
     c->side_p = c->side_t = nullptr;
     return false;
   }
-  static const bool split_bg = getenv("LSTUR_SPLIT_BG") != nullptr;   // experiment: a stream of its own for the table sweep
-  c->side_t = split_bg ? pooled_stream(2, false) : c->side_p;
-  if (!c->side_t) c->side_t = c->side_p;
+  c->side_t = c->side_p;   // staging and table sweep share ONE background queue
   return true;
 }
 bool fork_events(lstur_ctx* c) {
@@ -715,7 +698,7 @@ bool fork_events(lstur_ctx* c) {
 }
 bool prefetch_wanted(const lstur_ctx* c) {
   const Workspace& w = c->ws;
-  return c->pend.valid && !c->ready.valid && c->cur_lane == 0 && c->conv_cus == 0 && w.set[1].ids != w.set[0].ids;
+  return c->pend.valid && !c->ready.valid && w.set[1].ids != w.set[0].ids;
 }
 // `forked`: recorded on the caller's stream behind everything the staging must wait for
 bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
@@ -731,18 +714,16 @@ bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
   hipStream_t p = c->side_p;
   (void)hipStreamWaitEvent(p, forked, 0);
   const int nW = q.n * d.W, nt = nW + q.n * d.K1, pl = (d.k - 1) / 2;
-  const TitleOrder ord = title_order(d, q.n);
-  launch_expand_count(c->title_table, q.hist, nW, q.cands, q.n * d.K1, d.T, t.ids, t.vscratch, p, ord);
-  launch_compact_write_offsets(t.ids, nt * d.T, t.vscratch, t.vidx, t.vcount, d.T, d.Tp, conv3_dp(d.D) / 8 * 3, d.F, t.offA,
-                               t.offB, p, t.live, nW * d.T, (d.W - late_slots(d)) * q.n * d.T);
+  launch_expand_count(c->title_table, q.hist, nW, q.cands, q.n * d.K1, d.T, t.ids, t.vscratch, p);
+  launch_compact_write_offsets(t.ids, nt * d.T, t.vscratch, t.vidx, t.vcount, d.T, d.Tp, convx_dp(d.D) / 8 * d.np, d.F, t.offA,
+                               t.offB, p, t.live, nW * d.T);
   {
     ProfScope _ps(c, "gather", p, true);
-    static const int pf_blocks = getenv("LSTUR_PREFETCH_BLOCKS") ? atoi(getenv("LSTUR_PREFETCH_BLOCKS")) : 0;
-    launch_gather3(c->buf.word_emb, t.ids, t.e3, nt, d.T, d.D, pl, d.k - 1 - pl, c->cfg.dropout,
-                   dropout_key(c->cfg.seed, q.step, 0), true, p, pf_blocks, ord);
+    launch_gatherx(c->buf.word_emb, t.ids, t.e3, nt, d.T, d.D, pl, d.k - 1 - pl, c->cfg.dropout,
+                   dropout_key(c->cfg.seed, q.step, 0), true, d.np, w.cs, p, c->opt.prefetch_blocks);
   }
   // the attention passes' dropout decisions for that batch (stream 1 of its step), behind the gather
-  q.kbits = launch_attpool_keep_bits(t.live, t.kbits, nt, d.T, d.F, c->cfg.dropout, dropout_key(c->cfg.seed, q.step, 1), p, ord);
+  q.kbits = launch_attpool_keep_bits(t.live, t.kbits, nt, d.T, d.F, c->cfg.dropout, dropout_key(c->cfg.seed, q.step, 1), p);
   // lazily updated table: the rows that batch will read take their pending zero-gradient updates here, under the
   // recurrence (a row that waited 2 000 iterations is a 2 000-long chain per element: latency-bound work for idle CUs);
   // the forward's own catch-up then finds one iteration left
@@ -752,7 +733,6 @@ bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
     hipStream_t ls = lazy_stream(c);
     if (ls != p) (void)hipStreamWaitEvent(ls, forked, 0);
     lazy_catchup_rows(c, q.users, q.n, ls);
-    c->lazy_prefetched = true;
   }
   (void)hipEventRecord(c->ev_p1, p);
   q.launched = true;
@@ -768,6 +748,7 @@ void dense_gemm(const float* A, int lda, const float* B, int ldb, bool b_nk, flo
   else launch_gemm(A, lda, 0, B, ldb, b_nk ? 1 : 0, C, ldc, bias, M, N, K, 1.f, scratch, s);
 }
 
+thread_local bool g_wgrad_bf16x3 = false;   // (set from the context's options by run_backward)
 // G[M,N] = A^T . B (A [K][M], B [K][N]) as a deferred reduction: the parameter gradients behind the recurrence / Dense(U)
 void wgrad_gemm(const float* A, int lda, const float* B, int ldb, float* G, int ldg, int M, int N, int K, void* scratch,
                 hipStream_t s, ReduceJob* job) {
@@ -777,21 +758,26 @@ void wgrad_gemm(const float* A, int lda, const float* B, int ldb, float* G, int 
   // last product finished BEHIND the conv kernel gradient), and its thin form (two k-steps in flight, 92 VGPRs) still
   // measures 6-9 us per step behind the fp32 kernel (same box, 1.143 / 1.147 against 1.138 / 1.138 ms).
   // LSTUR_WGRAD_BF16X3=1 selects it for A/B runs.
-  static const bool x3 = getenv("LSTUR_WGRAD_BF16X3") != nullptr;
-  if (x3 && gemm3_tn_supported(lda, ldb, M, N, K)) launch_gemm3_tn(A, lda, B, ldb, G, ldg, M, N, K, 1.f, scratch, s, job);
+  if (g_wgrad_bf16x3 && gemm3_tn_supported(lda, ldb, M, N, K)) launch_gemm3_tn(A, lda, B, ldb, G, ldg, M, N, K, 1.f, scratch, s, job);
   else launch_gemm(A, lda, 1, B, ldb, 0, G, ldg, nullptr, M, N, K, 1.f, scratch, s, job);
 }
 
-// operand images of the weights the MFMA kernels read (conv: bf16x3 parts or the fp32 pack; GRU: resident strips)
-void pack_weight_images(lstur_ctx* c, hipStream_t sp) {
+// operand images of the weights the MFMA kernels read (conv: split 16-bit parts or the fp32 pack; GRU: resident strips).
+// `fresh`: the caller changed the weights (or this is the first pack): an f16x2 image takes its scale from the weights as
+// they are; otherwise from the maximum the previous pack saw, like the dense Adam launch that writes the image in the step
+// most one Keras-Adam step moves a parameter, in units of lr_t: |m_t| / sqrt(v_t) <= (1 - b1) / sqrt(1 - b2) / (1 - b1 / sqrt(b2))
+// (31.8 at .9 / .999); infinity when the series does not converge (b1 >= sqrt(b2)): packs are then always fresh
+float adam_growth_bound(const lstur_cfg& cf) {
+  const float q = cf.beta1 / sqrtf(cf.beta2);
+  if (!(cf.beta1 >= 0.f && cf.beta2 > 0.f && cf.beta2 < 1.f && q < 1.f)) return INFINITY;
+  return (1.0f - cf.beta1) / sqrtf(1.0f - cf.beta2) / (1.0f - q);
+}
+void pack_weight_images(lstur_ctx* c, hipStream_t sp, bool fresh, float lr_t = 0.f) {
   const Dims& d = c->d;
   Workspace& w = c->ws;
   const bool mhsa = d.enc == LSTUR_ENC_MHSA;
-  static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr;
-  static const bool gen1 = getenv("LSTUR_CONV_GEN1") != nullptr;
-  const bool use3 = !mhsa && w.conv_w3 && !conv_f32;
-  if (use3 && gen1) launch_conv3_pack_w(c->P("conv_w"), d.KD, d.F, w.conv_w3_v1, sp);
-  else if (use3) launch_conv3_pack_w2(c->P("conv_w"), d.D, d.k, d.F, w.conv_w3, sp);
+  const float grow = fresh ? 0.f : adam_growth_bound(c->cfg) * fabsf(lr_t);
+  if (d.np) launch_convx_pack_w(c->P("conv_w"), d.D, d.k, d.F, w.conv_w3, d.np, w.cs, c->pack_seq++, fresh || !isfinite(grow), grow, sp);
   else if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, sp);
   else launch_round_bf16(c->P("qkv_w"), w.qkv_w16, (size_t)d.D * 3 * d.F, sp);   // (D % 4 == 0: mhsa_supported)
   launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, sp);
@@ -809,10 +795,10 @@ void lazy_flush_all(lstur_ctx* c, hipStream_t s) {   // every row current for it
   if (!d.lazy || c->lazy_flushed_t == c->lazy_t) return;
   lazy_init(c, s);
   launch_lazy_flush(c->buf.user_emb, c->buf.user_m, c->buf.user_v, c->ws.lazy_last, c->ws.lazy_lrt, c->lazy_t, d.Nu, d.Ue,
-                    cf.beta1, cf.beta2, cf.eps, kLazyLog - 1, s);
+                    cf.beta1, cf.beta2, cf.eps, c->opt.lazy_log - 1, s);
   if (two_tables(d))
     launch_lazy_flush(c->buf.user_emb2, c->buf.user_m2, c->buf.user_v2, c->ws.lazy_last, c->ws.lazy_lrt, c->lazy_t, d.Nu, d.Ue,
-                      cf.beta1, cf.beta2, cf.eps, kLazyLog - 1, s);
+                      cf.beta1, cf.beta2, cf.eps, c->opt.lazy_log - 1, s);
   launch_fill_i32(c->ws.lazy_last, c->lazy_t, d.Nu, s);
   c->lazy_flushed_t = c->lazy_t;
 }
@@ -825,7 +811,7 @@ void lazy_begin_iteration(lstur_ctx* c, int t, hipStream_t s) {
     lazy_flush_all(c, s);
     c->lazy_t = c->lazy_flushed_t = t - 1;
     launch_fill_i32(c->ws.lazy_last, t - 1, c->d.Nu, s);
-  } else if (t - c->lazy_flushed_t >= kLazyLog - 2) {
+  } else if (t - c->lazy_flushed_t >= c->opt.lazy_log - 2) {
     lazy_flush_all(c, s);
   }
 }
@@ -837,20 +823,20 @@ void lazy_catchup_rows(lstur_ctx* c, const int32_t* rows, int n, hipStream_t s) 
   const bool two = two_tables(d);
   launch_lazy_catchup(c->buf.user_emb, c->buf.user_m, c->buf.user_v, two ? c->buf.user_emb2 : nullptr,
                       two ? c->buf.user_m2 : nullptr, two ? c->buf.user_v2 : nullptr, rows, n, c->ws.lazy_first,
-                      c->ws.lazy_last, c->ws.lazy_lrt, c->lazy_t, d.Ue, cf.beta1, cf.beta2, cf.eps, kLazyLog - 1, s);
+                      c->ws.lazy_last, c->ws.lazy_lrt, c->lazy_t, d.Ue, cf.beta1, cf.beta2, cf.eps, c->opt.lazy_log - 1, s);
 }
 // iteration t for the rows with a gradient (gsum / slot from the row combine; second table: combined here)
 void lazy_rows_step(lstur_ctx* c, const int32_t* rows, const float* row_grads2, int n_rows, int t, float lr_t, hipStream_t s) {
   const Dims& d = c->d;
   const lstur_cfg& cf = c->cfg;
   launch_lazy_rows_adam(c->buf.user_emb, c->buf.user_m, c->buf.user_v, rows, c->ws.slot, c->ws.gsum, n_rows, d.Ue,
-                        c->ws.lazy_last, c->ws.lazy_lrt, t, lr_t, cf.beta1, cf.beta2, cf.eps, kLazyLog - 1, s);
+                        c->ws.lazy_last, c->ws.lazy_lrt, t, lr_t, cf.beta1, cf.beta2, cf.eps, c->opt.lazy_log - 1, s);
   if (two_tables(d)) {
     launch_user_grad_combine(rows, row_grads2 ? row_grads2 : c->ws.duser2, n_rows, d.Ue, c->ws.first, c->ws.gsum2, c->ws.slot, s);
     launch_lazy_rows_adam(c->buf.user_emb2, c->buf.user_m2, c->buf.user_v2, rows, c->ws.slot, c->ws.gsum2, n_rows, d.Ue,
-                          c->ws.lazy_last, c->ws.lazy_lrt, t, lr_t, cf.beta1, cf.beta2, cf.eps, kLazyLog - 1, s);
+                          c->ws.lazy_last, c->ws.lazy_lrt, t, lr_t, cf.beta1, cf.beta2, cf.eps, c->opt.lazy_log - 1, s);
   }
-  launch_lazy_rows_mark(rows, c->ws.slot, n_rows, c->ws.lazy_last, c->ws.lazy_lrt, t, lr_t, kLazyLog - 1, s);
+  launch_lazy_rows_mark(rows, c->ws.slot, n_rows, c->ws.lazy_last, c->ws.lazy_lrt, t, lr_t, c->opt.lazy_log - 1, s);
   launch_user_slot_clear(rows, n_rows, c->ws.slot, s);
 }
 
@@ -889,7 +875,7 @@ bool table_stream(lstur_ctx* c) { return background_stream(c); }
 // batch's embedding gather, which keeps the bandwidth it is measured on.
 bool early_table_sweep_wanted(const lstur_ctx* c) {
   const auto& f = c->fused;
-  return f.on && !f.swept && c->cur_lane == 0 && c->conv_cus == 0 && has_user_table(c->d) && !c->d.lazy;
+  return f.on && !f.swept && has_user_table(c->d) && !c->d.lazy;
 }
 void early_table_sweep(lstur_ctx* c, int n, hipEvent_t forked, bool recurrent, bool after_prefetch) {
   auto& f = c->fused;
@@ -900,7 +886,7 @@ void early_table_sweep(lstur_ctx* c, int n, hipEvent_t forked, bool recurrent, b
   (void)hipStreamWaitEvent(st, forked, 0);
   launch_user_rows_mark(c->ws.user_rows, n, c->ws.slot, st);
   if (after_prefetch) (void)hipStreamWaitEvent(st, c->ev_p1, 0);
-  static const int env_blocks = getenv("LSTUR_SWEEP_BLOCKS") ? atoi(getenv("LSTUR_SWEEP_BLOCKS")) : -1;
+  const int env_blocks = c->opt.sweep_blocks;
   int sweep_blocks = 0;   // 0: full width
   if (recurrent) {
     const double bytes = (double)d.Nu * d.Ue * 4.0 * 6.0 * (two_tables(d) ? 2.0 : 1.0);
@@ -921,8 +907,8 @@ void early_table_sweep(lstur_ctx* c, int n, hipEvent_t forked, bool recurrent, b
 }
 bool finish_table_rows_wanted(lstur_ctx* c) {
   const auto& f = c->fused;
-  if (c->d.lazy) return f.on && !f.table_done && c->cur_lane == 0 && c->conv_cus == 0 && table_stream(c);
-  return f.on && f.swept && !f.table_done && c->cur_lane == 0;
+  if (c->d.lazy) return f.on && !f.table_done && table_stream(c);
+  return f.on && f.swept && !f.table_done;
 }
 // behind the row gradients (and their row masks): `forked` was recorded there on the caller's stream
 void finish_table_rows(lstur_ctx* c, int n, hipEvent_t forked) {
@@ -961,8 +947,7 @@ void finish_table_rows(lstur_ctx* c, int n, hipEvent_t forked) {
 // tables on every rank (tests/test_gpu_dp_two_ranks.py).  Anything else that reads the tables (evaluation, lstur_flush_tables,
 // a step without exchanged rows) runs the pending sweep first, in the open.  LSTUR_DP_DEFER=0: the sweep inside lstur_adam_step.
 bool defer_wanted(lstur_ctx* c) {
-  static const bool off = getenv("LSTUR_DP_DEFER") && !strcmp(getenv("LSTUR_DP_DEFER"), "0");
-  return !off && !c->d.lazy && has_user_table(c->d) && c->cur_lane == 0 && !c->lanes_active && background_stream(c);
+  return c->opt.dp_defer && !c->d.lazy && has_user_table(c->d) && background_stream(c);
 }
 void defer_join(lstur_ctx* c, hipStream_t s) {
   if (c->defer.inflight) (void)hipStreamWaitEvent(s, c->ev_t1, 0);
@@ -1032,44 +1017,38 @@ void lazy_init(lstur_ctx* c, hipStream_t s) {
     launch_fill_i32(c->ws.lazy_last, 0, d.Nu, s);
     (void)hipMemsetAsync(c->ws.lazy_lrt, 0, (size_t)kLazyLog * sizeof(float), s);
   }
-  // E3: the gather skips rows no window covers; the k tail of a window may still touch one (under a zero weight)
-  if (c->ws.e3) (void)hipMemsetAsync(c->ws.e3, 0, conv3_e3_elems(d.nt_max, d.T, d.D, d.k) * 2, s);
+  // Ex: the gather skips rows no window covers; the k tail of a window may still touch one (under a zero weight)
+  if (c->ws.e3) (void)hipMemsetAsync(c->ws.e3, 0, convx_e_elems(d.nt_max, d.T, d.D, d.k, d.np) * 2, s);
   if (c->ws.set[1].e3 && c->ws.set[1].e3 != c->ws.set[0].e3)
-    (void)hipMemsetAsync(c->ws.set[1].e3, 0, conv3_e3_elems(d.nt_max, d.T, d.D, d.k) * 2, s);
-  if (c->pipe_ok) {
-    (void)hipMemsetAsync(c->ws1.emb + (size_t)c->d1.nt_max * d.Tp * d.D, 0, kEmbSlack * sizeof(float), s);
-    if (c->ws1.e3) (void)hipMemsetAsync(c->ws1.e3, 0, conv3_e3_elems(c->d1.nt_max, d.T, d.D, d.k) * 2, s);
-    (void)hipMemsetAsync(c->grad1, 0, c->dense_total * sizeof(float), s);   // (the alignment gaps between its slots)
-  }
+    (void)hipMemsetAsync(c->ws.set[1].e3, 0, convx_e_elems(d.nt_max, d.T, d.D, d.k, d.np) * 2, s);
+  if (c->ws.cs) launch_convx_scales_init(c->ws.cs, s);
   c->lazy_init_done = true;
 }
 
 // titles already in ws.ids as [n*W history | n*k1 candidates] ; runs the network up to user_vec / doc_vec
 void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training, uint32_t step, hipStream_t s) {
   const Dims& d = c->d;
-  Workspace& w = *c->cur;
+  Workspace& w = c->ws;
   const int nW = n * d.W, nt = nW + n * k1;
   const float drop = training ? c->cfg.dropout : 0.f;
-  // dropout streams 0 (embeddings), 1 (conv outputs), 2 (dgru rows); lane 1 draws from streams 16 + these, at the
-  // element positions of its OWN title layout (restated in oracle/lstur_oracle.py: forward_backward_lanes)
-  const uint32_t lane_stream = 16u * (uint32_t)c->cur_lane;
-  const uint32_t key0 = dropout_key(c->cfg.seed, step, lane_stream), key1 = dropout_key(c->cfg.seed, step, lane_stream + 1);
+  // dropout streams 0 (embeddings), 1 (conv outputs), 2 (dgru / id_keep rows)
+  const uint32_t key0 = dropout_key(c->cfg.seed, step, 0), key1 = dropout_key(c->cfg.seed, step, 1);
   lazy_init(c, s);
-  // operand images of the weights used by MFMA kernels this step
   const bool mhsa = d.enc == LSTUR_ENC_MHSA;
-  // conv forward: fp32-grade bf16x3 contraction on the bf16 matrix cores (conv3f.hip) unless LSTUR_CONV_F32 asks for the
-  // exact-fp32 MFMA kernel of conv.hip
-  static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr;
-  const bool use3 = !mhsa && w.conv_w3 && !conv_f32;
-  static const bool gen1 = getenv("LSTUR_CONV_GEN1") != nullptr;   // A/B: first-generation bf16x3 kernels (conv3.hip, fp32 E)
+  const bool usex = d.np != 0;   // split-operand conv kernels (convx.hip); else the exact-fp32 MFMA kernels of conv.hip
+  // f16x2: the embeddings' scale follows the word table (bound at create, changed through lstur_params_changed)
+  if (d.np == 2 && !c->escale_valid) {
+    launch_convx_escale(c->buf.word_emb, (size_t)d.V * d.D, c->cfg.dropout, w.cs, s);
+    c->escale_valid = true;
+  }
+  // operand images of the weights used by MFMA kernels this step
   bool packs_forked = false;
-  hipStream_t sp = nullptr;
-  if (c->cur_lane == 0 && !c->images_valid) {   // (lane 1 shares lane 0's images: it starts behind lane 0's encoder)
+  if (!c->images_valid) {
     // (the Adam entry points leave valid images behind: this runs on a first step, after lstur_params_changed or in eval)
     // the two weight images depend on nothing in the batch: they are packed on the side stream, beside the title staging and
     // the gather, and joined in front of the conv forward; with the staging prefetched there is nothing to hide them under,
     // and two 5-us kernels in line cost less than a fork / join across queues (~10 us each way)
-    sp = c->staged_hit ? nullptr : wgrad_stream(c);
+    hipStream_t sp = c->staged_hit ? nullptr : wgrad_stream(c);
     if (sp) {
       (void)hipEventRecord(c->ev_w1, s);
       (void)hipStreamWaitEvent(sp, c->ev_w1, 0);
@@ -1077,62 +1056,53 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     } else {
       sp = s;
     }
-    pack_weight_images(c, sp);
+    pack_weight_images(c, sp, true);
     if (packs_forked) (void)hipEventRecord(c->ev_w3, sp);
     c->images_valid = true;
   }
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
-  // stable list of the non-pad tokens of this batch (+ the kernel gradient's row offsets), two launches
-  if (c->staged_hit && c->cur_lane == 0) {
-    // token ids, compacted list, offsets and E3 of this batch were staged by the prefetch of the previous step
+  if (c->staged_hit) {
+    // token ids, compacted list, offsets and Ex of this batch were staged by the prefetch of the previous step
     (void)hipStreamWaitEvent(s, c->ev_p1, 0);
   } else {
-  if (!c->counted_flag()) launch_compact_count(w.ids, nt * d.T, w.vscratch, s);
-  c->counted_flag() = false;
-  // (offA: a token's window offset in the units of its path -- 16-byte pieces of E3, or floats of the fp32 layout)
-  launch_compact_write_offsets(w.ids, nt * d.T, w.vscratch, w.vidx, w.vcount, d.T, d.Tp,
-                               (use3 && !gen1) ? conv3_dp(d.D) / 8 * 3 : d.D, d.F, w.offA, w.offB, s, w.live, nW * d.T,
-                               (d.W - late_slots(d)) * n * d.T);
-  if (use3 && !gen1)   // Embedding + Dropout straight into the pre-split layout of the bf16x3 conv kernels (rows nobody reads skipped)
-  {
-    ProfScope _ps(c, "gather", s, true);
-    launch_gather3(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, s, 0, title_order(d, n));
-  }
-  else
-  {
-    if (mhsa)   // bf16 rows for the projections (they rounded the fp32 rows the same way on their way into LDS)
+    // stable list of the non-pad tokens of this batch (+ the kernel gradient's row offsets), two launches
+    if (!c->counted) launch_compact_count(w.ids, nt * d.T, w.vscratch, s);
+    c->counted = false;
+    // (offA: a token's window offset in the units of its path -- 16-byte pieces of Ex, or floats of the fp32 layout)
+    launch_compact_write_offsets(w.ids, nt * d.T, w.vscratch, w.vidx, w.vcount, d.T, d.Tp,
+                                 usex ? convx_dp(d.D) / 8 * d.np : d.D, d.F, w.offA, w.offB, s, w.live, nW * d.T);
+    if (usex) {   // Embedding + Dropout straight into the pre-split layout of the conv kernels (rows nobody reads skipped)
+      ProfScope _ps(c, "gather", s, true);
+      launch_gatherx(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, d.np, w.cs, s);
+    } else if (mhsa) {   // bf16 rows for the projections (they rounded the fp32 rows the same way on their way into LDS)
       PROF("gather", launch_gather_bf16(c->buf.word_emb, w.ids, (unsigned short*)w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
-    else
+    } else {
       PROF("gather", launch_gather(c->buf.word_emb, w.ids, w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
-  }
+    }
   }
   if (packs_forked) (void)hipStreamWaitEvent(s, c->ev_w3, 0);   // the weight images are ready
   if (mhsa) {   // token stage = multi-head self-attention (build-defined, include/lstur.h: LSTUR_ENC_MHSA)
     PROF("qkv_proj", launch_proj_fwd_bf16e((const unsigned short*)w.emb, w.qkv_w16, c->P("qkv_b"), w.qkv, nt * d.T, 3 * d.F, d.D, s));
     PROF("mhsa_fwd", launch_mhsa_fwd_bf16(w.qkv, w.ids, w.conv, nt, d.T, d.F, d.heads, s));
-  } else if (use3 && gen1) {
-    PROF("conv_fwd", launch_conv3_fwd(w.emb, w.conv_w3_v1, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
-                                      w.vcount, s));
-  } else if (use3) {
+  } else if (usex) {
     ProfScope _ps(c, "conv_fwd", s, true);
-    launch_conv3_fwd2(w.e3, w.conv_w3, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx, w.vcount, 0,
-                      w.fwd2_scratch, s, c->conv_cus);
+    launch_convx_fwd(w.e3, w.conv_w3, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx, w.vcount, d.np, w.cs,
+                     w.fwd2_scratch, s);
   } else {
     PROF("conv_fwd", launch_conv_fwd(w.emb, w.conv_wp, c->P("conv_b"), w.ids, w.conv, nt, d.T, d.D, d.k, d.F, w.vidx,
                                      w.vcount, s));
   }
   PROF("attpool_fwd", launch_attpool_fwd(w.conv, w.ids, c->P("att_w"), c->P("att_b"), w.pooled, w.att_a, w.att_wt, nt, d.T, d.F,
-                                         drop, key1, s, w.live, (training && w.kbits_valid) ? w.kbits : nullptr,
-                                         title_order(d, n)));
+                                         drop, key1, s, w.live, (training && w.kbits_valid) ? w.kbits : nullptr));
   dense_gemm(w.pooled, d.F, c->P("dense_w"), d.U, false, w.docvec, d.U, c->P("dense_b"), nt, d.U, d.F, w.gemm_scratch, s);
   // user encoder (paper.py:584-633)
-  if (d.lazy && c->cur_lane == 0) lazy_catchup_rows(c, user, n, s);   // (large tables: the rows read below, made current)
+  if (d.lazy) lazy_catchup_rows(c, user, n, s);   // (large tables: the rows read below, made current)
   bool want_df = false;   // a deferred table sweep (data-parallel step) is pending: this batch's rows now, the rest under the recurrence
   if (c->defer.valid || c->defer.inflight) {
     defer_join(c, s);
     if (c->defer.valid) {
-      if (training && c->cur_lane == 0 && defer_wanted(c) && fork_events(c)) {
+      if (training && defer_wanted(c) && fork_events(c)) {
         defer_rows_now(c, user, n, s);
         want_df = true;
       } else {
@@ -1145,11 +1115,11 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   // whole-row dropout of the user embedding: dgru's Dropout(0.5, noise_shape=(None, 1)) (paper.py:610), or the id_keep
   // masking of cook.py:139-142 for every arch that reads the table
   const float row_p = training ? user_row_drop(c) : 0.f;
-  if (row_p > 0.f) launch_drop_rows(w.uvec, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
+  if (row_p > 0.f) launch_drop_rows(w.uvec, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, 2), s);
   const bool recurrent = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
   // background work for the recurrence to hide: the next batch's staging, then (fused step) the zero-gradient half of the
   // user-table sweep.  ONE fork point for both side streams, attached to the input projection's completion.
-  const bool want_pf = training && recurrent && use3 && !gen1 && prefetch_wanted(c);
+  const bool want_pf = training && recurrent && usex && prefetch_wanted(c);
   const bool want_sw = training && early_table_sweep_wanted(c);
   const bool fork_f = (want_pf || want_sw || want_df) && fork_events(c);
   if (fork_f) arm_stop_event(c->ev_f0);
@@ -1158,7 +1128,6 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     arm_stop_event(nullptr);
     (void)hipEventRecord(c->ev_f0, s);
   }
-  if (c->cur_ev_enc) (void)hipEventRecord(c->cur_ev_enc, s);   // the other lane's encoder may start: the recurrence follows
   if (fork_f) {
     const bool pf = want_pf && launch_prefetch(c, c->ev_f0);
     early_table_sweep(c, n, c->ev_f0, recurrent, pf);
@@ -1176,14 +1145,14 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
     const bool init_user = d.arch == LSTUR_ARCH_IGRU || two_tables(d);   // initial_state = user_vec
     PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, init_user ? w.uvec : nullptr, w.gru_up,
-                                   w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s, d.slot != 0));
+                                   w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s));
     if (d.arch == LSTUR_ARCH_PGRU) {        // GRU(U)(x) + user_vec (paper.py:624-626)
       launch_add2(w.hlast, w.uvec, w.uservec, (size_t)n * d.U, s);
     } else if (!direct) {
       const float* side = w.uvec;
       if (two_tables(d)) {     // the concatenated vector comes from the SECOND table (paper.py:617-619, 345-347)
         launch_gather_rows(c->buf.user_emb2, w.user_rows, w.uvec2, n, d.Ue, s);
-        if (row_p > 0.f) launch_drop_rows(w.uvec2, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
+        if (row_p > 0.f) launch_drop_rows(w.uvec2, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, 2), s);
         side = w.uvec2;
       }
       launch_concat2(w.hlast, d.H, side, d.Ue, w.cat, n, s);
@@ -1196,17 +1165,22 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
   }
   c->last_n = n;
   c->last_k1 = k1;
-  c->last_use3 = use3 && !gen1;
+  c->last_usex = usex;
 }
 
 // stats (may be NULL): the batch means of loss_i / correct_i ride the pass's single reduction launch
-void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats) {
+int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats) {
   const Dims& d = c->d;
-  Workspace& w = *c->cur;
+  Workspace& w = c->ws;
   const int nW = n * d.W, nt = nW + n * d.K1;
   const float drop = c->cfg.dropout;
-  const uint32_t lane_stream = 16u * (uint32_t)c->cur_lane;
-  const uint32_t key1 = dropout_key(c->cfg.seed, step, lane_stream + 1);
+  const uint32_t key1 = dropout_key(c->cfg.seed, step, 1);
+  g_wgrad_bf16x3 = c->opt.wgrad_bf16x3;
+  // f16x2 kernel gradient: the attention backward launches of this pass leave max |dC| in the words of this step's parity
+  // (main stream: word 0, side stream: word 1); the main launch clears the other parity's two words, which the previous
+  // pass used and the next one will write
+  const int par = c->bwd_seq++ & 1;
+  uint32_t* gm = d.np == 2 ? (uint32_t*)w.cs + kCsGmax : nullptr;
   // user encoder head
   const float* dhl = w.du;
   // LSTUR-con's Dense over [h | user_vec]: its parameter gradients feed nothing but the optimizer -- they go to the side stream
@@ -1233,58 +1207,36 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     (void)hipMemcpyAsync(w.duser, w.du, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
   }
   const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
-  ReduceJob jobs[kMaxReduceJobs];
+  ReduceJob jobs[kMaxReduceJobs];   // (make_dims bounds the count: 12 + kernel)
   int nj = 0;
   hipStream_t sw = wgrad_stream(c);
   if (!sw) sw = s;
-  // LSTUR_WG_STREAMS=2: the Dense(U) parameter gradients on a side stream of their own (in ONE queue behind the GRU's three
-  // products they start ~100 us after their inputs are ready and can run into the conv kernel gradient, which shares a CU
-  // with nothing).  Measured A/B on one box: the second queue takes more from the attention backward than it saves
-  // (1.69 / 1.72 ms against 1.58 / 1.59 ms per step), so one queue at high priority is the default.
-  static const bool one_side = !(getenv("LSTUR_WG_STREAMS") && !strcmp(getenv("LSTUR_WG_STREAMS"), "2"));
-  hipStream_t sw2 = (sw != s && c->side_w2 && !one_side) ? c->side_w2 : sw;
-  bool forked = false, forked2 = false;
-  auto join = [&]() {     // the step's single reduction (on s) reads what the side streams produced
+  bool forked = false;
+  auto join = [&]() {     // the step's single reduction (on s) reads what the side stream produced
     if (forked) {
       (void)hipEventRecord(c->ev_w3, sw);
       (void)hipStreamWaitEvent(s, c->ev_w3, 0);
     }
-    if (forked2) {
-      (void)hipEventRecord(c->ev_w4, sw2);
-      (void)hipStreamWaitEvent(s, c->ev_w4, 0);
-    }
   };
-  // the candidate titles' encoder backward, under the recurrence's backward (cand_split_wanted), and the late history
-  // slots' behind the first part of a recurrence backward cut in two (late_slots)
+  auto finish = [&]() -> int {
+    if (stats) {
+      jobs[nj++] = ReduceJob{w.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
+      jobs[nj++] = ReduceJob{w.correct_i, stats + 1, 1, 1, 1, n, 1, 1.0f / (float)n};
+      jobs[nj++] = ReduceJob{w.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};      // running sums for the
+      jobs[nj++] = ReduceJob{w.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};   // host's epoch means
+    }
+    join();
+    if (!launch_multi_reduce(jobs, nj, s)) return fail(LSTUR_ERR_STATE, "backward: too many deferred reductions");
+    return LSTUR_OK;
+  };
+  // the candidate titles' encoder backward, under the recurrence's backward (cand_split_wanted)
   const bool split = c->cand_forked && sw != s && !c->cfg.freeze_encoder;
   c->cand_forked = false;
   const int ncand = nt - nW;
-  const int Wl = split ? late_slots(d) : 0, Wh = d.W - Wl, nE = Wh * n, nL = nW - nE;   // early | late history titles
-  const bool late = Wl > 0 && has_gru && gemm3_supported(3 * d.H, 3 * d.H, nL, d.U, 3 * d.H) && gemm3_supported(d.U, d.U, nL, d.F, d.U);
-  // kernel-gradient slabs: [0] the side launches' slabs reduced ahead of time | the main launch's | the side launches'
-  const size_t slab_f = w.conv_w3 ? conv3_wgrad2_slab_floats(d.D, d.k, d.F) : 0;
-  const int main_slabs = split ? conv3_wgrad2_slabs(late ? nE : nW, d.T, d.D, d.k, d.F, c->conv_cus) : 0;
+  // kernel-gradient slabs: [0] the side launch's slabs reduced ahead of time | the main launch's | the side launch's
+  const size_t slab_f = d.np ? convx_wgrad_slab_floats(d.D, d.k, d.F) : 0;
+  const int main_slabs = split ? convx_wgrad_slabs(nW, d.T, d.D, d.k, d.F) : 0;
   const int side_base = 1 + main_slabs;
-  int cand_slabs = 0, late_slabs = 0;
-  auto side_attention_and_kernel_gradient = [&](int title0, int count, int range_sel, int slab_base, int cus, int* slabs) {
-    const int off_cb = 0, off_aw = (int)(c->G("att_w") - c->G("conv_b")), off_ab = (int)(c->G("att_b") - c->G("conv_b"));
-    const int ldp = off_ab + 1;
-    {   // (families of their own in the profile: these launches run beside the recurrence, off the critical path)
-      ProfScope _ps(c, "attpool_bwd_side", sw);
-      launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, w.att_ds, nt, d.T, d.F,
-                         drop, key1, sw, ldp, off_aw, off_cb, off_ab, 1, w.live, w.kbits_valid ? w.kbits : nullptr, title0, count,
-                         title_order(d, n));
-    }
-    ProfScope _ps(c, "conv_wgrad_side", sw, true);
-    (void)launch_conv3_wgrad2(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, sw, nullptr, w.offA,
-                              w.offB, 1.0f, cus, range_sel, slab_base, count, slabs);
-  };
-  auto side_done = [&]() {   // the side launches' slabs -> slab 0 (off the critical path), then the join event
-    ReduceJob pre{(const float*)w.wgrad_scratch + (size_t)side_base * slab_f, (float*)w.wgrad_scratch, d.k * conv3_dp(d.D), d.F, d.F,
-                  cand_slabs + late_slabs, slab_f, 1.0f, 0.f};
-    launch_multi_reduce(&pre, 1, sw);
-    (void)hipEventRecord(c->ev_c1, sw);
-  };
   if (split) {
     (void)hipStreamWaitEvent(sw, c->ev_c0, 0);
     forked = true;
@@ -1294,8 +1246,25 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     }
     dense_gemm(w.ddocvec + (size_t)nW * d.U, d.U, c->P("dense_w"), d.U, true, w.dpooled + (size_t)nW * d.F, d.F, nullptr, ncand,
                d.F, d.U, nullptr, sw);
-    side_attention_and_kernel_gradient(nW, ncand, 2, side_base, 0, &cand_slabs);
-    if (!late) side_done();
+    const int off_cb = 0, off_aw = (int)(c->G("att_w") - c->G("conv_b")), off_ab = (int)(c->G("att_b") - c->G("conv_b"));
+    const int ldp = off_ab + 1;
+    int cand_slabs = 0;
+    {   // (families of their own in the profile: these launches run beside the recurrence, off the critical path)
+      ProfScope _ps(c, "attpool_bwd_side", sw);
+      launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, w.att_ds, nt, d.T, d.F,
+                         drop, key1, sw, ldp, off_aw, off_cb, off_ab, 1, w.live, w.kbits_valid ? w.kbits : nullptr, nW, ncand,
+                         gm ? gm + 2 * par + 1 : nullptr, nullptr);
+    }
+    {
+      ProfScope _ps(c, "conv_wgrad_side", sw, true);
+      (void)launch_convx_wgrad(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, sw, nullptr, w.offA,
+                               w.offB, d.np, w.cs, 2 * par + 1, 1.0f, 2, side_base, ncand, &cand_slabs);
+    }
+    // the side launch's slabs -> slab 0 (off the critical path), then the join event
+    ReduceJob pre{(const float*)w.wgrad_scratch + (size_t)side_base * slab_f, (float*)w.wgrad_scratch, d.k * convx_dp(d.D), d.F, d.F,
+                  cand_slabs, slab_f, 1.0f, 0.f};
+    (void)launch_multi_reduce(&pre, 1, sw);
+    (void)hipEventRecord(c->ev_c1, sw);
   }
   // ONE event behind the recurrence serves both side streams (forks are merged wherever the dependencies allow), attached
   // to the recurrence kernel's own completion when nothing else sits between it and the fork
@@ -1307,36 +1276,17 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     float *hprev = w.hprev, *rh = w.rh;   // fast path: both already sit row-major in the tape (no copies)
     gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
     const bool attach = fork_b && !(user_row_drop(c) > 0.f) && !(c->prof_on && !c->prof_roofline_only);   // (a bracketed launch records behind it anyway)
-    if (late) {   // slots W - 1 .. Wh first; the late slots' encoder backward forks behind them
-      const bool attach_l = !(c->prof_on && !c->prof_roofline_only);
-      if (attach_l) arm_stop_event(c->ev_l0);
-      PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev, w.dh_mid, n, d.W, d.H, s, true,
-                                     d.W - 1, Wh));
-      if (!attach_l || stop_event_pending()) {
-        arm_stop_event(nullptr);
-        (void)hipEventRecord(c->ev_l0, s);
-      }
-      (void)hipStreamWaitEvent(sw, c->ev_l0, 0);
-      dense_gemm(w.dgates + (size_t)nE * 3 * d.H, 3 * d.H, c->P("gru_w"), 3 * d.H, true, w.ddocvec + (size_t)nE * d.U, d.U, nullptr,
-                 nL, d.U, 3 * d.H, nullptr, sw);
-      dense_gemm(w.ddocvec + (size_t)nE * d.U, d.U, c->P("dense_w"), d.U, true, w.dpooled + (size_t)nE * d.F, d.F, nullptr, nL, d.F,
-                 d.U, nullptr, sw);
-      side_attention_and_kernel_gradient(nE, nL, 4, side_base + cand_slabs, 240, &late_slabs);   // (16 CUs hold the recurrence)
-      side_done();
-    }
     if (attach) arm_stop_event(fe);
-    PROF("gru_bwd", launch_gru_bwd(late ? w.dh_mid : dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
-                                   (d.arch == LSTUR_ARCH_IGRU || two_tables(d)) ? w.duser : w.dh0, n, d.W,
-                                   d.H, s, d.slot != 0, late ? Wh - 1 : -1, 0));
+    PROF("gru_bwd", launch_gru_bwd(dhl, w.gmask, w.gru_tape, w.gru_up, w.dgates, rh, hprev,
+                                   (d.arch == LSTUR_ARCH_IGRU || two_tables(d)) ? w.duser : w.dh0, n, d.W, d.H, s));
     fe_recorded = attach && !stop_event_pending();
     arm_stop_event(nullptr);
   }
   {   // the row gradients of the user table(s) pass the forward's row mask and scale (dgru / id_keep)
     const float row_p = user_row_drop(c);
     if (row_p > 0.f) {
-      launch_drop_rows(w.duser, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
-      if (two_tables(d))
-        launch_drop_rows(w.duser2, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, lane_stream + 2), s);
+      launch_drop_rows(w.duser, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, 2), s);
+      if (two_tables(d)) launch_drop_rows(w.duser2, n, d.Ue, row_p, dropout_key(c->cfg.seed, step, 2), s);
     }
   }
   if (fork_b && !fe_recorded) (void)hipEventRecord(fe, s);
@@ -1358,23 +1308,13 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   } else {   // vo / niavg: no GRU in the graph -- its bucket slots get an exact zero gradient
     (void)hipMemsetAsync(c->G("gru_w"), 0, (size_t)(c->G("gru_b") + 3 * d.H - c->G("gru_w")) * sizeof(float), s);
   }
-  if (c->cfg.freeze_encoder) {   // loaded, non-trainable news encoder: nothing behind the doc vectors is trained
-    if (stats) {
-      jobs[nj++] = ReduceJob{w.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
-      jobs[nj++] = ReduceJob{w.correct_i, stats + 1, 1, 1, 1, n, 1, 1.0f / (float)n};
-      jobs[nj++] = ReduceJob{w.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
-      jobs[nj++] = ReduceJob{w.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
-    }
-    join();
-    launch_multi_reduce(jobs, nj, s);
-    return;
-  }
+  if (c->cfg.freeze_encoder)   // loaded, non-trainable news encoder: nothing behind the doc vectors is trained
+    return finish();
   // d(history doc vectors) = dgates . gru_w^T, masked by the history mask (paper.py:644-645)
   bool w2_recorded = false;
   if (has_gru) {
     if (sw != s) arm_stop_event(c->ev_w2);   // the Dense(U) parameter gradients fork behind this product
-    dense_gemm(w.dgates, 3 * d.H, c->P("gru_w"), 3 * d.H, true, w.ddocvec, d.U, nullptr, late ? nE : nW, d.U, 3 * d.H,
-               w.gemm_scratch, s);
+    dense_gemm(w.dgates, 3 * d.H, c->P("gru_w"), 3 * d.H, true, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, w.gemm_scratch, s);
     w2_recorded = sw != s && !stop_event_pending();
     arm_stop_event(nullptr);
   }
@@ -1395,14 +1335,12 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
   // news encoder backward (candidate rows of ddocvec were written by the scorer)
   if (sw != s) {          // Dense(U) parameter gradients: beside d(pooled) -> attention backward -> conv kernel gradient
     if (!w2_recorded) (void)hipEventRecord(c->ev_w2, s);
-    (void)hipStreamWaitEvent(sw2, c->ev_w2, 0);
-    if (sw2 == sw) forked = true;
-    else forked2 = true;
+    (void)hipStreamWaitEvent(sw, c->ev_w2, 0);
+    forked = true;
   }
-  wgrad_gemm(w.pooled, d.F, w.ddocvec, d.U, c->G("dense_w"), d.U, d.F, d.U, nt, w.gemm_scratch_k[3], sw2, &jobs[nj++]);
-  launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], sw2, &jobs[nj++]);
-  dense_gemm(w.ddocvec, d.U, c->P("dense_w"), d.U, true, w.dpooled, d.F, nullptr, late ? nE : split ? nW : nt, d.F, d.U,
-             w.gemm_scratch, s);
+  wgrad_gemm(w.pooled, d.F, w.ddocvec, d.U, c->G("dense_w"), d.U, d.F, d.U, nt, w.gemm_scratch_k[3], sw, &jobs[nj++]);
+  launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], sw, &jobs[nj++]);
+  dense_gemm(w.ddocvec, d.U, c->P("dense_w"), d.U, true, w.dpooled, d.F, nullptr, split ? nW : nt, d.F, d.U, w.gemm_scratch, s);
   // partial sums laid out like the bucket slice conv_b .. att_b -> one reduction straight into dense_grad
   if (d.enc == LSTUR_ENC_MHSA) {
     // partial sums: datt_w | datt_b like the bucket slice att_w .. att_b, the (unused) column sums of dconv behind them
@@ -1418,65 +1356,43 @@ void run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stat
     // slot alignment), so row D of [E | 1]^T . dQKV lands on it
     PROF("qkv_wgrad", launch_proj_wgrad_bf16e((const unsigned short*)w.emb, w.dqkv, c->G("qkv_w"), w.mh_scratch, d.D, 3 * d.F, nt * d.T, s,
                                              &jobs[nj++]));
-    if (stats) {
-      jobs[nj++] = ReduceJob{w.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
-      jobs[nj++] = ReduceJob{w.correct_i, stats + 1, 1, 1, 1, n, 1, 1.0f / (float)n};
-      jobs[nj++] = ReduceJob{w.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
-      jobs[nj++] = ReduceJob{w.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
-    }
-    join();
-    launch_multi_reduce(jobs, nj, s);
-    return;
+    return finish();
   }
   const int off_cb = 0, off_aw = (int)(c->G("att_w") - c->G("conv_b")), off_ab = (int)(c->G("att_b") - c->G("conv_b"));
   const int ldp = off_ab + 1;
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
                                          w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 1, w.live,
-                                         w.kbits_valid ? w.kbits : nullptr, 0, late ? nE : split ? nW : nt,
-                                         title_order(d, n)));
+                                         w.kbits_valid ? w.kbits : nullptr, 0, split ? nW : nt,
+                                         gm ? gm + 2 * par : nullptr, gm ? gm + 2 * (par ^ 1) : nullptr));
   if (split) (void)hipStreamWaitEvent(s, c->ev_c1, 0);   // the candidate titles' partial sums, gradient rows and slabs
   // (on the side stream this one found no free CU beside the conv kernel gradient and finished behind it)
   launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch_k[2], s, &jobs[nj++]);
   if (d.word_trainable) {   // conv input gradient -> word-table gradient (embedding dropout mask = stream 0 of the step)
     (void)hipMemsetAsync(c->buf.word_grad, 0, (size_t)d.V * d.D * sizeof(float), s);
     PROF("conv_dgrad", launch_conv_dgrad_scatter(w.dconv, c->P("conv_w"), w.ids, c->buf.word_grad, w.dgrad_scratch, nt, d.T,
-                                                  d.D, d.k, d.F, drop, dropout_key(c->cfg.seed, step, lane_stream), s));
+                                                  d.D, d.k, d.F, drop, dropout_key(c->cfg.seed, step, 0), s));
   }
-  static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr;
-  static const bool gen1 = getenv("LSTUR_CONV_GEN1") != nullptr;
-  if (w.conv_w3 && !conv_f32 && gen1)
-    PROF("conv_wgrad", launch_conv3_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vidx,
-                                          w.vcount, s, &jobs[nj++], w.offA, w.offB));
-  else if (w.conv_w3 && !conv_f32) {   // fp32-grade bf16x3 contraction (conv3f.hip), like the forward; one reduce job per tap
+  if (d.np) {   // split-operand contraction (convx.hip), like the forward; one reduce job per tap
     ProfScope _ps(c, "conv_wgrad", s, true);
-    nj += launch_conv3_wgrad2(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, s, &jobs[nj],
-                              w.offA, w.offB, 1.0f, c->conv_cus, late ? 3 : split ? 1 : 0, split ? 1 : 0,
-                              late ? nE : split ? nW : 0);
+    nj += launch_convx_wgrad(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, s, &jobs[nj],
+                             w.offA, w.offB, d.np, w.cs, 2 * par, 1.0f, split ? 1 : 0, split ? 1 : 0, split ? nW : 0);
   } else
     PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
                                          w.vidx, w.vcount, s, w.offA, w.offB,
                                          w.emb + (size_t)d.nt_max * d.Tp * d.D /* zero slack */, &jobs[nj++]));
-  if (stats) {
-    jobs[nj++] = ReduceJob{w.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
-    jobs[nj++] = ReduceJob{w.correct_i, stats + 1, 1, 1, 1, n, 1, 1.0f / (float)n};
-    jobs[nj++] = ReduceJob{w.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};      // running sums for the
-    jobs[nj++] = ReduceJob{w.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};   // host's epoch means
-  }
-  join();
-  launch_multi_reduce(jobs, nj, s);
+  return finish();
 }
 
 int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n, int k1, bool ids_form, hipStream_t s) {
   const Dims& d = c->d;
-  Workspace& w = *c->cur;
+  Workspace& w = c->ws;
   const size_t nW = (size_t)n * d.W;
   if (ids_form) {
     if (!c->title_table) return fail(LSTUR_ERR_STATE, "no title table bound (lstur_set_title_table)");
-    launch_expand_count(c->title_table, hist, (int)nW, cands, n * k1, d.T, w.ids, w.vscratch, s, title_order(d, n));
-    c->counted_flag() = true;
+    launch_expand_count(c->title_table, hist, (int)nW, cands, n * k1, d.T, w.ids, w.vscratch, s);
+    c->counted = true;
   } else {
-    if (d.slot) launch_permute_titles(hist, w.ids, (int)nW, d.T, title_order(d, n), s);
-    else (void)hipMemcpyAsync(w.ids, hist, nW * d.T * 4, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(w.ids, hist, nW * d.T * 4, hipMemcpyDeviceToDevice, s);
     (void)hipMemcpyAsync(w.ids + nW * d.T, cands, (size_t)n * k1 * d.T * 4, hipMemcpyDeviceToDevice, s);
   }
   return LSTUR_OK;
@@ -1489,41 +1405,29 @@ int stage_titles(lstur_ctx* c, const int32_t* hist, const int32_t* cands, int n,
 // compaction counts the tokens in front of the first candidate title), the kernel gradient's slabs of both launches are
 // reduced together in fixed order.  LSTUR_CAND_SPLIT=0: one launch each over all titles.
 bool cand_split_wanted(lstur_ctx* c, int n) {
-  static const bool off = getenv("LSTUR_CAND_SPLIT") && !strcmp(getenv("LSTUR_CAND_SPLIT"), "0");
-  static const bool other_conv = getenv("LSTUR_CONV_F32") != nullptr || getenv("LSTUR_CONV_GEN1") != nullptr;
   const Dims& d = c->d;
   const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
-  if (off || other_conv || !has_gru || c->lanes_active || c->cur != &c->ws || c->cur_lane != 0 || c->conv_cus != 0) return false;
-  if (d.enc != LSTUR_ENC_CNNATT || !c->ws.conv_w3 || d.word_trainable || c->cfg.freeze_encoder) return false;
+  if (!c->opt.cand_split || !has_gru || !d.np) return false;
+  if (d.enc != LSTUR_ENC_CNNATT || d.word_trainable || c->cfg.freeze_encoder) return false;
   if (d.head != LSTUR_HEAD_SOFTMAX || d.score != LSTUR_SCORE_DOT || !attpool_title_path(d.T, d.F)) return false;
   if (!gemm3_supported(d.U, d.U, n * d.K1, d.F, d.U) || !wgrad_stream(c)) return false;
   // the recurrence's backward must leave most of the chip idle (one workgroup per 4 samples): at B = 512 it holds 128 CUs
   // and the side launches only get in its way (same box: 6.05 against 5.94 ms per step)
   if (cdiv(n, 4) > 32) return false;
   if (!c->ev_c0 && (hipEventCreateWithFlags(&c->ev_c0, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&c->ev_l0, hipEventDisableTiming) != hipSuccess)) {
-    c->ev_c0 = c->ev_c1 = c->ev_l0 = nullptr;
+                    hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) != hipSuccess)) {
+    c->ev_c0 = c->ev_c1 = nullptr;
     return false;
   }
   return true;
 }
-// The LATE history slots' share of the encoder backward (opt-in: LSTUR_LATE_SLOTS=n).  The recurrence's backward walks the
-// slots from the last to the first, so d(gate inputs) of the late slots are final long before it ends: with slot-major
-// titles (Dims::slot) they are a contiguous range of GRU rows, titles and tokens.  The launch is cut at slot W - n: behind
-// its first part the late slots' d(doc vectors) -> d(pooled) -> attention backward -> conv kernel gradient run on the
-// parameter-gradient stream while the second part walks the early slots on 16 CUs.  Measured at the config-2 shapes
-// (same box): n = 6 / 9 / 12 / 15 / 18 slots cost 30 / 40 / 39 / 45 / 42 us per step MORE than n = 0 -- the recurrence
-// stretches by 15-40 % beside the attention backward and the kernel gradient, a kernel gradient over a third of the tokens
-// takes 1.6 x its share, and what spills past the recurrence starves the main stream's products (trace in DESIGN.md 4c).
-int late_slots(const Dims& d) { return d.late; }
 
 // Listwise score model on (uservec [n, Uu], candidate doc vectors [n*k1, U]) (paper.py:443-464).
 //   scores != NULL: test model, sigmoid(score) for k1 == 1 (paper.py:661-665)
 //   else: logits / probs / loss (+ `backward`: du, d(candidate doc vectors) and the score model's parameter gradients)
 void run_listwise_score(lstur_ctx* c, int n, int k1, float inv_n, bool backward, float* scores, hipStream_t s) {
   const Dims& d = c->d;
-  Workspace& w = *c->cur;
+  Workspace& w = c->ws;
   const int nW = n * d.W, rows = n * k1;
   const float* dvec = w.docvec + (size_t)nW * d.U;
   float* ddvec = w.ddocvec + (size_t)nW * d.U;
@@ -1587,109 +1491,12 @@ void run_listwise_score(lstur_ctx* c, int n, int k1, float inv_n, bool backward,
   launch_split_sum(dcat, d.Uu, d.U, k1, w.du, ddvec, n, s);
 }
 
-void set_lane(lstur_ctx* c, int lane) {
-  c->cur_lane = lane;
-  c->cur = lane ? &c->ws1 : &c->ws;
-  c->cur_grad = lane ? c->grad1 : c->buf.dense_grad;
-}
-
-// Two-lane training step.  The recurrence is a latency chain (50 dependent steps forward, 50 backward, ~180 us each) on
-// one workgroup per four samples -- 16 of 256 CUs at B = 64 -- and everything behind it waits.  The batch is therefore cut
-// into two sample ranges ("lanes") that run the whole chain encoder -> GRU -> scorer -> BPTT -> encoder backward one stage
-// apart on two streams: lane 1 starts when lane 0's encoder forward is done, so each lane's recurrences run beside the
-// other lane's encoder kernels (and lane 0's BPTT beside lane 1's forward recurrence).  Per-sample results land in lane
-// 0's arrays (lane 1 writes behind lane 0's rows); dense gradients in two buckets summed at the join; the loss scale is
-// 1 / n of the WHOLE batch in both lanes.  Same kernels, same data with LSTUR_STREAMS=1 (both lanes on the caller's
-// stream): bit-identical results.  Reference: the single Keras graph of task/paper.py:635-665 (no counterpart).
-int train_two_lanes(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int32_t* cands, int n, uint32_t step,
-                    float grad_scale, float* stats, hipStream_t s, bool ids_form) {
-  const Dims& d = c->d;
-  const int nA = lane0_share(n), nB = n - nA;
-  if (nB < 1 || nB > c->d1.B) return fail(LSTUR_ERR_STATE, "two-lane step: lane 1 capacity");
-  struct Active {
-    lstur_ctx* c;
-    explicit Active(lstur_ctx* x) : c(x) { c->lanes_active = true; }
-    ~Active() { c->lanes_active = false; }
-  } active(c);
-  Workspace &w0 = c->ws, &w1 = c->ws1;
-  if (!c->side) {
-    if (!(c->side = pooled_stream(3, false)) ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_enc0, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_done1, hipEventDisableTiming) != hipSuccess)
-      return fail(LSTUR_ERR_HIP, "two-lane step: stream / event creation failed");
-  }
-  const bool serial = getenv("LSTUR_STREAMS") && !strcmp(getenv("LSTUR_STREAMS"), "1");
-  hipStream_t sB = serial ? s : c->side;
-  // per-sample results of lane 1 behind lane 0's rows: the host-visible arrays stay contiguous over the batch
-  w1.user_rows = w0.user_rows + nA;
-  w1.duser = w0.duser + (size_t)nA * d.Ue;
-  if (w0.duser2) w1.duser2 = w0.duser2 + (size_t)nA * d.Ue;
-  w1.logits = w0.logits + (size_t)nA * d.K1;
-  w1.probs = w0.probs + (size_t)nA * d.K1;
-  w1.loss_i = w0.loss_i + nA;
-  w1.correct_i = w0.correct_i + nA;
-  const float inv_n = grad_scale / (float)n;
-  const size_t tstride = ids_form ? 1 : (size_t)d.T;       // ints per title in the caller's arrays
-  // the conv kernels plan their rounds for the CUs the other lane's recurrence leaves (one workgroup per 4 samples)
-  c->conv_cus = serial ? 0 : 256 - 16;
-  (void)hipEventRecord(c->ev_fork, s);          // lane 1 sees everything the caller enqueued so far (inputs, last Adam step)
-  if (!serial) (void)hipStreamWaitEvent(sB, c->ev_fork, 0);
-  // ---- lane 0 on the caller's stream
-  set_lane(c, 0);
-  int rc = stage_titles(c, hist, cands, nA, d.K1, ids_form, s);
-  if (rc) return rc;
-  c->cur_ev_enc = c->ev_enc0;
-  run_forward(c, user, nA, d.K1, true, step, s);
-  c->cur_ev_enc = nullptr;
-  run_listwise_score(c, nA, d.K1, inv_n, true, nullptr, s);
-  run_backward(c, nA, step, s, nullptr);
-  // ---- lane 1, one stage behind
-  set_lane(c, 1);
-  if (!serial) (void)hipStreamWaitEvent(sB, c->ev_enc0, 0);
-  rc = stage_titles(c, hist + (size_t)nA * d.W * tstride, cands + (size_t)nA * d.K1 * tstride, nB, d.K1, ids_form, sB);
-  if (rc) {
-    set_lane(c, 0);
-    return rc;
-  }
-  run_forward(c, user + nA, nB, d.K1, true, step, sB);
-  run_listwise_score(c, nB, d.K1, inv_n, true, nullptr, sB);
-  run_backward(c, nB, step, sB, nullptr);
-  (void)hipEventRecord(c->ev_done1, sB);
-  // ---- join: one gradient bucket, the batch statistics
-  set_lane(c, 0);
-  c->conv_cus = 0;
-  if (!serial) (void)hipStreamWaitEvent(s, c->ev_done1, 0);
-  launch_add2(c->buf.dense_grad, c->grad1, c->buf.dense_grad, c->dense_total, s);
-  if (stats) {
-    ReduceJob jobs[4];
-    jobs[0] = ReduceJob{w0.loss_i, stats, 1, 1, 1, n, 1, 1.0f / (float)n};
-    jobs[1] = ReduceJob{w0.correct_i, stats + 1, 1, 1, 1, n, 1, 1.0f / (float)n};
-    jobs[2] = ReduceJob{w0.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
-    jobs[3] = ReduceJob{w0.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};
-    launch_multi_reduce(jobs, 4, s);
-  }
-  c->last_n = n;
-  c->last_k1 = d.K1;
-  c->last_piped = true;
-  c->last_nA = nA;
-  return check_launch("forward_backward (two lanes)");
-}
-
 int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int32_t* cands, int n, uint32_t step,
                float grad_scale, float* stats, hipStream_t s, bool ids_form, bool backward, bool training) {
   if (!c || !user || !hist || !cands) return fail(LSTUR_ERR_ARG, "NULL argument");
   const Dims& d = c->d;
   if (d.head != LSTUR_HEAD_SOFTMAX) return fail(LSTUR_ERR_STATE, "context was created with a pointwise head");
   if (n < 1 || n > d.B) return fail(LSTUR_ERR_ARG, "n must be in [1, max_batch]");
-  static const bool conv_f32 = getenv("LSTUR_CONV_F32") != nullptr || getenv("LSTUR_CONV_GEN1") != nullptr;
-  if (backward && training && c->pipe_ok && n >= kPipeMin && !c->cfg.freeze_encoder && !conv_f32) {
-    c->fused.on = false;   // (the two-lane step keeps the one-piece sweep behind both lanes)
-    c->ws.kbits_valid = false;
-    return train_two_lanes(c, user, hist, cands, n, step, grad_scale, stats, s, ids_form);
-  }
-  set_lane(c, 0);
-  c->last_piped = false;
   // was this batch staged by a prefetch during the previous step?  (same arrays, same size, same step)
   auto& q = c->ready;
   c->staged_hit = backward && training && ids_form && q.valid && q.hist == hist && q.cands == cands && q.n == n &&
@@ -1706,7 +1513,10 @@ int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   c->staged_hit = false;
   run_listwise_score(c, n, d.K1, grad_scale / (float)n, backward, nullptr, s);
   if (stats && !backward) launch_mean2(w.loss_i, w.correct_i, n, stats, s);
-  if (backward) PROF("backward_total", run_backward(c, n, step, s, stats));
+  if (backward) {
+    ProfScope _ps(c, "backward_total", s);
+    if ((rc = run_backward(c, n, step, s, stats)) != LSTUR_OK) return rc;
+  }
   return check_launch(backward ? "forward_backward" : "evaluate");
 }
 
@@ -1745,8 +1555,6 @@ int point_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   const Dims& d = c->d;
   if (d.head == LSTUR_HEAD_SOFTMAX) return fail(LSTUR_ERR_STATE, "context was created with the listwise head");
   if (n < 1 || n > d.B) return fail(LSTUR_ERR_ARG, "n must be in [1, max_batch]");
-  set_lane(c, 0);
-  c->last_piped = false;
   c->ws.kbits_valid = false;
   int rc = stage_titles(c, hist, cand, n, 1, ids_form, s);
   if (rc) return rc;
@@ -1754,7 +1562,10 @@ int point_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   PROF("forward_total", run_forward(c, user, n, 1, training, step, s));
   run_point_head(c, labels, n, grad_scale / (float)n, true, backward, s);
   if (stats && !backward) launch_mean2(w.loss_i, w.correct_i, n, stats, s);
-  if (backward) PROF("backward_total", run_backward(c, n, step, s, stats));
+  if (backward) {
+    ProfScope _ps(c, "backward_total", s);
+    if ((rc = run_backward(c, n, step, s, stats)) != LSTUR_OK) return rc;
+  }
   return check_launch(backward ? "point_forward_backward" : "point_evaluate");
 }
 
@@ -1764,8 +1575,6 @@ int predict_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const i
   const Dims& d = c->d;
   int cap = d.nt_max / (d.W + 1);
   if (n < 1 || n > cap) return fail(LSTUR_ERR_ARG, "n exceeds max_predict_rows");
-  set_lane(c, 0);
-  c->last_piped = false;
   c->ws.kbits_valid = false;
   int rc = stage_titles(c, hist, cand, n, 1, ids_form, s);
   if (rc) return rc;
@@ -1789,7 +1598,8 @@ int predict_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const i
 extern "C" {
 
 const char* lstur_last_error(void) { return g_err.c_str(); }
-const char* lstur_version(void) { return "lstur-hip 0.1 (gfx950)"; }
+const char* lstur_version(void) { return "lstur-hip 0.3 (gfx950)"; }
+int lstur_abi_version(void) { return LSTUR_ABI_VERSION; }
 
 int lstur_query_sizes(const lstur_cfg* cfg, lstur_sizes* out) {
   Dims d;
@@ -1801,11 +1611,6 @@ int lstur_query_sizes(const lstur_cfg* cfg, lstur_sizes* out) {
   Workspace w;
   carve(d, nullptr, &w);
   size_t ws_bytes = w.bytes;
-  if (lanes_supported(d)) {      // lane 1 of the two-lane step: its own workspace + gradient bucket
-    Workspace w1;
-    carve(lane1_dims(d), nullptr, &w1);
-    ws_bytes += w1.bytes + (total * sizeof(float) + 255) / 256 * 256;
-  }
   out->word_emb = (size_t)d.V * d.D;
   out->dense = total;
   out->user_emb = (size_t)d.Nu * d.Ue;
@@ -1865,6 +1670,7 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
       ((uintptr_t)buf->dense_grad & 15) || ((uintptr_t)buf->user_emb & 15))
     return fail(LSTUR_ERR_ARG, "buffers must be 16-byte (workspace 256-byte) aligned");
   lstur_ctx* c = new lstur_ctx();
+  c->opt = Opts::read();
   c->cfg = *cfg;
   c->d = d;
   c->buf = *buf;
@@ -1875,25 +1681,6 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
   }
   carve(d, buf->workspace, &c->ws);
   size_t need = c->ws.bytes;
-  c->pipe_ok = lanes_supported(d);
-  c->d.slot = slot_major_wanted(d) ? 1 : 0;
-  {
-    const char* ls = getenv("LSTUR_LATE_SLOTS");
-    const int want = ls ? atoi(ls) : 0;
-    c->d.late = (c->d.slot && want >= 1 && want < d.W) ? want : 0;
-  }
-  if (c->pipe_ok) {
-    c->d1 = lane1_dims(d);
-    carve(c->d1, (char*)buf->workspace + need, &c->ws1);
-    need += c->ws1.bytes;
-    c->grad1 = (float*)((char*)buf->workspace + need);
-    need += (c->dense_total * sizeof(float) + 255) / 256 * 256;
-    // shared between the lanes: operand images of the weights (packed by lane 0), the optimizer's sparse-row scratch
-    Workspace &a = c->ws, &b = c->ws1;
-    b.conv_w3 = a.conv_w3; b.conv_w3_v1 = a.conv_w3_v1; b.conv_wp = a.conv_wp; b.gru_up = a.gru_up;
-    b.first = a.first; b.gsum = a.gsum; b.gsum2 = a.gsum2; b.slot = a.slot; b.dp_rows = a.dp_rows; b.dp_grads = a.dp_grads; b.dp_grads2 = a.dp_grads2;
-  }
-  set_lane(c, 0);
   if (need > buf->workspace_bytes) {
     delete c;
     return fail(LSTUR_ERR_ARG, "workspace too small (see lstur_query_sizes)");
@@ -1903,39 +1690,30 @@ int lstur_create(const lstur_cfg* cfg, const lstur_buffers* buf, lstur_ctx** out
 }
 
 int lstur_destroy(lstur_ctx* ctx) {
-  if (ctx && ctx->side) {
-    (void)hipStreamSynchronize(ctx->side);
-    (void)hipEventDestroy(ctx->ev_fork);
-    (void)hipEventDestroy(ctx->ev_enc0);
-    (void)hipEventDestroy(ctx->ev_done1);
-    // (pooled streams outlive the context)
-  }
-  if (ctx && ctx->side_p) {    // (side_t is the same stream)
+  if (!ctx) return LSTUR_OK;
+  // (pooled streams outlive the context; everything this context enqueued on them is drained before its events go)
+  if (ctx->side_p) {
     (void)hipStreamSynchronize(ctx->side_p);
+    if (ctx->side_t && ctx->side_t != ctx->side_p) (void)hipStreamSynchronize(ctx->side_t);
     (void)hipEventDestroy(ctx->ev_p0);
     (void)hipEventDestroy(ctx->ev_p1);
     (void)hipEventDestroy(ctx->ev_t0);
     (void)hipEventDestroy(ctx->ev_t1);
-
   }
-  if (ctx && ctx->ev_f0) (void)hipEventDestroy(ctx->ev_f0);
-  if (ctx && ctx->side_w) {
+  if (ctx->ev_f0) (void)hipEventDestroy(ctx->ev_f0);
+  if (ctx->side_w) {
     (void)hipStreamSynchronize(ctx->side_w);
     (void)hipEventDestroy(ctx->ev_w1);
     (void)hipEventDestroy(ctx->ev_w2);
     (void)hipEventDestroy(ctx->ev_w3);
-    if (ctx->side_w2) (void)hipStreamSynchronize(ctx->side_w2);
-    if (ctx->ev_w4) (void)hipEventDestroy(ctx->ev_w4);
-    if (ctx->ev_c0) (void)hipEventDestroy(ctx->ev_c0);
-    if (ctx->ev_c1) (void)hipEventDestroy(ctx->ev_c1);
-    if (ctx->ev_l0) (void)hipEventDestroy(ctx->ev_l0);
   }
-  if (ctx)
-    for (auto& k : ctx->prof)
-      for (size_t i = 0; i < k.start.size(); ++i) {
-        (void)hipEventDestroy(k.start[i]);
-        (void)hipEventDestroy(k.stop[i]);
-      }
+  if (ctx->ev_c0) (void)hipEventDestroy(ctx->ev_c0);
+  if (ctx->ev_c1) (void)hipEventDestroy(ctx->ev_c1);
+  for (auto& k : ctx->prof)
+    for (size_t i = 0; i < k.start.size(); ++i) {
+      (void)hipEventDestroy(k.start[i]);
+      (void)hipEventDestroy(k.stop[i]);
+    }
   delete ctx;
   return LSTUR_OK;
 }
@@ -2065,17 +1843,17 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
   bool packed = false;
   ImagePlan pl;
   {
-    static const bool conv_alt = getenv("LSTUR_CONV_F32") != nullptr || getenv("LSTUR_CONV_GEN1") != nullptr;
-    static const bool no_fuse = getenv("LSTUR_ADAM_PACK") && !strcmp(getenv("LSTUR_ADAM_PACK"), "0");
     const int kq = gru4_supported(d.H) ? gru4_pack_kq(d.H) : 0;
-    if (ctx->images_valid && !no_fuse && !conv_alt && d.enc != LSTUR_ENC_MHSA && ctx->ws.conv_w3 && kq > 0 && ctx->ws.gru_up) {
+    const float grow = adam_growth_bound(c) * fabsf(lr_t);
+    if (ctx->images_valid && ctx->opt.adam_pack && d.np && kq > 0 && ctx->ws.gru_up && isfinite(grow)) {
       int Kp = 0, Np = 0;
-      conv3_w2_dims(d.D, d.k, d.F, &Kp, &Np);
+      convx_w_dims(d.D, d.k, d.F, &Kp, &Np);
       pl.conv_off = (size_t)(ctx->P("conv_w") - ctx->buf.dense_param);
       pl.conv_cnt = (size_t)d.k * d.D * d.F;
-      pl.D = d.D; pl.Dp = conv3_dp(d.D); pl.F = d.F; pl.Np = Np;
+      pl.D = d.D; pl.Dp = convx_dp(d.D); pl.F = d.F; pl.Np = Np;
       pl.w3 = ctx->ws.conv_w3;
       pl.w3_part = (size_t)Kp * Np;
+      pl.np = d.np; pl.cs = ctx->ws.cs; pl.seq = ctx->pack_seq++; pl.grow = grow;
       pl.gru_off = (size_t)(ctx->P("gru_u") - ctx->buf.dense_param);
       pl.H = d.H; pl.KQ = kq;
       pl.gimg = ctx->ws.gru_up;
@@ -2096,7 +1874,7 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
   }
   // the next forward's weight images, behind the dense update (in front of the next conv forward they would be a bubble:
   // with the staging prefetched nothing else is left to hide them under)
-  if (!packed) pack_weight_images(ctx, s);
+  if (!packed) pack_weight_images(ctx, s, !ctx->images_valid, lr_t);
   ctx->images_valid = true;
   if (d.word_trainable)   // dense Keras-Adam sweep of the word table (TF-1 densifies the IndexedSlices gradient)
     launch_adam_flat(ctx->buf.word_emb, ctx->buf.word_grad, ctx->buf.word_m, ctx->buf.word_v, (size_t)d.V * d.D, lr_t,
@@ -2137,11 +1915,11 @@ int lstur_flush_tables(lstur_ctx* ctx, lstur_stream stream) {
   return check_launch("flush_tables");
 }
 int lstur_lazy_adam(lstur_ctx* ctx) { return (ctx && ctx->d.lazy) ? 1 : 0; }
-int lstur_slot_major(lstur_ctx* ctx) { return (ctx && ctx->d.slot) ? 1 : 0; }
 
 int lstur_params_changed(lstur_ctx* ctx) {
   if (!ctx) return fail(LSTUR_ERR_ARG, "ctx is NULL");
   ctx->images_valid = false;
+  ctx->escale_valid = false;            // (f16x2: the embeddings' scale follows the word table)
   ctx->ready = lstur_ctx::Pending();    // a staged batch holds embeddings of the old word table
   return LSTUR_OK;
 }
@@ -2152,8 +1930,7 @@ static int train_step_impl(lstur_ctx* ctx, const int32_t* user, const int32_t* h
                            bool ids_form) {
   if (!ctx || t < 1) return fail(LSTUR_ERR_ARG, "bad train step");
   const lstur_cfg& c = ctx->cfg;
-  static const bool off = getenv("LSTUR_FUSED_ADAM") && !strcmp(getenv("LSTUR_FUSED_ADAM"), "0");
-  ctx->fused.on = !off;
+  ctx->fused.on = ctx->opt.fused_adam;
   ctx->fused.swept = ctx->fused.table_done = false;
   ctx->fused.lr_t = lr * (sqrtf(1.0f - powf(c.beta2, (float)t)) / (1.0f - powf(c.beta1, (float)t)));
   ctx->fused.t = t;
@@ -2224,7 +2001,7 @@ int lstur_profile_read(lstur_ctx* ctx, int index, const char** name, float* tota
 int lstur_conv_scheme(lstur_ctx* ctx) {
   if (!ctx) return fail(LSTUR_ERR_ARG, "ctx is NULL");
   if (ctx->d.enc == LSTUR_ENC_MHSA) return 0;
-  return (ctx->ws.conv_w3 && !getenv("LSTUR_CONV_F32")) ? 1 : 2;
+  return ctx->d.np == 2 ? 3 : ctx->d.np == 3 ? 1 : 2;
 }
 
 int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* count) {
@@ -2243,12 +2020,8 @@ int lstur_peek(lstur_ctx* ctx, const char* name, const float** ptr, size_t* coun
       {"h_last", (d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU) ? w.uservec : w.hlast, n * d.H},
       {"dgates", w.dgates, n * d.W * 3 * d.H}, {"ddoc_vec", w.ddocvec, nt * d.U},
   };
-  if (ctx->last_piped && strcmp(name, "logits") && strcmp(name, "probs") && strcmp(name, "loss_i") && strcmp(name, "user_grad") &&
-      strcmp(name, "duser2"))
-    return fail(LSTUR_ERR_STATE, std::string(name) + ": title-level intermediates of a two-lane step live in two workspaces; "
-                                 "run with LSTUR_PIPELINE=0 to inspect them");
-  if (!strcmp(name, "emb") && ctx->last_use3)
-    return fail(LSTUR_ERR_STATE, "emb: the bf16x3 conv path keeps the embeddings pre-split (E3); run with LSTUR_CONV_F32=1");
+  if (!strcmp(name, "emb") && ctx->last_usex)
+    return fail(LSTUR_ERR_STATE, "emb: the split-operand conv path keeps the embeddings pre-split (Ex); run with LSTUR_CONV_F32=1");
   if (!strcmp(name, "emb") && d.enc == LSTUR_ENC_MHSA)
     return fail(LSTUR_ERR_STATE, "emb: the mhsa encoder keeps the gathered embeddings as bf16 rows");
   for (auto& e : tab)
@@ -2312,95 +2085,84 @@ int lstur_attpool_fwd(const float* conv_out, const int32_t* ids, const float* at
                      (hipStream_t)stream);
   return check_launch("attpool_fwd");
 }
-size_t lstur_conv3_w3_elems(int32_t dim, int32_t ksize, int32_t filters) {
-  return conv3_supported(dim, ksize, filters) ? conv3_w3_elems(dim, ksize, filters) : 0;
+// ---- split-operand conv family (convx.hip): parts = 2 (f16x2, with a scale block) or 3 (bf16x3, scales may be NULL) ----
+static int convx_args_ok(int32_t dim, int32_t ksize, int32_t filters, int32_t parts, const float* scales, const char* who) {
+  if (parts != 2 && parts != 3) return fail(LSTUR_ERR_ARG, std::string(who) + ": parts must be 2 (f16x2) or 3 (bf16x3)");
+  if (!convx_supported(dim, ksize, filters))
+    return fail(LSTUR_ERR_ARG, std::string(who) + ": dim % 4 == 0, filters <= 448, ksize <= 8");
+  if (parts == 2 && !scales) return fail(LSTUR_ERR_ARG, std::string(who) + ": parts == 2 needs the scale block");
+  return LSTUR_OK;
 }
-int lstur_conv3_pack_w(const float* w, int32_t dim, int32_t ksize, int32_t filters, uint16_t* w3, lstur_stream stream) {
-  if (!w || !w3) return fail(LSTUR_ERR_ARG, "conv3_pack_w: NULL");
-  if (!conv3_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
-  launch_conv3_pack_w(w, ksize * dim, filters, w3, (hipStream_t)stream);
-  return check_launch("conv3_pack_w");
+size_t lstur_convx_scales_bytes(void) { return kCsWords * sizeof(float); }
+int lstur_convx_scales_init(float* scales, lstur_stream stream) {
+  if (!scales) return fail(LSTUR_ERR_ARG, "convx_scales_init: NULL");
+  launch_convx_scales_init(scales, (hipStream_t)stream);
+  return check_launch("convx_scales_init");
 }
-int lstur_conv3_relu_mask_fwd(const float* emb_padded, const uint16_t* w3, const float* bias, const int32_t* ids, float* out,
-                              int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters,
-                              const int32_t* vidx, const int32_t* vcount, lstur_stream stream) {
-  if (!emb_padded || !w3 || !bias || !ids || !out) return fail(LSTUR_ERR_ARG, "conv3_fwd: NULL");
-  if (!conv3_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
-  if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "conv3_fwd: vidx and vcount go together");
-  launch_conv3_fwd(emb_padded, w3, bias, ids, out, n_titles, title_len, dim, ksize, filters, vidx, vcount, (hipStream_t)stream);
-  return check_launch("conv3_fwd");
+int lstur_convx_embedding_scale(const float* table, size_t count, float drop, float* scales, lstur_stream stream) {
+  if (!table || !scales || !(drop >= 0.f && drop < 1.f)) return fail(LSTUR_ERR_ARG, "convx_embedding_scale: bad argument");
+  launch_convx_escale(table, count, drop, scales, (hipStream_t)stream);
+  return check_launch("convx_embedding_scale");
 }
-size_t lstur_conv3_e3_elems(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize) {
-  return conv3_e3_elems(n_titles, title_len, dim, ksize);
+size_t lstur_convx_e_elems(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t parts) {
+  return (parts == 2 || parts == 3) ? convx_e_elems(n_titles, title_len, dim, ksize, parts) : 0;
 }
-int lstur_gather_split3(const float* table, const int32_t* ids, uint16_t* e3, int32_t n_titles, int32_t title_len,
-                        int32_t dim, int32_t pad_left, int32_t pad_right, float drop, uint32_t key, int32_t skip_unread,
-                        lstur_stream stream) {
-  if (!table || !ids || !e3 || dim % 4 || n_titles < 0) return fail(LSTUR_ERR_ARG, "gather_split3: bad argument (dim % 4)");
-  launch_gather3(table, ids, e3, n_titles, title_len, dim, pad_left, pad_right, drop, key, skip_unread != 0, (hipStream_t)stream);
-  return check_launch("gather_split3");
+int lstur_convx_gather(const float* table, const int32_t* ids, uint16_t* ex, int32_t n_titles, int32_t title_len, int32_t dim,
+                       int32_t pad_left, int32_t pad_right, float drop, uint32_t key, int32_t skip_unread, int32_t parts,
+                       const float* scales, lstur_stream stream) {
+  if (!table || !ids || !ex || dim % 4 || n_titles < 0 || (parts != 2 && parts != 3) || (parts == 2 && !scales))
+    return fail(LSTUR_ERR_ARG, "convx_gather: bad argument (dim % 4, parts 2 | 3, scales)");
+  launch_gatherx(table, ids, ex, n_titles, title_len, dim, pad_left, pad_right, drop, key, skip_unread != 0, parts, scales,
+                 (hipStream_t)stream);
+  return check_launch("convx_gather");
 }
-size_t lstur_conv3_w3_elems2(int32_t dim, int32_t ksize, int32_t filters) {
-  return conv3f_supported(dim, ksize, filters) ? conv3_w3_elems2(dim, ksize, filters) : 0;
+size_t lstur_convx_w_elems(int32_t dim, int32_t ksize, int32_t filters, int32_t parts) {
+  return ((parts == 2 || parts == 3) && convx_supported(dim, ksize, filters)) ? convx_w_elems(dim, ksize, filters, parts) : 0;
 }
-int lstur_conv3_pack_w2(const float* w, int32_t dim, int32_t ksize, int32_t filters, uint16_t* w3, lstur_stream stream) {
-  if (!w || !w3) return fail(LSTUR_ERR_ARG, "conv3_pack_w2: NULL");
-  if (!conv3f_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
-  launch_conv3_pack_w2(w, dim, ksize, filters, w3, (hipStream_t)stream);
-  return check_launch("conv3_pack_w2");
+int lstur_convx_pack_w(const float* w, int32_t dim, int32_t ksize, int32_t filters, uint16_t* wx, int32_t parts, float* scales,
+                       lstur_stream stream) {
+  if (!w || !wx) return fail(LSTUR_ERR_ARG, "convx_pack_w: NULL");
+  if (int rc = convx_args_ok(dim, ksize, filters, parts, scales, "convx_pack_w")) return rc;
+  launch_convx_pack_w(w, dim, ksize, filters, wx, parts, scales, 0, true, 0.f, (hipStream_t)stream);
+  return check_launch("convx_pack_w");
 }
-int lstur_conv3_relu_mask_fwd2(const uint16_t* e3, const uint16_t* w3, const float* bias, const int32_t* ids, float* out,
-                               int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters,
-                               const int32_t* vidx, const int32_t* vcount, int32_t variant, void* scratch,
-                               lstur_stream stream) {
-  if (!e3 || !w3 || !bias || !ids || !out) return fail(LSTUR_ERR_ARG, "conv3_fwd2: NULL");
-  if (!conv3f_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
-  if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "conv3_fwd2: vidx and vcount go together");
-  if (variant != 0 && variant != 2 && (variant < 10 || variant > 16))
-    return fail(LSTUR_ERR_ARG, "conv3_fwd2: variant 0 (2: the tap-sharing kernel, 10 .. 16: ablations)");
-  if (conv3_e3_elems(n_titles, title_len, dim, ksize) * 2 >= ((size_t)1 << 32) ||
+int lstur_convx_fwd(const uint16_t* ex, const uint16_t* wx, const float* bias, const int32_t* ids, float* out, int32_t n_titles,
+                    int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx, const int32_t* vcount,
+                    int32_t parts, const float* scales, void* scratch, lstur_stream stream) {
+  if (!ex || !wx || !bias || !ids || !out) return fail(LSTUR_ERR_ARG, "convx_fwd: NULL");
+  if (int rc = convx_args_ok(dim, ksize, filters, parts, scales, "convx_fwd")) return rc;
+  if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "convx_fwd: vidx and vcount go together");
+  if (convx_e_elems(n_titles, title_len, dim, ksize, parts) * 2 >= ((size_t)1 << 32) ||
       (size_t)n_titles * title_len * filters * 4 >= ((size_t)1 << 32))
-    return fail(LSTUR_ERR_ARG, "conv3_fwd2: more than 4 GiB of embeddings / outputs per call");
-  launch_conv3_fwd2(e3, w3, bias, ids, out, n_titles, title_len, dim, ksize, filters, vidx, vcount, variant, scratch,
-                    (hipStream_t)stream);
-  return check_launch("conv3_fwd2");
+    return fail(LSTUR_ERR_ARG, "convx_fwd: more than 4 GiB of embeddings / outputs per call");
+  launch_convx_fwd(ex, wx, bias, ids, out, n_titles, title_len, dim, ksize, filters, vidx, vcount, parts, scales, scratch,
+                   (hipStream_t)stream);
+  return check_launch("convx_fwd");
 }
-size_t lstur_conv3_fwd2_scratch(void) { return conv3_fwd2_scratch_bytes(); }
-size_t lstur_conv3_wgrad2_scratch(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters) {
-  return conv3f_supported(dim, ksize, filters) ? conv3_wgrad2_scratch_bytes(n_titles, title_len, dim, ksize, filters) : 0;
+size_t lstur_convx_fwd_scratch(void) { return convx_fwd_scratch_bytes(); }
+size_t lstur_convx_wgrad_scratch(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters) {
+  return convx_supported(dim, ksize, filters) ? convx_wgrad_scratch_bytes(n_titles, title_len, dim, ksize, filters) : 0;
 }
-int lstur_conv3_wgrad2(const uint16_t* e3, const float* dout, float* dw, void* scratch, int32_t* offsets, int32_t n_titles,
-                       int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx,
-                       const int32_t* vcount, lstur_stream stream) {
-  if (!e3 || !dout || !dw || !scratch || !offsets) return fail(LSTUR_ERR_ARG, "conv3_wgrad2: NULL");
-  if (!conv3f_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
-  if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "conv3_wgrad2: vidx and vcount go together");
-  if (ksize > kMaxReduceJobs) return fail(LSTUR_ERR_ARG, "conv3_wgrad2: ksize too large");
-  const int M = n_titles * title_len;
-  if (conv3_e3_elems(n_titles, title_len, dim, ksize) * 2 >= ((size_t)1 << 32) || (size_t)M * filters * 4 >= ((size_t)1 << 32))
-    return fail(LSTUR_ERR_ARG, "conv3_wgrad2: more than 4 GiB of embeddings / gradients per call");
-  hipStream_t s = (hipStream_t)stream;
-  launch_token_offsets(vidx, vcount, M, title_len, title_len + ksize - 1, conv3_dp(dim) / 8 * 3, filters, offsets, offsets + M, s);
-  ReduceJob jobs[kMaxReduceJobs];
-  const int nj = launch_conv3_wgrad2(e3, dout, dw, scratch, n_titles, title_len, dim, ksize, filters, vcount, s, jobs, offsets,
-                                     offsets + M);
-  if (M > 0) launch_multi_reduce(jobs, nj, s);
-  return check_launch("conv3_wgrad2");
-}
-size_t lstur_conv3_wgrad_scratch(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t filters) {
-  return conv3_supported(dim, ksize, filters) ? conv3_wgrad_scratch_bytes(n_titles, title_len, dim, ksize, filters) : 0;
-}
-int lstur_conv3_wgrad(const float* emb_padded, const float* dout, float* dw, void* scratch, int32_t n_titles,
+int lstur_convx_wgrad(const uint16_t* ex, const float* dout, float* dw, void* scratch, int32_t* offsets, int32_t n_titles,
                       int32_t title_len, int32_t dim, int32_t ksize, int32_t filters, const int32_t* vidx,
-                      const int32_t* vcount, lstur_stream stream) {
-  if (!emb_padded || !dout || !dw || !scratch) return fail(LSTUR_ERR_ARG, "conv3_wgrad: NULL");
-  if (!conv3_supported(dim, ksize, filters)) return fail(LSTUR_ERR_ARG, "conv3: dim % 4 == 0, filters <= 448");
-  if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "conv3_wgrad: vidx and vcount go together");
-  ReduceJob job;
-  launch_conv3_wgrad(emb_padded, dout, dw, scratch, n_titles, title_len, dim, ksize, filters, vidx, vcount,
-                     (hipStream_t)stream, &job);
-  if (job.nslices > 0) launch_multi_reduce(&job, 1, (hipStream_t)stream);
-  return check_launch("conv3_wgrad");
+                      const int32_t* vcount, int32_t parts, float* scales, lstur_stream stream) {
+  if (!ex || !dout || !dw || !scratch || !offsets) return fail(LSTUR_ERR_ARG, "convx_wgrad: NULL");
+  if (int rc = convx_args_ok(dim, ksize, filters, parts, scales, "convx_wgrad")) return rc;
+  if ((vidx == nullptr) != (vcount == nullptr)) return fail(LSTUR_ERR_ARG, "convx_wgrad: vidx and vcount go together");
+  const int M = n_titles * title_len;
+  if (convx_e_elems(n_titles, title_len, dim, ksize, parts) * 2 >= ((size_t)1 << 32) || (size_t)M * filters * 4 >= ((size_t)1 << 32))
+    return fail(LSTUR_ERR_ARG, "convx_wgrad: more than 4 GiB of embeddings / gradients per call");
+  hipStream_t s = (hipStream_t)stream;
+  launch_token_offsets(vidx, vcount, M, title_len, title_len + ksize - 1, convx_dp(dim) / 8 * parts, filters, offsets, offsets + M, s);
+  if (parts == 2) {   // the stand-alone call takes max |dout| over the rows it reads (in the step the attention backward leaves it)
+    (void)hipMemsetAsync((uint32_t*)scales + kCsGmax, 0, sizeof(uint32_t), s);
+    launch_absmax_rows(dout, M, filters, vidx, vcount, (uint32_t*)scales + kCsGmax, s);
+  }
+  ReduceJob jobs[kMaxReduceJobs];
+  const int nj = launch_convx_wgrad(ex, dout, dw, scratch, n_titles, title_len, dim, ksize, filters, vcount, s, jobs, offsets,
+                                    offsets + M, parts, scales, 0);
+  if (M > 0 && !launch_multi_reduce(jobs, nj, s)) return fail(LSTUR_ERR_STATE, "convx_wgrad: too many reductions");
+  return check_launch("convx_wgrad");
 }
 int lstur_mhsa_fwd(const float* qkv, const int32_t* ids, float* out, int32_t n_titles, int32_t title_len,
                    int32_t filters, int32_t heads, lstur_stream stream) {

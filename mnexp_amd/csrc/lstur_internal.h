@@ -23,7 +23,7 @@ struct ReduceJob {
   float alpha;
   float beta;
 };
-constexpr int kMaxReduceJobs = 24;
+constexpr int kMaxReduceJobs = 32;   // launch_multi_reduce refuses more (returns false)
 
 // Fork points without a bubble: hipEventRecord between two kernels of a stream is a barrier packet of its own and costs
 // ~6 us of idle GPU on this stack.  A launcher that goes through launch_k attaches the event to the kernel's OWN completion
@@ -57,20 +57,11 @@ inline void launch_k(F kern, dim3 grid, dim3 block, size_t lds, hipStream_t s, A
     hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
   }
 }
-void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s);
+bool launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s);
 
 
 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-// Slot-major history titles (the step's layout when the fast recurrence kernels run): physical title n = slot * nb + sample
-// for n < nW, the reference's order is sample * W + slot (candidate titles behind the history are the same in both).  A
-// dropout decision is drawn at the REFERENCE position of an element, so every kernel that hashes maps its title first.
-struct TitleOrder {
-  int nb, W, nW;   // nb == 0: physical order = reference order
-};
-__host__ __device__ inline int ref_title(const TitleOrder& o, int n) {
-  return (o.nb > 0 && n < o.nW) ? (n % o.nb) * o.W + n / o.nb : n;
-}
 __host__ __device__ static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 __host__ __device__ static inline int ceil16(int a) { return (a + 15) & ~15; }
 
@@ -84,11 +75,6 @@ void launch_gather(const float* table, const int32_t* ids, float* out, int n_tit
 // the same rows rounded to bf16 (the mhsa projections' A operand)
 void launch_gather_bf16(const float* table, const int32_t* ids, unsigned short* out, int n_titles, int T, int D, int pad_l,
                         int pad_r, float drop, uint32_t key, hipStream_t s);
-// the gather in the pre-split "E3" form of the bf16x3 conv kernels (layout: conv3f.hip); e3 = conv3_e3_elems() bf16
-// skip_unread: rows no window of a non-pad token covers are neither read nor written (the buffer must hold finite values)
-void launch_gather3(const float* table, const int32_t* ids, unsigned short* e3, int n_titles, int T, int D, int pad_l,
-                    int pad_r, float drop, uint32_t key, bool skip_unread, hipStream_t s, int max_blocks = 0,
-                    TitleOrder ord = TitleOrder{0, 0, 0});
 void launch_expand_titles(const int32_t* table, const int32_t* doc_ids, int32_t* out, int n, int T,
                           hipStream_t s);
 // stable list of non-pad tokens: vidx[0..*count) ; scratch = compact_scratch_ints(n) int32
@@ -98,14 +84,12 @@ void launch_compact_valid(const int32_t* ids, int n, int32_t* vidx, int32_t* cou
 // title expansion) or launch_compact_count; launch_compact_write_offsets then writes vidx, the count and (offA != NULL)
 // the conv kernel gradient's per-token row offsets
 void launch_expand_count(const int32_t* table, const int32_t* hist_ids, int n_hist, const int32_t* cand_ids, int n_cand,
-                         int T, int32_t* out, int32_t* block_counts, hipStream_t s, TitleOrder ord = TitleOrder{0, 0, 0});
-// token ids given per title in the reference's order -> the step's (slot-major) title order
-void launch_permute_titles(const int32_t* src, int32_t* dst, int n_titles, int T, TitleOrder ord, hipStream_t s);
+                         int T, int32_t* out, int32_t* block_counts, hipStream_t s);
 void launch_compact_count(const int32_t* ids, int n, int32_t* block_counts, hipStream_t s);
 void launch_compact_write_offsets(const int32_t* ids, int n, const int32_t* block_counts, int32_t* vidx, int32_t* count,
                                   int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s,
-                                  uint32_t* live = nullptr, int split_at = -1,   // count[1] = non-pad tokens in front of token split_at
-                                  int split_at2 = -1);                            // count[2]: the same for a second boundary   // live != NULL: + the titles' non-pad bit masks
+                                  uint32_t* live = nullptr,    // live != NULL: + the titles' non-pad bit masks
+                                  int split_at = -1);          // count[1] = non-pad tokens in front of token split_at
 size_t pack_b_floats(int K, int N);
 void launch_pack_b(const float* B, int ldb, int K, int N, float* packed, hipStream_t s);
 void launch_pack_b_t(const float* Bt, int ldb, int K, int N, float* packed, hipStream_t s);
@@ -122,10 +106,14 @@ void launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, fl
 // lands (split into three bf16 parts) in the conv kernels' W3 image, an updated gru_u element in the two resident-U images
 // that hold it.  The images' padding stays as the stand-alone pack kernels wrote it once.
 struct ImagePlan {
-  size_t conv_off = 0, conv_cnt = 0;   // conv_w slot of the bucket ([ksize * D, F]); 0: no W3 image
+  size_t conv_off = 0, conv_cnt = 0;   // conv_w slot of the bucket ([ksize * D, F]); 0: no split weight image
   int D = 0, Dp = 0, F = 0, Np = 0;
-  unsigned short* w3 = nullptr;
-  size_t w3_part = 0;                  // elements of one part of W3 (Kp * Np)
+  unsigned short* w3 = nullptr;        // the conv kernels' split weight image Wx (convx.hip)
+  size_t w3_part = 0;                  // elements of one part of it (Kp * Np)
+  int np = 3;                          // parts: 3 = bf16x3, 2 = f16x2 (then cs / seq: the scale block and the pack's
+  float* cs = nullptr;                 // sequence number, convx_pack_w_kernel's rule; grow: bound on one step's |dp|)
+  int seq = 0;
+  float grow = 0.f;
   size_t gru_off = 0;                  // gru_u slot ([H, 3H]); H == 0: no resident-U images
   int H = 0, KQ = 0;
   float* gimg = nullptr;
@@ -218,42 +206,49 @@ void launch_conv_dgrad_scatter(const float* dconv, const float* conv_w, const in
 void launch_token_offsets(const int32_t* vidx, const int32_t* vcount, int M, int T, int Tp, int D, int F, int32_t* offA,
                           int32_t* offB, hipStream_t s);
 
-// ---- conv3.hip: the same Conv1D as an fp32-grade "bf16x3" contraction on the bf16 matrix cores (F <= 448) --------
-bool conv3_supported(int D, int ksize, int F);
-size_t conv3_w3_elems(int D, int ksize, int F);                 // bf16 elements of the split weight image
-void launch_conv3_pack_w(const float* W, int K, int F, unsigned short* W3, hipStream_t s);   // W [K = k*D, F]
-// kernel gradient, same scheme; dw through *defer (token slabs in `scratch`: conv3_wgrad_scratch_bytes)
-size_t conv3_wgrad_scratch_bytes(int n_titles, int T, int D, int ksize, int F);
-void launch_conv3_wgrad(const float* emb, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
-                        int ksize, int F, const int32_t* vidx, const int32_t* vcount, hipStream_t s, ReduceJob* defer,
-                        const int32_t* offA = nullptr, const int32_t* offB = nullptr);   // per-token row offsets (optional)
-void launch_conv3_fwd(const float* emb, const unsigned short* W3, const float* bias, const int32_t* ids, float* out,
-                      int n_titles, int T, int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount,
-                      hipStream_t s);
-
-// ---- conv3f.hip: second generation of the bf16x3 forward (both operands pre-split; see the file header) --------
-void conv3_w2_dims(int D, int ksize, int F, int* Kp, int* Np);   // padded shape of the W3 image ([3][Kp][Np], k' = tap * Dp + d)
-int conv3_dp(int D);                                              // embedding row length of E3 (D rounded up to 8)
-size_t conv3_e3_elems(int n_titles, int T, int D, int ksize);   // bf16 elements of E3 incl. slack
-size_t conv3_w3_elems2(int D, int ksize, int F);                // bf16 elements of the k'-ordered split weight image
-bool conv3f_supported(int D, int ksize, int F);
-void launch_conv3_pack_w2(const float* W, int D, int ksize, int F, unsigned short* W3, hipStream_t s);
-// variant 0: the product kernel (10 .. 15: timing-only ablations); scratch (conv3_fwd2_scratch_bytes, or NULL): slabs
-// of the k-sliced tail tiles
-size_t conv3_fwd2_scratch_bytes(int ncu = 256);
-void launch_conv3_fwd2(const unsigned short* e3, const unsigned short* W3, const float* bias, const int32_t* ids, float* out,
-                       int n_titles, int T, int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount, int variant,
-                       void* scratch, hipStream_t s, int cus = 0);   // cus: CUs to plan the rounds for (0: all)
-
-// kernel gradient on the pre-split embeddings (same file): dw through ksize reduce jobs (one per tap); returns the job
-// count.  offA: per-token window offsets in 16-byte pieces of E3, offB: per-token row offsets in floats of dout.
-size_t conv3_wgrad2_scratch_bytes(int n_titles, int T, int D, int ksize, int F);
-int conv3_wgrad2_slabs(int plan_titles, int T, int D, int ksize, int F, int cus = 0);   // slabs a launch planned for these titles writes
-size_t conv3_wgrad2_slab_floats(int D, int ksize, int F);                              // floats of one slab ([k * Dp, F])
-int launch_conv3_wgrad2(const unsigned short* e3, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
-                        int ksize, int F, const int32_t* vcount, hipStream_t s, ReduceJob* jobs, const int32_t* offA,
-                        const int32_t* offB, float alpha = 1.0f, int cus = 0, int range_sel = 0, int slab_base = 0,
-                        int plan_titles = 0, int* slabs_out = nullptr);
+// ---- convx.hip: Conv1D as an fp32-grade contraction on the 16-bit matrix cores, both operands PRE-SPLIT into np parts:
+// np = 2 "f16x2" (two fp16 parts of the power-of-two scaled value, three products), np = 3 "bf16x3" (three bf16 parts, six
+// products).  The file holds the gather that writes the split embeddings "Ex", the weight pack, forward, kernel gradient.
+// Scale block `cs` (np == 2; kCsWords 32-bit words of device memory, launch_convx_scales_init):
+constexpr int kCsE = 0;       // float: power of two the embeddings are staged with
+constexpr int kCsW = 1;       // float: ... the current weight image was packed with
+constexpr int kCsFwd = 2;     // float: 1 / (sE sW), the forward's un-scale
+constexpr int kCsInvE = 3;    // float: 1 / sE
+constexpr int kCsWmax = 4;    // 3 x uint32: bits of max |conv_w| as seen by the last packs (rotating, convx.hip)
+constexpr int kCsEmax = 7;    // uint32: bits of max |word table|
+constexpr int kCsGmax = 8;    // 4 x uint32: bits of max |dC| of the attention backward launches [step parity][main | side]
+constexpr int kCsWords = 16;
+bool convx_supported(int D, int ksize, int F);                    // D % 4 == 0, F <= 448, ksize <= 8
+int convx_dp(int D);                                              // embedding row length of Ex (D rounded up to 8)
+size_t convx_e_elems(int n_titles, int T, int D, int ksize, int np);   // 16-bit elements of Ex incl. slack
+size_t convx_w_elems(int D, int ksize, int F, int np);                 // 16-bit elements of the split weight image
+void convx_w_dims(int D, int ksize, int F, int* Kp, int* Np);     // padded shape of the image ([np][Kp][Np], k' = tap * Dp + d)
+void launch_convx_scales_init(float* cs, hipStream_t s);
+void launch_absmax(const float* x, size_t n, uint32_t* out_bits, hipStream_t s);   // atomicMax of the bits of |x[i]|
+void launch_absmax_rows(const float* x, int rows, int cols, const int32_t* vidx, const int32_t* vcount, uint32_t* out_bits,
+                        hipStream_t s);                                             // ... over the listed rows only
+void launch_convx_escale(const float* table, size_t count, float drop, float* cs, hipStream_t s);
+// skip_unread: rows no window of a non-pad token covers are neither read nor written (the buffer must hold finite values)
+void launch_gatherx(const float* table, const int32_t* ids, unsigned short* ex, int n_titles, int T, int D, int pad_l,
+                    int pad_r, float drop, uint32_t key, bool skip_unread, int np, const float* cs, hipStream_t s,
+                    int max_blocks = 0);
+// fresh: the scale comes from W as it is; else from the previous pack's maximum + grow (how far a step can move a weight)
+void launch_convx_pack_w(const float* W, int D, int ksize, int F, unsigned short* Wx, int np, float* cs, int seq, bool fresh,
+                         float grow, hipStream_t s);
+// scratch (convx_fwd_scratch_bytes, or NULL): slabs of the k-sliced tail tiles
+size_t convx_fwd_scratch_bytes(int ncu = 256);
+void launch_convx_fwd(const unsigned short* ex, const unsigned short* Wx, const float* bias, const int32_t* ids, float* out,
+                      int n_titles, int T, int D, int ksize, int F, const int32_t* vidx, const int32_t* vcount, int np,
+                      const float* cs, void* scratch, hipStream_t s, int variant = 0);
+// kernel gradient on the pre-split embeddings: dw through ksize reduce jobs (one per tap); returns the job count.
+// offA: per-token window offsets in 16-byte pieces of Ex, offB: per-token row offsets in floats of dout.
+size_t convx_wgrad_scratch_bytes(int n_titles, int T, int D, int ksize, int F);
+int convx_wgrad_slabs(int plan_titles, int T, int D, int ksize, int F);   // slabs a launch planned for these titles writes
+size_t convx_wgrad_slab_floats(int D, int ksize, int F);                  // floats of one slab ([k * Dp, F])
+int launch_convx_wgrad(const unsigned short* ex, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
+                       int ksize, int F, const int32_t* vcount, hipStream_t s, ReduceJob* jobs, const int32_t* offA,
+                       const int32_t* offB, int np, const float* cs, int gslot, float alpha = 1.0f, int range_sel = 0,
+                       int slab_base = 0, int plan_titles = 0, int* slabs_out = nullptr, int variant = 0);
 
 // ---- gemm3.hip: C = A[M,K] . op(B) + bias, fp32-grade on the bf16 matrix cores (bf16x3), for the dense layers on the
 // step's critical path.  b_nk: B is [N][K] (C = A . B^T), else [K][N].  Check gemm3_supported first.
@@ -273,19 +268,21 @@ void launch_gemm3_tn(const float* A, int lda, const float* B, int ldb, float* C,
 // bit masks of launch_compact_write_offsets for the same ids -- one scalar per title instead of an ids read per row
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
                         float* a, float* w, int n_titles, int T, int F, float drop, uint32_t key, hipStream_t s,
-                        const uint32_t* live = nullptr, const uint32_t* kbits = nullptr, TitleOrder ord = TitleOrder{0, 0, 0});
+                        const uint32_t* live = nullptr, const uint32_t* kbits = nullptr);
 // kbits: the dropout keep decisions of (key, drop) for these titles in the title kernels' thread layout, made ahead of time
 // (attpool_keep_bits_words(n_titles) words; false: not applicable to this shape / drop == 0 -- pass NULL to the passes)
 size_t attpool_keep_bits_words(int n_titles);
 bool launch_attpool_keep_bits(const uint32_t* live, uint32_t* kbits, int n_titles, int T, int F, float drop, uint32_t key,
-                              hipStream_t s, TitleOrder ord = TitleOrder{0, 0, 0});
+                              hipStream_t s);
 int attpool_bwd_parts(int n_titles);
 // row_scratch: n_titles*T floats (dw -> ds)
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
                         float drop, uint32_t key, hipStream_t s, int ldp = 0, int off_aw = 0, int off_cb = 0,
                         int off_ab = 0, int relu = 1, const uint32_t* live = nullptr, const uint32_t* kbits = nullptr,
-                        int title0 = 0, int title_count = -1, TitleOrder ord = TitleOrder{0, 0, 0});
+                        int title0 = 0, int title_count = -1,
+                        uint32_t* gmax = nullptr,     // != NULL: atomicMax of the bits of |dc| over the rows written
+                        uint32_t* gzero = nullptr);   // != NULL: TWO words this launch clears (the other step parity's maxima)
 bool attpool_title_path(int T, int F);   // the title-resident kernels (the only ones that take a title sub-range)
 
 // ---- mhsa.hip (build-defined multi-head self-attention token stage; T <= 32, F/heads in {16, 32, 64}) -------
@@ -346,15 +343,10 @@ void launch_gru_pack(const float* U, int H, float* packed, hipStream_t s);
 // tape: gru_tape_floats(n, W, H) floats of scratch shared by forward and BPTT (layout private to the kernels).
 // xw [n*W,3H] row-major; hlast [n,H]; dgates [n*W,3H], rh / hprev [n*W,H] row-major.  Requires H <= 256.
 size_t gru_tape_floats(int n, int W, int H);
-// slot_major (fast path only: gru4_supported): the rows of xw / gmask / dgates / rh / hprev are ordered (step, sample) --
-// row = t * n + b -- instead of (sample, step): the history titles of one slot are then a contiguous row range.
-// t_hi / t_lo (fast path only): the BPTT launch walks steps t_hi .. t_lo (default: W - 1 .. 0); dh_last is the state gradient
-// behind step t_hi, dh0 the one in front of step t_lo -- a recurrence cut into two launches hands dh over through memory.
 void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
-                    float* hlast, int n, int W, int H, hipStream_t s, bool slot_major = false);
+                    float* hlast, int n, int W, int H, hipStream_t s);
 void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* packed, float* dgates,
-                    float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s, bool slot_major = false,
-                    int t_hi = -1, int t_lo = 0);
+                    float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s);
 // On the fast path the forward already leaves hprev and r*hprev row-major inside the tape: returns true and the two
 // pointers (pass them to launch_gru_bwd to skip its copies); false on the general path.
 bool gru_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh);
@@ -367,9 +359,8 @@ size_t gru4_tape_floats(int n, int W, int H);
 void gru4_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh);
 void launch_gru4_pack(const float* U, int H, float* img, hipStream_t s);
 void launch_gru4_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* img, float* tape, float* hlast,
-                     int n, int W, int H, hipStream_t s, bool slot_major = false);
+                     int n, int W, int H, hipStream_t s);
 void launch_gru4_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* img, float* dgates, float* rh,
-                     float* hprev, float* dh0, int n, int W, int H, hipStream_t s, bool slot_major = false, int t_hi = -1,
-                     int t_lo = 0);
+                     float* hprev, float* dh0, int n, int W, int H, hipStream_t s);
 
 }  // namespace lstur

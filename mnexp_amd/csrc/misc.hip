@@ -93,124 +93,6 @@ void launch_gather(const float* table, const int32_t* ids, float* out, int n_tit
                        (float4*)out, (uint32_t)total4, T, Tp, D4, pad_l, 0u, 0u, 1.0f);
 }
 
-// ---------------------------------------------------------------------------------------------
-// The same gather for the bf16x3 conv kernels (conv3f.hip / conv3.hip): every element leaves as its three bf16 parts
-// h | m | l (split3, bf16_mfma.h; h + m + l = the fp32 value the kernel above writes, exact to ~2^-25), in the layout "E3"
-// [title][pad_l + T + pad_r][Dp / 8][part][8]: the three 16-byte pieces of an 8-element chunk side by side, rows padded
-// with zeros to Dp = 8 * ceil(D / 8) elements.  One thread = one chunk: 32 bytes of a table row in, 48 contiguous bytes
-// out (a wave writes 3 KB in one piece); dropout mask and scale are applied in fp32 BEFORE the split, exactly as above.
-// ---------------------------------------------------------------------------------------------
-// Rows that no window of a non-pad token covers are SKIPPED (neither read nor written): the conv kernels run over the
-// non-pad tokens only (see compact_*), so with SKIP a padded row tp is needed iff some token t' in [t - pad_r, t + pad_l]
-// (t = tp - pad_l) of the title is non-pad -- 30 % fewer bytes at config 2 (titles are zero-padded at the end, histories at
-// the front).  The buffer must hold finite values from the start (the k tail of a window can touch a skipped row under a
-// zero weight): the step zeroes it once.
-template <bool DROP, bool SKIP>
-__global__ __launch_bounds__(256) void gather3_kernel(const float4* __restrict__ table, const int32_t* __restrict__ ids,
-                                                      uint4* __restrict__ out, uint32_t total8, int T, int Tp, int D4,
-                                                      int C8, int pad_l, int pad_r, uint32_t thresh, uint32_t key,
-                                                      float scale, TitleOrder ord) {
-  // A wave owns 64 consecutive chunks = 192 consecutive 16-byte pieces (3 KB) of the output.  Each lane produces the three
-  // pieces of ITS chunk; they cross LDS once so that every store instruction writes 1 KB of consecutive bytes (lane-strided
-  // 48-byte granules reached HBM as partial lines: 3.5 TB/s in the step, against the 4 + TB/s of whole-line stores).
-  __shared__ uint4 xbuf[4][192];
-  constexpr int U = 4;      // four chunks (eight 16-byte table loads) in flight per thread (1, 2, 8: the same or slower)
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t b0 = blockIdx.x * blockDim.x; b0 < total8; b0 += U * stride) {     // block-uniform trip count
-    const uint32_t i0 = b0 + threadIdx.x;
-    uint32_t c8[U], tok[U], htok[U];   // htok: the token's position in the reference's title order (dropout is drawn there)
-    bool inr[U], real[U];
-    int id[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t i = min(i0 + u * stride, total8 - 1u);
-      inr[u] = i0 + u * stride < total8;
-      const uint32_t row = i / (uint32_t)C8;
-      c8[u] = i - row * (uint32_t)C8;
-      const uint32_t n = row / (uint32_t)Tp;
-      const int t = (int)(row - n * (uint32_t)Tp) - pad_l;
-      real[u] = t >= 0 && t < T;
-      tok[u] = n * (uint32_t)T + (uint32_t)min(max(t, 0), T - 1);
-      htok[u] = DROP ? (uint32_t)ref_title(ord, (int)n) * (uint32_t)T + (uint32_t)min(max(t, 0), T - 1) : tok[u];
-      id[u] = ids[tok[u]];
-      if (SKIP) {
-        bool need = false;
-        for (int tt = max(t - pad_r, 0); tt <= min(t + pad_l, T - 1); ++tt) need |= ids[n * (uint32_t)T + (uint32_t)tt] != 0;
-        inr[u] = inr[u] && need;
-      }
-    }
-    float4 va[U], vb[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      va[u] = table[(size_t)id[u] * D4 + min((int)(2u * c8[u]), D4 - 1)];
-      vb[u] = table[(size_t)id[u] * D4 + min((int)(2u * c8[u] + 1u), D4 - 1)];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const unsigned long long live = __ballot(inr[u]);            // which chunks of this wave are written
-      if (live == 0ull) continue;                                   // (wave-uniform: no hashing / split for skipped rows)
-      float4 w[2] = {va[u], vb[u]};
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const uint32_t c4 = 2u * c8[u] + hf;
-        if (DROP) {
-          const uint32_t e = (htok[u] * (uint32_t)D4 + c4) * 4u;
-          bool k[4];
-          keep_quad(key, e, thresh, k);
-          w[hf].x = k[0] ? w[hf].x * scale : 0.f;
-          w[hf].y = k[1] ? w[hf].y * scale : 0.f;
-          w[hf].z = k[2] ? w[hf].z * scale : 0.f;
-          w[hf].w = k[3] ? w[hf].w * scale : 0.f;
-        }
-        if (!real[u] || (int)c4 >= D4) w[hf] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      u16x4 h0, m0, l0, h1, m1, l1;
-      split3(w[0], h0, m0, l0);
-      split3(w[1], h1, m1, l1);
-      auto pk = [](u16x4 a, u16x4 b) {
-        return make_uint4((uint32_t)a[0] | ((uint32_t)a[1] << 16), (uint32_t)a[2] | ((uint32_t)a[3] << 16),
-                          (uint32_t)b[0] | ((uint32_t)b[1] << 16), (uint32_t)b[2] | ((uint32_t)b[3] << 16));
-      };
-      xbuf[wv][lane * 3 + 0] = pk(h0, h1);
-      xbuf[wv][lane * 3 + 1] = pk(m0, m1);
-      xbuf[wv][lane * 3 + 2] = pk(l0, l1);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      uint4* o = out + (size_t)(b0 + wv * 64 + u * stride) * 3;     // first piece of the wave's 64 chunks
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int pc = q * 64 + lane;                               // piece pc belongs to chunk (= lane) pc / 3
-        const uint4 v = xbuf[wv][pc];
-        if ((live >> (pc / 3)) & 1ull) {
-          // streamed once, read much later (by the conv kernels of the next step): non-temporal, no cache allocation
-          typedef unsigned int u32x4nt __attribute__((ext_vector_type(4)));
-          __builtin_nontemporal_store(*(const u32x4nt*)&v, (u32x4nt*)(o + pc));
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-}
-
-void launch_gather3(const float* table, const int32_t* ids, unsigned short* e3, int n_titles, int T, int D, int pad_l,
-                    int pad_r, float drop, uint32_t key, bool skip_unread, hipStream_t s, int max_blocks, TitleOrder ord) {
-  const int Tp = T + pad_l + pad_r, D4 = D / 4, C8 = (D + 7) / 8;
-  const size_t total8 = (size_t)n_titles * Tp * C8;
-  if (total8 == 0) return;
-  // (max_blocks: a background launch beside latency-bound kernels takes a fraction of the chip on purpose)
-  const int blocks = (int)std::min<size_t>(cdivz(total8, 256 * 4), max_blocks > 0 ? max_blocks : 256 * 16);
-  const uint32_t th = drop > 0.f ? dropout_thresh(drop) : 0u;
-  const float sc = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
-  auto go = [&](auto kern) {
-    last_launch();
-    launch_k(kern, dim3(blocks), dim3(256), 0, s, (const float4*)table, ids, (uint4*)e3, (uint32_t)total8, T, Tp, D4, C8, pad_l,
-             pad_r, th, key, sc, ord);
-  };
-  if (drop > 0.f) skip_unread ? go(gather3_kernel<true, true>) : go(gather3_kernel<true, false>);
-  else skip_unread ? go(gather3_kernel<false, true>) : go(gather3_kernel<false, false>);
-}
-
 // doc ids -> token ids through the resident title table
 __global__ void expand_titles_kernel(const int32_t* __restrict__ table, const int32_t* __restrict__ doc_ids,
                                      int32_t* __restrict__ out, int total, int T) {
@@ -301,8 +183,7 @@ __global__ __launch_bounds__(256) void compact_write_kernel(const int32_t* __res
 __global__ __launch_bounds__(256) void expand_count_kernel(const int32_t* __restrict__ table,
                                                            const int32_t* __restrict__ hist_ids, int n_hist,
                                                            const int32_t* __restrict__ cand_ids, int n_total, int T,
-                                                           int32_t* __restrict__ out, int32_t* __restrict__ block_counts,
-                                                           TitleOrder ord) {
+                                                           int32_t* __restrict__ out, int32_t* __restrict__ block_counts) {
   const int n = n_total * T;
   const int i0 = blockIdx.x * kCompactBlock + threadIdx.x * 4;
   int c = 0;
@@ -311,7 +192,7 @@ __global__ __launch_bounds__(256) void expand_count_kernel(const int32_t* __rest
     const int i = i0 + k;
     if (i < n) {
       const int title = i / T, t = i - title * T;
-      const int doc = title < n_hist ? hist_ids[ref_title(ord, title)] : cand_ids[title - n_hist];   // (the caller's arrays: reference order)
+      const int doc = title < n_hist ? hist_ids[title] : cand_ids[title - n_hist];
       const int id = table[(size_t)doc * T + t];
       out[i] = id;
       c += id != 0;
@@ -322,22 +203,11 @@ __global__ __launch_bounds__(256) void expand_count_kernel(const int32_t* __rest
   if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
 }
 void launch_expand_count(const int32_t* table, const int32_t* hist_ids, int n_hist, const int32_t* cand_ids, int n_cand,
-                         int T, int32_t* out, int32_t* block_counts, hipStream_t s, TitleOrder ord) {
+                         int T, int32_t* out, int32_t* block_counts, hipStream_t s) {
   const int n = (n_hist + n_cand) * T;
   if (n > 0)
     hipLaunchKernelGGL(expand_count_kernel, dim3(cdiv(n, kCompactBlock)), dim3(256), 0, s, table, hist_ids, n_hist,
-                       cand_ids, n_hist + n_cand, T, out, block_counts, ord);
-}
-__global__ void permute_titles_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int total, int T,
-                                      TitleOrder ord) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int title = i / T, t = i - title * T;
-  dst[i] = src[(size_t)ref_title(ord, title) * T + t];
-}
-void launch_permute_titles(const int32_t* src, int32_t* dst, int n_titles, int T, TitleOrder ord, hipStream_t s) {
-  const int total = n_titles * T;
-  if (total) hipLaunchKernelGGL(permute_titles_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, src, dst, total, T, ord);
+                       cand_ids, n_hist + n_cand, T, out, block_counts);
 }
 // Second half of the compaction with the block prefix computed in place (<= a few hundred block counts, each block
 // sums its predecessors) and the conv kernel-gradient's per-token row offsets written along: offA = row of the padded
@@ -348,8 +218,7 @@ __global__ __launch_bounds__(256) void compact_write_offsets_kernel(const int32_
                                                                     int32_t* __restrict__ count_out, int T, int Tp, int D,
                                                                     int F, int32_t* __restrict__ offA,
                                                                     int32_t* __restrict__ offB, int nblk,
-                                                                    uint32_t* __restrict__ live, int split_at,
-                                                                    int split_at2) {
+                                                                    uint32_t* __restrict__ live, int split_at) {
   if ((int)blockIdx.x >= nblk) {   // trailing blocks: bit t of live[title] = token t is not a pad (t < 32): the attention
     const int title = ((int)blockIdx.x - nblk) * 256 + threadIdx.x;   // kernels read ONE scalar per title instead of ids
     if (title * T < n) {
@@ -380,18 +249,11 @@ __global__ __launch_bounds__(256) void compact_write_offsets_kernel(const int32_
   int pos = base + block_exclusive_scan_256(c, &total);
   // count_out[1]: the non-pad tokens in front of token `split_at` (a title boundary: history | candidates) -- the compacted
   // list is ascending, so [0, count_out[1]) and [count_out[1], count_out[0]) are the two title ranges' tokens
-  // (count_out[2]: the same for a second boundary in front of it -- early | late history slots of a slot-major step)
   if (i0 <= split_at && split_at < i0 + 4) {
     int before = pos;
 #pragma unroll
     for (int k = 0; k < 4; ++k) before += (i0 + k < split_at && v[k]) ? 1 : 0;
     count_out[1] = before;
-  }
-  if (i0 <= split_at2 && split_at2 < i0 + 4) {
-    int before = pos;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) before += (i0 + k < split_at2 && v[k]) ? 1 : 0;
-    count_out[2] = before;
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k)
@@ -408,17 +270,16 @@ __global__ __launch_bounds__(256) void compact_write_offsets_kernel(const int32_
   if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) {
     count_out[0] = base + total;
     if (split_at >= nblk * kCompactBlock || split_at < 0) count_out[1] = base + total;   // (no thread owns that index)
-    if (split_at2 >= nblk * kCompactBlock || split_at2 < 0) count_out[2] = base + total;
   }
 }
 size_t compact_scratch_ints(int n) { return (size_t)cdiv(n, kCompactBlock); }
 void launch_compact_write_offsets(const int32_t* ids, int n, const int32_t* block_counts, int32_t* vidx, int32_t* count,
                                   int T, int Tp, int D, int F, int32_t* offA, int32_t* offB, hipStream_t s,
-                                  uint32_t* live, int split_at, int split_at2) {
+                                  uint32_t* live, int split_at) {
   if (n <= 0) return;
   const int nblk = cdiv(n, kCompactBlock), lblk = live ? cdiv(n / T, 256) : 0;
   hipLaunchKernelGGL(compact_write_offsets_kernel, dim3(nblk + lblk), dim3(256), 0, s, ids, n, block_counts, vidx, count, T,
-                     Tp, D, F, offA, offB, nblk, live, split_at < 0 ? n : split_at, split_at2 < 0 ? n : split_at2);
+                     Tp, D, F, offA, offB, nblk, live, split_at < 0 ? n : split_at);
 }
 void launch_compact_count(const int32_t* ids, int n, int32_t* block_counts, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(compact_count_kernel, dim3(cdiv(n, kCompactBlock)), dim3(256), 0, s, ids, n, block_counts);
@@ -598,12 +459,14 @@ __global__ __launch_bounds__(256) void multi_reduce_kernel(ReduceJobs J) {
 static bool reduce_job_vec4_host(const ReduceJob& q) {
   return (q.cols % 4 == 0) && (q.ld % 4 == 0) && (q.stride % 4 == 0) && ((((uintptr_t)q.src) | ((uintptr_t)q.dst)) & 15) == 0;
 }
-void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s) {
+// false: more than kMaxReduceJobs non-empty jobs (nothing is launched: a dropped job would be a silently missing gradient)
+bool launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s) {
   ReduceJobs J;
   J.njobs = 0;
   int blocks = 0;
-  for (int k = 0; k < njobs && J.njobs < kMaxReduceJobs; ++k) {
+  for (int k = 0; k < njobs; ++k) {
     if (jobs[k].nslices <= 0) continue;
+    if (J.njobs == kMaxReduceJobs) return false;
     J.first_block[J.njobs] = blocks;
     J.job[J.njobs++] = jobs[k];
     const size_t work = (size_t)jobs[k].rows * jobs[k].cols;
@@ -611,6 +474,7 @@ void launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s) {
   }
   J.first_block[J.njobs] = blocks;
   if (blocks) hipLaunchKernelGGL(multi_reduce_kernel, dim3(blocks), dim3(256), 0, s, J);
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -642,7 +506,9 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
 // launch: blocks [0, flat_blocks) sweep the bucket, the rest handle one sample row per wave.
 __device__ __forceinline__ void combine_row(const int32_t* __restrict__ rows, const float* __restrict__ g, int n, int dim,
                                             float* __restrict__ gsum, int32_t* __restrict__ slot, int i, int lane);
-__device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, float pi);
+__device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, float pi, float sW, uint32_t& wmax);
+__device__ __forceinline__ float image_scale(const ImagePlan& P);
+__device__ __forceinline__ void image_finish(const ImagePlan& P, float sW, uint32_t wmax, bool first_thread);
 __global__ __launch_bounds__(256) void adam_flat_combine_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                 float* __restrict__ m, float* __restrict__ v, size_t n,
                                                                 float lr_t, float b1, float b2, float eps,
@@ -655,14 +521,17 @@ __global__ __launch_bounds__(256) void adam_flat_combine_kernel(float* __restric
     if (i < n_rows) combine_row(rows, rg, n_rows, dim, gsum, slot, i, threadIdx.x & 63);
     return;
   }
+  const float sW = image_scale(P);
+  uint32_t wmax = 0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)flat_blocks * 256) {
     float pi = p[i], mi = m[i], vi = v[i];
     adam1(pi, g[i], mi, vi, lr_t, b1, b2, eps);
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
-    image_scatter(P, i, pi);            // (an empty plan scatters nothing)
+    image_scatter(P, i, pi, sW, wmax);  // (an empty plan scatters nothing)
   }
+  image_finish(P, sW, wmax, blockIdx.x == 0 && threadIdx.x == 0);
 }
 void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                               float eps, const int32_t* rows, const float* rg, int n_rows, int dim, float* gsum,
@@ -674,16 +543,43 @@ void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size
                        rg, n_rows, dim, gsum, slot, plan ? *plan : ImagePlan());
 }
 // the updated element i of the bucket also goes into the weight images that hold it (ImagePlan, lstur_internal.h)
-__device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, float pi) {
-    if (i - P.conv_off < P.conv_cnt) {            // conv_w[tap * D + d][f] -> W3[part][tap * Dp + d][f]  (conv3_pack_w2_kernel)
+// f16x2 images: the scale comes from the maximum the previous pack saw, this launch leaves its own for the next one
+// (the rule of convx.hip: convx_pack_w_kernel, restated here so that the image costs no launch of its own)
+__device__ __forceinline__ float image_scale(const ImagePlan& P) {
+  return (P.conv_cnt && P.np == 2)
+             ? pow2_scale(__float_as_uint(__uint_as_float(((const uint32_t*)P.cs)[kCsWmax + P.seq % 3]) + P.grow), 13)
+             : 1.0f;
+}
+__device__ __forceinline__ void image_finish(const ImagePlan& P, float sW, uint32_t wmax, bool first_thread) {
+  if (!(P.conv_cnt && P.np == 2)) return;
+  uint32_t* cu = (uint32_t*)P.cs;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o, 64));
+  if ((threadIdx.x & 63) == 0 && wmax) atomicMax(cu + kCsWmax + (P.seq + 1) % 3, wmax);
+  if (first_thread) {
+    cu[kCsWmax + (P.seq + 2) % 3] = 0u;
+    P.cs[kCsW] = sW;
+    P.cs[kCsFwd] = 1.0f / (P.cs[kCsE] * sW);
+  }
+}
+__device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, float pi, float sW, uint32_t& wmax) {
+    if (i - P.conv_off < P.conv_cnt) {            // conv_w[tap * D + d][f] -> Wx[part][tap * Dp + d][f]  (convx_pack_w_kernel)
       const size_t j = i - P.conv_off;
       const int f = (int)(j % P.F), td = (int)(j / P.F), tap = td / P.D, d = td - tap * P.D;
       const size_t idx = ((size_t)tap * P.Dp + d) * P.Np + f;
-      u16x4 h, mm, l;
-      split3(make_float4(pi, 0.f, 0.f, 0.f), h, mm, l);
-      P.w3[idx] = h[0];
-      P.w3[P.w3_part + idx] = mm[0];
-      P.w3[2 * P.w3_part + idx] = l[0];
+      if (P.np == 2) {
+        u16x4 h, l;
+        split2(make_float4(fminf(fmaxf(pi * sW, -65504.f), 65504.f), 0.f, 0.f, 0.f), h, l);
+        P.w3[idx] = h[0];
+        P.w3[P.w3_part + idx] = l[0];
+        wmax = max(wmax, __float_as_uint(fabsf(pi)));
+      } else {
+        u16x4 h, mm, l;
+        split3(make_float4(pi, 0.f, 0.f, 0.f), h, mm, l);
+        P.w3[idx] = h[0];
+        P.w3[P.w3_part + idx] = mm[0];
+        P.w3[2 * P.w3_part + idx] = l[0];
+      }
     }
     if (P.H && i - P.gru_off < (size_t)3 * P.H * P.H) {   // gru_u[k][c]: the forward image and a transposed one (gru4_pack_kernel)
       const size_t j = i - P.gru_off;
@@ -697,14 +593,17 @@ __device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, floa
 }
 __global__ void adam_flat_pack_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                       float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, ImagePlan P) {
+  const float sW = image_scale(P);
+  uint32_t wmax = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float pi = p[i], mi = m[i], vi = v[i];
     adam1(pi, g[i], mi, vi, lr_t, b1, b2, eps);
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
-    image_scatter(P, i, pi);
+    image_scatter(P, i, pi, sW, wmax);
   }
+  image_finish(P, sW, wmax, blockIdx.x == 0 && threadIdx.x == 0);
 }
 void launch_adam_flat_pack(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
                            const ImagePlan& plan, hipStream_t s) {

@@ -210,8 +210,10 @@ class NativeModel:
         self._ctx = C.c_void_p()
         check(lib.lstur_create(C.byref(self.cfg), C.byref(bufs), C.byref(self._ctx)), 'lstur_create')
         # how the Conv1D contractions run, as the LIBRARY decides it: 'bf16x3' = fp32-grade 3-way split on the bf16 matrix
-        # cores (conv3f.hip), 'f32' = exact-fp32 MFMA (conv.hip; filters > 448 or LSTUR_CONV_F32=1), 'n/a' = mhsa encoder
-        self.conv_scheme = {0: 'n/a', 1: 'bf16x3', 2: 'f32'}[lib.lstur_conv_scheme(self._ctx)]
+        # cores (convx.hip), 'f16x2' = the same with two fp16 parts / three products (the default), 'f32' = exact-fp32 MFMA
+        # (conv.hip; filters > 448 or LSTUR_CONV_F32=1), 'n/a' = mhsa encoder
+        self.conv_scheme = {0: 'n/a', 1: 'bf16x3', 2: 'f32', 3: 'f16x2'}[lib.lstur_conv_scheme(self._ctx)]
+        self.lazy_table = bool(lib.lstur_lazy_adam(self._ctx))   # large user tables: dense Adam applied per row when it is next read
         self.optimizer = _Optimizer(lr)
         self.step = 0                       # dropout stream / fit step counter
         self.dist_group = dist_group

@@ -389,77 +389,6 @@ def test_config4_shapes_batch_512_one_million_users():
     np.testing.assert_allclose(model.user_emb.view(-1, Ue)[io].cpu().numpy(), want2, rtol=2e-5, atol=2e-7)
 
 
-@pytest.mark.parametrize('N,D,T,F,k', [(130, 300, 30, 400, 3), (3, 300, 30, 400, 3), (9, 12, 7, 16, 3), (7, 20, 6, 24, 5),
-                                       (11, 48, 11, 448, 1), (5, 16, 8, 230, 3)])
-def test_conv3_bf16x3_forward_is_fp32_grade(N, D, T, F, k):
-    """conv3.hip: the Conv1D forward as six bf16 MFMA products of 3-way split operands.  Held to the SAME bound as the
-    exact-fp32 MFMA kernel (2e-5 of the output scale against fp64) and to 4e-6 against that kernel directly."""
-    _need_gpu()
-    from mnexp_amd._lib import lib, check
-    rng = np.random.default_rng(N * 7 + F)
-    Tp = T + k - 1
-    pl = (k - 1) // 2
-    E = rng.normal(0, 0.3, size=(N, T, D)).astype(np.float32)
-    ids = rng.integers(0, 50, size=(N, T)).astype(np.int32)
-    ids[:, max(1, T - 4):] = 0
-    Wc = rng.normal(0, 0.05, size=(k, D, F)).astype(np.float32)
-    b = rng.normal(0, 0.1, size=F).astype(np.float32)
-    Ep = np.zeros((N, Tp, D), np.float32)
-    Ep[:, pl:pl + T] = E
-    Epd = torch.zeros(N * Tp * D + 256, dtype=torch.float32, device='cuda')
-    Epd[:N * Tp * D] = dev(Ep).view(-1)
-    Wd = dev(Wc.reshape(k * D, F))
-    w3 = torch.zeros(lib.lstur_conv3_w3_elems(D, k, F), dtype=torch.int16, device='cuda')
-    check(lib.lstur_conv3_pack_w(Wd.data_ptr(), D, k, F, w3.data_ptr(), stream()))
-    b_d, ids_d = dev(b), dev(ids)
-    out = torch.full((N * T, F), -7.0, dtype=torch.float32, device='cuda')
-    check(lib.lstur_conv3_relu_mask_fwd(Epd.data_ptr(), w3.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(), out.data_ptr(),
-                                        N, T, D, k, F, None, None, stream()))
-    x = torch.nn.functional.pad(dev(E).double().transpose(1, 2), (pl, k - 1 - pl))
-    ref = torch.relu(torch.nn.functional.conv1d(x, dev(Wc).double().permute(2, 1, 0), dev(b).double()))
-    ref = ref.transpose(1, 2) * (dev(ids) != 0).unsqueeze(-1)
-    scale = max(1.0, ref.abs().max().item())
-    err = (out.view(N, T, F).double() - ref).abs().max().item()
-    assert err < 2e-5 * scale, err
-    assert (out.view(N, T, F)[dev(ids) == 0] == 0).all()
-    # against the exact-fp32 MFMA kernel
-    Wp = pack_b(Wd)
-    out32 = torch.empty(N * T, F, dtype=torch.float32, device='cuda')
-    check(lib.lstur_conv1d_relu_mask_fwd(Epd.data_ptr(), Wp.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(),
-                                         out32.data_ptr(), N, T, D, k, F, None, None, stream()))
-    assert (out - out32).abs().max().item() < 4e-6 * scale
-    # over the compacted list of non-pad tokens: same rows bit-identical, pad rows untouched
-    vidx = torch.full((N * T,), -1, dtype=torch.int32, device='cuda')
-    vcount = torch.zeros(1, dtype=torch.int32, device='cuda')
-    vs = torch.zeros(max(1, lib.lstur_valid_tokens_scratch(N * T) // 4), dtype=torch.int32, device='cuda')
-    check(lib.lstur_valid_tokens(ids_d.data_ptr(), N * T, vidx.data_ptr(), vcount.data_ptr(), vs.data_ptr(), stream()))
-    out2 = torch.full((N * T, F), -7.0, dtype=torch.float32, device='cuda')
-    check(lib.lstur_conv3_relu_mask_fwd(Epd.data_ptr(), w3.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(), out2.data_ptr(),
-                                        N, T, D, k, F, vidx.data_ptr(), vcount.data_ptr(), stream()))
-    valid = dev(ids.reshape(-1) != 0)
-    assert torch.equal(out2[valid], out[valid])
-    assert (out2[~valid] == -7.0).all()
-    # ---- kernel gradient, same scheme: against fp64, against the exact-fp32 kernel, and over the compacted list
-    dC = rng.normal(size=(N * T, F)).astype(np.float32)
-    dC_d = dev(dC)
-    Ep_d = dev(Ep)
-    cols = torch.stack([Ep_d[:, j:j + T] for j in range(k)], dim=2).reshape(N * T, k * D).double()
-    ref_dw = cols.t() @ dC_d.double()
-    dw = torch.full((k * D, F), 3.0, dtype=torch.float32, device='cuda')
-    scr = torch.empty(lib.lstur_conv3_wgrad_scratch(N, T, D, k, F), dtype=torch.uint8, device='cuda')
-    check(lib.lstur_conv3_wgrad(Epd.data_ptr(), dC_d.data_ptr(), dw.data_ptr(), scr.data_ptr(), N, T, D, k, F, None, None,
-                                stream()))
-    wscale = ref_dw.abs().max().item()
-    assert (dw.double() - ref_dw).abs().max().item() < 2e-5 * wscale
-    dC_m = dC_d * valid.unsqueeze(-1)
-    ref2 = cols.t() @ dC_m.double()
-    dC_g = torch.where(valid.unsqueeze(-1), dC_d, torch.full_like(dC_d, float('nan')))   # pad rows must not be read
-    dw2 = torch.full((k * D, F), 3.0, dtype=torch.float32, device='cuda')
-    check(lib.lstur_conv3_wgrad(Epd.data_ptr(), dC_g.data_ptr(), dw2.data_ptr(), scr.data_ptr(), N, T, D, k, F,
-                                vidx.data_ptr(), vcount.data_ptr(), stream()))
-    assert (dw2.double() - ref2).abs().max().item() < 2e-5 * wscale
-
-
 def _split3_np(x):
     """bf16_mfma.h: split3 -- three round-to-nearest-even bf16 parts of an fp32 array (as uint16 bit patterns)."""
     def rne(v):
@@ -475,10 +404,38 @@ def _split3_np(x):
     return h, m, rne(r2)
 
 
+def _pow2_scale_np(mx, target):
+    """bf16_mfma.h: pow2_scale -- the power of two s with mx * s in [2^target, 2^(target + 1)) (1 for mx == 0)."""
+    mx = np.float32(mx)
+    if mx == 0:
+        return np.float32(1.0)
+    return np.float32(2.0 ** (target - int(np.floor(np.log2(float(mx))))))
+
+
+def _split2_np(x, s):
+    """bf16_mfma.h: split2 of x * s -- h = fp16(x s), l = fp16(x s - h), round-to-nearest-even (uint16 bit patterns)."""
+    v = (x.astype(np.float32) * np.float32(s)).astype(np.float32)
+    h = v.astype(np.float16)
+    l = (v - h.astype(np.float32)).astype(np.float32).astype(np.float16)
+    return h.view(np.uint16), l.view(np.uint16)
+
+
+def _convx_scales(lib, check, table_d=None, count=0, drop=0.0):
+    """a fresh scale block of the f16x2 kernels (+ the embedding scale of `table_d`)"""
+    cs = torch.zeros(lib.lstur_convx_scales_bytes() // 4, dtype=torch.float32, device='cuda')
+    check(lib.lstur_convx_scales_init(cs.data_ptr(), stream()))
+    if table_d is not None:
+        check(lib.lstur_convx_embedding_scale(table_d.data_ptr(), count, drop, cs.data_ptr(), stream()))
+    return cs
+
+
+@pytest.mark.parametrize('parts', [2, 3])
 @pytest.mark.parametrize('N,D,T,k,drop', [(37, 300, 30, 3, 0.2), (5, 12, 7, 3, 0.0), (6, 20, 6, 5, 0.5), (3, 48, 11, 1, 0.2)])
-def test_gather_split3_is_the_split_of_the_fp32_gather(N, D, T, k, drop):
-    """misc.hip: gather3_kernel writes h | m | l of exactly the values lstur_gather_f32 writes (same dropout mask, same
-    scale), in the E3 layout [title][Tp][Dp/8][part][8] with zero pad elements -- bit for bit."""
+def test_convx_gather_is_the_split_of_the_fp32_gather(N, D, T, k, drop, parts):
+    """convx.hip: gatherx_kernel writes the 16-bit parts of exactly the values lstur_gather_f32 writes (same dropout mask,
+    same 1 / (1 - p)) in the Ex layout [title][Tp][Dp/8][part][8] with zero pad elements -- bit for bit: parts = 3 the bf16
+    triple h | m | l, parts = 2 the fp16 pair h | l of the value times the power of two that puts max |table| / (1 - p) into
+    [2^14, 2^15) (restated here in NumPy)."""
     _need_gpu()
     from mnexp_amd._lib import lib, check
     rng = np.random.default_rng(D + N)
@@ -492,22 +449,31 @@ def test_gather_split3_is_the_split_of_the_fp32_gather(N, D, T, k, drop):
     t_d, i_d = dev(table), dev(ids)
     ref = torch.full((N * Tp * D + 256,), 9.0, dtype=torch.float32, device='cuda')
     check(lib.lstur_gather_f32(t_d.data_ptr(), i_d.data_ptr(), ref.data_ptr(), N, T, D, pl, pr, drop, 1234, stream()))
-    n3 = lib.lstur_conv3_e3_elems(N, T, D, k)
-    assert n3 >= N * Tp * Dp * 3
-    e3 = torch.full((n3,), 0x7FC0, dtype=torch.int16, device='cuda')
-    check(lib.lstur_gather_split3(t_d.data_ptr(), i_d.data_ptr(), e3.data_ptr(), N, T, D, pl, pr, drop, 1234, 0, stream()))
+    cs = _convx_scales(lib, check, t_d, V * D, drop) if parts == 2 else None
+    csp = cs.data_ptr() if parts == 2 else None
+    ne = lib.lstur_convx_e_elems(N, T, D, k, parts)
+    assert ne >= N * Tp * Dp * parts
+    ex = torch.full((ne,), 0x7FC0, dtype=torch.int16, device='cuda')
+    check(lib.lstur_convx_gather(t_d.data_ptr(), i_d.data_ptr(), ex.data_ptr(), N, T, D, pl, pr, drop, 1234, 0, parts, csp, stream()))
     torch.cuda.synchronize()
     E = ref[:N * Tp * D].cpu().numpy().reshape(N, Tp, D)
     Epad = np.zeros((N, Tp, Dp), np.float32)
     Epad[:, :, :D] = E
-    h, m, l = _split3_np(Epad)
-    want = np.stack([h, m, l], axis=0).reshape(3, N, Tp, Dp // 8, 8).transpose(1, 2, 3, 0, 4)    # [N][Tp][C8][part][8]
-    got = e3[:N * Tp * Dp * 3].cpu().numpy().view(np.uint16).reshape(N, Tp, Dp // 8, 3, 8)
+    if parts == 3:
+        pieces = _split3_np(Epad)
+    else:
+        ds = np.float32(1.0) / (np.float32(1.0) - np.float32(drop)) if drop > 0 else np.float32(1.0)
+        sE = _pow2_scale_np(np.abs(table).max() * ds, 14)
+        assert float(cs[0].item()) == float(sE)
+        assert np.abs(Epad * sE).max() < 65504
+        pieces = _split2_np(Epad, sE)
+    want = np.stack(pieces, axis=0).reshape(parts, N, Tp, Dp // 8, 8).transpose(1, 2, 3, 0, 4)    # [N][Tp][C8][part][8]
+    got = ex[:N * Tp * Dp * parts].cpu().numpy().view(np.uint16).reshape(N, Tp, Dp // 8, parts, 8)
     assert np.array_equal(got, want)
     # skip_unread: exactly the rows some non-pad token's window covers are written (same values), the others untouched
-    e3s = torch.full((n3,), 0x1234, dtype=torch.int16, device='cuda')
-    check(lib.lstur_gather_split3(t_d.data_ptr(), i_d.data_ptr(), e3s.data_ptr(), N, T, D, pl, pr, drop, 1234, 1, stream()))
-    gots = e3s[:N * Tp * Dp * 3].cpu().numpy().view(np.uint16).reshape(N, Tp, Dp // 8, 3, 8)
+    exs = torch.full((ne,), 0x1234, dtype=torch.int16, device='cuda')
+    check(lib.lstur_convx_gather(t_d.data_ptr(), i_d.data_ptr(), exs.data_ptr(), N, T, D, pl, pr, drop, 1234, 1, parts, csp, stream()))
+    gots = exs[:N * Tp * Dp * parts].cpu().numpy().view(np.uint16).reshape(N, Tp, Dp // 8, parts, 8)
     nonpad = np.zeros((N, Tp + k), bool)
     for j in range(k):                                    # token t covers padded rows t .. t + k - 1
         nonpad[:, j:j + T] |= ids != 0
@@ -516,95 +482,144 @@ def test_gather_split3_is_the_split_of_the_fp32_gather(N, D, T, k, drop):
     assert (gots[~need] == 0x1234).all() and (~need).any()
 
 
-@pytest.mark.parametrize('sliced', [True, False])
-@pytest.mark.parametrize('N,D,T,F,k', [(130, 300, 30, 400, 3), (3, 300, 30, 400, 3), (9, 12, 7, 16, 3), (7, 20, 6, 24, 5),
-                                       (11, 48, 11, 448, 1), (5, 16, 8, 230, 3), (40, 300, 30, 250, 3),
-                                       (1200, 300, 30, 400, 3)])
-def test_conv3_fwd2_presplit_is_fp32_grade(N, D, T, F, k, sliced):
-    """conv3f.hip: the bf16x3 forward on PRE-SPLIT operands (E3 from the gather, k'-ordered split weights).  Same bounds as
-    the first generation: 2e-5 of the output scale against fp64, 4e-6 against the exact-fp32 MFMA kernel, compacted list
-    = the full run.  `sliced`: with the scratch for the k-sliced tail tiles (tiles past the last whole round of 256 are cut
-    into <= 8 k slices summed by the fix-up kernel; N = 1200 gives 282 tiles = one round + a sliced tail)."""
-    _need_gpu()
-    from mnexp_amd._lib import lib, check
-    rng = np.random.default_rng(N * 7 + F)
-    V = 70
+def _convx_case(lib, check, rng, N, D, T, F, k, parts, sliced, table, Wc, dC, tag, bias_scale=1.0):
+    """forward + kernel gradient of the split-operand conv family on one case: errors against fp64 and against the
+    exact-fp32 MFMA kernels; returns them as fractions of the result scales"""
+    V = table.shape[0]
     Tp, pl = T + k - 1, (k - 1) // 2
-    table = rng.normal(0, 0.3, size=(V, D)).astype(np.float32)
     ids = rng.integers(0, V, size=(N, T)).astype(np.int32)
     ids[:, max(1, T - 4):] = 0
     ids[0, 1] = 0                                           # a pad token INSIDE a title: its row 0 embedding is gathered
-    Wc = rng.normal(0, 0.05, size=(k, D, F)).astype(np.float32)
-    b = rng.normal(0, 0.1, size=F).astype(np.float32)
+    b = (rng.normal(0, 0.1, size=F) * bias_scale).astype(np.float32)
     t_d, ids_d, b_d = dev(table), dev(ids), dev(b)
-    e3 = torch.zeros(lib.lstur_conv3_e3_elems(N, T, D, k), dtype=torch.int16, device='cuda')
-    check(lib.lstur_gather_split3(t_d.data_ptr(), ids_d.data_ptr(), e3.data_ptr(), N, T, D, pl, k - 1 - pl, 0.0, 0, 0, stream()))
+    cs = _convx_scales(lib, check, t_d, V * D, 0.0) if parts == 2 else None
+    csp = cs.data_ptr() if parts == 2 else None
+    ex = torch.zeros(lib.lstur_convx_e_elems(N, T, D, k, parts), dtype=torch.int16, device='cuda')
+    check(lib.lstur_convx_gather(t_d.data_ptr(), ids_d.data_ptr(), ex.data_ptr(), N, T, D, pl, k - 1 - pl, 0.0, 0, 0, parts, csp, stream()))
     Wd = dev(Wc.reshape(k * D, F))
-    w3 = torch.zeros(lib.lstur_conv3_w3_elems2(D, k, F), dtype=torch.int16, device='cuda')
-    check(lib.lstur_conv3_pack_w2(Wd.data_ptr(), D, k, F, w3.data_ptr(), stream()))
+    wx = torch.zeros(lib.lstur_convx_w_elems(D, k, F, parts), dtype=torch.int16, device='cuda')
+    check(lib.lstur_convx_pack_w(Wd.data_ptr(), D, k, F, wx.data_ptr(), parts, csp, stream()))
     out = torch.full((N * T, F), -7.0, dtype=torch.float32, device='cuda')
-    scr = torch.empty(lib.lstur_conv3_fwd2_scratch(), dtype=torch.uint8, device='cuda') if sliced else None
+    scr = torch.empty(lib.lstur_convx_fwd_scratch(), dtype=torch.uint8, device='cuda') if sliced else None
     scr_p = scr.data_ptr() if sliced else None
-    check(lib.lstur_conv3_relu_mask_fwd2(e3.data_ptr(), w3.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(), out.data_ptr(),
-                                         N, T, D, k, F, None, None, 0, scr_p, stream()))
+    check(lib.lstur_convx_fwd(ex.data_ptr(), wx.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(), out.data_ptr(), N, T, D, k, F,
+                              None, None, parts, csp, scr_p, stream()))
     E = dev(table)[dev(ids).long()]                        # [N, T, D]
     x = torch.nn.functional.pad(E.double().transpose(1, 2), (pl, k - 1 - pl))
     ref = torch.relu(torch.nn.functional.conv1d(x, dev(Wc).double().permute(2, 1, 0), dev(b).double()))
     ref = ref.transpose(1, 2) * (dev(ids) != 0).unsqueeze(-1)
-    scale = max(1.0, ref.abs().max().item())
-    err = (out.view(N, T, F).double() - ref).abs().max().item()
-    assert err < 2e-5 * scale, err
+    scale = max(1.0, ref.abs().max().item()) if bias_scale else ref.abs().max().item()
+    r = {}
+    assert torch.isfinite(out).all()
+    r['fwd_vs_f64'] = (out.view(N, T, F).double() - ref).abs().max().item() / scale
     assert (out.view(N, T, F)[dev(ids) == 0] == 0).all()
-    # against the exact-fp32 MFMA kernel on the fp32 gather
+    # the exact-fp32 MFMA kernel on the fp32 gather
     Epd = torch.zeros(N * Tp * D + 256, dtype=torch.float32, device='cuda')
     check(lib.lstur_gather_f32(t_d.data_ptr(), ids_d.data_ptr(), Epd.data_ptr(), N, T, D, pl, k - 1 - pl, 0.0, 0, stream()))
     Wp = pack_b(Wd)
     out32 = torch.empty(N * T, F, dtype=torch.float32, device='cuda')
     check(lib.lstur_conv1d_relu_mask_fwd(Epd.data_ptr(), Wp.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(),
                                          out32.data_ptr(), N, T, D, k, F, None, None, stream()))
-    assert (out - out32).abs().max().item() < 4e-6 * scale
+    r['f32_fwd_vs_f64'] = (out32.view(N, T, F).double() - ref).abs().max().item() / scale
+    r['fwd_vs_f32'] = (out - out32).abs().max().item() / scale
     # over the compacted list of non-pad tokens: same rows bit-identical, pad rows untouched
     vidx = torch.full((N * T,), -1, dtype=torch.int32, device='cuda')
     vcount = torch.zeros(1, dtype=torch.int32, device='cuda')
     vs = torch.zeros(max(1, lib.lstur_valid_tokens_scratch(N * T) // 4), dtype=torch.int32, device='cuda')
     check(lib.lstur_valid_tokens(ids_d.data_ptr(), N * T, vidx.data_ptr(), vcount.data_ptr(), vs.data_ptr(), stream()))
     out2 = torch.full((N * T, F), -7.0, dtype=torch.float32, device='cuda')
-    check(lib.lstur_conv3_relu_mask_fwd2(e3.data_ptr(), w3.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(), out2.data_ptr(),
-                                         N, T, D, k, F, vidx.data_ptr(), vcount.data_ptr(), 0, scr_p, stream()))
+    check(lib.lstur_convx_fwd(ex.data_ptr(), wx.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(), out2.data_ptr(), N, T, D, k, F,
+                              vidx.data_ptr(), vcount.data_ptr(), parts, csp, scr_p, stream()))
     valid = dev(ids.reshape(-1) != 0)
     if sliced:     # a different token count can cut the tail tiles into a different number of k slices
-        assert (out2[valid] - out[valid]).abs().max().item() < 2e-6 * scale
+        assert (out2[valid] - out[valid]).abs().max().item() < 2e-6 * scale, tag
     else:
-        assert torch.equal(out2[valid], out[valid])
-    assert (out2[~valid] == -7.0).all()
-    # the opt-in tap-sharing kernel (variant 2; taken for ksize == 3 and Dp % 16 == 0, else the call falls back): same bounds
-    out3 = torch.full((N * T, F), -7.0, dtype=torch.float32, device='cuda')
-    check(lib.lstur_conv3_relu_mask_fwd2(e3.data_ptr(), w3.data_ptr(), b_d.data_ptr(), ids_d.data_ptr(), out3.data_ptr(),
-                                         N, T, D, k, F, vidx.data_ptr(), vcount.data_ptr(), 2, scr_p, stream()))
-    assert (out3[valid].double() - ref.reshape(N * T, F)[valid]).abs().max().item() < 2e-5 * scale
-    assert (out3[valid] - out[valid]).abs().max().item() < 4e-6 * scale
-    assert (out3[~valid] == -7.0).all()
-    if not sliced:
-        return
-    # ---- kernel gradient on the same E3: against fp64, and over the compacted list with NaN in the rows it must not read
-    dC = rng.normal(size=(N * T, F)).astype(np.float32)
+        assert torch.equal(out2[valid], out[valid]), tag
+    assert (out2[~valid] == -7.0).all(), tag
+    # ---- kernel gradient on the same Ex: against fp64, and over the compacted list with NaN in the rows it must not read
     dC_d = dev(dC)
     Ep_d = Epd[:N * Tp * D].view(N, Tp, D)
     cols = torch.stack([Ep_d[:, j:j + T] for j in range(k)], dim=2).reshape(N * T, k * D).double()
     ref_dw = cols.t() @ dC_d.double()
     dw = torch.full((k * D, F), 3.0, dtype=torch.float32, device='cuda')
-    wscr = torch.empty(lib.lstur_conv3_wgrad2_scratch(N, T, D, k, F), dtype=torch.uint8, device='cuda')
+    wscr = torch.empty(lib.lstur_convx_wgrad_scratch(N, T, D, k, F), dtype=torch.uint8, device='cuda')
     offs = torch.zeros(2 * N * T, dtype=torch.int32, device='cuda')
-    check(lib.lstur_conv3_wgrad2(e3.data_ptr(), dC_d.data_ptr(), dw.data_ptr(), wscr.data_ptr(), offs.data_ptr(), N, T, D, k, F,
-                                 None, None, stream()))
+    check(lib.lstur_convx_wgrad(ex.data_ptr(), dC_d.data_ptr(), dw.data_ptr(), wscr.data_ptr(), offs.data_ptr(), N, T, D, k, F,
+                                None, None, parts, csp, stream()))
     wscale = ref_dw.abs().max().item()
-    assert (dw.double() - ref_dw).abs().max().item() < 2e-5 * wscale
+    assert torch.isfinite(dw).all()
+    r['wgrad_vs_f64'] = (dw.double() - ref_dw).abs().max().item() / wscale
+    dw32 = torch.full((k * D, F), 3.0, dtype=torch.float32, device='cuda')
+    s32 = torch.empty(lib.lstur_conv1d_wgrad_scratch(D, k, F), dtype=torch.uint8, device='cuda')
+    check(lib.lstur_conv1d_wgrad(Epd.data_ptr(), dC_d.data_ptr(), dw32.data_ptr(), s32.data_ptr(), N, T, D, k, F, None, None, stream()))
+    r['f32_wgrad_vs_f64'] = (dw32.double() - ref_dw).abs().max().item() / wscale
     ref2 = cols.t() @ (dC_d * valid.unsqueeze(-1)).double()
     dC_g = torch.where(valid.unsqueeze(-1), dC_d, torch.full_like(dC_d, float('nan')))   # pad rows must not be read
     dw2 = torch.full((k * D, F), 3.0, dtype=torch.float32, device='cuda')
-    check(lib.lstur_conv3_wgrad2(e3.data_ptr(), dC_g.data_ptr(), dw2.data_ptr(), wscr.data_ptr(), offs.data_ptr(), N, T, D, k, F,
-                                 vidx.data_ptr(), vcount.data_ptr(), stream()))
-    assert (dw2.double() - ref2).abs().max().item() < 2e-5 * wscale
+    check(lib.lstur_convx_wgrad(ex.data_ptr(), dC_g.data_ptr(), dw2.data_ptr(), wscr.data_ptr(), offs.data_ptr(), N, T, D, k, F,
+                                vidx.data_ptr(), vcount.data_ptr(), parts, csp, stream()))
+    r['wgrad_list_vs_f64'] = (dw2.double() - ref2).abs().max().item() / max(ref2.abs().max().item(), 1e-30)
+    return r
+
+
+@pytest.mark.parametrize('parts', [2, 3])
+@pytest.mark.parametrize('sliced', [True, False])
+@pytest.mark.parametrize('N,D,T,F,k', [(130, 300, 30, 400, 3), (3, 300, 30, 400, 3), (9, 12, 7, 16, 3), (7, 20, 6, 24, 5),
+                                       (11, 48, 11, 448, 1), (5, 16, 8, 230, 3), (40, 300, 30, 250, 3),
+                                       (1200, 300, 30, 400, 3)])
+def test_convx_presplit_is_fp32_grade(N, D, T, F, k, sliced, parts):
+    """convx.hip: Conv1D forward and kernel gradient on PRE-SPLIT operands (Ex from the gather, k'-ordered split weights),
+    parts = 2 (f16x2: three fp16 products on power-of-two scaled data) and 3 (bf16x3: six bf16 products).  Both are held to
+    the SAME bounds as the exact-fp32 MFMA kernels: 2e-5 of the result scale against fp64, 4e-6 against the exact-fp32
+    kernel, and at most twice that kernel's own error against fp64 (+ 3e-7 of scale: the floor of a 2^-22 operand split).
+    `sliced`: with the scratch for the k-sliced tail tiles (tiles past the last whole round of 256 are cut into <= 8 k slices
+    summed by the fix-up kernel; N = 1200 gives 282 tiles = one round + a sliced tail)."""
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    rng = np.random.default_rng(N * 7 + F)
+    table = rng.normal(0, 0.3, size=(70, D)).astype(np.float32)
+    Wc = rng.normal(0, 0.05, size=(k, D, F)).astype(np.float32)
+    dC = rng.normal(size=(N * T, F)).astype(np.float32)
+    r = _convx_case(lib, check, rng, N, D, T, F, k, parts, sliced, table, Wc, dC, 'plain')
+    print('convx parts=%d N=%d D=%d F=%d k=%d: %s' % (parts, N, D, F, k, {a: '%.2e' % b for a, b in r.items()}))
+    assert r['fwd_vs_f64'] < 2e-5 and r['fwd_vs_f32'] < 4e-6, r
+    assert r['fwd_vs_f64'] <= 2 * r['f32_fwd_vs_f64'] + 3e-7, r
+    assert r['wgrad_vs_f64'] < 2e-5 and r['wgrad_list_vs_f64'] < 2e-5, r
+    assert r['wgrad_vs_f64'] <= 2 * r['f32_wgrad_vs_f64'] + 3e-7, r
+
+
+@pytest.mark.parametrize('case', ['outliers', 'tiny', 'huge', 'mixed_gradient'])
+def test_convx_f16x2_adversarial_dynamic_range(case):
+    """The fp16 pair covers 11 + 11 bits below the tensor's LARGEST magnitude, with an absolute floor 2^-37 under it: operands
+    whose magnitudes spread over many binades (outliers in the word table / the weight / the gradient), tensors far outside
+    the fp16 range (1e-12, 3e6) -- the power-of-two scales must bring every one of them in, no overflow, no flush that shows
+    at the result's scale.  Bounds as in the plain test."""
+    _need_gpu()
+    from mnexp_amd._lib import lib, check
+    N, D, T, F, k = 40, 300, 30, 400, 3
+    rng = np.random.default_rng(11)
+    table = rng.normal(0, 0.3, size=(70, D)).astype(np.float32)
+    Wc = rng.normal(0, 0.05, size=(k, D, F)).astype(np.float32)
+    dC = rng.normal(size=(N * T, F)).astype(np.float32)
+    if case == 'outliers':          # a few elements 2^10 .. 2^14 times the bulk
+        table[rng.integers(0, 70, 20), rng.integers(0, D, 20)] *= 3000.0
+        Wc.reshape(-1)[rng.integers(0, Wc.size, 50)] *= 1000.0
+        dC.reshape(-1)[rng.integers(0, dC.size, 50)] *= 16000.0
+    elif case == 'tiny':
+        table *= 1e-12
+        Wc *= 1e-9
+        dC *= 1e-20
+    elif case == 'huge':
+        table *= 3e6
+        Wc *= 1e5
+        dC *= 1e9
+    else:                           # gradient rows whose scales differ by 2^30 (early / late training samples in one batch)
+        dC *= np.exp2(rng.integers(-30, 1, size=(N * T, 1))).astype(np.float32)
+    r = _convx_case(lib, check, rng, N, D, T, F, k, 2, True, table, Wc, dC, case, bias_scale=0.0)
+    print('convx f16x2 %s: %s' % (case, {a: '%.2e' % b for a, b in r.items()}))
+    assert r['fwd_vs_f64'] < 2e-5 and r['fwd_vs_f64'] <= 2 * r['f32_fwd_vs_f64'] + 3e-7, r
+    assert r['wgrad_vs_f64'] < 2e-5 and r['wgrad_vs_f64'] <= 2 * r['f32_wgrad_vs_f64'] + 3e-7, r
+    assert r['wgrad_list_vs_f64'] < 2e-5, r
 
 
 @pytest.mark.parametrize('N,T,F,drop', [(37, 30, 400, 0.2), (9, 32, 512, 0.0), (21, 11, 80, 0.25), (5, 30, 404, 0.2)])

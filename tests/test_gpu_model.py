@@ -78,8 +78,6 @@ def test_forward_backward_matches_oracle(arch, dims, B, W, T, K1, drop):
     ref_doc = ref['doc_vec'].copy()                # the library masks padded history slots in place
     ref_doc[:B * W] *= (hist != 0).any(-1).reshape(-1, 1)
     got_doc = model.peek('doc_vec').cpu().numpy().reshape(-1, dims['U'])
-    if lib.lstur_slot_major(model._ctx):           # the step keeps history titles as (slot, sample): back to (sample, slot)
-        got_doc[:B * W] = got_doc[:B * W].reshape(W, B, -1).transpose(1, 0, 2).reshape(B * W, -1)
     rel_close(got_doc, ref_doc, 1e-3, 'doc_vec')
     g = model.get_grads()
     for n in O.dense_param_names(arch):

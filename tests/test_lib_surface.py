@@ -164,3 +164,90 @@ def test_prefetched_draws_exactly_count_items_in_order_and_reraises():
     assert next(it) == 1
     with pytest.raises(RuntimeError, match='feed broke'):
         next(it)
+
+
+# ---- the ABI guard and the binding a maintainer copies from INTEGRATION.md ------------------------------------------
+_CTYPE = {'int32_t': C.c_int32, 'uint32_t': C.c_uint32, 'float': C.c_float, 'size_t': C.c_size_t}
+
+
+def header_struct(name):
+    """[(field, ctypes type)] of `typedef struct <name> { ... } <name>;` in include/lstur.h (pointers -> c_void_p)"""
+    text = open(os.path.join(ROOT, 'include', 'lstur.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (name, name), text, flags=re.S).group(1)
+    out = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        m = re.match(r'(const\s+)?(\w+)\s*(\*?)\s*(.+)$', decl)
+        ctype = C.c_void_p if m.group(3) or '*' in m.group(4) else _CTYPE[m.group(2)]
+        for fname in m.group(4).split(','):
+            out.append((fname.replace('*', '').strip(), ctype))
+    return out
+
+
+def integration_snippet():
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    a = text.index('# --- BEGIN GENERATED')
+    b = text.index('# --- END GENERATED ---')
+    ns = {'C': C}
+    exec(text[a:b], ns)              # the generated block is plain ctypes declarations
+    return ns
+
+
+def test_integration_snippet_is_the_header_and_the_binding():
+    """INTEGRATION.md's binding block is generated from mnexp_amd/_lib.py (tools/gen_integration_snippet.py) and both agree
+    with include/lstur.h field by field: a maintainer who copies it passes structs of the size the library reads."""
+    import subprocess
+    import sys
+    assert subprocess.call([sys.executable, os.path.join(ROOT, 'tools', 'gen_integration_snippet.py'), '--check']) == 0
+    ns = integration_snippet()
+    for cname, hname, ours in (('Cfg', 'lstur_cfg', _lib.Cfg), ('Sizes', 'lstur_sizes', _lib.Sizes),
+                               ('Buffers', 'lstur_buffers', _lib.Buffers)):
+        want = header_struct(hname)
+        assert [(n, t) for n, t in ns[cname]._fields_] == want, cname
+        assert [(n, t) for n, t in ours._fields_] == want, cname
+        assert C.sizeof(ns[cname]) == C.sizeof(ours)
+    assert ns['ARCH'] == _lib.ARCH and ns['SCORE'] == _lib.SCORE
+    text = open(os.path.join(ROOT, 'include', 'lstur.h')).read()
+    hdr_abi = int(re.search(r'#define LSTUR_ABI_VERSION (\d+)', text).group(1))
+    assert ns['ABI_VERSION'] == _lib.ABI_VERSION == hdr_abi == _lib.lib.lstur_abi_version()
+    for i, nm in enumerate(re.findall(r'LSTUR_ARCH_(\w+) = (\d+)', text)):
+        assert _lib.ARCH[nm[0].lower()] == int(nm[1])
+
+
+def test_a_cfg_of_another_size_is_refused_not_read_past():
+    """the round-2 binding (no struct_size, no id_keep: 96 bytes) and a cfg whose struct_size lies are refused by every
+    entry point that takes a lstur_cfg"""
+    cfg = _lib.make_cfg(4, 3, 5, 2, 10, 8, 8, 3, 8, 4)
+    assert cfg.struct_size == C.sizeof(_lib.Cfg)
+    for bad in (0, C.sizeof(_lib.Cfg) - 4, C.sizeof(_lib.Cfg) + 4):
+        cfg.struct_size = bad
+        s = _lib.Sizes()
+        assert _lib.lib.lstur_query_sizes(C.byref(cfg), C.byref(s)) == -1
+        assert b'struct_size' in _lib.lib.lstur_last_error()
+        off, cnt = C.c_size_t(), C.c_size_t()
+        assert _lib.lib.lstur_param(C.byref(cfg), b'conv_w', C.byref(off), C.byref(cnt)) == -1
+        assert _lib.lib.lstur_param_name(C.byref(cfg), 0) is None
+        assert _lib.lib.lstur_dp_tail_floats(C.byref(cfg), 2) == 0
+        bufs = _lib.Buffers(*([256] * 9), 1 << 20)
+        ctx = C.c_void_p()
+        assert _lib.lib.lstur_create(C.byref(cfg), C.byref(bufs), C.byref(ctx)) == -1
+
+
+def test_conv_width_is_bounded_by_the_reduction_launch():
+    """the backward pass hands one reduction job per conv tap to ONE launch of at most 32 jobs; a width that does
+    not fit is refused when the configuration is made, not truncated at run time"""
+    _lib.query_sizes(_lib.make_cfg(4, 3, 5, 2, 10, 8, 8, 20, 8, 4))
+    with pytest.raises(_lib.LsturError, match='kernel'):
+        _lib.query_sizes(_lib.make_cfg(4, 3, 5, 2, 10, 8, 8, 21, 8, 4))
+
+
+def test_product_library_carries_no_timing_only_kernels():
+    """the ablation kernels (WRONG results by design) and the measurement knobs are compiled into the bench-only library
+    (make ablate, -DLSTUR_ABLATE) alone"""
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    for needle in (b'ABLATE', b'LSTUR_GRU4_DEBUG', b'LSTUR_GRU_DEBUG', b'LSTUR_CONV_GEN1', b'LSTUR_CONV_FWD3', b'LSTUR_PIPELINE',
+                   b'LSTUR_LATE_SLOTS', b'LSTUR_SLOT_MAJOR', b'LSTUR_SPLIT_BG', b'LSTUR_ONE_SIDE', b'LSTUR_WG_STREAMS'):
+        assert needle not in blob, needle

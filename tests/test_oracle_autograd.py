@@ -6,7 +6,7 @@ import torch
 
 from conftest import make_batch
 from oracle import lstur_oracle as O
-import torch_ref as TR
+from oracle import torch_ref as TR
 
 DIMS = dict(V=60, D=12, F=16, k=3, U=8, N_u=11)
 
