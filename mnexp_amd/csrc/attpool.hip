@@ -356,8 +356,7 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
                                                             float* __restrict__ parts, int T, int F, uint32_t thresh,
                                                             uint32_t key, float scale, int ldp, int off_aw, int off_cb,
                                                             int off_ab, int relu, const uint32_t* __restrict__ kbits,
-                                                            int title0, uint32_t* __restrict__ gmax,
-                                                            uint32_t* __restrict__ gzero) {
+                                                            int title0, float* __restrict__ gparts) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // dw[32] | (unused)[32] | red[4][2][F]
   float* dwL = sm;
   float* red = sm + 64;
@@ -427,7 +426,12 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
       ((float4*)(red + (wv * 2 + 0) * F))[lane + 64 * h] = gaw[h];
       ((float4*)(red + (wv * 2 + 1) * F))[lane + 64 * h] = gcb[h];
     }
+  if (gparts) {    // max |dc| of this title (fmaxf drops NaNs: a NaN gradient shows in the loss, not in the scale)
+    gm = wave_max(gm);
+    if (lane == 0) sm[32 + wv] = gm;
+  }
   __syncthreads();
+  if (gparts && threadIdx.x == 0) gparts[n] = fmaxf(fmaxf(sm[32], sm[33]), fmaxf(sm[34], sm[35]));
   float* pr = parts + (size_t)n * ldp;
   for (int j = threadIdx.x; j < 2 * F; j += 256) {
     const int which = j / F, f = j - which * F;
@@ -441,11 +445,6 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
     for (int t = 0; t < T; ++t) gab += lane_value(ds_t, t);
     if (lane == 0) pr[off_ab] = gab;
   }
-  if (gmax) {      // (a NaN gradient compares false everywhere: it does not raise the maximum, it shows in the loss)
-    gm = wave_max(gm);
-    if (lane == 0 && gm > 0.f) atomicMax(gmax, __float_as_uint(gm));
-  }
-  if (gzero && blockIdx.x == 0 && threadIdx.x == 0) gzero[0] = gzero[1] = 0u;
 }
 
 void launch_attpool_fwd(const float* c, const int32_t* ids, const float* att_w, const float* att_b, float* pooled,
@@ -538,8 +537,7 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
     const float* __restrict__ c, const int32_t* __restrict__ ids, const float* __restrict__ att_w,
     const float* __restrict__ w, const float* __restrict__ ds, const float* __restrict__ dpooled,
     float* __restrict__ dc, float* __restrict__ parts, int rows, int T, int F, uint32_t thresh, uint32_t key,
-    float scale, int ldp, int off_aw, int off_cb, int off_ab, int relu, uint32_t* __restrict__ gmax,
-    uint32_t* __restrict__ gzero) {
+    float scale, int ldp, int off_aw, int off_cb, int off_ab, int relu, float* __restrict__ gparts) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [2][F] partials of sub-stream 1
   float gm = 0.f;
   const int cols = VEC == 4 ? F / 4 : F;
@@ -631,18 +629,19 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
     for (int row = r0; row < r1; ++row) gab += ds[row];   // ds is 0 on masked / pad rows
     pr[off_ab] = gab;
   }
-  if (gmax) {
+  if (gparts) {    // max |dc| over this block's rows
+    __shared__ float gms[4];
     gm = wave_max(gm);
-    if ((threadIdx.x & 63) == 0 && gm > 0.f) atomicMax(gmax, __float_as_uint(gm));
+    if ((threadIdx.x & 63) == 0) gms[threadIdx.x >> 6] = gm;
+    __syncthreads();
+    if (threadIdx.x == 0) gparts[blockIdx.x] = fmaxf(fmaxf(gms[0], gms[1]), fmaxf(gms[2], gms[3]));
   }
-  if (gzero && blockIdx.x == 0 && threadIdx.x == 0) gzero[0] = gzero[1] = 0u;
 }
 
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
                         float drop, uint32_t key, hipStream_t s, int ldp, int off_aw, int off_cb, int off_ab, int relu,
-                        const uint32_t* live, const uint32_t* kbits, int title0, int title_count, uint32_t* gmax,
-                        uint32_t* gzero) {
+                        const uint32_t* live, const uint32_t* kbits, int title0, int title_count, float* gparts) {
   if (ldp <= 0) {   // default layout of the public entry point: datt_w[F] | dconv_b[F] | datt_b
     ldp = 2 * F + 1;
     off_aw = 0;
@@ -659,7 +658,7 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
     if (cnt > 0)
       hipLaunchKernelGGL(att_bwd_title_kernel, dim3(cnt), dim3(256), (64 + 8 * F) * sizeof(float), s, c, ids, live, att_w, a,
                          w, dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu,
-                         thresh ? kbits : nullptr, title0, gmax, gzero);
+                         thresh ? kbits : nullptr, title0, gparts);
     return;
   }
   if (F % 4 == 0) {
@@ -667,13 +666,13 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
                        thresh, key, scale);
     hipLaunchKernelGGL(att_bwd_ds_kernel, dim3(cdiv(n_titles, 128)), dim3(128), 0, s, row_scratch, w, a, n_titles, T);
     hipLaunchKernelGGL(att_bwd_dc_kernel<4>, dim3(nparts), dim3(128 * kDcRsub), 2 * F * sizeof(float), s, c, ids, att_w, w, row_scratch, dpooled, dc,
-                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu, gmax, gzero);
+                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu, gparts);
   } else {
     hipLaunchKernelGGL(att_bwd_dw_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, s, c, w, dpooled, row_scratch, rows, T, F,
                        thresh, key, scale);
     hipLaunchKernelGGL(att_bwd_ds_kernel, dim3(cdiv(n_titles, 128)), dim3(128), 0, s, row_scratch, w, a, n_titles, T);
     hipLaunchKernelGGL(att_bwd_dc_kernel<1>, dim3(nparts), dim3(128 * kDcRsub), 2 * F * sizeof(float), s, c, ids, att_w, w, row_scratch, dpooled, dc,
-                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu, gmax, gzero);
+                       parts, rows, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu, gparts);
   }
 }
 

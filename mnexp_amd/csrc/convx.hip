@@ -137,11 +137,13 @@ void launch_convx_escale(const float* table, size_t count, float drop, float* cs
 }
 // a fresh block: every scale 1, every maximum 0
 __global__ void cs_init_kernel(float* __restrict__ cs) {
-  const int i = threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= kCsWords) return;
   cs[i] = (i == kCsE || i == kCsW || i == kCsFwd || i == kCsInvE) ? 1.0f : 0.0f;
 }
-void launch_convx_scales_init(float* cs, hipStream_t s) { hipLaunchKernelGGL(cs_init_kernel, dim3(1), dim3(64), 0, s, cs); }
+void launch_convx_scales_init(float* cs, hipStream_t s) {
+  hipLaunchKernelGGL(cs_init_kernel, dim3(cdiv(kCsWords, 256)), dim3(256), 0, s, cs);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Gather: Embedding + Dropout (paper.py:132-147) into Ex.  One thread = one 8-element chunk: 32 bytes of a table row in,
@@ -282,8 +284,28 @@ void launch_gatherx(const float* table, const int32_t* ids, unsigned short* ex, 
 // the same rule in the stand-alone kernel below and in the dense Adam launch that writes the image in the training step
 // (misc.hip: image_scatter).
 // ---------------------------------------------------------------------------------------------
+// the maximum a rotating slot holds (every lane of the wave gets it; EXEC must be full)
+__device__ __forceinline__ uint32_t wmax_read(const uint32_t* cu, int slot, int lane) {
+  uint32_t m = cu[wmax_word(slot, lane & (kWmaxLanes - 1))];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  return m;
+}
+// a workgroup of 256 threads leaves its maximum in slot `add` and (first workgroup) clears slot `clear`
+__device__ __forceinline__ void wmax_leave(uint32_t* cu, uint32_t m, int add, int clear) {
+  __shared__ uint32_t wm[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    if (m) atomicMax(cu + wmax_word(add, blockIdx.x & (kWmaxLanes - 1)), m);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < kWmaxLanes) cu[wmax_word(clear, threadIdx.x)] = 0u;
+}
 template <int NP>
-__global__ void convx_pack_w_kernel(const float* __restrict__ W, int D, int Dp, int ksize, int F, int Kp, int Np,
+__global__ __launch_bounds__(256) void convx_pack_w_kernel(const float* __restrict__ W, int D, int Dp, int ksize, int F, int Kp, int Np,
                                     unsigned short* __restrict__ Wx, float* __restrict__ cs, int seq, float grow) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = i < (size_t)Kp * Np;
@@ -292,7 +314,7 @@ __global__ void convx_pack_w_kernel(const float* __restrict__ W, int D, int Dp, 
   const float v = (in && tap < ksize && d < D && n < F) ? W[((size_t)tap * D + d) * F + n] : 0.f;
   if constexpr (NP == 2) {
     uint32_t* cu = (uint32_t*)cs;
-    const float sW = pow2_scale(__float_as_uint(__uint_as_float(cu[kCsWmax + seq % 3]) + grow), 13);
+    const float sW = pow2_scale(__float_as_uint(__uint_as_float(wmax_read(cu, seq % 3, threadIdx.x & 63)) + grow), 13);
     u16x4 h, l;
     const float vs = fminf(fmaxf(v * sW, -65504.f), 65504.f);
     split2(make_float4(vs, 0.f, 0.f, 0.f), h, l);
@@ -300,12 +322,8 @@ __global__ void convx_pack_w_kernel(const float* __restrict__ W, int D, int Dp, 
       Wx[i] = h[0];
       Wx[(size_t)Kp * Np + i] = l[0];
     }
-    uint32_t m = __float_as_uint(fabsf(v));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(cu + kCsWmax + (seq + 1) % 3, m);
+    wmax_leave(cu, __float_as_uint(fabsf(v)), (seq + 1) % 3, (seq + 2) % 3);
     if (i == 0) {
-      cu[kCsWmax + (seq + 2) % 3] = 0u;
       cs[kCsW] = sW;
       cs[kCsFwd] = 1.0f / (cs[kCsE] * sW);
     }
@@ -326,8 +344,8 @@ void launch_convx_pack_w(const float* W, int D, int ksize, int F, unsigned short
   const dim3 grid((unsigned)cdivz(total, 256));
   if (np == 2) {
     if (fresh) {
-      (void)hipMemsetAsync((uint32_t*)cs + kCsWmax, 0, 3 * sizeof(uint32_t), s);
-      launch_absmax(W, (size_t)ksize * D * F, (uint32_t*)cs + kCsWmax + seq % 3, s);
+      (void)hipMemsetAsync((uint32_t*)cs + kCsWmax, 0, (size_t)(kCsWords - kCsWmax) * sizeof(uint32_t), s);
+      launch_absmax(W, (size_t)ksize * D * F, (uint32_t*)cs + wmax_word(seq % 3, 0), s);
     }
     hipLaunchKernelGGL(convx_pack_w_kernel<2>, grid, dim3(256), 0, s, W, D, convx_dp(D), ksize, F, Kp, Np, Wx, cs, seq,
                        fresh ? 0.f : grow);
@@ -712,7 +730,7 @@ __global__ __launch_bounds__(GX_THREADS, 2) void convx_wgrad_kernel(
     const unsigned short* __restrict__ Ex, uint32_t e_bytes, const float* __restrict__ G, uint32_t g_bytes,
     float* __restrict__ slabs, const int32_t* __restrict__ vcount, int M, int F, int Kq, int mblocks, int nblocks, int nslabs,
     const int32_t* __restrict__ offA, const int32_t* __restrict__ offB, int range_sel, int slab_base,
-    const float* __restrict__ cs, int gslot) {
+    const float* __restrict__ cs, const float* __restrict__ gparts, int g_n) {
   constexpr int A_IMG = gx_a_img(NP), STAGE = gx_stage(NP), APC = NP;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -733,8 +751,23 @@ __global__ __launch_bounds__(GX_THREADS, 2) void convx_wgrad_kernel(
   // live work of this wave: its row tile must start inside k' < Kq; column tiles inside F
   const bool row_live = kd0 + wv * 32 < Kq;
   const int na = row_live ? max(0, min(GX_TN, (F - f0 + 31) / 32)) : 0;
-  // NP = 2: power-of-two scale of dC from the maximum the attention backward left (exact to undo)
-  const float sG = NP == 2 ? pow2_scale(((const uint32_t*)cs)[kCsGmax + gslot], 14) : 1.0f;
+  // NP = 2: power-of-two scale of dC (exact to undo) from the maxima the attention backward's workgroups left, one per
+  // title of this launch's range: every workgroup takes the maximum of the g_n entries itself (a few loads per thread, no
+  // atomics, no zeroing: same-address atomicMax from 14 000 waves cost the attention backward 100 us)
+  float sG = 1.0f;
+  if constexpr (NP == 2) {
+    float gm = 0.f;
+    for (int i = tid; i < g_n; i += GX_THREADS) gm = fmaxf(gm, gparts[i]);
+    gm = wave_max(gm);
+    float* gred = (float*)smem;
+    if (lane == 0) gred[wv] = gm;
+    __syncthreads();
+    gm = gred[0];
+#pragma unroll
+    for (int i = 1; i < GX_TM; ++i) gm = fmaxf(gm, gred[i]);
+    __syncthreads();                                   // (smem is the stage buffer from here on)
+    sG = pow2_scale(__float_as_uint(gm), 14);
+  }
 
   f32x16 acc[GX_TN];
 #pragma unroll
@@ -887,11 +920,11 @@ __global__ __launch_bounds__(GX_THREADS, 2) void convx_wgrad_kernel(
 // count.  A step may cut the token list at a title boundary (range_sel 2: the tokens behind vcount[1], 1: those in front)
 // and give each part its own launch: the parts' slabs lie one after the other (slab_base = slabs of the launches before,
 // plan_titles = the titles of this part for the slab count) and the LAST launch writes the jobs over all of them
-// (jobs == NULL: none).  gslot: which of the tracked maxima of dC applies (np == 2).
+// (jobs == NULL: none).  gparts [g_n] (np == 2): maxima of |dout| whose largest bounds every row this launch reads.
 int launch_convx_wgrad(const unsigned short* ex, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
                        int ksize, int F, const int32_t* vcount, hipStream_t s, ReduceJob* jobs, const int32_t* offA,
-                       const int32_t* offB, int np, const float* cs, int gslot, float alpha, int range_sel, int slab_base,
-                       int plan_titles, int* slabs_out, int variant) {
+                       const int32_t* offB, int np, const float* cs, const float* gparts, int g_n, float alpha, int range_sel,
+                       int slab_base, int plan_titles, int* slabs_out, int variant) {
   const int M = n_titles * T, Dp = convx_dp(D), Kq = ksize * Dp;
   if (slabs_out) *slabs_out = 0;
   if (M == 0) {
@@ -909,7 +942,7 @@ int launch_convx_wgrad(const unsigned short* ex, const float* dout, float* dw, v
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     last_launch();
     launch_k(kern, grid, dim3(GX_THREADS), lds, s, ex, e_bytes, dout, g_bytes, (float*)scratch, vcount, M, F, Kq, mblocks, nblocks,
-             ns, offA, offB, vcount ? range_sel : 0, slab_base, cs, gslot);
+             ns, offA, offB, vcount ? range_sel : 0, slab_base, cs, gparts, g_n);
   };
   (void)variant;
 #ifdef LSTUR_ABLATE

@@ -304,7 +304,7 @@ struct Workspace {
   float* correct_i; float* parts; float* conv_wp; float* gru_up;
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
-  int32_t* lazy_last; float* lazy_lrt; int32_t* lazy_first; int32_t* dp_rows; int32_t* pend_rows; float* dp_grads; float* dp_grads2; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* e3; float* cs; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; unsigned short* qkv_w16; void* mh_scratch;
+  int32_t* lazy_last; float* lazy_lrt; int32_t* lazy_first; int32_t* dp_rows; int32_t* pend_rows; float* dp_grads; float* dp_grads2; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* e3; float* cs; float* gparts; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; unsigned short* qkv_w16; void* mh_scratch;
   int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   // the staged form of a batch (token ids, their compacted list + offsets, the gathered embeddings) exists twice: while a
   // step runs on one set, the NEXT batch can be staged into the other (lstur_prefetch_ids); ids / e3 / vidx / ... above
@@ -436,6 +436,7 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->conv_w3 = c3 ? (unsigned short*)take(convx_w_elems(d.D, d.k, d.F, d.np) * 2) : nullptr;
   w->e3 = c3 ? (unsigned short*)take(convx_e_elems((int)nt, d.T, d.D, d.k, d.np) * 2) : nullptr;
   w->cs = c3 ? (float*)take(kCsWords * sizeof(float)) : nullptr;
+  w->gparts = c3 ? (float*)take(nt * f4) : nullptr;   // max |dC| per title, left by the attention backward (f16x2 kernel gradient)
   w->fwd2_scratch = c3 ? take(convx_fwd_scratch_bytes()) : nullptr;
   w->qkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;     // bf16 Q | K | V rows
   w->dqkv = mh ? (unsigned short*)take(nt * d.T * 3 * d.F * 2) : nullptr;
@@ -534,7 +535,6 @@ struct lstur_ctx {
   bool images_valid = false;            // conv / GRU weight images match dense_param (packed behind the last Adam)
   bool escale_valid = false;            // f16x2: the embedding scale matches the word table (lstur_params_changed clears it)
   int pack_seq = 0;                     // f16x2: packs of the conv weight image so far (rotating maxima, convx.hip)
-  int bwd_seq = 0;                      // f16x2: backward passes so far (parity of the dC maxima the attention backward leaves)
   int lazy_t = 0;                       // lazy Adam: iterations applied so far (rows are current for last[row] <= lazy_t)
   int lazy_flushed_t = 0;               // ... and the iteration of the last full flush (the lr_t log is a ring)
   std::vector<ParamSlot> layout;
@@ -1176,11 +1176,10 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
   const float drop = c->cfg.dropout;
   const uint32_t key1 = dropout_key(c->cfg.seed, step, 1);
   g_wgrad_bf16x3 = c->opt.wgrad_bf16x3;
-  // f16x2 kernel gradient: the attention backward launches of this pass leave max |dC| in the words of this step's parity
-  // (main stream: word 0, side stream: word 1); the main launch clears the other parity's two words, which the previous
-  // pass used and the next one will write
-  const int par = c->bwd_seq++ & 1;
-  uint32_t* gm = d.np == 2 ? (uint32_t*)w.cs + kCsGmax : nullptr;
+  // f16x2 kernel gradient: the attention backward leaves max |dC| of every title in gparts[title] (title path; the
+  // streaming kernels: one entry per workgroup), the kernel-gradient launches scale by the maximum over their titles
+  float* gp = d.np == 2 ? w.gparts : nullptr;
+  const bool gp_titles = attpool_title_path(d.T, d.F);
   // user encoder head
   const float* dhl = w.du;
   // LSTUR-con's Dense over [h | user_vec]: its parameter gradients feed nothing but the optimizer -- they go to the side stream
@@ -1253,12 +1252,12 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
       ProfScope _ps(c, "attpool_bwd_side", sw);
       launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, w.att_ds, nt, d.T, d.F,
                          drop, key1, sw, ldp, off_aw, off_cb, off_ab, 1, w.live, w.kbits_valid ? w.kbits : nullptr, nW, ncand,
-                         gm ? gm + 2 * par + 1 : nullptr, nullptr);
+                         gp);
     }
     {
       ProfScope _ps(c, "conv_wgrad_side", sw, true);
       (void)launch_convx_wgrad(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, sw, nullptr, w.offA,
-                               w.offB, d.np, w.cs, 2 * par + 1, 1.0f, 2, side_base, ncand, &cand_slabs);
+                               w.offB, d.np, w.cs, gp ? gp + nW : nullptr, ncand, 1.0f, 2, side_base, ncand, &cand_slabs);
     }
     // the side launch's slabs -> slab 0 (off the critical path), then the join event
     ReduceJob pre{(const float*)w.wgrad_scratch + (size_t)side_base * slab_f, (float*)w.wgrad_scratch, d.k * convx_dp(d.D), d.F, d.F,
@@ -1362,8 +1361,7 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
   const int ldp = off_ab + 1;
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
                                          w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 1, w.live,
-                                         w.kbits_valid ? w.kbits : nullptr, 0, split ? nW : nt,
-                                         gm ? gm + 2 * par : nullptr, gm ? gm + 2 * (par ^ 1) : nullptr));
+                                         w.kbits_valid ? w.kbits : nullptr, 0, split ? nW : nt, gp));
   if (split) (void)hipStreamWaitEvent(s, c->ev_c1, 0);   // the candidate titles' partial sums, gradient rows and slabs
   // (on the side stream this one found no free CU beside the conv kernel gradient and finished behind it)
   launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch_k[2], s, &jobs[nj++]);
@@ -1375,7 +1373,8 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
   if (d.np) {   // split-operand contraction (convx.hip), like the forward; one reduce job per tap
     ProfScope _ps(c, "conv_wgrad", s, true);
     nj += launch_convx_wgrad(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, s, &jobs[nj],
-                             w.offA, w.offB, d.np, w.cs, 2 * par, 1.0f, split ? 1 : 0, split ? 1 : 0, split ? nW : 0);
+                             w.offA, w.offB, d.np, w.cs, gp, !gp_titles ? attpool_bwd_parts(nt) : split ? nW : nt, 1.0f,
+                             split ? 1 : 0, split ? 1 : 0, split ? nW : 0);
   } else
     PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,
                                          w.vidx, w.vcount, s, w.offA, w.offB,
@@ -2155,12 +2154,12 @@ int lstur_convx_wgrad(const uint16_t* ex, const float* dout, float* dw, void* sc
   hipStream_t s = (hipStream_t)stream;
   launch_token_offsets(vidx, vcount, M, title_len, title_len + ksize - 1, convx_dp(dim) / 8 * parts, filters, offsets, offsets + M, s);
   if (parts == 2) {   // the stand-alone call takes max |dout| over the rows it reads (in the step the attention backward leaves it)
-    (void)hipMemsetAsync((uint32_t*)scales + kCsGmax, 0, sizeof(uint32_t), s);
-    launch_absmax_rows(dout, M, filters, vidx, vcount, (uint32_t*)scales + kCsGmax, s);
+    (void)hipMemsetAsync(scales + kCsGmax, 0, sizeof(float), s);
+    launch_absmax_rows(dout, M, filters, vidx, vcount, (uint32_t*)scales + kCsGmax, s);   // (bits of a non-negative float)
   }
   ReduceJob jobs[kMaxReduceJobs];
   const int nj = launch_convx_wgrad(ex, dout, dw, scratch, n_titles, title_len, dim, ksize, filters, vcount, s, jobs, offsets,
-                                    offsets + M, parts, scales, 0);
+                                    offsets + M, parts, scales, parts == 2 ? scales + kCsGmax : nullptr, 1);
   if (M > 0 && !launch_multi_reduce(jobs, nj, s)) return fail(LSTUR_ERR_STATE, "convx_wgrad: too many reductions");
   return check_launch("convx_wgrad");
 }

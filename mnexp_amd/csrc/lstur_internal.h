@@ -214,10 +214,16 @@ constexpr int kCsE = 0;       // float: power of two the embeddings are staged w
 constexpr int kCsW = 1;       // float: ... the current weight image was packed with
 constexpr int kCsFwd = 2;     // float: 1 / (sE sW), the forward's un-scale
 constexpr int kCsInvE = 3;    // float: 1 / sE
-constexpr int kCsWmax = 4;    // 3 x uint32: bits of max |conv_w| as seen by the last packs (rotating, convx.hip)
 constexpr int kCsEmax = 7;    // uint32: bits of max |word table|
-constexpr int kCsGmax = 8;    // 4 x uint32: bits of max |dC| of the attention backward launches [step parity][main | side]
-constexpr int kCsWords = 16;
+constexpr int kCsGmax = 8;    // float: max |dC| of a stand-alone kernel-gradient call (in the step: the attention backward's
+                              // per-workgroup maxima, lstur_internal.h: launch_attpool_bwd gparts)
+// max |conv_w| as seen by the last packs: 3 rotating slots (convx.hip) of kWmaxLanes words, kWmaxStride words apart -- a
+// workgroup adds its maximum to word (workgroup % kWmaxLanes) of a slot, a reader takes the maximum over the slot's words:
+// thousands of atomicMax on ONE address cost the dense Adam launch 60 us (they serialise in one L2 channel)
+constexpr int kWmaxLanes = 64, kWmaxStride = 64;
+constexpr int kCsWmax = 64;
+constexpr int kCsWords = kCsWmax + 3 * kWmaxLanes * kWmaxStride;
+__host__ __device__ inline int wmax_word(int slot, int lane) { return kCsWmax + (slot * kWmaxLanes + lane) * kWmaxStride; }
 bool convx_supported(int D, int ksize, int F);                    // D % 4 == 0, F <= 448, ksize <= 8
 int convx_dp(int D);                                              // embedding row length of Ex (D rounded up to 8)
 size_t convx_e_elems(int n_titles, int T, int D, int ksize, int np);   // 16-bit elements of Ex incl. slack
@@ -247,8 +253,8 @@ int convx_wgrad_slabs(int plan_titles, int T, int D, int ksize, int F);   // sla
 size_t convx_wgrad_slab_floats(int D, int ksize, int F);                  // floats of one slab ([k * Dp, F])
 int launch_convx_wgrad(const unsigned short* ex, const float* dout, float* dw, void* scratch, int n_titles, int T, int D,
                        int ksize, int F, const int32_t* vcount, hipStream_t s, ReduceJob* jobs, const int32_t* offA,
-                       const int32_t* offB, int np, const float* cs, int gslot, float alpha = 1.0f, int range_sel = 0,
-                       int slab_base = 0, int plan_titles = 0, int* slabs_out = nullptr, int variant = 0);
+                       const int32_t* offB, int np, const float* cs, const float* gparts, int g_n, float alpha = 1.0f,
+                       int range_sel = 0, int slab_base = 0, int plan_titles = 0, int* slabs_out = nullptr, int variant = 0);
 
 // ---- gemm3.hip: C = A[M,K] . op(B) + bias, fp32-grade on the bf16 matrix cores (bf16x3), for the dense layers on the
 // step's critical path.  b_nk: B is [N][K] (C = A . B^T), else [K][N].  Check gemm3_supported first.
@@ -281,8 +287,8 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
                         float drop, uint32_t key, hipStream_t s, int ldp = 0, int off_aw = 0, int off_cb = 0,
                         int off_ab = 0, int relu = 1, const uint32_t* live = nullptr, const uint32_t* kbits = nullptr,
                         int title0 = 0, int title_count = -1,
-                        uint32_t* gmax = nullptr,     // != NULL: atomicMax of the bits of |dc| over the rows written
-                        uint32_t* gzero = nullptr);   // != NULL: TWO words this launch clears (the other step parity's maxima)
+                        float* gparts = nullptr);     // != NULL: gparts[workgroup] = max |dc| over the rows it wrote (title
+                                                      // path: one entry per title, indexed by title; else attpool_bwd_parts)
 bool attpool_title_path(int T, int F);   // the title-resident kernels (the only ones that take a title sub-range)
 
 // ---- mhsa.hip (build-defined multi-head self-attention token stage; T <= 32, F/heads in {16, 32, 64}) -------

@@ -508,7 +508,7 @@ __device__ __forceinline__ void combine_row(const int32_t* __restrict__ rows, co
                                             float* __restrict__ gsum, int32_t* __restrict__ slot, int i, int lane);
 __device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, float pi, float sW, uint32_t& wmax);
 __device__ __forceinline__ float image_scale(const ImagePlan& P);
-__device__ __forceinline__ void image_finish(const ImagePlan& P, float sW, uint32_t wmax, bool first_thread);
+__device__ __forceinline__ void image_finish(const ImagePlan& P, float sW, uint32_t wmax, bool first_block);
 __global__ __launch_bounds__(256) void adam_flat_combine_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                 float* __restrict__ m, float* __restrict__ v, size_t n,
                                                                 float lr_t, float b1, float b2, float eps,
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void adam_flat_combine_kernel(float* __restric
     v[i] = vi;
     image_scatter(P, i, pi, sW, wmax);  // (an empty plan scatters nothing)
   }
-  image_finish(P, sW, wmax, blockIdx.x == 0 && threadIdx.x == 0);
+  image_finish(P, sW, wmax, blockIdx.x == 0);
 }
 void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                               float eps, const int32_t* rows, const float* rg, int n_rows, int dim, float* gsum,
@@ -545,19 +545,29 @@ void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size
 // the updated element i of the bucket also goes into the weight images that hold it (ImagePlan, lstur_internal.h)
 // f16x2 images: the scale comes from the maximum the previous pack saw, this launch leaves its own for the next one
 // (the rule of convx.hip: convx_pack_w_kernel, restated here so that the image costs no launch of its own)
+// (workgroups of 256 threads, EXEC full: every thread of the sweep's blocks calls both)
 __device__ __forceinline__ float image_scale(const ImagePlan& P) {
-  return (P.conv_cnt && P.np == 2)
-             ? pow2_scale(__float_as_uint(__uint_as_float(((const uint32_t*)P.cs)[kCsWmax + P.seq % 3]) + P.grow), 13)
-             : 1.0f;
+  if (!(P.conv_cnt && P.np == 2)) return 1.0f;
+  const uint32_t* cu = (const uint32_t*)P.cs;
+  uint32_t m = cu[wmax_word(P.seq % 3, threadIdx.x & (kWmaxLanes - 1))];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  return pow2_scale(__float_as_uint(__uint_as_float(m) + P.grow), 13);
 }
-__device__ __forceinline__ void image_finish(const ImagePlan& P, float sW, uint32_t wmax, bool first_thread) {
+__device__ __forceinline__ void image_finish(const ImagePlan& P, float sW, uint32_t wmax, bool first_block) {
   if (!(P.conv_cnt && P.np == 2)) return;
   uint32_t* cu = (uint32_t*)P.cs;
+  __shared__ uint32_t wm[4];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o, 64));
-  if ((threadIdx.x & 63) == 0 && wmax) atomicMax(cu + kCsWmax + (P.seq + 1) % 3, wmax);
-  if (first_thread) {
-    cu[kCsWmax + (P.seq + 2) % 3] = 0u;
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = wmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    if (m) atomicMax(cu + wmax_word((P.seq + 1) % 3, blockIdx.x & (kWmaxLanes - 1)), m);
+  }
+  if (first_block && threadIdx.x < kWmaxLanes) cu[wmax_word((P.seq + 2) % 3, threadIdx.x)] = 0u;
+  if (first_block && threadIdx.x == 0) {
     P.cs[kCsW] = sW;
     P.cs[kCsFwd] = 1.0f / (P.cs[kCsE] * sW);
   }
@@ -603,7 +613,7 @@ __global__ void adam_flat_pack_kernel(float* __restrict__ p, const float* __rest
     v[i] = vi;
     image_scatter(P, i, pi, sW, wmax);
   }
-  image_finish(P, sW, wmax, blockIdx.x == 0 && threadIdx.x == 0);
+  image_finish(P, sW, wmax, blockIdx.x == 0);
 }
 void launch_adam_flat_pack(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
                            const ImagePlan& plan, hipStream_t s) {

@@ -4,7 +4,10 @@ FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled on gfx950 (MI355X_MICRO
 import collections, csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-FAMILIES = {'gather': 'gather3_kernel', 'gather_f32': 'gather_kernel', 'conv_fwd': 'conv3_fwd2_kernel', 'conv_fwd_fix': 'conv3_fwd2_fix', 'conv_wgrad': 'conv3_wgrad2_kernel<0, false>', 'conv_wgrad_side': 'conv3_wgrad2_kernel<0, true>',
+# (kernel-name substrings; the split-operand kernels carry their part count as the first template argument, the side launch of
+#  the kernel gradient -- candidate titles, beside the recurrence's backward -- its own instantiation <np, 0, true>)
+FAMILIES = {'gather': 'gatherx_kernel', 'gather_f32': 'gather_kernel', 'conv_fwd': 'convx_fwd_kernel', 'conv_fwd_fix': 'convx_fwd_fix',
+            'conv_wgrad': ', 0, false>', 'conv_wgrad_side': ', 0, true>',
             'conv_fwd_f32': 'conv_fwd_kernel', 'conv_wgrad_f32': 'conv_wgrad_glds', 'adam_user_table': 'adam_table_kernel',
             'att_fwd': 'att_fwd_title_kernel', 'att_bwd': 'att_bwd_title_kernel', 'att_score': 'att_score_kernel', 'att_pool': 'att_pool_kernel', 'att_bwd_dc': 'att_bwd_dc_kernel',
             'gru_fwd': 'gru4_fwd_kernel', 'gru_bwd': 'gru4_bwd_kernel', 'multi_reduce': 'multi_reduce_kernel'}
@@ -16,7 +19,7 @@ def per_kernel(csv_path, counter):
         if r['Counter_Name'] != counter:
             continue
         for fam, pat in FAMILIES.items():
-            if pat in r['Kernel_Name']:
+            if pat in r['Kernel_Name'] and (not pat.startswith(',') or 'convx_wgrad_kernel' in r['Kernel_Name']):
                 tot[fam] += float(r['Counter_Value'])
                 cnt[fam] += 1
     return tot, cnt
