@@ -212,26 +212,26 @@ def cpu_baseline_torch(wl, titles, word, batches, budget_s=12.0):
 
 
 def e2e_legs(wl, word, steps, dropout, device):
-    """End-to-end throughput of the drop-in path: files in the reference's formats (mnexp_amd.synth: DocMeta.tsv +
-    ClickData.tsv of the workload's shape; 6 000 users keep the load short) -> task loading -> samples from (a) the C++
-    feed (--native-feed) and (b) the task's own Python generators in id form (--ids) -> host batch -> H2D -> step, ALL
-    inside the timed region.  The samples are real click histories (mostly shorter than the window, so fewer non-pad
-    tokens per step than the device-resident headline, whose histories are 90 % full)."""
+    """End-to-end throughput of the drop-in path: files in the reference's formats (DocMeta.tsv + ClickData.tsv of the
+    workload's FULL shape -- all its users and docs -- written by the C++ generator of include/lstur_data.h) -> task loading
+    with the C++ loaders (`task_load_s`: DocMeta + ClickData parsing, doc-id check) -> samples from (a) the C++ feed
+    (--native-feed) and (b) the task's own Python generators in id form (--ids) -> host batch -> H2D -> step, ALL inside the
+    timed region.  The samples are real click histories (mostly shorter than the window, so fewer non-pad tokens per step
+    than the device-resident headline, whose histories are 90 % full)."""
     import contextlib
     import io
     import random
     import shutil
     import tempfile
     import torch
-    from mnexp_amd import synth, settings, task as T
+    from mnexp_amd import settings, task as T
     from mnexp_amd.native_model import NativeModel
-    from mnexp_amd.data_native import NativeTrainFeed
+    from mnexp_amd.data_native import synth_write
     d = tempfile.mkdtemp(prefix='lstur_bench_e2e_')
     try:
-        rng = np.random.default_rng(0)
-        topic, titles = synth.make_docs(wl['N_d'], wl['V'], wl['T'], rng)
-        synth.write_docmeta(os.path.join(d, 'DocMeta.tsv'), titles)
-        synth.write_clickdata(os.path.join(d, 'ClickData.tsv'), 6000, topic, 20, 4, rng)
+        t0 = time.perf_counter()
+        synth_write(d, wl['N_d'], wl['V'], wl['T'], wl['N_u'], 20, 4, seed=0)
+        write_s = time.perf_counter() - t0
         open(os.path.join(d, 'Vocab.tsv'), 'w').close()          # (the word table comes from the bench: same shape)
         settings.public_config = dict(input_training_data_path=d, input_validation_data_path=d,
                                       input_previous_model_path=d, output_model_path=d, log_dir=d)
@@ -242,7 +242,7 @@ def e2e_legs(wl, word, steps, dropout, device):
                     learning_rate_decay=0.5, dropout=dropout, user_embedding_dim=wl['U'],
                     title_filter_shape=(wl['F'], wl['k']), score_model='dot', enable_pretrain_encoder=False,
                     textual_embedding_trainable=False, name='', gain=1.0, seed=1, ids=True, native_feed=True,
-                    background=True, pretrain_name='')
+                    native_load=True, background=True, pretrain_name='')
         with contextlib.redirect_stdout(io.StringIO()):
             cfg = settings.Config(base)
         t0 = time.perf_counter()
@@ -251,10 +251,12 @@ def e2e_legs(wl, word, steps, dropout, device):
         model = NativeModel(word, len(h.data), wl['B'], wl['W'], wl['T'], wl['K1'] - 1, wl['F'], wl['k'], wl['U'],
                             arch=wl['arch'], dropout=dropout, lr=1e-3, seed=7, device=device,
                             title_table=h.docs.title_table)
-        out = dict(users=len(h.data), task_load_s=round(load_s, 1), steps=steps)
+        out = dict(users=len(h.data), docs=wl['N_d'], task_load_s=round(load_s, 2), synth_write_s=round(write_s, 1),
+                   clickdata_mb=round(os.path.getsize(os.path.join(d, 'ClickData.tsv')) / 1e6, 1), steps=steps,
+                   loader='C++ (liblstur_data.so: lstur_docs_load + lstur_clicks_load incl. the doc-id check)')
         np.random.seed(0)
         random.seed(0)
-        for name, feed in (('native_feed', NativeTrainFeed(h, seed=1)), ('python_ids_feed', h.train_ids)):
+        for name, feed in (('native_feed', h.native_feed()), ('python_ids_feed', h.train_ids)):
             nonpad = []
             # one batch of look-ahead, as NativeModel.fit_generator does: the next batch is uploaded and announced to the
             # library (lstur_prefetch_ids) before the current step is launched
@@ -536,7 +538,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['parity'] = parity_check(model, wl, titles, batches[0])
-            if args.e2e_steps > 0 and wl.get('encoder', 'cnnatt') == 'cnnatt' and wl['B'] <= 64:
+            if args.e2e_steps > 0 and wl.get('encoder', 'cnnatt') == 'cnnatt':
                 out['e2e'] = e2e_legs(wl, word, args.e2e_steps, args.dropout, 'cuda:%d' % local)
             out['cpu_baseline'] = cpu_baseline(wl, titles, word, batches)
         else:

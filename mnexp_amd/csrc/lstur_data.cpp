@@ -7,6 +7,7 @@
 // with NumPy's legacy RandomState algorithms restated from their published definitions:
 //   MT19937 (init_genrand / genrand_int32), randint via masked rejection on 32-bit draws,
 //   shuffle of a Python list = Fisher-Yates from the back with random_interval.
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -97,7 +98,8 @@ struct Clicks {
 // and reads as the pad doc 0 IN PLACE afterwards
 struct ClickWindow {
   int W = 0;
-  int64_t delta = 0;                // 0: plain window
+  bool timed = false;               // the `...Days` window
+  int64_t delta = 0;                // seconds an entry stays visible
   int64_t pushes = 0;
   std::vector<int32_t> ids;
   std::vector<int64_t> exp;
@@ -110,21 +112,21 @@ struct ClickWindow {
   void push(int32_t doc, int64_t t) {
     memmove(ids.data(), ids.data() + 1, (size_t)(W - 1) * sizeof(int32_t));
     ids[W - 1] = doc;
-    if (delta) {
+    if (timed) {
       memmove(exp.data(), exp.data() + 1, (size_t)(W - 1) * sizeof(int64_t));
       exp[W - 1] = t + delta;
     }
     ++pushes;
   }
   void get(int64_t t, int32_t* out) const {
-    if (!delta) {
+    if (!timed) {
       memcpy(out, ids.data(), (size_t)W * sizeof(int32_t));
       return;
     }
     for (int i = 0; i < W; ++i) out[i] = exp[i] >= t ? ids[i] : 0;
   }
   int64_t count(int64_t t) const {      // plain: pushes so far (Window.count); days: visible entries (count(time))
-    if (!delta) return pushes;
+    if (!timed) return pushes;
     int64_t n = 0;
     for (int i = 0; i < W; ++i) n += exp[i] >= t;
     return n;
@@ -141,8 +143,22 @@ struct lstur_data {
   int64_t user, imp, pidx;
   ClickWindow win;
   bool user_open;
-  std::vector<int32_t> pending;     // pointwise: the K negative rows that follow a positive row
-  size_t pend_at = 0;
+  // pointwise: the K negative rows that follow a positive row.  The reference's generator yields the positive row FIRST and
+  // draws the negatives when it is resumed (`for neg in impression.negative_samples(K)` behind the yield, paper.py:52-57):
+  // a pool shuffle between the two consumes the generator state in between, so the draw is deferred the same way
+  struct Pending {
+    std::vector<int32_t> rows;      // K records (heads filled, candidates drawn on demand)
+    size_t at = 0;
+    const Clicks* src = nullptr;    // != NULL: the negatives of impression `imp` are still to be drawn
+    int64_t imp = 0;
+    bool empty() const { return at >= rows.size(); }
+    void clear() {
+      rows.clear();
+      at = 0;
+      src = nullptr;
+    }
+  };
+  Pending pending;
   // sample arena + pool of slot ids (pool order = the Python list's order)
   std::vector<int32_t> arena;
   std::vector<int32_t> free_slots, pool;
@@ -150,8 +166,7 @@ struct lstur_data {
   int64_t v_user = 0, v_imp = 0, v_pidx = 0;
   bool v_open = false;
   ClickWindow v_win;
-  std::vector<int32_t> v_pending;
-  size_t v_pend_at = 0;
+  Pending v_pending;
   // ---- test_gen: one pass over the same users, one impression at a time
   int64_t t_user = 0, t_imp = 0;
   bool t_open = false;
@@ -163,14 +178,12 @@ struct lstur_data {
     pool.clear();
     free_slots.clear();
     pending.clear();
-    pend_at = 0;
     const int cap = 100 * B + B + 8;
     arena.assign((size_t)cap * rec, 0);
     for (int i = cap - 1; i >= 0; --i) free_slots.push_back(i);
     v_user = 0;
     v_open = false;
     v_pending.clear();
-    v_pend_at = 0;
     t_user = 0;
     t_open = false;
   }
@@ -184,7 +197,7 @@ struct lstur_data {
       if (tr.imp_off[u + 1] > tr.imp_off[u] && va.imp_off[u + 1] > va.imp_off[u]) return true;
     return false;
   }
-  int64_t time_of(const Clicks& c, int64_t i) const { return win.delta ? c.time[i] : 0; }
+  int64_t time_of(const Clicks& c, int64_t i) const { return win.timed ? c.time[i] : 0; }
   // one record: user | window as seen at `t` | cands | label
   void fill_head(int32_t* dst, int64_t u, const ClickWindow& w, int64_t t) const {
     dst[0] = (int32_t)u;
@@ -197,8 +210,7 @@ struct lstur_data {
   }
   // the record(s) of one positive click: listwise one record; pointwise the positive row into dst and K negative rows
   // into `queue` (they are emitted next, task/paper.py:52-57)
-  void emit_click(int32_t* dst, int64_t u, const ClickWindow& w, const Clicks& c, int64_t i, int32_t p,
-                  std::vector<int32_t>* queue, size_t* queue_at) {
+  void emit_click(int32_t* dst, int64_t u, const ClickWindow& w, const Clicks& c, int64_t i, int32_t p, Pending* queue) {
     const int64_t t = time_of(c, i);
     fill_head(dst, u, w, t);
     int32_t* cd = dst + 1 + W;
@@ -210,24 +222,29 @@ struct lstur_data {
     }
     cd[0] = p;
     cd[1] = 1;
-    std::vector<int32_t> negs(K);
-    draw_negatives(c, i, negs.data());
-    queue->assign((size_t)K * rec, 0);
-    *queue_at = 0;
-    for (int k = 0; k < K; ++k) {
-      int32_t* r = queue->data() + (size_t)k * rec;
-      memcpy(r, dst, (size_t)(1 + W) * sizeof(int32_t));
-      r[1 + W] = negs[k];
-      r[2 + W] = 0;
+    queue->rows.assign((size_t)K * rec, 0);
+    queue->at = 0;
+    queue->src = &c;
+    queue->imp = i;
+    for (int k = 0; k < K; ++k) memcpy(queue->rows.data() + (size_t)k * rec, dst, (size_t)(1 + W) * sizeof(int32_t));
+  }
+  // the next queued negative row (draws the impression's K negatives when the first one is asked for)
+  void pop_pending(Pending* q, int32_t* dst) {
+    if (q->src) {
+      std::vector<int32_t> negs(K);
+      draw_negatives(*q->src, q->imp, negs.data());
+      for (int k = 0; k < K; ++k) {
+        q->rows[(size_t)k * rec + 1 + W] = negs[k];
+        q->rows[(size_t)k * rec + 2 + W] = 0;
+      }
+      q->src = nullptr;
     }
+    memcpy(dst, q->rows.data() + q->at, (size_t)rec * sizeof(int32_t));
+    q->at += rec;
   }
   // next record of train_gen into dst (rec ints)   task/paper.py:38-60, 385-399, 528-542, 698-716
   void next_sample(int32_t* dst) {
-    if (pend_at < pending.size()) {
-      memcpy(dst, pending.data() + pend_at, (size_t)rec * sizeof(int32_t));
-      pend_at += rec;
-      return;
-    }
+    if (!pending.empty()) return pop_pending(&pending, dst);
     for (;;) {
       if (!user_open) {
         while (tr.imp_off[user + 1] == tr.imp_off[user]) {   // `if ih:` -- users without training history are skipped
@@ -253,7 +270,7 @@ struct lstur_data {
       const int32_t p = tr.pos[pidx++];
       const int64_t t = time_of(tr, imp);
       const bool emit = win.count(t) > 0;
-      if (emit) emit_click(dst, user, win, tr, imp, p, &pending, &pend_at);
+      if (emit) emit_click(dst, user, win, tr, imp, p, &pending);
       win.push(p, t);                      // ch.push(pos): the history excludes the current click
       if (emit) return;
     }
@@ -267,11 +284,7 @@ struct lstur_data {
   bool both(int64_t u) const { return tr.imp_off[u + 1] > tr.imp_off[u] && va.imp_off[u + 1] > va.imp_off[u]; }
   // next record of valid_gen   task/paper.py:62-77, 401-418, 544-562, 718-735
   void next_valid(int32_t* dst) {
-    if (v_pend_at < v_pending.size()) {
-      memcpy(dst, v_pending.data() + v_pend_at, (size_t)rec * sizeof(int32_t));
-      v_pend_at += rec;
-      return;
-    }
+    if (!v_pending.empty()) return pop_pending(&v_pending, dst);
     for (;;) {
       if (!v_open) {
         while (!both(v_user)) v_user = (v_user + 1) % n_users;
@@ -292,7 +305,7 @@ struct lstur_data {
         continue;
       }
       const int32_t p = va.pos[v_pidx++];
-      emit_click(dst, v_user, v_win, va, v_imp, p, &v_pending, &v_pend_at);
+      emit_click(dst, v_user, v_win, va, v_imp, p, &v_pending);
       return;
     }
   }
@@ -364,6 +377,7 @@ int finish_create(lstur_data* d, lstur_data** out) {
   d->rec = 1 + d->W + d->C + 1;
   d->win.W = d->v_win.W = d->t_win.W = d->W;
   d->v_win.delta = d->t_win.delta = d->win.delta;
+  d->v_win.timed = d->t_win.timed = d->win.timed;
   d->rng.seed(0);
   d->restart();
   *out = d;
@@ -413,11 +427,11 @@ int lstur_data_create(int32_t n_users, const int64_t* imp_off, const int64_t* po
 // mode 0: listwise samples (Seq2VecPaperSoftmax[Id]); 1: pointwise rows (Seq2VecPaper / ...Dot / ...Id: a positive row,
 // then K rows of sampled negatives).  days > 0: the time-aware window of the `...Days` tasks (needs time stamps).
 int lstur_data_create_from_clicks(const lstur_clicks* c, int32_t window, int32_t negatives, int32_t batch, int32_t rank,
-                                  int32_t world, int32_t mode, int32_t days, lstur_data** out) {
+                                  int32_t world, int32_t mode, double days, lstur_data** out) {
   if (!c || !out) return fail("NULL argument");
   const int32_t n_users = lstur_clicks_users(c);
   if (n_users < 1 || window < 1 || negatives < 0 || batch < 1 || world < 1 || rank < 0 || rank >= world || mode < 0 || mode > 1 ||
-      days < 0)
+      !(days >= 0))
     return fail("bad dimensions");
   if (days > 0 && !lstur_clicks_timed(c)) return fail("the `...Days` tasks need a time stamp in every impression");
   lstur_data* d = new lstur_data();
@@ -428,7 +442,9 @@ int lstur_data_create_from_clicks(const lstur_clicks* c, int32_t window, int32_t
   d->rank = rank;
   d->world = world;
   d->mode = mode;
-  d->win.delta = (int64_t)days * 86400;
+  // timedelta(days=days) has microsecond resolution, the time stamps whole seconds: click + delta >= t  <=>  t - click <= floor(delta)
+  d->win.timed = days > 0;
+  d->win.delta = (int64_t)floor(llround(days * 86400e6) / 1e6);
   for (int which = 0; which < 2; ++which) {
     const int64_t *io, *po, *no, *tm;
     const int32_t *p, *n;

@@ -13,7 +13,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/lstur_data.h"
@@ -55,6 +57,17 @@ void split(Span s, const char* sep, std::vector<Span>* out) {
   const size_t k = strlen(sep);
   const char* p = s.p;
   const char* end = s.p + s.n;
+  if (k == 1) {                       // (the token and column separators: memchr, no needle set-up per call)
+    for (;;) {
+      const char* q = (const char*)memchr(p, sep[0], (size_t)(end - p));
+      if (!q) {
+        out->push_back(Span{p, (size_t)(end - p)});
+        return;
+      }
+      out->push_back(Span{p, (size_t)(q - p)});
+      p = q + 1;
+    }
+  }
   for (;;) {
     const char* q = (const char*)memmem(p, (size_t)(end - p), sep, k);
     if (!q) {
@@ -186,7 +199,6 @@ int lstur_docs_load(const char* path, int32_t title_len, lstur_docs** out) {
     ++lineno;
     Span line{p, (size_t)(nl - p)};
     p = nl + 1;
-    if (p >= end && line.n == 0) break;                       // (the terminator this loader appended)
     split(line, "\t", &cols);
     if (cols.size() < 5) return lstur_data_fail(at(path, lineno) + "fewer than 5 tab-separated columns");
     int64_t idx;
@@ -227,53 +239,50 @@ int lstur_docs_destroy(lstur_docs* d) {
   return 0;
 }
 
-int lstur_clicks_load(const char* path, const uint8_t* present, int32_t doc_count, lstur_clicks** out) {
-  if (!path || !out) return lstur_data_fail("clicks_load: bad argument");
-  std::string text, why;
-  if (!read_file(path, &text, &why)) return lstur_data_fail(why);
-  lstur_clicks* c = new lstur_clicks();
+// one chunk of whole lines -> its own CSR pair (offsets relative to the chunk); returns "" or the error (line = 1-based
+// line number inside the chunk)
+static std::string parse_click_chunk(const char* p, const char* end, const uint8_t* present, int32_t doc_count, ClickSet (&set)[2],
+                                     int32_t* n_users, int32_t* timed, int64_t* err_line) {
   std::vector<Span> cols, imps, fields, toks;
   std::vector<int64_t> ids;
   int64_t lineno = 0;
-  const char* p = text.data();
-  const char* end = p + text.size();
-  auto bail = [&](const std::string& m) {
-    delete c;
-    return lstur_data_fail(m);
+  auto bad = [&](const char* m) {
+    *err_line = lineno;
+    return std::string(m);
   };
   while (p < end) {
     const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
     ++lineno;
     Span line{p, (size_t)(nl - p)};
     p = nl + 1;
-    if (p >= end && line.n == 0) break;
     split(line, "\t", &cols);
-    if (cols.size() < 4) return bail(at(path, lineno) + "fewer than 4 tab-separated columns");
+    if (cols.size() < 4) return bad("fewer than 4 tab-separated columns");
     for (int which = 0; which < 2; ++which) {
-      ClickSet& s = c->set[which];
+      ClickSet& s = set[which];
       const Span col = cols[2 + which];
       if (col.n) {                                             // `if cols[k] else []`
         split(col, "#N#", &imps);
         for (const Span& d : imps) {
           if (d.starts_with("#TAB#")) continue;                // impressions without positives are dropped (paper.py:21)
           split(d, "#TAB#", &fields);
-          if (fields.size() < 2) return bail(at(path, lineno) + "impression without a '#TAB#' negatives field");
+          if (fields.size() < 2) return bad("impression without a '#TAB#' negatives field");
           for (int f = 0; f < 2; ++f) {
-            if (!int_list(fields[f], &ids, &toks)) return bail(at(path, lineno) + "impression: invalid literal for int()");
+            if (!int_list(fields[f], &ids, &toks)) return bad("impression: invalid literal for int()");
             std::vector<int32_t>& dst = f ? s.neg : s.pos;
             for (int64_t v : ids) {
-              if (present && (v < 0 || v >= doc_count || !present[v]))
-                return bail(at(path, lineno) + "unknown doc id " + std::to_string(v));
-              if (v < INT32_MIN || v > INT32_MAX) return bail(at(path, lineno) + "doc id out of range");
+              if (present && (v < 0 || v >= doc_count || !present[v])) {
+                *err_line = lineno;
+                return "unknown doc id " + std::to_string(v);
+              }
+              if (v < INT32_MIN || v > INT32_MAX) return bad("doc id out of range");
               dst.push_back((int32_t)v);
             }
           }
           int64_t t = INT64_MIN;
           if (fields.size() >= 3) {
-            if (!parse_time(fields[2], &t))
-              return bail(at(path, lineno) + "time data does not match format '%m/%d/%Y %I:%M:%S %p'");
+            if (!parse_time(fields[2], &t)) return bad("time data does not match format '%m/%d/%Y %I:%M:%S %p'");
           } else {
-            c->timed = 0;
+            *timed = 0;
           }
           s.time.push_back(t);
           s.pos_off.push_back((int64_t)s.pos.size());
@@ -282,9 +291,91 @@ int lstur_clicks_load(const char* path, const uint8_t* present, int32_t doc_coun
       }
       s.imp_off.push_back((int64_t)s.time.size());
     }
-    c->n_users++;
+    ++*n_users;
   }
-  if (c->n_users == 0) return bail(std::string(path) + ": no user rows");
+  return std::string();
+}
+
+int lstur_clicks_load(const char* path, const uint8_t* present, int32_t doc_count, lstur_clicks** out) {
+  if (!path || !out) return lstur_data_fail("clicks_load: bad argument");
+  std::string text, why;
+  if (!read_file(path, &text, &why)) return lstur_data_fail(why);
+  // (an empty line -- also a trailing one -- has fewer than 4 columns: the reference raises IndexError there)
+  const char* begin = text.data();
+  const char* end = begin + text.size();
+  // chunks of whole lines, one per hardware thread (a 1 M-user file is ~3 GB of text)
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt ? std::min(nt, 32u) : 4u;
+  if ((size_t)(end - begin) < ((size_t)1 << 22)) nt = 1;
+  std::vector<const char*> cut{begin};
+  for (unsigned t = 1; t < nt; ++t) {
+    const char* q = begin + (size_t)(end - begin) * t / nt;
+    if (q <= cut.back()) continue;
+    const char* nl = (const char*)memchr(q, '\n', (size_t)(end - q));
+    if (!nl || nl + 1 >= end) break;
+    cut.push_back(nl + 1);
+  }
+  cut.push_back(end);
+  const size_t nc = cut.size() - 1;
+  struct Part {
+    ClickSet set[2];
+    int32_t users = 0, timed = 1;
+    int64_t err_line = 0;
+    std::string err;
+  };
+  std::vector<Part> parts(nc);
+  std::vector<std::thread> th;
+  for (size_t k = 0; k < nc; ++k)
+    th.emplace_back([&, k]() {
+      Part& P = parts[k];
+      const size_t bytes = (size_t)(cut[k + 1] - cut[k]);      // (one allocation per array instead of a doubling chain)
+      for (int w = 0; w < 2; ++w) {
+        const size_t share = w ? bytes / 5 : bytes;             // the training period holds most of a line
+        P.set[w].pos.reserve(share / 16);
+        P.set[w].neg.reserve(share / 9);
+        P.set[w].time.reserve(share / 80);
+        P.set[w].pos_off.reserve(share / 80);
+        P.set[w].neg_off.reserve(share / 80);
+      }
+      P.err = parse_click_chunk(cut[k], cut[k + 1], present, doc_count, P.set, &P.users, &P.timed, &P.err_line);
+    });
+  for (auto& t : th) t.join();
+  int64_t lines_before = 0;
+  for (size_t k = 0; k < nc; ++k) {                            // the first failure in file order, with its absolute line
+    if (!parts[k].err.empty()) return lstur_data_fail(at(path, lines_before + parts[k].err_line) + parts[k].err);
+    lines_before += parts[k].users;
+  }
+  lstur_clicks* c = new lstur_clicks();
+  for (int which = 0; which < 2; ++which) {
+    ClickSet& s = c->set[which];
+    size_t n_imp = 0, n_pos = 0, n_neg = 0, n_usr = 0;
+    for (const Part& P : parts) n_imp += P.set[which].time.size(), n_pos += P.set[which].pos.size(), n_neg += P.set[which].neg.size(), n_usr += (size_t)P.users;
+    s.imp_off.reserve(n_usr + 1);
+    s.pos_off.reserve(n_imp + 1);
+    s.neg_off.reserve(n_imp + 1);
+    s.time.reserve(n_imp);
+    s.pos.reserve(n_pos);
+    s.neg.reserve(n_neg);
+    for (Part& P : parts) {
+      const ClickSet& q = P.set[which];
+      const int64_t i0 = (int64_t)s.time.size(), p0 = (int64_t)s.pos.size(), n0 = (int64_t)s.neg.size();
+      for (size_t i = 1; i < q.imp_off.size(); ++i) s.imp_off.push_back(i0 + q.imp_off[i]);
+      for (size_t i = 1; i < q.pos_off.size(); ++i) s.pos_off.push_back(p0 + q.pos_off[i]);
+      for (size_t i = 1; i < q.neg_off.size(); ++i) s.neg_off.push_back(n0 + q.neg_off[i]);
+      s.time.insert(s.time.end(), q.time.begin(), q.time.end());
+      s.pos.insert(s.pos.end(), q.pos.begin(), q.pos.end());
+      s.neg.insert(s.neg.end(), q.neg.begin(), q.neg.end());
+      P.set[which] = ClickSet();                                // (free the part as soon as it is merged)
+    }
+  }
+  for (const Part& P : parts) {
+    c->n_users += P.users;
+    c->timed &= P.timed;
+  }
+  if (c->n_users == 0) {
+    delete c;
+    return lstur_data_fail(std::string(path) + ": no user rows");
+  }
   *out = c;
   return 0;
 }
@@ -330,7 +421,6 @@ int lstur_vocab_load(const char* path, int32_t dim, float** matrix, int32_t* row
     ++lineno;
     Span line = strip(Span{p, (size_t)(nl - p)});              // line.strip()
     p = nl + 1;
-    if (p >= end && line.n == 0) break;
     split(line, "\t", &cols);
     const Span vec = cols.back();
     int64_t spaces = 0;

@@ -68,6 +68,17 @@ def allgather_rows(rows, row_grads, group=None):
     return all_rows, all_grads
 
 
+def allreduce_sums(values, group=None):
+    """sum a short list of Python floats over the ranks (float64; evaluation statistics, mnexp_amd/task/paper.py)"""
+    t = torch.tensor(list(values), dtype=torch.float64)
+    if not (dist.is_available() and dist.is_initialized()) or world_size(group) == 1:
+        return t.tolist()
+    if dist.get_backend(group) == 'nccl':
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().tolist()
+
+
 def replica_checksum(tensors, group=None):
     """max over ranks of |sum - mean over ranks(sum)| for each tensor: 0.0 when replicas are bit-identical."""
     sums = torch.stack([t.double().sum() for t in tensors])

@@ -66,6 +66,8 @@ _TRAIN_OPTIONS = [
     (('--ids',), dict(is_flag=True, help='feed doc-id batches; titles stay resident on the GPU')),
     (('--native-feed',), dict(is_flag=True, help='C++ sample feed (liblstur_data.so): the same batches as the Python '
                                                   'generators for np.random.seed(--seed), implies --ids')),
+    (('--native-load/--python-load',), dict(default=True, help='parse DocMeta / ClickData / Vocab.tsv with the C++ loaders '
+                                                                '(liblstur_data.so; same tables, same errors) or in Python')),
 ]
 
 
@@ -82,9 +84,9 @@ def run_training(config, task_handler=None):
         task_handler = task.get(config)
     native_feed = bool(getattr(config, 'native_feed', False))
     use_ids = bool(getattr(config, 'ids', False)) or native_feed
-    if native_feed:
-        from .data_native import NativeTrainFeed
-        training_data = NativeTrainFeed(task_handler, seed=int(getattr(config, 'seed', 0) or 0))
+    feed = task_handler.native_feed() if (native_feed and hasattr(task_handler, 'native_feed')) else None
+    if feed is not None:
+        training_data = feed
     else:
         training_data = task_handler.train_ids if use_ids else task_handler.train
     model = None
@@ -116,8 +118,8 @@ def run_training(config, task_handler=None):
 def train(config):
     from . import dist
     dist.maybe_init_from_env()
-    # under data parallelism every rank trains and evaluates (validation / test walk ALL users on every rank, so the
-    # metrics are the single-GPU ones), but only rank 0 writes the log file and the console
+    # under data parallelism every rank trains on its shard of users; the callback's test impressions are dealt out over the
+    # ranks and their metric sums all-reduced (the single-GPU numbers); only rank 0 writes the log file and the console
     handlers = [logging.FileHandler(config.log_output), logging.StreamHandler()] if dist.rank() == 0 else [logging.NullHandler()]
     logging.basicConfig(format='%(asctime)s : %(levelname)s : %(message)s', level=logging.INFO, handlers=handlers)
     run_training(config)

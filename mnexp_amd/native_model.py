@@ -240,7 +240,8 @@ class NativeModel:
             raise _lib.LsturError('news encoder {!r} is not on the native path (have cnnatt, mhsa)'.format(enc))
         head = getattr(task, 'head', 'softmax')
         score_model = getattr(cfg, 'score_model', 'dot') if head == 'softmax' else 'dot'
-        emb = utils.load_textual_embedding(cfg.title_embedding_input, cfg.textual_embedding_dim)
+        emb = utils.load_textual_embedding(cfg.title_embedding_input, cfg.textual_embedding_dim,
+                                           native=bool(getattr(cfg, 'native_load', False)))
         vmax = int(task.docs.title_table.max())
         if vmax >= emb.shape[0]:
             raise IndexError('title token id {} outside the {}-row word table'.format(vmax, emb.shape[0]))

@@ -32,7 +32,7 @@ _TRAIN_KEYS = ('task arch round days epochs batch_size training_step validation_
 # keys of the other reference commands, accepted so a shared Config dict still loads
 _OTHER_KEYS = ('evaluate_sessions target use_vertical pipeline_input lrd_on_epochs '
                'use_generator user_feature_size doc_feature_size use_vertical_type').split()
-_NATIVE_KEYS = ('device', 'world_size', 'seed', 'ids', 'native_feed')
+_NATIVE_KEYS = ('device', 'world_size', 'seed', 'ids', 'native_feed', 'native_load')
 
 
 class PythonLiteralOption(click.Option):

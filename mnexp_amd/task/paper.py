@@ -43,6 +43,17 @@ class Seq2VecPaper(Seq2Vec):
     def _load_data(self):
         """ClickData.tsv col[2] = training-period history, col[3] = validation-period history."""
         logging.info('[+] loading data')
+        self._feed = None
+        if getattr(self.config, 'native_load', False):
+            # C++ loader (include/lstur_data.h): CSR arrays instead of a list of Python objects per user; the doc-id check
+            # runs inside it; `self.data` stays a sequence of (training impressions, validation impressions)
+            from ..data_native import ClickData, LazyUsers
+            self.clicks = ClickData(self.config.training_data_input, present=self.docs.present)
+            self.data = LazyUsers(self.clicks, self.Impression)
+            super(Seq2VecPaper, self)._load_data()
+            logging.info('[-] loaded data')
+            return
+        self.clicks = None
         self.data = []
         with open(self.config.training_data_input) as file:
             for line in file:
@@ -61,6 +72,20 @@ class Seq2VecPaper(Seq2Vec):
     def save_model(self):
         pass                                          # paper.py:254-255
 
+    def native_feed(self):
+        """ONE C++ feed per task (training, validation and test generators share its generator state like the reference's
+        share NumPy's global one) when --native-feed is set and the configuration is on its path; else None"""
+        if not getattr(self.config, 'native_feed', False):
+            return None
+        if getattr(self, '_feed', None) is None:
+            from ..data_native import NativeFeed
+            try:
+                self._feed = NativeFeed(self, seed=int(getattr(self.config, 'seed', 0) or 0))
+            except NotImplementedError as e:
+                logging.info('[*] native feed not used: {}'.format(e))
+                self._feed = False
+        return self._feed or None
+
     # ---- pointwise samples: (user?, hist_ids[W], [candidate], label) -------------------------------
     has_user = False
     head = 'point_mlp'                                # score_encoder, paper.py:223-227
@@ -68,8 +93,9 @@ class Seq2VecPaper(Seq2Vec):
     def _users(self, shard=False):
         """(user id or None, (train impressions, valid impressions)) per ClickData row.  ``shard=True`` (the TRAINING
         generators under data parallelism): only the rows this rank owns, r, r+N, ... (mnexp_amd/dist.py)
-        -- for the id-less tasks too, or every rank would train on the same samples.  Validation / test generators walk
-        every user on every rank, so the reported metrics are those of the single-GPU run."""
+        -- for the id-less tasks too, or every rank would train on the same samples.  The validation generator walks every
+        user on every rank; the test impressions of the callback are dealt out over the ranks (`_report`), which all-reduces
+        the metric sums: the reported numbers are those of the single-GPU run."""
         from .. import dist
         w, r = dist.world_size(), dist.rank()
         idx = dist.shard_users(len(self.data), r, w) if (shard and w > 1) else range(len(self.data))
@@ -174,6 +200,25 @@ class Seq2VecPaper(Seq2Vec):
         self.model = NativeModel.from_task(self, user_count=len(self.data) if self.has_user else 0)
         self.test_model = self.model.test_view()
 
+    def _report(self, limit):
+        """Mean per-impression AUC / nDCG@10 / nDCG@5 / MRR over the first `limit` validation impressions (paper.py:504-516).
+        Under data parallelism the impressions are dealt out over the ranks (i % world == rank) and the per-metric sums and
+        the count are all-reduced: every rank reports the single-process means without predicting every impression."""
+        from .. import dist
+        w, r = dist.world_size(), dist.rank()
+        sums, n = np.zeros(7), 0
+        for i, y_pred, y_true in self.test_items(limit, r, w):
+            sums += (roc_auc_score(y_true, y_pred), utils.ndcg_score(y_true, y_pred, 10), utils.ndcg_score(y_true, y_pred, 5),
+                     utils.mrr_score(y_true, y_pred), np.sum(y_true), len(y_true), i)
+            n += 1
+        if w > 1:
+            tot = dist.allreduce_sums(list(sums) + [n])
+            sums, n = np.array(tot[:7]), int(round(tot[7]))
+        v = sums / max(n, 1)
+        utils.logging_evaluation(dict(auc=v[0], ndcgx=v[1], ndcgv=v[2], mrr=v[3]))
+        utils.logging_evaluation(dict(pos=v[4], size=v[5], num=v[6] * 2 + 1))
+        return dict(auc=v[0], ndcgx=v[1], ndcgv=v[2], mrr=v[3])
+
     def callback(self, epoch):
         """task/seq2vec.py:296-321 (the pointwise tasks do not override it): the running AUC metric is
         re-initialised, lr *= decay, then mean per-impression AUC / nDCG@10 / nDCG@5 / MRR over the first
@@ -183,14 +228,7 @@ class Seq2VecPaper(Seq2Vec):
         self.model.optimizer.lr = self.model.optimizer.lr * self.config.learning_rate_decay
 
         def report():
-            rows = [(roc_auc_score(y_true, y_pred), utils.ndcg_score(y_true, y_pred, 10),
-                     utils.ndcg_score(y_true, y_pred, 5), utils.mrr_score(y_true, y_pred), np.sum(y_true),
-                     len(y_true), i)
-                    for i, (y_pred, y_true) in zip(range(self.config.testing_impression), self.test)]
-            v = [np.mean(x) for x in zip(*rows)]
-            utils.logging_evaluation(dict(auc=v[0], ndcgx=v[1], ndcgv=v[2], mrr=v[3]))
-            utils.logging_evaluation(dict(pos=v[4], size=v[5], num=v[6] * 2 + 1))
-            return dict(auc=v[0], ndcgx=v[1], ndcgv=v[2], mrr=v[3])
+            return self._report(self.config.testing_impression)
 
         self.last_metrics = report()
         if epoch == self.config.epochs - 1 and os.path.exists(self.config.testing_data_input):
@@ -271,17 +309,8 @@ class Seq2VecPaperSoftmax(Seq2VecPaper):
         self.model.optimizer.lr = self.model.optimizer.lr * self.config.learning_rate_decay
         self.model, self.test_model = self.test_model, self.model
 
-        def rows(limit):
-            for i, (y_pred, y_true) in zip(range(limit), self.test):
-                yield (roc_auc_score(y_true, y_pred), utils.ndcg_score(y_true, y_pred, 10),
-                       utils.ndcg_score(y_true, y_pred, 5), utils.mrr_score(y_true, y_pred),
-                       np.sum(y_true), len(y_true), i)
-
         def report(limit):
-            v = [np.mean(x) for x in zip(*rows(limit))]
-            utils.logging_evaluation(dict(auc=v[0], ndcgx=v[1], ndcgv=v[2], mrr=v[3]))
-            utils.logging_evaluation(dict(pos=v[4], size=v[5], num=v[6] * 2 + 1))
-            return dict(auc=v[0], ndcgx=v[1], ndcgv=v[2], mrr=v[3])
+            return self._report(limit)
 
         self.last_metrics = report(self.config.validation_impression)
         if epoch == self.config.epochs - 1:

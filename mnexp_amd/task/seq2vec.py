@@ -102,6 +102,13 @@ class Seq2Vec:
         """DocMeta.tsv: col[1] doc index, col[4] title ids; first non-empty '#N#' segment kept."""
         logging.info("[+] loading docs metadata")
         T = self.config.title_shape
+        if getattr(self.config, 'native_load', False):     # the same table from the C++ loader (include/lstur_data.h)
+            from ..data_native import load_docs
+            table, present = load_docs(self.config.doc_meta_input, T)
+            self.doc_count = len(present)
+            self.docs = DocTable(table, present)
+            logging.info("[-] loaded docs metadata")
+            return
         title_parser = document.DocumentParser(document.parse_document(), document.pad_document(1, T))
         rows = {}
         with open(self.config.doc_meta_input) as file:
@@ -162,22 +169,47 @@ class Seq2Vec:
 
     @property
     def valid_ids(self):
+        feed = self.native_feed()
+        if feed is not None:                   # the same batches from the C++ feed (include/lstur_data.h)
+            yield from feed.valid_batches()
         gen = self.valid_gen_ids()
         B = self.config.batch_size
         while True:
             yield self._stack_ids([next(gen) for _ in range(B)])
 
+    def native_feed(self):
+        """the task's C++ sample feed (None: the Python generators) -- tasks with a natively loaded ClickData override"""
+        return None
+
+    def test_items(self, limit=None, rank=0, world=1):
+        """(i, scores, labels) of validation impression i for i = rank, rank + world, ... < limit: `test` with the
+        impressions dealt out over the ranks of a data-parallel run (world == 1: every impression)."""
+        native = hasattr(self.model, 'predict_ids')
+        feed = self.native_feed()
+        if feed is not None:
+            it = feed.test_impressions(rank, world) if world > 1 else enumerate(feed.test_impressions())
+            for i, (ids, labels) in it:
+                if limit is not None and i >= limit:
+                    return
+                yield i, self.model.predict_ids(*ids).reshape(-1), labels
+            return
+        for i, rows in enumerate(self.test_gen_ids()):
+            if limit is not None and i >= limit:
+                return
+            if i % world != rank:
+                continue
+            if native:
+                ids, labels = self._stack_ids(rows)
+                yield i, self.model.predict_ids(*ids).reshape(-1), labels
+            else:
+                X, labels = self._expand(rows)
+                yield i, self.model.predict(X).reshape(-1), labels
+
     @property
     def test(self):
         """Per validation impression: [scores, labels] (seq2vec.py:202-206)."""
-        native = hasattr(self.model, 'predict_ids')
-        for rows in self.test_gen_ids():
-            if native:
-                ids, labels = self._stack_ids(rows)
-                yield [self.model.predict_ids(*ids).reshape(-1), labels]
-            else:
-                X, labels = self._expand(rows)
-                yield [self.model.predict(X).reshape(-1), labels]
+        for _, y_pred, y_true in self.test_items():
+            yield [y_pred, y_true]
 
     def build_model(self, epoch):
         if epoch == 0:

@@ -11,11 +11,16 @@ import os
 import numpy as np
 
 
-def load_textual_embedding(path, dimension):
+def load_textual_embedding(path, dimension, native=False):
     """Vocab.tsv rows ``word \\t index \\t "v0 v1 ..."`` -> float32 [max_index+1, dimension].
     Rows whose vector does not have exactly ``dimension`` fields are skipped; missing
-    indices (row 0 included) are zero."""
+    indices (row 0 included) are zero.  native: the C++ loader (include/lstur_data.h), the same matrix."""
     logging.info('[+] loading embedding data from {}'.format(os.path.split(path)[-1]))
+    if native:
+        from .data_native import load_vocab
+        matrix = load_vocab(path, dimension)
+        logging.info('[-] loaded {} rows from {}'.format(len(matrix), os.path.split(path)[-1]))
+        return matrix
     rows = {}
     with open(path) as f:
         for line in f:

@@ -103,3 +103,59 @@ def test_task_shards_users_across_ranks(monkeypatch):
     got = list(h2._users(shard=True))
     assert [d is h2.data[i] for (u, d), i in zip(got, range(2, len(h2.data), 3))] == [True] * len(got)
     assert all(u is None for u, _ in got)
+
+
+class _HashModel:
+    """stands in for the GPU model: a deterministic score per (user, history, candidate) row"""
+
+    class _Opt:
+        lr = 1e-3
+
+    optimizer = _Opt()
+
+    def predict_ids(self, user, hist, cand):
+        h = (user.astype(np.int64) * 7919 + hist.astype(np.int64).sum(axis=1) * 104729 + cand.astype(np.int64).reshape(-1) * 1299709) % 1000003
+        return (h / 1000003.0).astype(np.float32)
+
+
+def _eval_worker(rank, world, port, native, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from test_data_path import make_config, GOLD
+    from mnexp_amd import task
+    h = task.get(make_config(os.path.join(GOLD, 'tiny'), native_load=native, native_feed=native, validation_impression=37))
+    h.model = h.test_model = _HashModel()
+    seen = [i for i, _, _ in h.test_items(37, rank, world)]
+    assert all(i % world == rank for i in seen) and len(seen) in (37 // world, 37 // world + 1)
+    h.callback(0)
+    out.put((rank, h.last_metrics, len(seen)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('native', [False, True])
+def test_evaluation_is_sharded_by_impression_and_reduces_to_the_single_process_metrics(native):
+    """SURVEY.md 8e / reference callback task/paper.py:497-524: under data parallelism rank r predicts validation impressions
+    r, r + N, ... only; the all-reduced (sum of metric, count) gives every rank the single-process AUC / nDCG / MRR."""
+    from test_data_path import make_config, GOLD
+    from mnexp_amd import task
+    h = task.get(make_config(os.path.join(GOLD, 'tiny'), native_load=native, native_feed=native, validation_impression=37))
+    h.model = h.test_model = _HashModel()
+    h.callback(0)
+    want = h.last_metrics
+    assert 0.0 < want['auc'] < 1.0
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, native, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = [q.get(timeout=5) for _ in range(world)]
+    assert sum(n for _, _, n in got) == 37
+    for _, m, _ in got:
+        for k in want:
+            assert abs(m[k] - want[k]) < 1e-12, (k, m[k], want[k])

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_header_symbols_exported():
     text = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'lstur_data.h')).read(), flags=re.S)
-    syms = sorted(set(re.findall(r'\b(lstur_data_[a-z0-9_]+)\s*\(', text)))
+    syms = sorted(set(re.findall(r'\b(lstur_(?:data|docs|clicks|vocab|synth)_[a-z0-9_]+)\s*\(', text)))
     assert syms == sorted(data_native.SIGNATURES)
     for s in syms:
         assert hasattr(data_native.lib, s)
