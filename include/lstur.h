@@ -437,7 +437,9 @@ int lstur_gru_pack_u(const float* gru_u, int32_t H, float* packed, lstur_stream 
  *   xw [n,W,3H] input projection incl. bias (row-major, gates z|r|h); gmask uint8 [n,W]; h0 [n,H] or NULL (zeros)
  *   hlast [n,H] = output of the last step.  tape: lstur_gru_tape_floats(n,W,H) floats of scratch that carries the
  *   saved activations to lstur_gru_bwd (layout opaque to the caller).  H <= 256; H <= 200 runs the kernels that
- *   keep the recurrent matrix resident in registers + LDS (set LSTUR_GRU_GENERIC=1 to force the general ones). */
+ *   keep the recurrent matrix resident in registers + LDS (set LSTUR_GRU_GENERIC=1 to force the general ones); their
+ *   forward computes the recurrent products as fp32-grade fp16 pairs (three v_mfma_f32_4x4x4_16b_f16 products on
+ *   power-of-two scaled operands, like the conv kernels; LSTUR_GRU_F32=1: fp32 MFMAs) -- pack and forward read the switch. */
 size_t lstur_gru_tape_floats(int32_t n, int32_t W, int32_t H);
 int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
                   float* hlast, int32_t n, int32_t W, int32_t H, lstur_stream stream);

@@ -39,18 +39,23 @@
 
 namespace lstur {
 
-constexpr int FX_BK = 16;
+// k-depth of a forward stage.  16 for both schemes: a 32-deep stage for the fp16 pair (two stages of 128 x 32 + 32 x 448 images
+// in two parts just fit the 160 KB of LDS; half the barriers and fragment-read restarts) was built and measured at the same
+// time within the box-to-box spread (hot 136.0 against 138.7 us, cold 151.9 against 150.6 us, tools/bench_convx.py) at 256
+// VGPRs + 4 spilled: the kernel is not bound by its barriers (the ablation says so too: -3 us without them).  The kernel
+// keeps the stage depth as a parameter.
+__host__ __device__ constexpr int fx_bk(int np) { return np == 2 ? 16 : 16; }
 
 int convx_dp(int D) { return (D + 7) / 8 * 8; }
-static int fx_kp(int D, int ksize) { return cdiv(ksize * convx_dp(D), FX_BK) * FX_BK; }
+static int fx_kp(int D, int ksize, int np) { return cdiv(ksize * convx_dp(D), fx_bk(np)) * fx_bk(np); }
 static int fx_np(int F) { return cdiv(F, 32) * 32; }
 // 16-bit elements of Ex for n_titles titles (+ slack: the k tail of the last window and clamped loads stay inside)
 size_t convx_e_elems(int n_titles, int T, int D, int ksize, int np) {
   return (size_t)n_titles * (T + ksize - 1) * convx_dp(D) * np + (size_t)np * 256;
 }
-size_t convx_w_elems(int D, int ksize, int F, int np) { return (size_t)np * fx_kp(D, ksize) * fx_np(F); }
-void convx_w_dims(int D, int ksize, int F, int* Kp, int* Np) {
-  *Kp = fx_kp(D, ksize);
+size_t convx_w_elems(int D, int ksize, int F, int np) { return (size_t)np * fx_kp(D, ksize, np) * fx_np(F); }
+void convx_w_dims(int D, int ksize, int F, int np, int* Kp, int* Np) {
+  *Kp = fx_kp(D, ksize, np);
   *Np = fx_np(F);
 }
 bool convx_supported(int D, int ksize, int F) { return D % 4 == 0 && F >= 1 && F <= 448 && ksize >= 1 && ksize <= 8; }
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256) void convx_pack_w_kernel(const float* __restri
 // fresh: the maximum is taken from W itself first (a first pack, or the caller changed the weights)
 void launch_convx_pack_w(const float* W, int D, int ksize, int F, unsigned short* Wx, int np, float* cs, int seq, bool fresh,
                          float grow, hipStream_t s) {
-  const int Kp = fx_kp(D, ksize), Np = fx_np(F);
+  const int Kp = fx_kp(D, ksize, np), Np = fx_np(F);
   const size_t total = (size_t)Kp * Np;
   const dim3 grid((unsigned)cdivz(total, 256));
   if (np == 2) {
@@ -356,10 +361,13 @@ void launch_convx_pack_w(const float* W, int D, int ksize, int F, unsigned short
 
 __host__ __device__ constexpr int fx_rows(int RWM) { return 32 * RWM; }   // RWM = row waves x row tiles per wave
 __host__ __device__ constexpr int fx_sb(int CW, int NTW) { return tr_stride(CW * NTW * 32); }
-// one stage: NP A images [BM][16] (32-byte rows, 16-byte halves swizzled by row bit 3) + NP B images [16][SB]
+// one stage: NP A images [BM][BK] (rows of BK / 8 sixteen-byte pieces, swizzled so that the 16 lanes of a ds_read_b128
+// group hit 16 different bank slots) + NP B images [BK][SB]
 __host__ __device__ constexpr int fx_stage(int NP, int RW, int CW, int NTW) {
-  return NP * fx_rows(RW) * FX_BK + NP * FX_BK * fx_sb(CW, NTW) + 64 * 8;   // + a 16-byte trash slot per lane
+  return NP * fx_rows(RW) * fx_bk(NP) + NP * fx_bk(NP) * fx_sb(CW, NTW) + 64 * 8;   // + a 16-byte trash slot per lane
 }
+// 16-byte piece p of row r inside an A image row (BK = 16: 2 pieces, 32-byte rows; BK = 32: 4 pieces, 64-byte rows)
+__host__ __device__ constexpr int fx_apiece(int BK, int r, int p) { return BK == 16 ? (p ^ ((r >> 3) & 1)) : (p ^ ((r >> 2) & 3)); }
 __host__ __device__ constexpr size_t fx_lds(int NP, int RW, int CW, int NTW) {
   return 2 * fx_stage(NP, RW, CW, NTW) * sizeof(unsigned short) + 2 * fx_rows(RW) * sizeof(int32_t);
 }
@@ -386,10 +394,11 @@ __global__ __launch_bounds__(RW* CW * 64, 2) void convx_fwd_kernel(
     const float* __restrict__ bias, const int32_t* __restrict__ ids, float* __restrict__ C,
     const int32_t* __restrict__ vidx, const int32_t* __restrict__ vcount, int M, int T, int Tp, int Dp8, int F, int Kp,
     int Np, int ncu, float* __restrict__ slabs, const float* __restrict__ cs) {
+  constexpr int BK = fx_bk(NP), KP8 = BK / 8, KSUB = BK / 16;
   constexpr int BM = fx_rows(RW), NTH = RW * CW * 64, SB = fx_sb(CW, NTW), BCOLS = CW * NTW * 32;
-  constexpr int A_IMG = BM * FX_BK, B_IMG = FX_BK * SB, STAGE = fx_stage(NP, RW, CW, NTW);
-  constexpr int A_PCS = BM * 2 * NP, A_PER = (A_PCS + NTH - 1) / NTH;     // 16-byte pieces (row, k-half, part) of a step
-  constexpr int B_CH = NP * FX_BK * (BCOLS / 8), B_PER = (B_CH + NTH - 1) / NTH;
+  constexpr int A_IMG = BM * BK, B_IMG = BK * SB, STAGE = fx_stage(NP, RW, CW, NTW);
+  constexpr int A_PCS = BM * KP8 * NP, A_PER = (A_PCS + NTH - 1) / NTH;     // 16-byte pieces (row, k-eighth, part) of a step
+  constexpr int B_CH = NP * BK * (BCOLS / 8), B_PER = (B_CH + NTH - 1) / NTH;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   int32_t* rowm = (int32_t*)(smem + 2 * STAGE);           // output row of each tile row (-1: none)
   float* rowkeep = (float*)(rowm + BM);                   // 1 / 0: id != 0
@@ -415,18 +424,18 @@ __global__ __launch_bounds__(RW* CW * 64, 2) void convx_fwd_kernel(
   const int nt_lo = wn * NTW;
   const int my_nt = max(0, min(NTW, NT - nt_lo));          // scalar (wave-uniform by construction)
 
-  // A loader role: piece idx = row * 2 NP + q, q = k-half * NP + part: the pieces of a row and step are 32 NP contiguous bytes
+  // A loader role: piece idx = row * KP8 NP + q, q = k-eighth * NP + part: the pieces of a row and step are 2 BK NP contiguous bytes
   uint32_t a_off[A_PER];
   int a_lds[A_PER];
 #pragma unroll
   for (int p = 0; p < A_PER; ++p) {
-    const int idx = tid + p * NTH, arow = idx / (2 * NP), q = idx - arow * (2 * NP), seg = q / NP, part = q - seg * NP;
+    const int idx = tid + p * NTH, arow = idx / (KP8 * NP), q = idx - arow * (KP8 * NP), seg = q / NP, part = q - seg * NP;
     const bool use = A_PCS % NTH == 0 || idx < A_PCS;
     const int i = min(m0 + min(arow, BM - 1), count - 1);
     const int m = vidx ? vidx[i] : i;
     const int title = m / T, t = m - title * T;
     a_off[p] = use ? ((uint32_t)(title * Tp + t) * (uint32_t)Dp8 * (uint32_t)NP + (uint32_t)q) * 16u : kBufOob;
-    a_lds[p] = use ? part * A_IMG + arow * FX_BK + ((seg ^ ((arow >> 3) & 1)) << 3) : trash;
+    a_lds[p] = use ? part * A_IMG + arow * BK + (fx_apiece(BK, arow, seg) << 3) : trash;
     if (use && q == 0) {
       rowm[arow] = (m0 + arow < count) ? m : -1;
       rowkeep[arow] = ids[m] != 0 ? 1.f : 0.f;
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(RW* CW * 64, 2) void convx_fwd_kernel(
   for (int i = 0; i < B_PER; ++i) {
     const int idx = tid + i * NTH;
     constexpr int C8 = BCOLS / 8;
-    const int img = idx / (FX_BK * C8), rem = idx - img * (FX_BK * C8), krow = rem / C8, ch = rem - krow * C8;
+    const int img = idx / (BK * C8), rem = idx - img * (BK * C8), krow = rem / C8, ch = rem - krow * C8;
     const bool use = idx < B_CH && ch * 8 < Np;
     b_goff[i] = use ? (((uint32_t)img * (uint32_t)Kp + (uint32_t)krow) * (uint32_t)Np + (uint32_t)(ch * 8)) * 2u : kBufOob;
     b_loff[i] = use ? NP * A_IMG + img * B_IMG + krow * SB + ch * 8 : trash;
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(RW* CW * 64, 2) void convx_fwd_kernel(
   float4 rb[B_PER];
   int it0_ = 0;
   auto load = [&](int k0) {
-    if ((OPT & 4) && k0 >= (it0_ + 2) * FX_BK) return;     // timing-only ablation: no global loads inside the loop
+    if ((OPT & 4) && k0 >= (it0_ + 2) * BK) return;     // timing-only ablation: no global loads inside the loop
 #pragma unroll
     for (int p = 0; p < A_PER; ++p) ra[p] = buf_load4(rsE, a_off[p], (uint32_t)k0 * (2u * NP));
 #pragma unroll
@@ -471,18 +480,20 @@ __global__ __launch_bounds__(RW* CW * 64, 2) void convx_fwd_kernel(
     for (int i = 0; i < B_PER; ++i) *(float4*)(st + b_loff[i]) = rb[i];
   };
 
-  const int nit_all = Kp / FX_BK;
+  const int nit_all = Kp / BK;
   const int it0 = sliced ? ks * nit_all / tp.S : 0, it1 = sliced ? (ks + 1) * nit_all / tp.S : nit_all;
   it0_ = it0;
   const int nit = it1 - it0;                       // >= 1 for nit_all >= S (S <= 8; guarded by the launcher)
-  load(it0 * FX_BK);
+  load(it0 * BK);
   store(0);
-  if (nit > 1) load((it0 + 1) * FX_BK);
+  if (nit > 1) load((it0 + 1) * BK);
   __syncthreads();
 
-  // fragment addresses (elements): A = row-major [row][16] with the k-halves swizzled; B by transposed reads
+  // fragment addresses (elements): A = row-major [row][BK] with the 16-byte pieces swizzled; B by transposed reads
   const int arow = 32 * wm + (lane & 31);
-  const int a_frag = arow * FX_BK + (((lane >> 5) ^ ((arow >> 3) & 1)) << 3);
+  int a_frag[KSUB];
+#pragma unroll
+  for (int ss = 0; ss < KSUB; ++ss) a_frag[ss] = arow * BK + (fx_apiece(BK, arow, 2 * ss + (lane >> 5)) << 3);
   // The k-loop exists once per number NA of live column tiles of the wave (a compile-time constant inside): straight-line
   // code with no test in it, so the compiler counts its LDS reads exactly (lgkmcnt(N), not (0)) and keeps the reads of
   // tile j + 1 in flight under the products of tile j.
@@ -491,36 +502,42 @@ __global__ __launch_bounds__(RW* CW * 64, 2) void convx_fwd_kernel(
     for (int it = 0; it < nit; ++it) {
       if (it + 1 < nit) {
         if (!(OPT & 8) || it == 0) store((it & 1) ^ 1);
-        if (it + 2 < nit) load((it0 + it + 2) * FX_BK);
+        if (it + 2 < nit) load((it0 + it + 2) * BK);
       }
       if constexpr (NA > 0) {
         const unsigned short* st = smem + (it & 1) * STAGE;
-        u16x8 af[NP];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) af[q] = *(const u16x8*)(st + q * A_IMG + a_frag);
         const unsigned short* bp = st + NP * A_IMG;
-        auto frags = [&](int j, u16x8 (&b)[NP]) {
+        // the stage's KSUB 16-deep sub-steps x NA column tiles as one straight-line sequence: the B fragments of item
+        // i + 1 are read while the products of item i run
+        u16x8 af[KSUB][NP];
+#pragma unroll
+        for (int ss = 0; ss < KSUB; ++ss)
+#pragma unroll
+          for (int q = 0; q < NP; ++q) af[ss][q] = *(const u16x8*)(st + q * A_IMG + a_frag[ss]);
+        auto frags = [&](int i, u16x8 (&b)[NP]) {
+          const int ss = i / NA, j = i - ss * NA;
           const int x0 = (wn * NTW + j) * 32;                // column inside this workgroup's window
 #pragma unroll
-          for (int q = 0; q < NP; ++q) b[q] = tr_frag(bp + q * B_IMG, SB, 0, x0, lane);
+          for (int q = 0; q < NP; ++q) b[q] = tr_frag(bp + q * B_IMG, SB, 16 * ss, x0, lane);
         };
+        constexpr int NI = KSUB * NA;
         u16x8 bA[NP], bB[NP];
         if (OPT & 32) {                      // timing-only ablation: no B fragment reads (operands = whatever A holds)
 #pragma unroll
-          for (int q = 0; q < NP; ++q) bA[q] = af[0];
+          for (int q = 0; q < NP; ++q) bA[q] = af[0][0];
 #pragma unroll
-          for (int j = 0; j < NA; ++j) {
+          for (int i = 0; i < NI; ++i) {
             asm volatile("" : "+v"(bA[0]), "+v"(bA[1]));
-            acc[j] = tile_products<NP>(af, bA, acc[j]);
+            acc[i % NA] = tile_products<NP>(af[i / NA], bA, acc[i % NA]);
           }
         } else {
           frags(0, bA);
 #pragma unroll
-          for (int j = 0; j < NA; j += 2) {
-            if (j + 1 < NA) frags(j + 1, bB);
-            acc[j] = tile_products<NP>(af, bA, acc[j]);
-            if (j + 2 < NA) frags(j + 2, bA);
-            if (j + 1 < NA) acc[j + 1] = tile_products<NP>(af, bB, acc[j + 1]);
+          for (int i = 0; i < NI; i += 2) {
+            if (i + 1 < NI) frags(i + 1, bB);
+            acc[i % NA] = tile_products<NP>(af[i / NA], bA, acc[i % NA]);
+            if (i + 2 < NI) frags(i + 2, bA);
+            if (i + 1 < NI) acc[(i + 1) % NA] = tile_products<NP>(af[(i + 1) / NA], bB, acc[(i + 1) % NA]);
           }
         }
       }
@@ -642,11 +659,11 @@ void launch_convx_fwd(const unsigned short* ex, const unsigned short* Wx, const 
                       const float* cs, void* scratch, hipStream_t s, int variant) {
   const int M = n_titles * T;
   if (M == 0) return;
-  const int Tp = T + ksize - 1, Dp = convx_dp(D), Np = fx_np(F), Kp = fx_kp(D, ksize);
+  const int Tp = T + ksize - 1, Dp = convx_dp(D), Np = fx_np(F), Kp = fx_kp(D, ksize, np);
   const uint32_t e_bytes = (uint32_t)std::min(convx_e_elems(n_titles, T, D, ksize, np) * 2, (size_t)0xFFFFFFFFu);
   const int tiles = cdiv(M, 128);
   // tail slicing needs at least one k-step per slice; without scratch every tile is a plain tile (ncu = "infinite")
-  const int ncu = (scratch && Kp / FX_BK >= 8) ? std::min(convx_ncu(), 256) : 0;   // scratch holds <= 256 slabs; 0: no slicing
+  const int ncu = (scratch && Kp / fx_bk(np) >= 8) ? std::min(convx_ncu(), 256) : 0;   // scratch holds <= 256 slabs; 0: no slicing
   // grid: every tile as a plain tile, or whole rounds + at most ncu slices (the device decides from the token count)
   const int grid = tiles + ncu;
   if (ncu <= 0) last_launch();
@@ -657,6 +674,7 @@ void launch_convx_fwd(const unsigned short* ex, const unsigned short* Wx, const 
   };
   (void)variant;
 #ifdef LSTUR_ABLATE
+  if (const char* e = getenv("LSTUR_CONVX_FWD_VARIANT")) variant = atoi(e);   // (bench-only library: tools/bench_convx.py --ablate)
   if (variant >= 10 && variant <= 15 && np == 2) {
     switch (variant) {
       case 10: go(convx_fwd_kernel<2, 4, 2, 7, 4>, fx_lds(2, 4, 2, 7)); break;
@@ -946,6 +964,7 @@ int launch_convx_wgrad(const unsigned short* ex, const float* dout, float* dw, v
   };
   (void)variant;
 #ifdef LSTUR_ABLATE
+  if (const char* e = getenv("LSTUR_CONVX_WGRAD_VARIANT")) variant = atoi(e);
   if (variant && np == 2) {
     switch (variant) {
       case 1: go(convx_wgrad_kernel<2, 1>, gx_lds(2)); break;

@@ -646,15 +646,15 @@ size_t gru_pack_floats(int H) { return gru4_supported(H) ? gru4_pack_floats(H) :
 size_t gru_tape_floats(int n, int W, int H) {
   return gru4_supported(H) ? gru4_tape_floats(n, W, H) : generic_tape_floats(n, W, H);
 }
-void launch_gru_pack(const float* U, int H, float* packed, hipStream_t s) {
-  if (gru4_supported(H)) return launch_gru4_pack(U, H, packed, s);
+void launch_gru_pack(const float* U, int H, float* packed, hipStream_t s, bool f16, int seq) {
+  if (gru4_supported(H)) return launch_gru4_pack(U, H, packed, s, f16, seq);
   const size_t sixth = generic_pack_floats(H) / 6;   // u_zr 2/6 | u_h 1/6 | ut_h 1/6 | ut_zr 2/6
   generic_pack(U, H, packed, packed + 2 * sixth, packed + 3 * sixth, packed + 4 * sixth, s);
 }
 void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
-                    float* hlast, int n, int W, int H, hipStream_t s) {
+                    float* hlast, int n, int W, int H, hipStream_t s, bool f16) {
   if (!n) return;
-  if (gru4_supported(H)) return launch_gru4_fwd(xw, gmask, h0, packed, tape, hlast, n, W, H, s);
+  if (gru4_supported(H)) return launch_gru4_fwd(xw, gmask, h0, packed, tape, hlast, n, W, H, s, f16);
   const size_t sixth = generic_pack_floats(H) / 6;
   generic_fwd(xw, gmask, h0, packed, packed + 2 * sixth, tape, hlast, n, W, H, s);
 }

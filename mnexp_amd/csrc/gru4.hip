@@ -24,12 +24,51 @@
 // Saved activations / gradients are plain row-major tensors (lane = column => coalesced), addressed through
 // buffer descriptors (scalar row/step offset + one per-lane column offset; out-of-range columns are dropped by
 // the range check) -- no address VGPRs, no exec-mask branches.
+//
+// FORWARD, F16 = true (the default since round 3; LSTUR_GRU_F32=1 selects the fp32 instructions): the products run on
+// v_mfma_f32_4x4x4_16b_f16 -- FOUR k per instruction at the cycles of the one-k fp32 instruction (tools/probe_mfma4h_rate.hip:
+// 8.5 against 8.5 cycles per instruction in two chains) -- on fp16 PAIRS of both operands (bf16_mfma.h: x s = h + l, three
+// products hh + hl + lh per fp32-grade product): 3 K / 4 instead of K instructions per 64 columns.  An operand element
+// keeps its 4 bytes -- a (k-quad, column) group of the images is [h0 h1 h2 h3 | l0 l1 l2 l3] instead of four floats -- so the
+// register / LDS budget of the resident-U design is unchanged.  Scales (powers of two, undone exactly per accumulator): the
+// recurrent matrix by max |U| (kept with the operand images, lstur_internal.h: gru4 pack tail); the forward's state
+// vectors by max(1, max |h0| of the workgroup's rows) (|h_t| <= max(|h_t-1|, 1): a convex combination with a tanh).
+// Measured (tools/bench_gru.py, same box, cycle stamps of the bench-only library): 6 560 against 7 220 cycles per step (155 against
+// 166 us at B = 64, W = 50): the MFMA streams shrink by 25 % / 15 %, the epilogues grow by 45 % / 20 % (a pair costs a
+// multiply, three conversions, a subtraction and two 16-bit LDS stores where a float cost one store).
+// BPTT stays on the fp32 instructions: its fp16 form was built and measured SLOWER (183 against 174 us): its three gradient
+// vectors change scale with dh from step to step (a lagged per-step maximum, clamped stores) and every step writes 16
+// pairs per lane -- the epilogue work outweighs the shorter MFMA streams.  Its images (itz, itr, ith) therefore stay floats.
 #include <utility>
 
+#include "bf16_mfma.h"
 #include "lstur_device.h"
 #include "lstur_internal.h"
 
 namespace lstur {
+
+typedef _Float16 g4h4 __attribute__((ext_vector_type(4)));
+// the h | l halves of a 16-byte pair group
+__device__ __forceinline__ g4h4 pair_h(const float4& v) { return __builtin_bit_cast(g4h4, make_float2(v.x, v.y)); }
+__device__ __forceinline__ g4h4 pair_l(const float4& v) { return __builtin_bit_cast(g4h4, make_float2(v.z, v.w)); }
+template <int ABID>
+__device__ __forceinline__ f32x4 mfma4h(g4h4 a, g4h4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 4, ABID, 0);
+}
+// element (k, row) of a pair image: the halfword of its h part (the l part sits 4 halfwords behind it)
+__device__ __forceinline__ unsigned short* pair_ptr(float* img, int k) {
+  return (unsigned short*)img + 2 * ((k >> 2) * 16) + (k & 3);     // + row * 8
+}
+// v (already scaled) -> its fp16 pair at p (h) and p + 4 (l); clamped to the fp16 range (a second fence: the scales keep
+// the operands far inside it)
+template <bool CLAMP = true>
+__device__ __forceinline__ void store_pair(unsigned short* p, float v) {
+  if (CLAMP) v = fminf(fmaxf(v, -65504.f), 65504.f);
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)(v - (float)h);
+  p[0] = __builtin_bit_cast(unsigned short, h);
+  p[4] = __builtin_bit_cast(unsigned short, l);
+}
 
 constexpr int G4_THREADS = 256;   // 4 waves, 1 per SIMD -> 512 registers per wave
 constexpr size_t G4_LDS_MAX = 160 * 1024;
@@ -59,16 +98,16 @@ struct AVec {
 constexpr int LDS_AHEAD = 6;   // k-quads the LDS operand reads run in front of their MFMAs (~120-cycle round trip)
 // Resident k-quads (QR1) of the strip in register slot 1; its last KQ - QR1 quads sit in a per-wave LDS tail
 // [q][64 lanes][4].  (2 x 200 operand registers + the working set of a step do not fit 512 at H = 200.)
-__host__ __device__ constexpr int fwd_slot1(int KQ) { return KQ > 40 ? 40 : KQ; }
+__host__ __device__ constexpr int fwd_slot1(int KQ) { return KQ > 41 ? 41 : KQ; }   // (41: the state's second image of the fp16 form needs the 4 KB of LDS a 40-quad slot's tail took)
 __host__ __device__ constexpr int bwd_slot1(int KQ) { return KQ > 36 ? 36 : KQ; }   // BPTT keeps more values live
 
 // One k-quad of up to two strips that share the A vector.  Strip 0 is resident in slot 0 (or absent); strip 1 is
 // resident in slot 1 (+ LDS tail), absent, or read from an LDS image (layout below).  LDS operands pass through
 // `ring`, read LDS_AHEAD quads early.  MFMAs of the two strips alternate so that no accumulator is reused within
 // 4 issues.
-template <int KQ, int QR1, int Q, int M0, int M1>
+template <int KQ, int QR1, int Q, int M0, int M1, bool F16>
 __device__ __forceinline__ void quad_step(const float4& a, const float4 (&u0)[KQ], const float4 (&u1)[QR1],
-                                          const float* __restrict__ l1, float4 (&ring)[LDS_AHEAD], f32x4 (&c)[4]) {
+                                          const float* __restrict__ l1, float4 (&ring)[LDS_AHEAD], f32x4 (&c)[6]) {
   constexpr int QP = Q + LDS_AHEAD;
   float4 b1 = make_float4(0.f, 0.f, 0.f, 0.f);
   bool pinned = false;
@@ -83,6 +122,18 @@ __device__ __forceinline__ void quad_step(const float4& a, const float4 (&u0)[KQ
     if (QP < KQ) ring[QP % LDS_AHEAD] = *(const float4*)(l1 + QP * 4);
     pinned = true;
   }
+  if (F16) {   // three products of the fp16 pairs, four k each, in THREE chains per strip: an accumulator comes round again
+               // after 3 (one strip) or 6 (two strips) instructions -- with l h and h h in one chain the single-strip
+               // stream ran at the chain's latency (12.1 cycles per MFMA, tools/bench_gru.py stamps) instead of its issue rate
+    if (M0 == M_RES) c[0] = mfma4h<Q % 16>(pair_l(a), pair_h(u0[Q]), c[0]);
+    if (M1 != M_NONE) c[3] = mfma4h<Q % 16>(pair_l(a), pair_h(b1), c[3]);
+    if (M0 == M_RES) c[1] = mfma4h<Q % 16>(pair_h(a), pair_l(u0[Q]), c[1]);
+    if (M1 != M_NONE) c[4] = mfma4h<Q % 16>(pair_h(a), pair_l(b1), c[4]);
+    if (M0 == M_RES) c[2] = mfma4h<Q % 16>(pair_h(a), pair_h(u0[Q]), c[2]);
+    if (M1 != M_NONE) c[5] = mfma4h<Q % 16>(pair_h(a), pair_h(b1), c[5]);
+    if (pinned) __builtin_amdgcn_sched_barrier(0);
+    return;
+  }
   if (M0 == M_RES) c[0] = mfma4<Q % 16>(a.x, u0[Q].x, c[0]);
   if (M1 != M_NONE) c[2] = mfma4<Q % 16>(a.x, b1.x, c[2]);
   if (M0 == M_RES) c[1] = mfma4<Q % 16>(a.y, u0[Q].y, c[1]);
@@ -93,31 +144,36 @@ __device__ __forceinline__ void quad_step(const float4& a, const float4 (&u0)[KQ
   if (M1 != M_NONE) c[3] = mfma4<Q % 16>(a.w, b1.w, c[3]);
   if (pinned) __builtin_amdgcn_sched_barrier(0);   // pin: the read of quad Q+LDS_AHEAD stays in front of quad Q
 }
-template <int KQ, int QR1, int M0, int M1, size_t... Q>
+template <int KQ, int QR1, int M0, int M1, bool F16, size_t... Q>
 __device__ __forceinline__ void strips_impl(const float4 (&u0)[KQ], const float4 (&u1)[QR1],
                                             const float* __restrict__ l1, const AVec<KQ>& a, f32x4& r0, f32x4& r1,
                                             std::index_sequence<Q...>) {
-  f32x4 c[4];
+  f32x4 c[6];      // fp32: strip 0 -> c[0], c[1]; strip 1 -> c[2], c[3].  F16: strip 0 -> c[0 .. 2]; strip 1 -> c[3 .. 5]
 #pragma unroll
-  for (int i = 0; i < 4; ++i) c[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 6; ++i) c[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 ring[LDS_AHEAD];
   if (M1 == M_LDS) {
 #pragma unroll
     for (int d = 0; d < LDS_AHEAD; ++d) ring[d] = *(const float4*)(l1 + (d < KQ ? d : 0) * 4);
   }
-  (quad_step<KQ, QR1, (int)Q, M0, M1>(a.v[Q / 16], u0, u1, l1, ring, c), ...);
-  r0 = c[0] + c[1];
-  r1 = c[2] + c[3];
+  (quad_step<KQ, QR1, (int)Q, M0, M1, F16>(a.v[Q / 16], u0, u1, l1, ring, c), ...);
+  if (F16) {       // small terms first
+    r0 = (c[0] + c[1]) + c[2];
+    r1 = (c[3] + c[4]) + c[5];
+  } else {
+    r0 = c[0] + c[1];
+    r1 = c[2] + c[3];
+  }
 }
 // r0 = A . strip0, r1 = A . strip1 for the 4 rows (register j) at this lane's strip column.
 // l1: M_RES -> this lane's slot-1 tail; M_LDS -> this lane's column of an LDS operand image.
-template <int KQ, int QR1, int M0, int M1>
+template <int KQ, int QR1, int M0, int M1, bool F16 = false>
 __device__ __forceinline__ void run_strips(const float4 (&u0)[KQ], const float4 (&u1)[QR1],
                                            const float* __restrict__ l1, const float* __restrict__ aimg, int lane,
                                            f32x4& r0, f32x4& r1) {
   AVec<KQ> a;
   a.load(aimg, lane);
-  strips_impl<KQ, QR1, M0, M1>(u0, u1, l1, a, r0, r1, std::make_index_sequence<KQ>{});
+  strips_impl<KQ, QR1, M0, M1, F16>(u0, u1, l1, a, r0, r1, std::make_index_sequence<KQ>{});
 }
 // LDS operand images are column-major [column][KQP][4] with KQP = KQ | 1 quads per column: the k-quads of a lane's
 // column are at immediate offsets (no address arithmetic in the MFMA stream), and an odd quad count per column
@@ -186,13 +242,41 @@ int gru4_kq(int H) {
   return q <= 10 ? 10 : (q <= 32 ? 32 : 50);
 }
 int gru4_pack_kq(int H) { return gru4_kq(H); }
-size_t gru4_pack_floats(int H) {
+// behind the six images: a tail of kGruTailWords 32-bit words -- [0] sU (the power of two the pair images carry), [1] 1 / sU,
+// and from word kWmaxStride on three rotating slots of max |U| (the scheme of the conv weight image, lstur_internal.h:
+// wmax_word; convx.hip: convx_pack_w_kernel).  fp32 images ignore it.
+size_t gru4_image_floats(int H) {
   const int KQ = gru4_kq(H);
   return KQ ? (size_t)KQ * 4 * 6 * H : 0;
 }
-__global__ void gru4_pack_kernel(const float* __restrict__ U, int H, int KQ, float* __restrict__ img) {
+size_t gru4_pack_floats(int H) { return gru4_kq(H) ? gru4_image_floats(H) + kGruTailWords : 0; }
+bool gru4_f16_env() { return getenv("LSTUR_GRU_F32") == nullptr; }
+// element U[k][c] of the recurrent matrix -> its place(s) in the images; f16: the fp16 pair of v * sU instead of the float
+__device__ __forceinline__ void gru4_put(float* __restrict__ img, size_t group4, int j, float v, bool f16, float sU) {
+  if (!f16) {
+    img[group4 + j] = v;
+    return;
+  }
+  store_pair((unsigned short*)img + 2 * group4 + j, v * sU);
+}
+__global__ __launch_bounds__(256) void gru4_pack_kernel(const float* __restrict__ U, int H, int KQ, float* __restrict__ img,
+                                                        int f16, int seq, float grow) {
   const size_t e = (size_t)KQ * 4 * H;   // floats of an N = H image
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t* tail = (uint32_t*)(img + 6 * e);
+  float sU = 1.0f;
+  if (f16) {   // the scale of the previous pack's maximum (+ what one optimizer step can add), this pack's maximum for the next
+    uint32_t m = tail[gru_wmax_word(seq % 3, threadIdx.x & (kWmaxLanes - 1))];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    sU = pow2_scale(__float_as_uint(__uint_as_float(m) + grow), 13);
+    if (i == 0) {
+      ((float*)tail)[0] = sU;
+      ((float*)tail)[1] = 1.0f / sU;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < kWmaxLanes) tail[gru_wmax_word((seq + 2) % 3, threadIdx.x)] = 0u;
+    // (this pack's own maximum: the caller's absmax launch wrote slot seq % 3 from U itself and mirrors it into the next slot)
+  }
   if (i >= 6 * e) return;
   const int H3 = 3 * H;
   float v = 0.f;
@@ -209,13 +293,22 @@ __global__ void gru4_pack_kernel(const float* __restrict__ U, int H, int KQ, flo
       else v = U[(size_t)c * H3 + (which - 1) * H + k];
     }
   }
-  img[i] = v;
+  gru4_put(img, i & ~(size_t)3, (int)(i & 3), v, f16 != 0 && i < 3 * e, sU);   // pairs: the FORWARD's images (izr, ih)
 }
-void launch_gru4_pack(const float* U, int H, float* img, hipStream_t s) {
+// Stand-alone pack (a first pack, or the caller changed the weights): max |U| from U itself, then the images.  The dense
+// Adam launch writes the images in the training step (misc.hip: image_scatter) and keeps the rotating maxima going.
+void launch_gru4_pack(const float* U, int H, float* img, hipStream_t s, bool f16, int seq) {
   const int KQ = gru4_kq(H);
   if (!KQ) return;
-  const size_t total = gru4_pack_floats(H);
-  hipLaunchKernelGGL(gru4_pack_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, U, H, KQ, img);
+  const size_t total = gru4_image_floats(H);
+  uint32_t* tail = (uint32_t*)(img + total);
+  if (f16) {
+    (void)hipMemsetAsync(tail, 0, (size_t)kGruTailWords * sizeof(uint32_t), s);
+    launch_absmax(U, (size_t)3 * H * H, tail + gru_wmax_word(seq % 3, 0), s);
+    (void)hipMemcpyAsync(tail + gru_wmax_word((seq + 1) % 3, 0), tail + gru_wmax_word(seq % 3, 0), sizeof(uint32_t),
+                         hipMemcpyDeviceToDevice, s);
+  }
+  hipLaunchKernelGGL(gru4_pack_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, U, H, KQ, img, f16 ? 1 : 0, seq, 0.f);
 }
 
 // tape of the fast path: row-major sections ZR [n*W,2H] | HH [n*W,H] | HP [n*W,H] | RH [n*W,H]
@@ -224,7 +317,7 @@ size_t gru4_tape_floats(int n, int W, int H) { return gru4_kq(H) ? (size_t)5 * n
 
 // ---- forward -------------------------------------------------------------------------------------
 struct Gru4Fwd {
-  const float* xw; const uint8_t* gmask; const float* h0; const float* izr; const float* ih;
+  const float* xw; const uint8_t* gmask; const float* h0; const float* izr; const float* ih; const float* tail;
   float* zr; float* hh; float* hp; float* rh; float* hlast;
   int n, W, H, dbg;   // dbg: measurement knobs (LSTUR_GRU4_DEBUG): 1 no global stores, 8 per-segment cycle stamps
   int sb, st;         // row of (sample b, step t) in xw / gmask / the tape = b * sb + t * st: (W, 1) sample-major, (1, n) slot-major
@@ -245,14 +338,16 @@ struct FwdPlan {
 };
 static size_t gru4_fwd_lds(int H, int KQ) {
   const FwdPlan p(H);
-  return ((size_t)3 * KQ * 16 + 16 + (size_t)kqp(KQ) * p.wl * 4 + (size_t)4 * (KQ - fwd_slot1(KQ)) * 256) * sizeof(float);
+  return ((size_t)4 * KQ * 16 + 32 + (size_t)kqp(KQ) * p.wl * 4 + (size_t)4 * (KQ - fwd_slot1(KQ)) * 256) * sizeof(float);
 }
 
-struct FwdLds { float *hA, *rhA, *zA, *dummy; const float* uL; int wl; const float* tail; };
+// hA: the state as floats (element-wise reads); F16: h16 = the same state as the MFMA operand (fp16 pairs of h sA), rhA holds
+// pairs of r h sA; sA / inv: the operand scale of this workgroup's rows and 1 / (sA sU)
+struct FwdLds { float *hA, *rhA, *zA, *h16, *dummy; const float* uL; int wl; const float* tail; float sA, inv; };
 
 // Time loop of one wave role.  NP1: resident [z|r] strips of this wave (slot 0 = strip wv, slot 1 = strip wv+4).
 // P2: candidate strip M_NONE | M_RES (slot 1) | M_LDS; c2 = its first hidden column, lcol = its first image column.
-template <int KQ, int NP1, int P2>
+template <int KQ, int NP1, int P2, bool F16>
 __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L, int wv, int lane, int c2base, int lcol,
                                               const float4 (&u0)[KQ], const float4 (&u1)[fwd_slot1(KQ)]) {
   const int H = g.H, W = g.W, n = g.n, H2 = 2 * H, H3 = 3 * H;
@@ -263,6 +358,7 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
   // phase-1 strips: per-lane column, LDS destination of the gate (z -> zA, r*h -> rhA, past 2H -> dummy), h source
   uint32_t o1[2], o1r[2];
   float* dst1[2];
+  unsigned short* dst1p[2];      // F16: where an r lane puts the pair of r h sA
   const float* hsrc[2];
   bool isr[2];
 #pragma unroll
@@ -273,7 +369,8 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
     const int hc = isr[s] ? c - H : c;
     o1[s] = v ? c * 4 : kBufOob;
     o1r[s] = (v && isr[s]) ? hc * 4 : kBufOob;
-    dst1[s] = v ? (isr[s] ? L.rhA : L.zA) + aidx(hc, 0) : L.dummy;
+    dst1[s] = v ? (isr[s] ? (F16 ? L.dummy : L.rhA + aidx(hc, 0)) : L.zA + aidx(hc, 0)) : L.dummy;
+    dst1p[s] = (v && isr[s]) ? pair_ptr(L.rhA, hc) : (unsigned short*)L.dummy;
     hsrc[s] = L.hA + aidx(v ? hc : 0, 0);
   }
   const int c2 = c2base + lane;             // hidden column of the candidate strip
@@ -282,6 +379,8 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
   const float* zsrc = L.zA + aidx(v2 ? c2 : 0, 0);
   const float* hsrc2 = L.hA + aidx(v2 ? c2 : 0, 0);
   float* hdst2 = v2 ? L.hA + aidx(c2, 0) : L.dummy;
+  unsigned short* hdst2p = v2 ? pair_ptr(L.h16, c2) : (unsigned short*)L.dummy;
+  const float sA = L.sA, inv = L.inv;
   const float* uLl = L.uL + (size_t)(P2 == M_LDS ? min(lcol + lane, L.wl - 1) : 0) * kqp(KQ) * 4;
   uint32_t rb[4];   // row * W (the launcher keeps n*W*3H below 2^30)
   bool rok[4];
@@ -320,7 +419,7 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
         for (int j = 0; j < 4; ++j) hv[s][j] = hsrc[s][j * 4];
       __builtin_amdgcn_sched_barrier(0);   // keep the gate-input loads in front of the MFMA stream
       f32x4 acc[2];
-      run_strips<KQ, fwd_slot1(KQ), M_RES, NP1 == 2 ? M_RES : M_NONE>(u0, u1, L.tail, L.hA, lane, acc[0], acc[1]);
+      run_strips<KQ, fwd_slot1(KQ), M_RES, NP1 == 2 ? M_RES : M_NONE, F16>(u0, u1, L.tail, F16 ? L.h16 : L.hA, lane, acc[0], acc[1]);
       if (P2 != M_NONE) {   // the previous step's hh / hp stores have long completed
 #pragma unroll
         for (int j = 0; j < 4; ++j) { keep(k2h[j]); keep(k2p[j]); }
@@ -330,9 +429,10 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
       for (int s = 0; s < NP1; ++s)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float gt = hard_sigmoid(acc[s][j] + x1[s][j]);
+          const float gt = hard_sigmoid((F16 ? acc[s][j] * inv : acc[s][j]) + x1[s][j]);
           const float val = isr[s] ? gt * hv[s][j] : gt;
           dst1[s][j * 4] = val;
+          if (F16) store_pair<false>(dst1p[s] + j * 8, val * sA);     // (z lanes and lanes past 2H: into the sink; |r h sA| <= 2^13)
           k1[s][j] = gt;
           k1r[s][j] = val;
           buf_store1(k1[s][j], rzr, rok[j] ? o1[s] : kBufOob, (rb[j] + (uint32_t)t * ST) * H2 * 4);
@@ -358,13 +458,15 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
       }
       __builtin_amdgcn_sched_barrier(0);
       f32x4 acc, unused;
-      run_strips<KQ, fwd_slot1(KQ), M_NONE, P2>(u0, u1, P2 == M_RES ? L.tail : uLl, L.rhA, lane, unused, acc);
+      run_strips<KQ, fwd_slot1(KQ), M_NONE, P2, F16>(u0, u1, P2 == M_RES ? L.tail : uLl, L.rhA, lane, unused, acc);
       LSTUR_STAMP(3)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float hhv = fast_tanh(acc[j] + x2[j]);
+        const float hhv = fast_tanh((F16 ? acc[j] * inv : acc[j]) + x2[j]);
         const float hn = z[j] * hp[j] + (1.0f - z[j]) * hhv;
-        hdst2[j * 4] = rm.at(j, t) ? hn : hp[j];   // K.rnn: a masked step carries the previous state/output
+        const float hst = rm.at(j, t) ? hn : hp[j];   // K.rnn: a masked step carries the previous state/output
+        hdst2[j * 4] = hst;
+        if (F16) store_pair<false>(hdst2p + j * 8, hst * sA);
         k2h[j] = hhv;
         k2p[j] = hp[j];
         buf_store1(k2h[j], rhh, rok[j] ? o2 : kBufOob, (rb[j] + (uint32_t)t * ST) * H * 4);
@@ -386,7 +488,7 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
     for (int k = 0; k < 6; ++k) g.hlast[wv * 8 + k] = (float)st[k];
 }
 
-template <int KQ>
+template <int KQ, bool F16>
 __global__ __launch_bounds__(G4_THREADS) void gru4_fwd_kernel(Gru4Fwd g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = g.H, n = g.n, H2 = 2 * H;
@@ -397,8 +499,9 @@ __global__ __launch_bounds__(G4_THREADS) void gru4_fwd_kernel(Gru4Fwd g) {
   L.hA = smem;                      // state, A image
   L.rhA = L.hA + KQ * 16;           // r*h, A image
   L.zA = L.rhA + KQ * 16;           // z, same layout
-  L.dummy = L.zA + KQ * 16;         // sink for lanes past the last column
-  float* uL = L.dummy + 16;         // U_h[:, nres*64 : H] image [wl][KQP][4]
+  L.h16 = L.zA + KQ * 16;           // F16: the state as the MFMA operand (pairs)
+  L.dummy = L.h16 + KQ * 16;        // sink for lanes past the last column (32 floats: pair stores reach halfword 28)
+  float* uL = L.dummy + 32;         // U_h[:, nres*64 : H] image [wl][KQP][4]
   L.uL = uL;
   L.wl = P.wl;
   constexpr int QR1 = fwd_slot1(KQ);
@@ -406,11 +509,35 @@ __global__ __launch_bounds__(G4_THREADS) void gru4_fwd_kernel(Gru4Fwd g) {
   L.tail = tailL;
   const int b0 = blockIdx.x * 4;
 
-  for (int i = tid; i < 3 * KQ * 16 + 16; i += G4_THREADS) smem[i] = 0.f;
+  for (int i = tid; i < 4 * KQ * 16 + 32; i += G4_THREADS) smem[i] = 0.f;
+  L.sA = 1.0f;
+  L.inv = 1.0f;
+  if (F16) {   // operand scale of this workgroup's rows: max(1, max |h0|) -> 2^12 (|h_t| never exceeds that maximum)
+    float m = 1.0f;
+    for (int i = tid; i < 4 * H; i += G4_THREADS) {
+      const int row = i / H, col = i - row * H, b = b0 + row;
+      if (g.h0 && b < n) m = fmaxf(m, fabsf(g.h0[(size_t)b * H + col]));
+    }
+    m = wave_max(m);
+    float* red = smem + 4 * KQ * 16 + 16;       // (second half of the sink: zeroed above, cleared again below)
+    __syncthreads();
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    if (tid < 4) red[tid] = 0.f;
+    L.sA = pow2_scale(__float_as_uint(m), 12);
+    const float sU = g.tail[0];                             // the pack's tail: [0] sU
+    L.inv = 1.0f / (L.sA * sU);
+  }
   __syncthreads();
   for (int i = tid; i < 4 * H; i += G4_THREADS) {
     const int row = i / H, col = i - row * H, b = b0 + row;
-    if (g.h0 && b < n) L.hA[aidx(col, row)] = g.h0[(size_t)b * H + col];
+    if (g.h0 && b < n) {
+      const float v = g.h0[(size_t)b * H + col];
+      L.hA[aidx(col, row)] = v;
+      if (F16) store_pair(pair_ptr(L.h16, col) + row * 8, v * L.sA);
+    }
   }
   for (int i = tid; i < KQ * P.wl; i += G4_THREADS) {
     const int q = i / P.wl, col = i - q * P.wl;
@@ -449,9 +576,9 @@ __global__ __launch_bounds__(G4_THREADS) void gru4_fwd_kernel(Gru4Fwd g) {
   }
   __syncthreads();
 #define LSTUR_ROLE(A, B) \
-  if (np1 == A && p2 == B) gru4_fwd_loop<KQ, A, B>(g, L, wv, lane, c2base, lcol, u0, u1); else
+  if (np1 == A && p2 == B) gru4_fwd_loop<KQ, A, B, F16>(g, L, wv, lane, c2base, lcol, u0, u1); else
   LSTUR_ROLE(2, M_LDS) LSTUR_ROLE(2, M_NONE) LSTUR_ROLE(1, M_RES) LSTUR_ROLE(1, M_NONE) LSTUR_ROLE(0, M_RES)
-  gru4_fwd_loop<KQ, 0, M_NONE>(g, L, wv, lane, c2base, lcol, u0, u1);
+  gru4_fwd_loop<KQ, 0, M_NONE, F16>(g, L, wv, lane, c2base, lcol, u0, u1);
 #undef LSTUR_ROLE
 
   for (int i = tid; i < 4 * H; i += G4_THREADS) {
@@ -760,17 +887,22 @@ void gru4_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh)
 }
 
 void launch_gru4_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* img, float* tape, float* hlast,
-                     int n, int W, int H, hipStream_t s) {
+                     int n, int W, int H, hipStream_t s, bool f16) {
   const int KQ = gru4_kq(H);
   const size_t e = (size_t)n * W * H, ie = (size_t)KQ * 4 * H;
-  Gru4Fwd a{xw, gmask, h0, img, img + 2 * ie, tape, tape + 2 * e, tape + 3 * e, tape + 4 * e, hlast, n, W, H, gru4_dbg(),
+  Gru4Fwd a{xw, gmask, h0, img, img + 2 * ie, img + 6 * ie, tape, tape + 2 * e, tape + 3 * e, tape + 4 * e, hlast, n, W, H, gru4_dbg(),
             W, 1};
   const size_t lds = gru4_fwd_lds(H, KQ);
   const dim3 grid(cdiv(n, 4)), block(G4_THREADS);
-#define LSTUR_G4F(Q)                                              \
-  {                                                               \
-    set_lds(gru4_fwd_kernel<Q>, lds);                             \
-    hipLaunchKernelGGL(gru4_fwd_kernel<Q>, grid, block, lds, s, a); \
+#define LSTUR_G4F(Q)                                                            \
+  {                                                                             \
+    if (f16) {                                                                  \
+      set_lds(gru4_fwd_kernel<Q, true>, lds);                                   \
+      hipLaunchKernelGGL((gru4_fwd_kernel<Q, true>), grid, block, lds, s, a);   \
+    } else {                                                                    \
+      set_lds(gru4_fwd_kernel<Q, false>, lds);                                  \
+      hipLaunchKernelGGL((gru4_fwd_kernel<Q, false>), grid, block, lds, s, a);  \
+    }                                                                           \
   }
   if (KQ == 10) LSTUR_G4F(10) else if (KQ == 32) LSTUR_G4F(32) else LSTUR_G4F(50)
 #undef LSTUR_G4F

@@ -61,6 +61,7 @@ struct Opts {
   bool dp_defer;       // LSTUR_DP_DEFER=0: the data-parallel step sweeps the user table inside lstur_adam_step
   bool prof_attach;    // LSTUR_PROF_ATTACH=0: timing brackets recorded around the kernels instead of riding them
   bool wgrad_bf16x3;   // LSTUR_WGRAD_BF16X3=1: parameter-gradient GEMMs on the bf16x3 kernel
+  bool gru_f16;        // LSTUR_GRU_F32=1: the recurrence on fp32 4x4x1 MFMAs instead of fp16-pair 4x4x4 ones (gru4.hip)
   int sweep_blocks;    // LSTUR_SWEEP_BLOCKS=n: workgroups of the thin table sweep (-1: planned)
   int prefetch_blocks; // LSTUR_PREFETCH_BLOCKS=n: workgroups of a prefetched gather (0: all)
   int lazy_log;        // LSTUR_LAZY_LOG=n (power of two): entries of the lazy table's lr_t ring (tests: force wraps)
@@ -79,6 +80,7 @@ struct Opts {
     o.dp_defer = !is("LSTUR_DP_DEFER", "0");
     o.prof_attach = !is("LSTUR_PROF_ATTACH", "0");
     o.wgrad_bf16x3 = getenv("LSTUR_WGRAD_BF16X3") != nullptr;
+    o.gru_f16 = gru4_f16_env();
     o.sweep_blocks = getenv("LSTUR_SWEEP_BLOCKS") ? atoi(getenv("LSTUR_SWEEP_BLOCKS")) : -1;
     o.prefetch_blocks = getenv("LSTUR_PREFETCH_BLOCKS") ? atoi(getenv("LSTUR_PREFETCH_BLOCKS")) : 0;
     o.lazy_log = kLazyLog;
@@ -535,6 +537,7 @@ struct lstur_ctx {
   bool images_valid = false;            // conv / GRU weight images match dense_param (packed behind the last Adam)
   bool escale_valid = false;            // f16x2: the embedding scale matches the word table (lstur_params_changed clears it)
   int pack_seq = 0;                     // f16x2: packs of the conv weight image so far (rotating maxima, convx.hip)
+  int gru_seq = 0;                      // ... and of the recurrent matrix's fp16-pair images (gru4.hip)
   int lazy_t = 0;                       // lazy Adam: iterations applied so far (rows are current for last[row] <= lazy_t)
   int lazy_flushed_t = 0;               // ... and the iteration of the last full flush (the lr_t log is a ring)
   std::vector<ParamSlot> layout;
@@ -780,7 +783,7 @@ void pack_weight_images(lstur_ctx* c, hipStream_t sp, bool fresh, float lr_t = 0
   if (d.np) launch_convx_pack_w(c->P("conv_w"), d.D, d.k, d.F, w.conv_w3, d.np, w.cs, c->pack_seq++, fresh || !isfinite(grow), grow, sp);
   else if (!mhsa) launch_pack_b(c->P("conv_w"), d.F, d.KD, d.F, w.conv_wp, sp);
   else launch_round_bf16(c->P("qkv_w"), w.qkv_w16, (size_t)d.D * 3 * d.F, sp);   // (D % 4 == 0: mhsa_supported)
-  launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, sp);
+  launch_gru_pack(c->P("gru_u"), d.H, w.gru_up, sp, c->opt.gru_f16, c->gru_seq++);   // (a stand-alone pack is always fresh)
 }
 
 bool has_user_table(const Dims& d) {
@@ -1145,7 +1148,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
     const bool init_user = d.arch == LSTUR_ARCH_IGRU || two_tables(d);   // initial_state = user_vec
     PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, init_user ? w.uvec : nullptr, w.gru_up,
-                                   w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s));
+                                   w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s, c->opt.gru_f16));
     if (d.arch == LSTUR_ARCH_PGRU) {        // GRU(U)(x) + user_vec (paper.py:624-626)
       launch_add2(w.hlast, w.uvec, w.uservec, (size_t)n * d.U, s);
     } else if (!direct) {
@@ -1846,7 +1849,7 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
     const float grow = adam_growth_bound(c) * fabsf(lr_t);
     if (ctx->images_valid && ctx->opt.adam_pack && d.np && kq > 0 && ctx->ws.gru_up && isfinite(grow)) {
       int Kp = 0, Np = 0;
-      convx_w_dims(d.D, d.k, d.F, &Kp, &Np);
+      convx_w_dims(d.D, d.k, d.F, d.np, &Kp, &Np);
       pl.conv_off = (size_t)(ctx->P("conv_w") - ctx->buf.dense_param);
       pl.conv_cnt = (size_t)d.k * d.D * d.F;
       pl.D = d.D; pl.Dp = convx_dp(d.D); pl.F = d.F; pl.Np = Np;
@@ -1856,6 +1859,7 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
       pl.gru_off = (size_t)(ctx->P("gru_u") - ctx->buf.dense_param);
       pl.H = d.H; pl.KQ = kq;
       pl.gimg = ctx->ws.gru_up;
+      pl.gru_f16 = ctx->opt.gru_f16 ? 1 : 0; pl.gru_seq = ctx->gru_seq++; pl.ggrow = grow;
       packed = true;
     }
   }
@@ -2242,7 +2246,7 @@ int lstur_gemm_f32(const float* A, int32_t lda, int32_t ta, const float* B, int3
 size_t lstur_gru_pack_floats(int32_t H) { return gru_pack_floats(H); }
 int lstur_gru_pack_u(const float* gru_u, int32_t H, float* packed, lstur_stream stream) {
   if (!gru_u || !packed || H < 1 || H > 256) return fail(LSTUR_ERR_ARG, "gru pack: bad argument");
-  launch_gru_pack(gru_u, H, packed, (hipStream_t)stream);
+  launch_gru_pack(gru_u, H, packed, (hipStream_t)stream, gru4_f16_env(), 0);
   return check_launch("gru_pack");
 }
 size_t lstur_gru_tape_floats(int32_t n, int32_t W, int32_t H) { return gru_tape_floats(n, W, H); }
@@ -2251,7 +2255,7 @@ int lstur_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const 
   if (!xw || !gmask || !packed || !tape || !hlast || n < 0 || W < 1 || H < 1 || H > 256 ||
       (size_t)n * W * 3 * H >= ((size_t)1 << 30))
     return fail(LSTUR_ERR_ARG, "gru fwd: bad argument");
-  launch_gru_fwd(xw, gmask, h0, packed, tape, hlast, n, W, H, (hipStream_t)stream);
+  launch_gru_fwd(xw, gmask, h0, packed, tape, hlast, n, W, H, (hipStream_t)stream, gru4_f16_env());
   return check_launch("gru_fwd");
 }
 int lstur_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* packed, float* dgates,

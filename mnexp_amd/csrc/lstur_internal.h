@@ -117,6 +117,8 @@ struct ImagePlan {
   size_t gru_off = 0;                  // gru_u slot ([H, 3H]); H == 0: no resident-U images
   int H = 0, KQ = 0;
   float* gimg = nullptr;
+  int gru_f16 = 0, gru_seq = 0;        // fp16-pair images: scale from the tail's rotating maxima (gru4.hip), + ggrow
+  float ggrow = 0.f;
 };
 void launch_adam_flat_pack(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
                            const ImagePlan& plan, hipStream_t s);
@@ -224,11 +226,14 @@ constexpr int kWmaxLanes = 64, kWmaxStride = 64;
 constexpr int kCsWmax = 64;
 constexpr int kCsWords = kCsWmax + 3 * kWmaxLanes * kWmaxStride;
 __host__ __device__ inline int wmax_word(int slot, int lane) { return kCsWmax + (slot * kWmaxLanes + lane) * kWmaxStride; }
+// the same for the recurrent matrix, in the tail behind the GRU's operand images (gru4.hip): [0] sU, [1] 1 / sU, the slots
+constexpr int kGruTailWords = kWmaxStride + 3 * kWmaxLanes * kWmaxStride;
+__host__ __device__ inline int gru_wmax_word(int slot, int lane) { return kWmaxStride + (slot * kWmaxLanes + lane) * kWmaxStride; }
 bool convx_supported(int D, int ksize, int F);                    // D % 4 == 0, F <= 448, ksize <= 8
 int convx_dp(int D);                                              // embedding row length of Ex (D rounded up to 8)
 size_t convx_e_elems(int n_titles, int T, int D, int ksize, int np);   // 16-bit elements of Ex incl. slack
 size_t convx_w_elems(int D, int ksize, int F, int np);                 // 16-bit elements of the split weight image
-void convx_w_dims(int D, int ksize, int F, int* Kp, int* Np);     // padded shape of the image ([np][Kp][Np], k' = tap * Dp + d)
+void convx_w_dims(int D, int ksize, int F, int np, int* Kp, int* Np);   // padded shape of the image ([np][Kp][Np], k' = tap * Dp + d)
 void launch_convx_scales_init(float* cs, hipStream_t s);
 void launch_absmax(const float* x, size_t n, uint32_t* out_bits, hipStream_t s);   // atomicMax of the bits of |x[i]|
 void launch_absmax_rows(const float* x, int rows, int cols, const int32_t* vidx, const int32_t* vcount, uint32_t* out_bits,
@@ -345,12 +350,15 @@ void launch_gemm(const float* A, int lda, int ta, const float* B, int ldb, int t
 // ---- gru.hip / gru4.hip --------------------------------------------------------------------------
 // Operand images of the recurrent matrix U [H,3H]: ONE opaque buffer of gru_pack_floats(H) floats (one launch).
 size_t gru_pack_floats(int H);
-void launch_gru_pack(const float* U, int H, float* packed, hipStream_t s);
+// f16 (fast path only): the FORWARD's recurrent products as fp16 pairs on v_mfma_f32_4x4x4_16b_f16 (gru4.hip) -- pack and
+// forward of one context must agree on it (the BPTT's operand images stay floats).  seq: the pack's sequence number (rotating maxima of |U|, like the conv weight image).
+bool gru4_f16_env();                        // !LSTUR_GRU_F32 (read where a context / a stand-alone call is set up)
+void launch_gru_pack(const float* U, int H, float* packed, hipStream_t s, bool f16 = false, int seq = 0);
 // tape: gru_tape_floats(n, W, H) floats of scratch shared by forward and BPTT (layout private to the kernels).
 // xw [n*W,3H] row-major; hlast [n,H]; dgates [n*W,3H], rh / hprev [n*W,H] row-major.  Requires H <= 256.
 size_t gru_tape_floats(int n, int W, int H);
 void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
-                    float* hlast, int n, int W, int H, hipStream_t s);
+                    float* hlast, int n, int W, int H, hipStream_t s, bool f16 = false);
 void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* packed, float* dgates,
                     float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s);
 // On the fast path the forward already leaves hprev and r*hprev row-major inside the tape: returns true and the two
@@ -363,9 +371,10 @@ int gru4_pack_kq(int H);            // k-quads per column of the resident-U imag
 size_t gru4_pack_floats(int H);
 size_t gru4_tape_floats(int n, int W, int H);
 void gru4_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh);
-void launch_gru4_pack(const float* U, int H, float* img, hipStream_t s);
+size_t gru4_image_floats(int H);     // floats of the six operand images (the pack's tail follows: scale, rotating maxima)
+void launch_gru4_pack(const float* U, int H, float* img, hipStream_t s, bool f16 = false, int seq = 0);
 void launch_gru4_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* img, float* tape, float* hlast,
-                     int n, int W, int H, hipStream_t s);
+                     int n, int W, int H, hipStream_t s, bool f16 = false);
 void launch_gru4_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* img, float* dgates, float* rh,
                      float* hprev, float* dh0, int n, int W, int H, hipStream_t s);
 

@@ -506,9 +506,13 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
 // launch: blocks [0, flat_blocks) sweep the bucket, the rest handle one sample row per wave.
 __device__ __forceinline__ void combine_row(const int32_t* __restrict__ rows, const float* __restrict__ g, int n, int dim,
                                             float* __restrict__ gsum, int32_t* __restrict__ slot, int i, int lane);
-__device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, float pi, float sW, uint32_t& wmax);
-__device__ __forceinline__ float image_scale(const ImagePlan& P);
-__device__ __forceinline__ void image_finish(const ImagePlan& P, float sW, uint32_t wmax, bool first_block);
+struct ImgState {          // the scales this launch writes the fp16-pair images with, the maxima it sees
+  float sW, sU;
+  uint32_t wmax, umax;
+};
+__device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, float pi, ImgState& S);
+__device__ __forceinline__ ImgState image_scale(const ImagePlan& P);
+__device__ __forceinline__ void image_finish(const ImagePlan& P, const ImgState& S, bool first_block);
 __global__ __launch_bounds__(256) void adam_flat_combine_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                 float* __restrict__ m, float* __restrict__ v, size_t n,
                                                                 float lr_t, float b1, float b2, float eps,
@@ -521,17 +525,16 @@ __global__ __launch_bounds__(256) void adam_flat_combine_kernel(float* __restric
     if (i < n_rows) combine_row(rows, rg, n_rows, dim, gsum, slot, i, threadIdx.x & 63);
     return;
   }
-  const float sW = image_scale(P);
-  uint32_t wmax = 0;
+  ImgState S = image_scale(P);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)flat_blocks * 256) {
     float pi = p[i], mi = m[i], vi = v[i];
     adam1(pi, g[i], mi, vi, lr_t, b1, b2, eps);
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
-    image_scatter(P, i, pi, sW, wmax);  // (an empty plan scatters nothing)
+    image_scatter(P, i, pi, S);         // (an empty plan scatters nothing)
   }
-  image_finish(P, sW, wmax, blockIdx.x == 0);
+  image_finish(P, S, blockIdx.x == 0);
 }
 void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                               float eps, const int32_t* rows, const float* rg, int n_rows, int dim, float* gsum,
@@ -546,43 +549,73 @@ void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size
 // f16x2 images: the scale comes from the maximum the previous pack saw, this launch leaves its own for the next one
 // (the rule of convx.hip: convx_pack_w_kernel, restated here so that the image costs no launch of its own)
 // (workgroups of 256 threads, EXEC full: every thread of the sweep's blocks calls both)
-__device__ __forceinline__ float image_scale(const ImagePlan& P) {
-  if (!(P.conv_cnt && P.np == 2)) return 1.0f;
-  const uint32_t* cu = (const uint32_t*)P.cs;
-  uint32_t m = cu[wmax_word(P.seq % 3, threadIdx.x & (kWmaxLanes - 1))];
+__device__ __forceinline__ uint32_t slot_max(const uint32_t* words, int first_word) {   // first_word: word of lane 0 of the slot
+  uint32_t m = words[first_word + (int)(threadIdx.x & (kWmaxLanes - 1)) * kWmaxStride];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  return pow2_scale(__float_as_uint(__uint_as_float(m) + P.grow), 13);
+  return m;
 }
-__device__ __forceinline__ void image_finish(const ImagePlan& P, float sW, uint32_t wmax, bool first_block) {
-  if (!(P.conv_cnt && P.np == 2)) return;
-  uint32_t* cu = (uint32_t*)P.cs;
-  __shared__ uint32_t wm[4];
+__device__ __forceinline__ ImgState image_scale(const ImagePlan& P) {
+  ImgState S{1.0f, 1.0f, 0u, 0u};
+  if (P.conv_cnt && P.np == 2)
+    S.sW = pow2_scale(__float_as_uint(__uint_as_float(slot_max((const uint32_t*)P.cs, wmax_word(P.seq % 3, 0))) + P.grow), 13);
+  if (P.H && P.gru_f16) {
+    const uint32_t* tail = (const uint32_t*)(P.gimg + (size_t)P.KQ * 4 * 6 * P.H);
+    S.sU = pow2_scale(__float_as_uint(__uint_as_float(slot_max(tail, gru_wmax_word(P.gru_seq % 3, 0))) + P.ggrow), 13);
+  }
+  return S;
+}
+// a workgroup leaves its maximum in word (workgroup % lanes) of slot `add` and (first workgroup) clears slot `clear`
+__device__ __forceinline__ void slot_leave(uint32_t* words, uint32_t m, int add_word0, int clear_word0, bool first_block, uint32_t* wm) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o, 64));
-  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = wmax;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
-    if (m) atomicMax(cu + wmax_word((P.seq + 1) % 3, blockIdx.x & (kWmaxLanes - 1)), m);
+    m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    if (m) atomicMax(words + add_word0 + (int)(blockIdx.x & (kWmaxLanes - 1)) * kWmaxStride, m);
   }
-  if (first_block && threadIdx.x < kWmaxLanes) cu[wmax_word((P.seq + 2) % 3, threadIdx.x)] = 0u;
-  if (first_block && threadIdx.x == 0) {
-    P.cs[kCsW] = sW;
-    P.cs[kCsFwd] = 1.0f / (P.cs[kCsE] * sW);
+  if (first_block && threadIdx.x < kWmaxLanes) words[clear_word0 + (int)threadIdx.x * kWmaxStride] = 0u;
+  __syncthreads();
+}
+__device__ __forceinline__ void image_finish(const ImagePlan& P, const ImgState& S, bool first_block) {
+  __shared__ uint32_t wm[4];
+  if (P.conv_cnt && P.np == 2) {
+    slot_leave((uint32_t*)P.cs, S.wmax, wmax_word((P.seq + 1) % 3, 0), wmax_word((P.seq + 2) % 3, 0), first_block, wm);
+    if (first_block && threadIdx.x == 0) {
+      P.cs[kCsW] = S.sW;
+      P.cs[kCsFwd] = 1.0f / (P.cs[kCsE] * S.sW);
+    }
+  }
+  if (P.H && P.gru_f16) {
+    float* tail = P.gimg + (size_t)P.KQ * 4 * 6 * P.H;
+    slot_leave((uint32_t*)tail, S.umax, gru_wmax_word((P.gru_seq + 1) % 3, 0), gru_wmax_word((P.gru_seq + 2) % 3, 0), first_block, wm);
+    if (first_block && threadIdx.x == 0) {
+      tail[0] = S.sU;
+      tail[1] = 1.0f / S.sU;
+    }
   }
 }
-__device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, float pi, float sW, uint32_t& wmax) {
+// the fp16 pair of v (scaled) at group (4 elements = 16 bytes), element j   (gru4.hip: gru4_put)
+__device__ __forceinline__ void put_pair(float* img, size_t group4, int j, float v) {
+  v = fminf(fmaxf(v, -65504.f), 65504.f);
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)(v - (float)h);
+  unsigned short* p = (unsigned short*)img + 2 * group4 + j;
+  p[0] = __builtin_bit_cast(unsigned short, h);
+  p[4] = __builtin_bit_cast(unsigned short, l);
+}
+__device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, float pi, ImgState& S) {
     if (i - P.conv_off < P.conv_cnt) {            // conv_w[tap * D + d][f] -> Wx[part][tap * Dp + d][f]  (convx_pack_w_kernel)
       const size_t j = i - P.conv_off;
       const int f = (int)(j % P.F), td = (int)(j / P.F), tap = td / P.D, d = td - tap * P.D;
       const size_t idx = ((size_t)tap * P.Dp + d) * P.Np + f;
       if (P.np == 2) {
         u16x4 h, l;
-        split2(make_float4(fminf(fmaxf(pi * sW, -65504.f), 65504.f), 0.f, 0.f, 0.f), h, l);
+        split2(make_float4(fminf(fmaxf(pi * S.sW, -65504.f), 65504.f), 0.f, 0.f, 0.f), h, l);
         P.w3[idx] = h[0];
         P.w3[P.w3_part + idx] = l[0];
-        wmax = max(wmax, __float_as_uint(fabsf(pi)));
+        S.wmax = max(S.wmax, __float_as_uint(fabsf(pi)));
       } else {
         u16x4 h, mm, l;
         split3(make_float4(pi, 0.f, 0.f, 0.f), h, mm, l);
@@ -595,25 +628,30 @@ __device__ __forceinline__ void image_scatter(const ImagePlan& P, size_t i, floa
       const size_t j = i - P.gru_off;
       const int H = P.H, c = (int)(j % (3 * H)), k = (int)(j / (3 * H));
       const size_t e = (size_t)P.KQ * 4 * H;
-      if (c < 2 * H) P.gimg[((size_t)(k >> 2) * 2 * H + c) * 4 + (k & 3)] = pi;                          // izr
-      else P.gimg[2 * e + ((size_t)(k >> 2) * H + (c - 2 * H)) * 4 + (k & 3)] = pi;                      // ih
       const int which = 1 + c / H, kk = c - (which - 1) * H;                                             // itz | itr | ith
-      P.gimg[2 * e + (size_t)which * e + ((size_t)(kk >> 2) * H + k) * 4 + (kk & 3)] = pi;
+      const size_t g_zr = ((size_t)(k >> 2) * 2 * H + c) * 4, g_h = 2 * e + ((size_t)(k >> 2) * H + (c - 2 * H)) * 4;
+      const size_t g_t = 2 * e + (size_t)which * e + ((size_t)(kk >> 2) * H + k) * 4;
+      if (P.gru_f16) {      // the forward's images (izr, ih) as fp16 pairs; the BPTT's stay floats (gru4.hip)
+        put_pair(P.gimg, c < 2 * H ? g_zr : g_h, k & 3, pi * S.sU);
+        S.umax = max(S.umax, __float_as_uint(fabsf(pi)));
+      } else {
+        P.gimg[(c < 2 * H ? g_zr : g_h) + (k & 3)] = pi;
+      }
+      P.gimg[g_t + (kk & 3)] = pi;
     }
 }
 __global__ void adam_flat_pack_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                       float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, ImagePlan P) {
-  const float sW = image_scale(P);
-  uint32_t wmax = 0;
+  ImgState S = image_scale(P);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float pi = p[i], mi = m[i], vi = v[i];
     adam1(pi, g[i], mi, vi, lr_t, b1, b2, eps);
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
-    image_scatter(P, i, pi, sW, wmax);
+    image_scatter(P, i, pi, S);
   }
-  image_finish(P, sW, wmax, blockIdx.x == 0);
+  image_finish(P, S, blockIdx.x == 0);
 }
 void launch_adam_flat_pack(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
                            const ImagePlan& plan, hipStream_t s) {
