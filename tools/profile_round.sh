@@ -1,6 +1,6 @@
 #!/bin/bash
 # All profile passes of a round for the default bench workload; summaries -> gpurun_out/<tag>_*.  usage: profile_round.sh TAG
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 CMD="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-profile"
