@@ -339,7 +339,9 @@ int lstur_conv1d_relu_mask_fwd(const float* emb_padded, const float* w_packed, c
  * away; tests/test_gpu_kernels.py holds both to the bound of the exact-fp32 MFMA kernel against fp64.
  * Layouts: "Ex" = [title][title_len + ksize - 1][ceil8(dim) / 8][part][8] 16-bit (lstur_convx_e_elems elements incl. slack;
  * written by lstur_convx_gather: out = table[ids] (x dropout mask / (1 - drop)) (x scale), zero rows left and right;
- * skip_unread != 0: rows that no window of a non-pad token covers are left untouched -- ex must then hold finite values);
+ * skip_unread != 0: rows that no window of a non-pad token covers are left untouched -- ex must then hold finite values;
+ * live (or NULL; title_len <= 32): bit t of live[title] = token t is not a pad -- with skip_unread the kernel then takes the
+ * covered rows from these words instead of reading the neighbours' ids);
  * weight image wx = lstur_convx_pack_w(conv_w [ksize * dim, filters]) of lstur_convx_w_elems elements.
  * Call order for parts = 2: lstur_convx_scales_init, lstur_convx_embedding_scale(table), lstur_convx_pack_w, then gather /
  * forward / kernel gradient in any order. */
@@ -349,7 +351,7 @@ int lstur_convx_embedding_scale(const float* table, size_t count, float drop, fl
 size_t lstur_convx_e_elems(int32_t n_titles, int32_t title_len, int32_t dim, int32_t ksize, int32_t parts);
 int lstur_convx_gather(const float* table, const int32_t* ids, uint16_t* ex, int32_t n_titles, int32_t title_len, int32_t dim,
                        int32_t pad_left, int32_t pad_right, float drop, uint32_t key, int32_t skip_unread, int32_t parts,
-                       const float* scales, lstur_stream stream);
+                       const float* scales, const uint32_t* live, lstur_stream stream);
 size_t lstur_convx_w_elems(int32_t dim, int32_t ksize, int32_t filters, int32_t parts);
 int lstur_convx_pack_w(const float* w, int32_t dim, int32_t ksize, int32_t filters, uint16_t* wx, int32_t parts, float* scales,
                        lstur_stream stream);

@@ -93,7 +93,7 @@ SIGNATURES = {
     'lstur_convx_scales_init': (_I, [_P, _P]),
     'lstur_convx_embedding_scale': (_I, [_P, _Z, _F, _P, _P]),
     'lstur_convx_e_elems': (_Z, [_I, _I, _I, _I, _I]),
-    'lstur_convx_gather': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _I, _I, _P, _P]),
+    'lstur_convx_gather': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _I, _I, _P, _P, _P]),
     'lstur_convx_w_elems': (_Z, [_I, _I, _I, _I]),
     'lstur_convx_pack_w': (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     'lstur_convx_fwd_scratch': (_Z, []),

@@ -161,13 +161,19 @@ void launch_convx_scales_init(float* cs, hipStream_t s) {
 // the front).  The buffer must hold finite values from the start (the k tail of a window can touch a skipped row under a
 // zero weight): the step zeroes it once.
 // ---------------------------------------------------------------------------------------------
-template <int NP, bool DROP, bool SKIP>
+// LIVE: which rows are covered comes from the title's non-pad bit mask (bit t of live[title], T <= 32; the compaction kernel
+// leaves it) instead of the neighbours' ids: behind a step's traffic those id loads come from HBM and the table load hangs on
+// them -- 45 -> 35 us from cold caches (tools/probe_gather.hip, profiles/r03_probe_gather.txt).
+template <int NP, bool DROP, bool SKIP, bool LIVE>
 __global__ __launch_bounds__(256) void gatherx_kernel(const float4* __restrict__ table, const int32_t* __restrict__ ids,
-                                                      uint4* __restrict__ out, uint32_t total8, int T, int Tp, int D4,
-                                                      int C8, int pad_l, int pad_r, uint32_t thresh, uint32_t key,
-                                                      float scale, const float* __restrict__ cs) {
+                                                      const uint32_t* __restrict__ live_mask, uint4* __restrict__ out,
+                                                      uint32_t total8, int T, int Tp, int D4, int C8, int pad_l, int pad_r,
+                                                      uint32_t thresh, uint32_t key, float scale,
+                                                      const float* __restrict__ cs) {
   __shared__ uint4 xbuf[4][64 * NP];
-  constexpr int U = 4;      // four chunks (eight 16-byte table loads) in flight per thread (1, 2, 8: the same or slower)
+  // two chunks (four 16-byte table loads) in flight per thread: 54 registers = 8 waves per SIMD; four chunks cost three of
+  // the eight waves and ran 2 us slower from cold caches, one or eight chunks 3 to 6 us slower
+  constexpr int U = 2;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t stride = gridDim.x * blockDim.x;
   const float sE = NP == 2 ? cs[kCsE] : 1.0f;
@@ -187,7 +193,11 @@ __global__ __launch_bounds__(256) void gatherx_kernel(const float4* __restrict__
       real[u] = t >= 0 && t < T;
       tok[u] = n * (uint32_t)T + (uint32_t)min(max(t, 0), T - 1);
       id[u] = ids[tok[u]];
-      if (SKIP) {
+      if (SKIP && LIVE) {
+        const int lo = max(t - pad_r, 0), hi = min(t + pad_l, T - 1);
+        const uint32_t win = hi >= lo ? ((0xFFFFFFFFu >> (31 - (hi - lo))) << lo) : 0u;
+        inr[u] = inr[u] && (live_mask[n] & win) != 0u;
+      } else if (SKIP) {
         bool need = false;
         for (int tt = max(t - pad_r, 0); tt <= min(t + pad_l, T - 1); ++tt) need |= ids[n * (uint32_t)T + (uint32_t)tt] != 0;
         inr[u] = inr[u] && need;
@@ -257,25 +267,33 @@ __global__ __launch_bounds__(256) void gatherx_kernel(const float4* __restrict__
 
 void launch_gatherx(const float* table, const int32_t* ids, unsigned short* ex, int n_titles, int T, int D, int pad_l,
                     int pad_r, float drop, uint32_t key, bool skip_unread, int np, const float* cs, hipStream_t s,
-                    int max_blocks) {
+                    int max_blocks, const uint32_t* live) {
   const int Tp = T + pad_l + pad_r, D4 = D / 4, C8 = (D + 7) / 8;
   const size_t total8 = (size_t)n_titles * Tp * C8;
   if (total8 == 0) return;
+  if (T > 32 || !skip_unread) live = nullptr;   // (one 32-bit word per title)
   // (max_blocks: a background launch beside latency-bound kernels takes a fraction of the chip on purpose)
-  const int blocks = (int)std::min<size_t>(cdivz(total8, 256 * 4), max_blocks > 0 ? max_blocks : 256 * 16);
+  const int blocks = (int)std::min<size_t>(cdivz(total8, 256 * 2), max_blocks > 0 ? max_blocks : 256 * 32);
   const uint32_t th = drop > 0.f ? dropout_thresh(drop) : 0u;
   const float sc = drop > 0.f ? 1.0f / (1.0f - drop) : 1.0f;
   auto go = [&](auto kern) {
     last_launch();
-    launch_k(kern, dim3(blocks), dim3(256), 0, s, (const float4*)table, ids, (uint4*)ex, (uint32_t)total8, T, Tp, D4, C8, pad_l,
-             pad_r, th, key, sc, cs);
+    launch_k(kern, dim3(blocks), dim3(256), 0, s, (const float4*)table, ids, live, (uint4*)ex, (uint32_t)total8, T, Tp, D4, C8,
+             pad_l, pad_r, th, key, sc, cs);
+  };
+  auto pick = [&](auto np_c, auto drop_c) {
+    constexpr int NP = decltype(np_c)::value;
+    constexpr bool DR = decltype(drop_c)::value;
+    if (!skip_unread) go(gatherx_kernel<NP, DR, false, false>);
+    else if (live) go(gatherx_kernel<NP, DR, true, true>);
+    else go(gatherx_kernel<NP, DR, true, false>);
   };
   if (np == 2) {
-    if (drop > 0.f) skip_unread ? go(gatherx_kernel<2, true, true>) : go(gatherx_kernel<2, true, false>);
-    else skip_unread ? go(gatherx_kernel<2, false, true>) : go(gatherx_kernel<2, false, false>);
+    if (drop > 0.f) pick(std::integral_constant<int, 2>{}, std::true_type{});
+    else pick(std::integral_constant<int, 2>{}, std::false_type{});
   } else {
-    if (drop > 0.f) skip_unread ? go(gatherx_kernel<3, true, true>) : go(gatherx_kernel<3, true, false>);
-    else skip_unread ? go(gatherx_kernel<3, false, true>) : go(gatherx_kernel<3, false, false>);
+    if (drop > 0.f) pick(std::integral_constant<int, 3>{}, std::true_type{});
+    else pick(std::integral_constant<int, 3>{}, std::false_type{});
   }
 }
 

@@ -723,7 +723,7 @@ bool launch_prefetch(lstur_ctx* c, hipEvent_t forked) {
   {
     ProfScope _ps(c, "gather", p, true);
     launch_gatherx(c->buf.word_emb, t.ids, t.e3, nt, d.T, d.D, pl, d.k - 1 - pl, c->cfg.dropout,
-                   dropout_key(c->cfg.seed, q.step, 0), true, d.np, w.cs, p, c->opt.prefetch_blocks);
+                   dropout_key(c->cfg.seed, q.step, 0), true, d.np, w.cs, p, c->opt.prefetch_blocks, t.live);
   }
   // the attention passes' dropout decisions for that batch (stream 1 of its step), behind the gather
   q.kbits = launch_attpool_keep_bits(t.live, t.kbits, nt, d.T, d.F, c->cfg.dropout, dropout_key(c->cfg.seed, q.step, 1), p);
@@ -1077,7 +1077,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
                                  usex ? convx_dp(d.D) / 8 * d.np : d.D, d.F, w.offA, w.offB, s, w.live, nW * d.T);
     if (usex) {   // Embedding + Dropout straight into the pre-split layout of the conv kernels (rows nobody reads skipped)
       ProfScope _ps(c, "gather", s, true);
-      launch_gatherx(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, d.np, w.cs, s);
+      launch_gatherx(c->buf.word_emb, w.ids, w.e3, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, true, d.np, w.cs, s, 0, w.live);
     } else if (mhsa) {   // bf16 rows for the projections (they rounded the fp32 rows the same way on their way into LDS)
       PROF("gather", launch_gather_bf16(c->buf.word_emb, w.ids, (unsigned short*)w.emb, nt, d.T, d.D, pl, d.k - 1 - pl, drop, key0, s));
     } else {
@@ -2112,11 +2112,12 @@ size_t lstur_convx_e_elems(int32_t n_titles, int32_t title_len, int32_t dim, int
 }
 int lstur_convx_gather(const float* table, const int32_t* ids, uint16_t* ex, int32_t n_titles, int32_t title_len, int32_t dim,
                        int32_t pad_left, int32_t pad_right, float drop, uint32_t key, int32_t skip_unread, int32_t parts,
-                       const float* scales, lstur_stream stream) {
+                       const float* scales, const uint32_t* live, lstur_stream stream) {
   if (!table || !ids || !ex || dim % 4 || n_titles < 0 || (parts != 2 && parts != 3) || (parts == 2 && !scales))
     return fail(LSTUR_ERR_ARG, "convx_gather: bad argument (dim % 4, parts 2 | 3, scales)");
+  if (live && title_len > 32) return fail(LSTUR_ERR_ARG, "convx_gather: the non-pad masks hold 32 tokens per title");
   launch_gatherx(table, ids, ex, n_titles, title_len, dim, pad_left, pad_right, drop, key, skip_unread != 0, parts, scales,
-                 (hipStream_t)stream);
+                 (hipStream_t)stream, 0, live);
   return check_launch("convx_gather");
 }
 size_t lstur_convx_w_elems(int32_t dim, int32_t ksize, int32_t filters, int32_t parts) {

@@ -242,7 +242,7 @@ void launch_convx_escale(const float* table, size_t count, float drop, float* cs
 // skip_unread: rows no window of a non-pad token covers are neither read nor written (the buffer must hold finite values)
 void launch_gatherx(const float* table, const int32_t* ids, unsigned short* ex, int n_titles, int T, int D, int pad_l,
                     int pad_r, float drop, uint32_t key, bool skip_unread, int np, const float* cs, hipStream_t s,
-                    int max_blocks = 0);
+                    int max_blocks = 0, const uint32_t* live = nullptr);
 // fresh: the scale comes from W as it is; else from the previous pack's maximum + grow (how far a step can move a weight)
 void launch_convx_pack_w(const float* W, int D, int ksize, int F, unsigned short* Wx, int np, float* cs, int seq, bool fresh,
                          float grow, hipStream_t s);

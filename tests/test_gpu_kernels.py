@@ -459,7 +459,7 @@ def test_convx_gather_is_the_split_of_the_fp32_gather(N, D, T, k, drop, parts):
     ne = lib.lstur_convx_e_elems(N, T, D, k, parts)
     assert ne >= N * Tp * Dp * parts
     ex = torch.full((ne,), 0x7FC0, dtype=torch.int16, device='cuda')
-    check(lib.lstur_convx_gather(t_d.data_ptr(), i_d.data_ptr(), ex.data_ptr(), N, T, D, pl, pr, drop, 1234, 0, parts, csp, stream()))
+    check(lib.lstur_convx_gather(t_d.data_ptr(), i_d.data_ptr(), ex.data_ptr(), N, T, D, pl, pr, drop, 1234, 0, parts, csp, None, stream()))
     torch.cuda.synchronize()
     E = ref[:N * Tp * D].cpu().numpy().reshape(N, Tp, D)
     Epad = np.zeros((N, Tp, Dp), np.float32)
@@ -476,15 +476,19 @@ def test_convx_gather_is_the_split_of_the_fp32_gather(N, D, T, k, drop, parts):
     got = ex[:N * Tp * Dp * parts].cpu().numpy().view(np.uint16).reshape(N, Tp, Dp // 8, parts, 8)
     assert np.array_equal(got, want)
     # skip_unread: exactly the rows some non-pad token's window covers are written (same values), the others untouched
-    exs = torch.full((ne,), 0x1234, dtype=torch.int16, device='cuda')
-    check(lib.lstur_convx_gather(t_d.data_ptr(), i_d.data_ptr(), exs.data_ptr(), N, T, D, pl, pr, drop, 1234, 1, parts, csp, stream()))
-    gots = exs[:N * Tp * Dp * parts].cpu().numpy().view(np.uint16).reshape(N, Tp, Dp // 8, parts, 8)
     nonpad = np.zeros((N, Tp + k), bool)
     for j in range(k):                                    # token t covers padded rows t .. t + k - 1
         nonpad[:, j:j + T] |= ids != 0
     need = nonpad[:, :Tp]
-    assert np.array_equal(gots[need], want[need])
-    assert (gots[~need] == 0x1234).all() and (~need).any()
+    # ... found from the neighbours' ids, or from the titles' non-pad bit masks (what the training step hands over)
+    live = dev(((ids != 0).astype(np.uint64) << np.arange(T, dtype=np.uint64)).sum(1).astype(np.uint32).view(np.int32))
+    for lv in (None, live.data_ptr()):
+        exs = torch.full((ne,), 0x1234, dtype=torch.int16, device='cuda')
+        check(lib.lstur_convx_gather(t_d.data_ptr(), i_d.data_ptr(), exs.data_ptr(), N, T, D, pl, pr, drop, 1234, 1, parts, csp, lv,
+                                     stream()))
+        gots = exs[:N * Tp * Dp * parts].cpu().numpy().view(np.uint16).reshape(N, Tp, Dp // 8, parts, 8)
+        assert np.array_equal(gots[need], want[need])
+        assert (gots[~need] == 0x1234).all() and (~need).any()
 
 
 def _convx_case(lib, check, rng, N, D, T, F, k, parts, sliced, table, Wc, dC, tag, bias_scale=1.0):
@@ -500,7 +504,7 @@ def _convx_case(lib, check, rng, N, D, T, F, k, parts, sliced, table, Wc, dC, ta
     cs = _convx_scales(lib, check, t_d, V * D, 0.0) if parts == 2 else None
     csp = cs.data_ptr() if parts == 2 else None
     ex = torch.zeros(lib.lstur_convx_e_elems(N, T, D, k, parts), dtype=torch.int16, device='cuda')
-    check(lib.lstur_convx_gather(t_d.data_ptr(), ids_d.data_ptr(), ex.data_ptr(), N, T, D, pl, k - 1 - pl, 0.0, 0, 0, parts, csp, stream()))
+    check(lib.lstur_convx_gather(t_d.data_ptr(), ids_d.data_ptr(), ex.data_ptr(), N, T, D, pl, k - 1 - pl, 0.0, 0, 0, parts, csp, None, stream()))
     Wd = dev(Wc.reshape(k * D, F))
     wx = torch.zeros(lib.lstur_convx_w_elems(D, k, F, parts), dtype=torch.int16, device='cuda')
     check(lib.lstur_convx_pack_w(Wd.data_ptr(), D, k, F, wx.data_ptr(), parts, csp, stream()))

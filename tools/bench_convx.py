@@ -62,6 +62,7 @@ def main():
     lens[rng.random(N) < 0.14] = 0                      # front-padded history slots: all-pad titles
     ids[np.arange(T)[None, :] >= lens[:, None]] = 0
     ids_d = torch.from_numpy(ids).cuda()
+    live = torch.from_numpy(((ids != 0).astype(np.uint64) << np.arange(T, dtype=np.uint64)).sum(1).astype(np.uint32).view(np.int32)).cuda()
     table = torch.randn(V, D, device='cuda') * 0.1
     table[0] = 0
     W = torch.randn(k * D, F, device='cuda') * 0.05
@@ -93,7 +94,7 @@ def main():
         offs = torch.zeros(2 * N * T, dtype=torch.int32, device='cuda')
         keep = (cs, ex, wx, scr, wscr, offs)
         g = lambda parts=parts, cs=cs, ex=ex: check(lib.lstur_convx_gather(
-            table.data_ptr(), ids_d.data_ptr(), ex.data_ptr(), N, T, D, 1, 1, 0.2, 7, 1, parts, cs.data_ptr(), stream()))
+            table.data_ptr(), ids_d.data_ptr(), ex.data_ptr(), N, T, D, 1, 1, 0.2, 7, 1, parts, cs.data_ptr(), live.data_ptr(), stream()))
         f = lambda parts=parts, cs=cs, ex=ex, wx=wx, scr=scr: check(lib.lstur_convx_fwd(
             ex.data_ptr(), wx.data_ptr(), b.data_ptr(), ids_d.data_ptr(), out.data_ptr(), N, T, D, k, F, vidx.data_ptr(),
             vcount.data_ptr(), parts, cs.data_ptr(), scr.data_ptr(), stream()))
