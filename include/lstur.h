@@ -226,6 +226,13 @@ size_t lstur_dp_tail_floats(const lstur_cfg* cfg, int32_t world);
 int lstur_dp_stage(lstur_ctx* ctx, float* tail, int32_t rank, int32_t world, lstur_stream stream);
 int lstur_dp_unpack(lstur_ctx* ctx, const float* tail, int32_t world, int32_t n, const int32_t** rows,
                     const float** grads, lstur_stream stream);
+/* The same exchange without launches of its own: after lstur_dp_attach(ctx, tail, rank, world) every forward_backward
+ * stages the tail inside its final reduction launch (no lstur_dp_stage; tail == NULL detaches), and
+ * lstur_adam_step_dp(ctx, lr, t, tail, world, n) takes the REDUCED tail as it stands -- with full batches (n == max_batch)
+ * the row-gradient matrix is read in place and the row numbers are converted inside the dense Adam launch; a ragged
+ * last batch goes through lstur_dp_unpack internally. */
+int lstur_dp_attach(lstur_ctx* ctx, float* tail, int32_t rank, int32_t world);
+int lstur_adam_step_dp(lstur_ctx* ctx, float lr, int32_t t, const float* tail, int32_t world, int32_t n, lstur_stream stream);
 
 /* keras.optimizers.Adam update (paper.py:657) of the dense bucket from dense_grad, and the DENSE
  * update of the whole user table (TF-1 densifies the IndexedSlices gradient) from n_rows sparse

@@ -75,6 +75,8 @@ SIGNATURES = {
     'lstur_dp_tail_floats': (_Z, [C.POINTER(Cfg), _I]),
     'lstur_dp_stage': (_I, [_P, _P, _I, _I, _P]),
     'lstur_dp_unpack': (_I, [_P, _P, _I, _I, C.POINTER(_P), C.POINTER(_P), _P]),
+    'lstur_dp_attach': (_I, [_P, _P, _I, _I]),
+    'lstur_adam_step_dp': (_I, [_P, _F, _I, _P, _I, _I, _P]),
     'lstur_predict': (_I, [_P, _P, _P, _P, _I, _P, _P]),
     'lstur_predict_ids': (_I, [_P, _P, _P, _P, _I, _P, _P]),
     'lstur_evaluate': (_I, [_P, _P, _P, _P, _I, _P, _P]),

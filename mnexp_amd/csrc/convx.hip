@@ -659,6 +659,9 @@ __global__ __launch_bounds__(256) void convx_fwd_fix_kernel(const float* __restr
 size_t convx_fwd_scratch_bytes(int ncu) { return (size_t)ncu * 128 * 448 * sizeof(float); }
 static int convx_ncu() {
   static int ncu = 0;
+#ifdef LSTUR_ABLATE
+  if (const char* e = getenv("LSTUR_PROBE_NCU")) return atoi(e);   // (timing probes: kernels planned for a chip that shares CUs)
+#endif
   if (!ncu) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -745,7 +748,10 @@ static int gx_nblocks(int F) { return cdiv(cdiv(F, 32), GX_TN); }
 static int gx_slabs(int M, int Kq, int F) {
   const int per = gx_mblocks(Kq) * gx_nblocks(F);
   const int rounds = std::max(1, cdiv(M, 120000));                 // ~105 600 tokens at B = 64 -> one round
-  const int want = rounds * 256 / per / 8 * 8;                     // whole multiples of 8 slabs: the same share for every XCD
+  int want = rounds * 256 / per / 8 * 8;                           // whole multiples of 8 slabs: the same share for every XCD
+#ifdef LSTUR_ABLATE
+  if (const char* e = getenv("LSTUR_PROBE_NCU")) want = rounds * atoi(e) / per;
+#endif
   return std::max(1, std::min(std::max(8, want), std::max(1, M / 512)));
 }
 // (twice the slab count of one launch + one: a step may give the candidate titles' tokens a launch of their own and reduce

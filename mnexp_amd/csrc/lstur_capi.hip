@@ -239,8 +239,8 @@ bool make_dims(const lstur_cfg* c, Dims* d, std::string* why) {
     d->np = !cx ? 0 : (d->word_trainable || Opts::is("LSTUR_CONV_SCHEME", "bf16x3")) ? 3 : 2;
   }
   // the backward pass hands its deferred reductions to ONE launch: 4 (GRU) + 2 (Dense) + 1 (conv_b / attention) + kernel (one
-  // per tap) + 4 (batch statistics) + 1 (mhsa) jobs
-  if (12 + d->k > kMaxReduceJobs) {
+  // per tap) + 4 (batch statistics) + 1 (mhsa) + 9 (data-parallel staging of the user rows, lstur_dp_attach) jobs
+  if (21 + d->k > kMaxReduceJobs) {
     *why = "kernel (conv width) too large for the step's single reduction launch";
     return false;
   }
@@ -307,7 +307,7 @@ struct Workspace {
   void* wgrad_scratch; void* gemm_scratch; size_t gemm_scratch_bytes; void* gemm_scratch_k[4]; float* colsum_scratch_k[3]; int32_t* first; float* gsum; int32_t* slot;
   float* scat; float* spre; float* sds; float* sdhid; float* sdcat;
   int32_t* lazy_last; float* lazy_lrt; int32_t* lazy_first; int32_t* dp_rows; int32_t* pend_rows; float* dp_grads; float* dp_grads2; float* dgrad_scratch; float* lw_a; float* lw_b; float* lw_c; float* lw_d; float* lw_s; float* lw_ds; float* lw_ones; float* ua_a; float* ua_w; float* ua_parts; float* ua_ds; float* uvec2; float* duser2; float* gsum2; unsigned short* conv_w3; unsigned short* e3; float* cs; float* gparts; void* fwd2_scratch; unsigned short* qkv; unsigned short* dqkv; unsigned short* qkv_w16; void* mh_scratch;
-  int32_t* user_rows; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
+  int32_t* user_rows; float* user_rows_f; float* scores; float* colsum_scratch; int32_t* vidx; int32_t* vcount; int32_t* vscratch; float* att_ds; int32_t* offA; int32_t* offB;
   // the staged form of a batch (token ids, their compacted list + offsets, the gathered embeddings) exists twice: while a
   // step runs on one set, the NEXT batch can be staged into the other (lstur_prefetch_ids); ids / e3 / vidx / ... above
   // always point at the set of the running step
@@ -448,7 +448,8 @@ void carve(const Dims& d, void* base, Workspace* w) {
   w->pend_rows = (int32_t*)take((size_t)d.rows_cap * 4);   // rows of a deferred table sweep (marked until it has run)
   w->dp_grads = (float*)take((size_t)d.rows_cap * d.Ue * f4);
   w->dp_grads2 = ii ? (float*)take((size_t)d.rows_cap * d.Ue * f4) : nullptr;
-  w->user_rows = (int32_t*)take(nc * 4);
+  w->user_rows = (int32_t*)take(nc * 8);   // + the same numbers as floats behind them (data-parallel staging)
+  w->user_rows_f = w->user_rows ? (float*)(w->user_rows + nc) : nullptr;
   w->scores = (float*)take(nc * f4);
   w->colsum_scratch = (float*)take((size_t)kColsumSlices * std::max(std::max(3 * d.H, d.U), (int)(3 * ((d.F + kParamAlign - 1) / kParamAlign * kParamAlign) + 64)) * f4);
   for (int k = 0; k < 3; ++k)
@@ -488,6 +489,8 @@ struct ProfKernel {
 
 struct lstur_ctx {
   Opts opt;
+  float* dp_tail = nullptr;   // lstur_dp_attach: the backward pass stages this rank's user rows here
+  int dp_rank = 0, dp_world = 1;
   bool prof_on = false;
   bool prof_roofline_only = false;   // lstur_profile(ctx, 2): brackets around gather / conv_fwd / conv_wgrad only
   std::deque<ProfKernel> prof;  // deque: nested ProfScopes hold pointers across push_back
@@ -1063,6 +1066,23 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     if (packs_forked) (void)hipEventRecord(c->ev_w3, sp);
     c->images_valid = true;
   }
+#ifdef LSTUR_ABLATE
+  // TIMING ONLY (wrong results): what would a recurrence that runs BESIDE the news encoder buy?  LSTUR_PIPE_PROBE bit 0: the
+  // forward recurrence starts here on the parameter-gradient stream (stale inputs); bit 1: the history titles' encoder
+  // backward runs beside BPTT (run_backward)
+  static const int pipe_probe = getenv("LSTUR_PIPE_PROBE") ? atoi(getenv("LSTUR_PIPE_PROBE")) : 0;
+  static hipEvent_t px0 = nullptr, px1 = nullptr;
+  bool probe_fwd = false;
+  if ((pipe_probe & 1) && training && d.arch == LSTUR_ARCH_IGRU && wgrad_stream(c)) {
+    if (!px0) { (void)hipEventCreateWithFlags(&px0, hipEventDisableTiming); (void)hipEventCreateWithFlags(&px1, hipEventDisableTiming); }
+    hipStream_t sw = wgrad_stream(c);
+    (void)hipEventRecord(px0, s);
+    (void)hipStreamWaitEvent(sw, px0, 0);
+    launch_gru_fwd(w.xw, w.gmask, w.uvec, w.gru_up, w.gru_tape, w.uservec, n, d.W, d.H, sw, c->opt.gru_f16);
+    (void)hipEventRecord(px1, sw);
+    probe_fwd = true;
+  }
+#endif
   // news encoder over all titles of the batch (TimeDistributed + K1 candidate calls, paper.py:641-650)
   const int pl = (d.k - 1) / 2;
   if (c->staged_hit) {
@@ -1114,7 +1134,7 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     }
   }
   launch_hist_mask(w.ids, w.docvec, w.hmask, w.gmask, nW, d.T, d.U, s, c->buf.user_emb, user, w.user_rows, w.uvec, n,
-                   d.Ue);
+                   d.Ue, w.user_rows_f);
   // whole-row dropout of the user embedding: dgru's Dropout(0.5, noise_shape=(None, 1)) (paper.py:610), or the id_keep
   // masking of cook.py:139-142 for every arch that reads the table
   const float row_p = training ? user_row_drop(c) : 0.f;
@@ -1147,6 +1167,10 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     // igru / nigru: the last state IS the user vector (H == U): the recurrence writes it in place
     const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
     const bool init_user = d.arch == LSTUR_ARCH_IGRU || two_tables(d);   // initial_state = user_vec
+#ifdef LSTUR_ABLATE
+    if (probe_fwd) (void)hipStreamWaitEvent(s, px1, 0);
+    else
+#endif
     PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, init_user ? w.uvec : nullptr, w.gru_up,
                                    w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s, c->opt.gru_f16));
     if (d.arch == LSTUR_ARCH_PGRU) {        // GRU(U)(x) + user_vec (paper.py:624-626)
@@ -1209,7 +1233,7 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
     (void)hipMemcpyAsync(w.duser, w.du, (size_t)n * d.U * 4, hipMemcpyDeviceToDevice, s);
   }
   const bool has_gru = d.arch != LSTUR_ARCH_VO && d.arch != LSTUR_ARCH_NIAVG && d.arch != LSTUR_ARCH_NIATT;
-  ReduceJob jobs[kMaxReduceJobs];   // (make_dims bounds the count: 12 + kernel)
+  ReduceJob jobs[kMaxReduceJobs];   // (make_dims bounds the count: 21 + kernel)
   int nj = 0;
   hipStream_t sw = wgrad_stream(c);
   if (!sw) sw = s;
@@ -1227,6 +1251,10 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
       jobs[nj++] = ReduceJob{w.loss_i, stats + 2, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};      // running sums for the
       jobs[nj++] = ReduceJob{w.correct_i, stats + 3, 1, 1, 1, n, 1, 1.0f / (float)n, 1.0f};   // host's epoch means
     }
+    // data-parallel step (lstur_dp_attach): this rank's (row, gradient) pairs go into the bucket's tail in the same launch
+    if (c->dp_tail && has_user_table(d) && c->buf.user_emb)
+      nj += dp_stage_jobs(w.user_rows_f, w.duser, two_tables(d) ? w.duser2 : nullptr, n, d.B, d.Ue, c->dp_tail, c->dp_rank,
+                          c->dp_world, &jobs[nj]);
     join();
     if (!launch_multi_reduce(jobs, nj, s)) return fail(LSTUR_ERR_STATE, "backward: too many deferred reductions");
     return LSTUR_OK;
@@ -1235,6 +1263,9 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
   const bool split = c->cand_forked && sw != s && !c->cfg.freeze_encoder;
   c->cand_forked = false;
   const int ncand = nt - nW;
+#ifdef LSTUR_ABLATE
+  const bool probe_bwd = split && getenv("LSTUR_PIPE_PROBE") && (atoi(getenv("LSTUR_PIPE_PROBE")) & 2);
+#endif
   // kernel-gradient slabs: [0] the side launch's slabs reduced ahead of time | the main launch's | the side launch's
   const size_t slab_f = d.np ? convx_wgrad_slab_floats(d.D, d.k, d.F) : 0;
   const int main_slabs = split ? convx_wgrad_slabs(nW, d.T, d.D, d.k, d.F) : 0;
@@ -1262,6 +1293,17 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
       (void)launch_convx_wgrad(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, sw, nullptr, w.offA,
                                w.offB, d.np, w.cs, gp ? gp + nW : nullptr, ncand, 1.0f, 2, side_base, ncand, &cand_slabs);
     }
+#ifdef LSTUR_ABLATE
+    if (getenv("LSTUR_PIPE_PROBE") && (atoi(getenv("LSTUR_PIPE_PROBE")) & 2)) {   // TIMING ONLY: stale dgates
+      dense_gemm(w.dgates, 3 * d.H, c->P("gru_w"), 3 * d.H, true, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, w.gemm_scratch_k[0], sw);
+      dense_gemm(w.ddocvec, d.U, c->P("dense_w"), d.U, true, w.dpooled, d.F, nullptr, nW, d.F, d.U, w.gemm_scratch_k[0], sw);
+      launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, w.att_ds, nt, d.T, d.F,
+                         drop, key1, sw, ldp, off_aw, off_cb, off_ab, 1, w.live, w.kbits_valid ? w.kbits : nullptr, 0, nW, gp);
+      ProfScope _ps(c, "conv_wgrad", sw, true);
+      nj += launch_convx_wgrad(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, sw, &jobs[nj], w.offA,
+                               w.offB, d.np, w.cs, gp, nW, 1.0f, 1, 1, nW);
+    }
+#endif
     // the side launch's slabs -> slab 0 (off the critical path), then the join event
     ReduceJob pre{(const float*)w.wgrad_scratch + (size_t)side_base * slab_f, (float*)w.wgrad_scratch, d.k * convx_dp(d.D), d.F, d.F,
                   cand_slabs, slab_f, 1.0f, 0.f};
@@ -1298,14 +1340,18 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
     gru_tape_rows(w.gru_tape, n, d.W, d.H, &hprev, &rh);
     // GRU parameter gradients (their split-K / column-sum partials are reduced by ONE launch at the end of the pass), on
     // the side stream: nothing but that reduction reads them
-    if (sw != s) {
-      (void)hipStreamWaitEvent(sw, fe, 0);
+    hipStream_t sg = sw;
+#ifdef LSTUR_ABLATE
+    if (probe_bwd) sg = s;
+#endif
+    if (sg != s) {
+      (void)hipStreamWaitEvent(sg, fe, 0);
       forked = true;
     }
-    wgrad_gemm(w.docvec, d.U, w.dgates, 3 * d.H, c->G("gru_w"), 3 * d.H, d.U, 3 * d.H, nW, w.gemm_scratch_k[0], sw, &jobs[nj++]);
-    launch_colsum2(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, w.colsum_scratch_k[0], sw, &jobs[nj++]);
-    wgrad_gemm(hprev, d.H, w.dgates, 3 * d.H, c->G("gru_u"), 3 * d.H, d.H, 2 * d.H, nW, w.gemm_scratch_k[1], sw, &jobs[nj++]);
-    wgrad_gemm(rh, d.H, w.dgates + 2 * d.H, 3 * d.H, c->G("gru_u") + 2 * d.H, 3 * d.H, d.H, d.H, nW, w.gemm_scratch_k[2], sw,
+    wgrad_gemm(w.docvec, d.U, w.dgates, 3 * d.H, c->G("gru_w"), 3 * d.H, d.U, 3 * d.H, nW, w.gemm_scratch_k[0], sg, &jobs[nj++]);
+    launch_colsum2(w.dgates, nW, 3 * d.H, 3 * d.H, c->G("gru_b"), 1.f, w.colsum_scratch_k[0], sg, &jobs[nj++]);
+    wgrad_gemm(hprev, d.H, w.dgates, 3 * d.H, c->G("gru_u"), 3 * d.H, d.H, 2 * d.H, nW, w.gemm_scratch_k[1], sg, &jobs[nj++]);
+    wgrad_gemm(rh, d.H, w.dgates + 2 * d.H, 3 * d.H, c->G("gru_u") + 2 * d.H, 3 * d.H, d.H, d.H, nW, w.gemm_scratch_k[2], sg,
                &jobs[nj++]);
   } else {   // vo / niavg: no GRU in the graph -- its bucket slots get an exact zero gradient
     (void)hipMemsetAsync(c->G("gru_w"), 0, (size_t)(c->G("gru_b") + 3 * d.H - c->G("gru_w")) * sizeof(float), s);
@@ -1316,6 +1362,9 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
   bool w2_recorded = false;
   if (has_gru) {
     if (sw != s) arm_stop_event(c->ev_w2);   // the Dense(U) parameter gradients fork behind this product
+#ifdef LSTUR_ABLATE
+    if (!probe_bwd)
+#endif
     dense_gemm(w.dgates, 3 * d.H, c->P("gru_w"), 3 * d.H, true, w.ddocvec, d.U, nullptr, nW, d.U, 3 * d.H, w.gemm_scratch, s);
     w2_recorded = sw != s && !stop_event_pending();
     arm_stop_event(nullptr);
@@ -1340,8 +1389,17 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
     (void)hipStreamWaitEvent(sw, c->ev_w2, 0);
     forked = true;
   }
-  wgrad_gemm(w.pooled, d.F, w.ddocvec, d.U, c->G("dense_w"), d.U, d.F, d.U, nt, w.gemm_scratch_k[3], sw, &jobs[nj++]);
-  launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], sw, &jobs[nj++]);
+  {
+    hipStream_t sg = sw;
+#ifdef LSTUR_ABLATE
+    if (probe_bwd) sg = s;
+#endif
+    wgrad_gemm(w.pooled, d.F, w.ddocvec, d.U, c->G("dense_w"), d.U, d.F, d.U, nt, w.gemm_scratch_k[3], sg, &jobs[nj++]);
+    launch_colsum2(w.ddocvec, nt, d.U, d.U, c->G("dense_b"), 1.f, w.colsum_scratch_k[1], sg, &jobs[nj++]);
+  }
+#ifdef LSTUR_ABLATE
+  if (!probe_bwd)
+#endif
   dense_gemm(w.ddocvec, d.U, c->P("dense_w"), d.U, true, w.dpooled, d.F, nullptr, split ? nW : nt, d.F, d.U, w.gemm_scratch, s);
   // partial sums laid out like the bucket slice conv_b .. att_b -> one reduction straight into dense_grad
   if (d.enc == LSTUR_ENC_MHSA) {
@@ -1362,6 +1420,9 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
   }
   const int off_cb = 0, off_aw = (int)(c->G("att_w") - c->G("conv_b")), off_ab = (int)(c->G("att_b") - c->G("conv_b"));
   const int ldp = off_ab + 1;
+#ifdef LSTUR_ABLATE
+  if (!probe_bwd)
+#endif
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
                                          w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 1, w.live,
                                          w.kbits_valid ? w.kbits : nullptr, 0, split ? nW : nt, gp));
@@ -1373,6 +1434,9 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
     PROF("conv_dgrad", launch_conv_dgrad_scatter(w.dconv, c->P("conv_w"), w.ids, c->buf.word_grad, w.dgrad_scratch, nt, d.T,
                                                   d.D, d.k, d.F, drop, dropout_key(c->cfg.seed, step, 0), s));
   }
+#ifdef LSTUR_ABLATE
+  if (probe_bwd) return finish();   // (the kernel gradient ran on the side stream)
+#endif
   if (d.np) {   // split-operand contraction (convx.hip), like the forward; one reduce job per tap
     ProfScope _ps(c, "conv_wgrad", s, true);
     nj += launch_convx_wgrad(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, s, &jobs[nj],
@@ -1803,6 +1867,21 @@ int lstur_dp_stage(lstur_ctx* ctx, float* tail, int32_t rank, int32_t world, lst
                   rank, world, (hipStream_t)stream);
   return check_launch("dp_stage");
 }
+int lstur_dp_attach(lstur_ctx* ctx, float* tail, int32_t rank, int32_t world) {
+  if (!ctx) return fail(LSTUR_ERR_ARG, "dp attach: ctx is NULL");
+  if (!tail) {
+    ctx->dp_tail = nullptr;
+    return LSTUR_OK;
+  }
+  const Dims& d = ctx->d;
+  if (world < 1 || rank < 0 || rank >= world) return fail(LSTUR_ERR_ARG, "dp attach: bad rank / world");
+  if ((size_t)world * d.B > (size_t)d.rows_cap) return fail(LSTUR_ERR_ARG, "dp attach: world size above 8");
+  if (d.Nu >= (1 << 24)) return fail(LSTUR_ERR_ARG, "dp attach: row numbers above 2^24 are not exact as float");
+  ctx->dp_tail = tail;
+  ctx->dp_rank = rank;
+  ctx->dp_world = world;
+  return LSTUR_OK;
+}
 int lstur_dp_unpack(lstur_ctx* ctx, const float* tail, int32_t world, int32_t n, const int32_t** rows, const float** grads,
                     lstur_stream stream) {
   if (!ctx || !tail || !rows || !grads || world < 1 || n < 0) return fail(LSTUR_ERR_ARG, "dp unpack: bad argument");
@@ -1817,13 +1896,16 @@ int lstur_dp_unpack(lstur_ctx* ctx, const float* tail, int32_t world, int32_t n,
 
 // Keras Adam over everything trainable.  rows == NULL: this process's own rows of the last step.  skip_table: the fused
 // step already swept the user table(s) on its side stream (joined here).  Leaves valid weight images for the next forward.
+// rows_f (lstur_adam_step_dp, full batches): the reduced tail read in place -- row numbers as floats (the first launch leaves
+// them as int32 in ws.dp_rows = `rows`), row_grads / grads2_in point into the tail
 static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, const float* row_grads, int32_t n_rows,
-                     hipStream_t s, bool skip_table) {
+                     hipStream_t s, bool skip_table, const float* rows_f = nullptr, const float* grads2_in = nullptr) {
   const Dims& d = ctx->d;
   const lstur_cfg& c = ctx->cfg;
   const float* row_grads2 = nullptr;   // second table (iigru / iicgru): own rows -> ws.duser2, exchanged rows -> ws.dp_grads2
   const bool exchanged = rows != nullptr;   // the data-parallel step: rows and gradients of every rank's batch
-  if (rows && two_tables(d)) {
+  if (rows_f) row_grads2 = grads2_in;
+  else if (rows && two_tables(d)) {
     if (rows != ctx->ws.dp_rows || row_grads != ctx->ws.dp_grads)
       return fail(LSTUR_ERR_ARG, "iigru: external user rows must come from lstur_dp_unpack (it carries both tables' gradients)");
     row_grads2 = ctx->ws.dp_grads2;
@@ -1873,7 +1955,7 @@ static int adam_impl(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, c
   } else {   // (the split / data-parallel sequence: + the duplicate-row combine of the row gradients in the same launch)
     launch_adam_flat_combine(ctx->buf.dense_param, ctx->buf.dense_grad, ctx->buf.dense_m, ctx->buf.dense_v,
                              ctx->dense_total, lr_t, c.beta1, c.beta2, c.eps, rows, row_grads, n_rows, d.Ue,
-                             ctx->ws.gsum, ctx->ws.slot, s, packed ? &pl : nullptr);
+                             ctx->ws.gsum, ctx->ws.slot, s, packed ? &pl : nullptr, rows_f, rows_f ? ctx->ws.dp_rows : nullptr);
   }
   // the next forward's weight images, behind the dense update (in front of the next conv forward they would be a bubble:
   // with the staging prefetched nothing else is left to hide them under)
@@ -1909,6 +1991,19 @@ int lstur_adam_step(lstur_ctx* ctx, float lr, int32_t t, const int32_t* rows, co
                     lstur_stream stream) {
   if (!ctx || t < 1) return fail(LSTUR_ERR_ARG, "bad adam step");
   return adam_impl(ctx, lr, t, rows, row_grads, n_rows, (hipStream_t)stream, false);
+}
+
+int lstur_adam_step_dp(lstur_ctx* ctx, float lr, int32_t t, const float* tail, int32_t world, int32_t n, lstur_stream stream) {
+  if (!ctx || t < 1 || !tail || world < 1 || n < 0) return fail(LSTUR_ERR_ARG, "bad data-parallel adam step");
+  const Dims& d = ctx->d;
+  if (n > d.B || (size_t)world * d.B > (size_t)d.rows_cap) return fail(LSTUR_ERR_ARG, "adam step (dp): too many rows");
+  const size_t WB = (size_t)world * d.B;
+  if (n == d.B && has_user_table(d))   // full batches: the reduced tail IS the row list and the row-gradient matrix
+    return adam_impl(ctx, lr, t, ctx->ws.dp_rows, tail + WB, world * n, (hipStream_t)stream, false, tail,
+                     two_tables(d) ? tail + WB * (1 + d.Ue) : nullptr);
+  launch_dp_unpack(tail, n, d.B, d.Ue, world, ctx->ws.dp_rows, ctx->ws.dp_grads, two_tables(d) ? ctx->ws.dp_grads2 : nullptr,
+                   (hipStream_t)stream);
+  return adam_impl(ctx, lr, t, ctx->ws.dp_rows, ctx->ws.dp_grads, world * n, (hipStream_t)stream, false);
 }
 
 int lstur_flush_tables(lstur_ctx* ctx, lstur_stream stream) {

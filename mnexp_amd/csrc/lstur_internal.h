@@ -23,7 +23,7 @@ struct ReduceJob {
   float alpha;
   float beta;
 };
-constexpr int kMaxReduceJobs = 32;   // launch_multi_reduce refuses more (returns false)
+constexpr int kMaxReduceJobs = 41;   // launch_multi_reduce refuses more (returns false)
 
 // Fork points without a bubble: hipEventRecord between two kernels of a stream is a barrier packet of its own and costs
 // ~6 us of idle GPU on this stack.  A launcher that goes through launch_k attaches the event to the kernel's OWN completion
@@ -125,7 +125,8 @@ void launch_adam_flat_pack(float* p, const float* g, float* m, float* v, size_t 
 // the same sweep + launch_user_grad_combine(rows, rg, ...) in one launch
 void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                               float eps, const int32_t* rows, const float* rg, int n_rows, int dim, float* gsum,
-                              int32_t* slot, hipStream_t s, const ImagePlan* plan = nullptr);
+                              int32_t* slot, hipStream_t s, const ImagePlan* plan = nullptr, const float* rows_f = nullptr,
+                              int32_t* rows_out = nullptr);   // rows_f: the row numbers as floats (-> rows_out as int32)
 // dense Adam sweep of the user table; slot[row] = index into gsum or -1
 void launch_adam_table(float* p, float* m, float* v, const int32_t* slot, const float* gsum, int n_rows,
                        int dim, float lr_t, float b1, float b2, float eps, hipStream_t s);
@@ -136,6 +137,8 @@ void launch_user_grad_combine(const int32_t* rows, const float* g, int n, int di
 void launch_dp_stage(const int32_t* rows, const float* g, const float* g2, int n, int B, int Ue, float* tail, int rank,
                      int world, hipStream_t s);
 void launch_dp_unpack(const float* tail, int n, int B, int Ue, int world, int32_t* rows, float* g, float* g2, hipStream_t s);
+int dp_stage_jobs(const float* rows_f, const float* g, const float* g2, int n, int B, int Ue, float* tail, int rank, int world,
+                  ReduceJob* jobs);   // the staging as <= 9 jobs of the backward pass's reduction launch
 void launch_user_slot_clear(const int32_t* rows, int n, int32_t* slot, hipStream_t s);
 // lazy dense Adam of large user tables (misc.hip): a row takes its pending zero-gradient updates when it is next read or
 // updated; last[row] = the iteration it is current for, lrt[t] = the lr_t of iteration t
@@ -164,7 +167,8 @@ void launch_fill_i32(int32_t* p, int32_t v, size_t n, hipStream_t s);
 // + (table != NULL) the user-embedding gather of the batch in the same launch: user_rows[b] = user[b], uvec[b] = table[user[b]]
 void launch_hist_mask(const int32_t* hist_ids, float* hv, uint8_t* hmask, uint8_t* gmask, int nW, int T, int U,
                       hipStream_t s, const float* table = nullptr, const int32_t* user = nullptr,
-                      int32_t* user_rows = nullptr, float* uvec = nullptr, int n = 0, int Ue = 0);
+                      int32_t* user_rows = nullptr, float* uvec = nullptr, int n = 0, int Ue = 0,
+                      float* user_rows_f = nullptr);
 void launch_scale_rows_u8(float* x, const uint8_t* mask, int rows, int cols, hipStream_t s);
 void launch_gather_rows(const float* table, const int32_t* rows, float* out, int n, int dim, hipStream_t s);
 // concat: out[b, :a_cols] = a[b], out[b, a_cols:] = bm[b]

@@ -465,7 +465,7 @@ bool launch_multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t s) {
   J.njobs = 0;
   int blocks = 0;
   for (int k = 0; k < njobs; ++k) {
-    if (jobs[k].nslices <= 0) continue;
+    if (jobs[k].nslices == 0 || (size_t)jobs[k].rows * jobs[k].cols == 0) continue;   // (nslices < 0: dst = 0)
     if (J.njobs == kMaxReduceJobs) return false;
     J.first_block[J.njobs] = blocks;
     J.job[J.njobs++] = jobs[k];
@@ -504,8 +504,10 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
 }
 // Adam over the dense bucket + the duplicate-row combine of the sparse user gradient (independent work) in one
 // launch: blocks [0, flat_blocks) sweep the bucket, the rest handle one sample row per wave.
-__device__ __forceinline__ void combine_row(const int32_t* __restrict__ rows, const float* __restrict__ g, int n, int dim,
-                                            float* __restrict__ gsum, int32_t* __restrict__ slot, int i, int lane);
+template <bool RF>
+__device__ __forceinline__ void combine_row_t(const int32_t* __restrict__ rows, const float* __restrict__ rows_f,
+                                              int32_t* __restrict__ rows_out, const float* __restrict__ g, int n, int dim,
+                                              float* __restrict__ gsum, int32_t* __restrict__ slot, int i, int lane);
 struct ImgState {          // the scales this launch writes the fp16-pair images with, the maxima it sees
   float sW, sU;
   uint32_t wmax, umax;
@@ -519,10 +521,14 @@ __global__ __launch_bounds__(256) void adam_flat_combine_kernel(float* __restric
                                                                 int flat_blocks, const int32_t* __restrict__ rows,
                                                                 const float* __restrict__ rg, int n_rows, int dim,
                                                                 float* __restrict__ gsum, int32_t* __restrict__ slot,
-                                                                ImagePlan P) {
+                                                                ImagePlan P, const float* __restrict__ rows_f,
+                                                                int32_t* __restrict__ rows_out) {
   if ((int)blockIdx.x >= flat_blocks) {
     const int i = (blockIdx.x - flat_blocks) * 4 + (threadIdx.x >> 6);
-    if (i < n_rows) combine_row(rows, rg, n_rows, dim, gsum, slot, i, threadIdx.x & 63);
+    if (i < n_rows) {
+      if (rows_f) combine_row_t<true>(nullptr, rows_f, rows_out, rg, n_rows, dim, gsum, slot, i, threadIdx.x & 63);
+      else combine_row_t<false>(rows, nullptr, nullptr, rg, n_rows, dim, gsum, slot, i, threadIdx.x & 63);
+    }
     return;
   }
   ImgState S = image_scale(P);
@@ -538,12 +544,12 @@ __global__ __launch_bounds__(256) void adam_flat_combine_kernel(float* __restric
 }
 void launch_adam_flat_combine(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                               float eps, const int32_t* rows, const float* rg, int n_rows, int dim, float* gsum,
-                              int32_t* slot, hipStream_t s, const ImagePlan* plan) {
+                              int32_t* slot, hipStream_t s, const ImagePlan* plan, const float* rows_f, int32_t* rows_out) {
   const int fb = (int)std::min<size_t>(cdivz(n, 256), 4096);
   const int cb = cdiv(n_rows, 4);
   if (fb + cb)
     hipLaunchKernelGGL(adam_flat_combine_kernel, dim3(fb + cb), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps, fb, rows,
-                       rg, n_rows, dim, gsum, slot, plan ? *plan : ImagePlan());
+                       rg, n_rows, dim, gsum, slot, plan ? *plan : ImagePlan(), rows_f, rows_out);
 }
 // the updated element i of the bucket also goes into the weight images that hold it (ImagePlan, lstur_internal.h)
 // f16x2 images: the scale comes from the maximum the previous pack saw, this launch leaves its own for the next one
@@ -932,11 +938,25 @@ __global__ void first_occurrence_kernel(const int32_t* __restrict__ rows, int n,
 // gsum[i,:] = sum over j >= i (ascending) with rows[j] == rows[i] of g[j,:], for the first occurrence i of each row.
 // One wave per sample row; matches are found 64 rows at a time by ballot, so the usual case (no duplicate) costs
 // n/64 loads instead of n.
+// rows_f != NULL: the row numbers arrive as floats (the reduced tail of a data-parallel step, read in place); every row's
+// number is then also left as an int32 in rows_out for the kernels that follow
+template <bool RF>
+__device__ __forceinline__ void combine_row_t(const int32_t* __restrict__ rows, const float* __restrict__ rows_f,
+                                              int32_t* __restrict__ rows_out, const float* __restrict__ g, int n, int dim,
+                                              float* __restrict__ gsum, int32_t* __restrict__ slot, int i, int lane);
 __device__ __forceinline__ void combine_row(const int32_t* __restrict__ rows, const float* __restrict__ g, int n, int dim,
                                             float* __restrict__ gsum, int32_t* __restrict__ slot, int i, int lane) {
-  const int r = rows[i];
+  combine_row_t<false>(rows, nullptr, nullptr, g, n, dim, gsum, slot, i, lane);
+}
+template <bool RF>
+__device__ __forceinline__ void combine_row_t(const int32_t* __restrict__ rows, const float* __restrict__ rows_f,
+                                              int32_t* __restrict__ rows_out, const float* __restrict__ g, int n, int dim,
+                                              float* __restrict__ gsum, int32_t* __restrict__ slot, int i, int lane) {
+  auto R = [&](int j) { return RF ? (int)(rows_f[j] + 0.5f) : rows[j]; };
+  const int r = R(i);
+  if (RF && lane == 0) rows_out[i] = r;
   bool dup = false;
-  for (int j = lane; j < i; j += 64) dup |= rows[j] == r;
+  for (int j = lane; j < i; j += 64) dup |= R(j) == r;
   if (__any(dup)) return;   // not the first occurrence
   for (int c0 = 0; c0 < dim; c0 += 512) {   // 512 columns per pass
     float acc[8];
@@ -944,7 +964,7 @@ __device__ __forceinline__ void combine_row(const int32_t* __restrict__ rows, co
     for (int k = 0; k < 8; ++k) acc[k] = (c0 + lane + 64 * k < dim) ? g[(size_t)i * dim + c0 + lane + 64 * k] : 0.f;
     for (int j0 = (i + 1) & ~63; j0 < n; j0 += 64) {
       const int j = j0 + lane;
-      unsigned long long mask = __ballot(j > i && j < n && rows[j] == r);
+      unsigned long long mask = __ballot(j > i && j < n && R(min(j, n - 1)) == r);
       while (mask) {   // ascending sample order
         const int jj = j0 + __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -970,25 +990,26 @@ void launch_user_grad_combine(const int32_t* rows, const float* g, int n, int di
   if (n) hipLaunchKernelGGL(combine_rows_kernel, dim3(n), dim3(64), 0, s, rows, g, n, dim, gsum, slot);
 }
 // ---- data-parallel exchange of the sparse user-row gradients inside the dense bucket's ONE all-reduce -------------
-// tail (behind the dense gradients in the caller's bucket) = world slots of [B row numbers as float | B x Ue grads];
-// a rank fills its own slot and zeroes the others, so the sum over ranks IS the concatenation (x + 0 + ... + 0 = x).
+// tail (behind the dense gradients in the caller's bucket) = [world x B row numbers as float | world x B x Ue gradients
+// (| the same of a second table)]; a rank fills its own B-slot of every region and zeroes the others, so the sum over ranks
+// IS the concatenation (x + 0 + ... + 0 = x) -- and with full batches (n == B) the reduced gradient region is the row-gradient
+// matrix [world * n, Ue] as it stands (lstur_adam_step_dp reads it in place).
 __global__ void dp_stage_kernel(const int32_t* __restrict__ rows, const float* __restrict__ g, const float* __restrict__ g2,
                                 int n, int B, int Ue, float* __restrict__ tail, int rank, int world) {
-  const int ntab = g2 ? 2 : 1, S = B * (1 + ntab * Ue);
+  const int ntab = g2 ? 2 : 1, WB = world * B;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= world * S) return;
-  const int k = i / S, e = i - k * S;
+  if (i >= WB * (1 + ntab * Ue)) return;
   float v = 0.f;
-  if (k == rank) {
-    if (e < B) v = e < n ? (float)rows[e] : 0.f;
-    else {
-      const int x = e - B, tab = x / (B * Ue), r = x - tab * (B * Ue);   // r = j * Ue + c
-      v = r / Ue < n ? (tab ? g2 : g)[r] : 0.f;
-    }
+  if (i < WB) {
+    const int k = i / B, e = i - k * B;
+    if (k == rank && e < n) v = (float)rows[e];
+  } else {
+    const int x = i - WB, tab = x / (WB * Ue), y = x - tab * (WB * Ue), j = y / Ue, k = j / B, e = j - k * B;
+    if (k == rank && e < n) v = (tab ? g2 : g)[(size_t)e * Ue + (y - j * Ue)];
   }
   tail[i] = v;
 }
-// g2 != NULL: a second table's row gradients travel in the same slot (iigru / iicgru: [B rows | B x Ue | B x Ue])
+// g2 != NULL: a second table's row gradients travel behind the first's (iigru / iicgru)
 void launch_dp_stage(const int32_t* rows, const float* g, const float* g2, int n, int B, int Ue, float* tail, int rank,
                      int world, hipStream_t s) {
   const int total = world * B * (1 + (g2 ? 2 : 1) * Ue);
@@ -997,21 +1018,37 @@ void launch_dp_stage(const int32_t* rows, const float* g, const float* g2, int n
 // reduced tail -> rows int32 [world*n], grads [world*n, Ue] (and grads2) in rank order (every rank passed the same n)
 __global__ void dp_unpack_kernel(const float* __restrict__ tail, int n, int B, int Ue, int world, int32_t* __restrict__ rows,
                                  float* __restrict__ g, float* __restrict__ g2) {
-  const int ntab = g2 ? 2 : 1, S = B * (1 + ntab * Ue);
+  const int ntab = g2 ? 2 : 1, WB = world * B, Wn = world * n;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int per = n * (1 + ntab * Ue);
-  if (i >= world * per) return;
-  const int k = i / per, e = i - k * per;
-  const float* slot = tail + (size_t)k * S;
-  if (e < n) rows[k * n + e] = (int32_t)(slot[e] + 0.5f);
-  else {
-    const int x = e - n, tab = x / (n * Ue), r = x - tab * (n * Ue);
-    (tab ? g2 : g)[(size_t)k * n * Ue + r] = slot[B + tab * (B * Ue) + r];
+  if (i >= Wn * (1 + ntab * Ue)) return;
+  if (i < Wn) {
+    const int k = i / n, e = i - k * n;
+    rows[i] = (int32_t)(tail[k * B + e] + 0.5f);
+  } else {
+    const int x = i - Wn, tab = x / (Wn * Ue), y = x - tab * (Wn * Ue), j = y / Ue, k = j / n, e = j - k * n;
+    (tab ? g2 : g)[y] = tail[(size_t)WB + (size_t)tab * WB * Ue + (size_t)(k * B + e) * Ue + (y - j * Ue)];
   }
 }
 void launch_dp_unpack(const float* tail, int n, int B, int Ue, int world, int32_t* rows, float* g, float* g2, hipStream_t s) {
   const int total = world * n * (1 + (g2 ? 2 : 1) * Ue);
   if (total) hipLaunchKernelGGL(dp_unpack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, tail, n, B, Ue, world, rows, g, g2);
+}
+// the staging as jobs of the backward pass's ONE reduction launch (a "reduction" of one slice is a copy, of a negative
+// slice count a zero fill): rank's slot of every region, zeros in front of and behind it.  rows_f: the batch's row numbers
+// as floats (the history-mask launch leaves them).  Returns the number of jobs written (<= 9).
+int dp_stage_jobs(const float* rows_f, const float* g, const float* g2, int n, int B, int Ue, float* tail, int rank, int world,
+                  ReduceJob* jobs) {
+  int nj = 0;
+  auto region = [&](const float* src, float* base, int width) {   // a region of world * B * width floats
+    const int lo = rank * B * width, used = n * width, total = world * B * width;
+    if (lo) jobs[nj++] = ReduceJob{src, base, 1, lo, lo, -1, 0, 0.f, 0.f};
+    jobs[nj++] = ReduceJob{src, base + lo, 1, used, used, 1, 0, 1.0f, 0.f};
+    if (total - lo - used) jobs[nj++] = ReduceJob{src, base + lo + used, 1, total - lo - used, total - lo - used, -1, 0, 0.f, 0.f};
+  };
+  region(rows_f, tail, 1);
+  region(g, tail + (size_t)world * B, Ue);
+  if (g2) region(g2, tail + (size_t)world * B * (1 + Ue), Ue);
+  return nj;
 }
 
 __global__ void slot_clear_kernel(const int32_t* __restrict__ rows, int n, int32_t* __restrict__ slot) {
@@ -1040,12 +1077,15 @@ __global__ __launch_bounds__(256) void hist_mask_kernel(const int32_t* __restric
                                                         int nW, int T, int U, int mask_blocks,
                                                         const float* __restrict__ table, const int32_t* __restrict__ user,
                                                         int32_t* __restrict__ user_rows, float* __restrict__ uvec, int n,
-                                                        int Ue) {
+                                                        int Ue, float* __restrict__ user_rows_f) {
   if ((int)blockIdx.x >= mask_blocks) {
     const int b = (blockIdx.x - mask_blocks) * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
     if (b >= n) return;
     const int r = user[b];
-    if (l == 0) user_rows[b] = r;
+    if (l == 0) {
+      user_rows[b] = r;
+      if (user_rows_f) user_rows_f[b] = (float)r;   // (the data-parallel staging copies these into the gradient bucket's tail)
+    }
     for (int c = l; c < Ue; c += 64) uvec[(size_t)b * Ue + c] = table[(size_t)r * Ue + c];
     return;
   }
@@ -1070,11 +1110,11 @@ __global__ __launch_bounds__(256) void hist_mask_kernel(const int32_t* __restric
 }
 void launch_hist_mask(const int32_t* hist_ids, float* hv, uint8_t* hmask, uint8_t* gmask, int nW, int T, int U,
                       hipStream_t s, const float* table, const int32_t* user, int32_t* user_rows, float* uvec, int n,
-                      int Ue) {
+                      int Ue, float* user_rows_f) {
   const int mb = cdiv(nW, 4), ub = table ? cdiv(n, 4) : 0;
   if (mb + ub)
     hipLaunchKernelGGL(hist_mask_kernel, dim3(mb + ub), dim3(256), 0, s, hist_ids, hv, hmask, gmask, nW, T, U, mb, table,
-                       user, user_rows, uvec, n, Ue);
+                       user, user_rows, uvec, n, Ue, user_rows_f);
 }
 
 __global__ void scale_rows_u8_kernel(float* __restrict__ x, const uint8_t* __restrict__ mask, size_t total, int cols) {

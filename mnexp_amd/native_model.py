@@ -222,6 +222,7 @@ class NativeModel:
             self.world = torch.distributed.get_world_size(dist_group)
         # test hook: run the RCCL collectives even with one rank (exercises the exact DP call sequence)
         self.force_collectives = False
+        self._dp_attached = None            # decided by the first data-parallel step (_dp_prepare)
         self.title_table = None
         if title_table is not None:
             self.set_title_table(title_table)
@@ -563,6 +564,7 @@ class NativeModel:
             self.optimizer.iterations = t
             self.step += 1
             return
+        self._dp_prepare()
         if self.pointwise:
             fn = lib.lstur_point_forward_backward_ids if ids_form else lib.lstur_point_forward_backward
             check(fn(self._ctx, user.data_ptr(), hist.data_ptr(), cands.data_ptr(), labels.data_ptr(), n, self.step,
@@ -575,12 +577,42 @@ class NativeModel:
         self.optimizer.iterations += 1
         t = self.optimizer.iterations
         if self.world > 1 or self.force_collectives:
-            rows, grads = self._allreduce_grads(n)
-            check(lib.lstur_adam_step(self._ctx, self.optimizer.lr, t, rows.data_ptr(), grads.data_ptr(),
-                                      int(rows.shape[0]), s), 'lstur_adam_step')
+            if self._dp_attached:
+                # the backward pass staged this rank's rows into the bucket's tail; ONE all-reduce; the reduced tail goes to
+                # the optimizer as it stands (include/lstur.h: lstur_dp_attach / lstur_adam_step_dp)
+                from . import dist as D
+                if self.word_trainable:
+                    D.allreduce_bucket(self.word_grad, self.dist_group, prescaled=True)
+                dense, used = self.sizes.dense, self._dp_used
+                # (diagnostic, one rank only: LSTUR_DP_NO_COLLECTIVE=1 leaves the RCCL call out -- what is left of the split
+                #  sequence's cost is the library's own share, tools/ab_dp.sh)
+                if not (self.world == 1 and os.environ.get('LSTUR_DP_NO_COLLECTIVE')):
+                    D.allreduce_bucket(self._bucket[:dense + used], self.dist_group, prescaled=True)
+                check(lib.lstur_adam_step_dp(self._ctx, self.optimizer.lr, t, self._bucket[dense:].data_ptr(),
+                                             max(1, self.world), n, s), 'lstur_adam_step_dp')
+            else:
+                rows, grads = self._allreduce_grads(n)
+                check(lib.lstur_adam_step(self._ctx, self.optimizer.lr, t, rows.data_ptr(), grads.data_ptr(),
+                                          int(rows.shape[0]), s), 'lstur_adam_step')
         else:
             check(lib.lstur_adam_step(self._ctx, self.optimizer.lr, t, None, None, 0, s), 'lstur_adam_step')
         self.step += 1
+
+    def _dp_prepare(self):
+        """the one-collective exchange without launches of its own (include/lstur.h: lstur_dp_attach): the backward pass
+        stages this rank's user rows into the tail of the gradient bucket inside its own reduction launch.
+        LSTUR_DP_FOLD=0: the stand-alone lstur_dp_stage / lstur_dp_unpack launches (same results)."""
+        if self._dp_attached is not None:
+            return
+        from . import dist as D
+        world = max(1, self.world)
+        ok = (world <= 8 and self.cfg.n_users < (1 << 24) and self.sizes.dense % 4 == 0 and self.has_user
+              and (self.world > 1 or self.force_collectives) and os.environ.get('LSTUR_DP_FOLD', '1') != '0')
+        if ok:
+            self._dp_used = int(lib.lstur_dp_tail_floats(C.byref(self.cfg), world))
+            check(lib.lstur_dp_attach(self._ctx, self._bucket[self.sizes.dense:].data_ptr(), D.rank(self.dist_group), world),
+                  'lstur_dp_attach')
+        self._dp_attached = ok
 
     def _allreduce_grads(self, n):
         """Data parallelism over RCCL: ONE all-reduce per step.  The library stages this
