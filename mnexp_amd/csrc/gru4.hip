@@ -342,8 +342,9 @@ static size_t gru4_fwd_lds(int H, int KQ) {
 }
 
 // hA: the state as floats (element-wise reads); F16: h16 = the same state as the MFMA operand (fp16 pairs of h sA), rhA holds
-// pairs of r h sA; sA / inv: the operand scale of this workgroup's rows and 1 / (sA sU)
-struct FwdLds { float *hA, *rhA, *zA, *h16, *dummy; const float* uL; int wl; const float* tail; float sA, inv; };
+// pairs of r h sA; sA / inv: the operand scale of each of this workgroup's four rows and 1 / (sA sU) -- per ROW: a sample's
+// result must not depend on which samples share its workgroup
+struct FwdLds { float *hA, *rhA, *zA, *h16, *dummy; const float* uL; int wl; const float* tail; float sA[4], inv[4]; };
 
 // Time loop of one wave role.  NP1: resident [z|r] strips of this wave (slot 0 = strip wv, slot 1 = strip wv+4).
 // P2: candidate strip M_NONE | M_RES (slot 1) | M_LDS; c2 = its first hidden column, lcol = its first image column.
@@ -380,7 +381,9 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
   const float* hsrc2 = L.hA + aidx(v2 ? c2 : 0, 0);
   float* hdst2 = v2 ? L.hA + aidx(c2, 0) : L.dummy;
   unsigned short* hdst2p = v2 ? pair_ptr(L.h16, c2) : (unsigned short*)L.dummy;
-  const float sA = L.sA, inv = L.inv;
+  float sA[4], inv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sA[j] = L.sA[j]; inv[j] = L.inv[j]; }
   const float* uLl = L.uL + (size_t)(P2 == M_LDS ? min(lcol + lane, L.wl - 1) : 0) * kqp(KQ) * 4;
   uint32_t rb[4];   // row * W (the launcher keeps n*W*3H below 2^30)
   bool rok[4];
@@ -429,10 +432,10 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
       for (int s = 0; s < NP1; ++s)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float gt = hard_sigmoid((F16 ? acc[s][j] * inv : acc[s][j]) + x1[s][j]);
+          const float gt = hard_sigmoid((F16 ? acc[s][j] * inv[j] : acc[s][j]) + x1[s][j]);
           const float val = isr[s] ? gt * hv[s][j] : gt;
           dst1[s][j * 4] = val;
-          if (F16) store_pair<false>(dst1p[s] + j * 8, val * sA);     // (z lanes and lanes past 2H: into the sink; |r h sA| <= 2^13)
+          if (F16) store_pair<false>(dst1p[s] + j * 8, val * sA[j]);     // (z lanes and lanes past 2H: into the sink; |r h sA| <= 2^13)
           k1[s][j] = gt;
           k1r[s][j] = val;
           buf_store1(k1[s][j], rzr, rok[j] ? o1[s] : kBufOob, (rb[j] + (uint32_t)t * ST) * H2 * 4);
@@ -462,11 +465,11 @@ __device__ __forceinline__ void gru4_fwd_loop(const Gru4Fwd& g, const FwdLds& L,
       LSTUR_STAMP(3)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float hhv = fast_tanh((F16 ? acc[j] * inv : acc[j]) + x2[j]);
+        const float hhv = fast_tanh((F16 ? acc[j] * inv[j] : acc[j]) + x2[j]);
         const float hn = z[j] * hp[j] + (1.0f - z[j]) * hhv;
         const float hst = rm.at(j, t) ? hn : hp[j];   // K.rnn: a masked step carries the previous state/output
         hdst2[j * 4] = hst;
-        if (F16) store_pair<false>(hdst2p + j * 8, hst * sA);
+        if (F16) store_pair<false>(hdst2p + j * 8, hst * sA[j]);
         k2h[j] = hhv;
         k2p[j] = hp[j];
         buf_store1(k2h[j], rhh, rok[j] ? o2 : kBufOob, (rb[j] + (uint32_t)t * ST) * H * 4);
@@ -510,25 +513,33 @@ __global__ __launch_bounds__(G4_THREADS) void gru4_fwd_kernel(Gru4Fwd g) {
   const int b0 = blockIdx.x * 4;
 
   for (int i = tid; i < 4 * KQ * 16 + 32; i += G4_THREADS) smem[i] = 0.f;
-  L.sA = 1.0f;
-  L.inv = 1.0f;
-  if (F16) {   // operand scale of this workgroup's rows: max(1, max |h0|) -> 2^12 (|h_t| never exceeds that maximum)
-    float m = 1.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) L.sA[j] = L.inv[j] = 1.0f;
+  if (F16) {   // operand scale of every row: max(1, max |h0| of the row) -> 2^12 (|h_t| never exceeds that maximum)
+    float m[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     for (int i = tid; i < 4 * H; i += G4_THREADS) {
       const int row = i / H, col = i - row * H, b = b0 + row;
-      if (g.h0 && b < n) m = fmaxf(m, fabsf(g.h0[(size_t)b * H + col]));
+      const float v = (g.h0 && b < n) ? fabsf(g.h0[(size_t)b * H + col]) : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[j] = row == j ? fmaxf(m[j], v) : m[j];
     }
-    m = wave_max(m);
-    float* red = smem + 4 * KQ * 16 + 16;       // (second half of the sink: zeroed above, cleared again below)
+    float* red = smem + 4 * KQ * 16 + 16;       // (second half of the sink: zeroed above, cleared again below; 16 floats)
     __syncthreads();
-    if (lane == 0) red[wv] = m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m[j] = wave_max(m[j]);
+      if (lane == 0) red[wv * 4 + j] = m[j];
+    }
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    if (tid < 4) red[tid] = 0.f;
-    L.sA = pow2_scale(__float_as_uint(m), 12);
     const float sU = g.tail[0];                             // the pack's tail: [0] sU
-    L.inv = 1.0f / (L.sA * sU);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float mj = fmaxf(fmaxf(red[j], red[4 + j]), fmaxf(red[8 + j], red[12 + j]));
+      L.sA[j] = pow2_scale(__float_as_uint(mj), 12);
+      L.inv[j] = 1.0f / (L.sA[j] * sU);
+    }
+    __syncthreads();
+    if (tid < 16) red[tid] = 0.f;
   }
   __syncthreads();
   for (int i = tid; i < 4 * H; i += G4_THREADS) {
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(G4_THREADS) void gru4_fwd_kernel(Gru4Fwd g) {
     if (g.h0 && b < n) {
       const float v = g.h0[(size_t)b * H + col];
       L.hA[aidx(col, row)] = v;
-      if (F16) store_pair(pair_ptr(L.h16, col) + row * 8, v * L.sA);
+      if (F16) store_pair(pair_ptr(L.h16, col) + row * 8, v * (row == 0 ? L.sA[0] : row == 1 ? L.sA[1] : row == 2 ? L.sA[2] : L.sA[3]));
     }
   }
   for (int i = tid; i < KQ * P.wl; i += G4_THREADS) {
