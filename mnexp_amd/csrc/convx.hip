@@ -747,7 +747,10 @@ static int gx_nblocks(int F) { return cdiv(cdiv(F, 32), GX_TN); }
 // slabs: about one workgroup per CU (or whole multiples), at least 512 tokens each
 static int gx_slabs(int M, int Kq, int F) {
   const int per = gx_mblocks(Kq) * gx_nblocks(F);
-  const int rounds = std::max(1, cdiv(M, 120000));                 // ~105 600 tokens at B = 64 -> one round
+  // ONE round whatever the token count: a workgroup keeps its tile in registers over as many tokens as its slab has, and
+  // every further round of slabs is 1.46 MB more per tile to write and to reduce (B = 512: eight rounds of 256 slabs cost
+  // the kernel 8 % and the step's reduction 60 us against one round of 32 slabs, 4.10 -> 3.99 ms per step)
+  const int rounds = 1;
   int want = rounds * 256 / per / 8 * 8;                           // whole multiples of 8 slabs: the same share for every XCD
 #ifdef LSTUR_ABLATE
   if (const char* e = getenv("LSTUR_PROBE_NCU")) want = rounds * atoi(e) / per;
