@@ -71,7 +71,17 @@ __global__ __launch_bounds__(256) void gemm3_kernel(const float* __restrict__ A,
                                                     int N, int Kfull, uint32_t bytesA, uint32_t bytesB, int k_per_split) {
   extern __shared__ __attribute__((aligned(16))) unsigned short sm3[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-  const int m0 = blockIdx.y * G3_T, n0 = blockIdx.x * G3_T;
+  // C = A . op(B) launches come as a 1-D grid in XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs
+  // (each with its own L2), so the column tiles (workgroups) that read the SAME rows of A get ids 8 apart --
+  // they run on one XCD at about the same time and all but the first find the rows in its L2
+  int by = blockIdx.y, bx = blockIdx.x;
+  if (!A_KM) {
+    const int tn = k_per_split, seq = blockIdx.x >> 3;   // (k_per_split carries the column-tile count of these launches)
+    by = (seq / tn) * 8 + (blockIdx.x & 7);
+    bx = seq - (seq / tn) * tn;
+    if (by * G3_T >= M) return;
+  }
+  const int m0 = by * G3_T, n0 = bx * G3_T;
   const int kbeg = A_KM ? (int)blockIdx.z * k_per_split : 0, K = A_KM ? min(Kfull, kbeg + k_per_split) : Kfull;
   constexpr int AIMG = A_KM ? G3_BIMG : G3_AIMG;      // elements of one part of the A tile image
   constexpr int BUF = 3 * AIMG + 3 * G3_BIMG;
@@ -165,11 +175,12 @@ void launch_gemm3(const float* A, int lda, const float* B, int ldb, bool b_nk, f
   g3_attrs();
   const uint32_t bytesA = (uint32_t)(((size_t)(M - 1) * lda + K) * 4);
   const uint32_t bytesB = (uint32_t)((b_nk ? (size_t)(N - 1) * ldb + K : (size_t)(K - 1) * ldb + N) * 4);
-  const dim3 grid(cdiv(N, G3_T), cdiv(M, G3_T));
+  const int tn = cdiv(N, G3_T), tm = cdiv(M, G3_T);
+  const dim3 grid(cdiv(tm, 8) * 8 * tn);   // XCD-aware linear id (see the kernel)
   if (b_nk)
-    launch_k(gemm3_kernel<false, true, 8>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB, K);
+    launch_k(gemm3_kernel<false, true, 8>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB, tn);
   else
-    launch_k(gemm3_kernel<false, false, 8>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB, K);
+    launch_k(gemm3_kernel<false, false, 8>, grid, dim3(256), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, K, bytesA, bytesB, tn);
 }
 
 // C[M,N] = A^T . B with A [K][M], B [K][N] (parameter gradients: long K, small M x N), split along K into slabs in
