@@ -17,6 +17,9 @@
 namespace lstur {
 
 constexpr int G3_T = 64, G3_K = 32;                    // tile, k-step
+#ifndef G3_PIPE
+#define G3_PIPE 1
+#endif
 constexpr int G3_SA = G3_K + 8;                        // [x][k] image row: 80 bytes (conflict-free 16-byte fragment reads)
 constexpr int G3_SB = tr_stride(G3_T);                 // [k][n] image row (transposed fragment reads)
 constexpr int G3_AIMG = G3_T * G3_SA;                  // elements of one part of an [x][k] tile
@@ -104,7 +107,21 @@ __global__ __launch_bounds__(256) void gemm3_kernel(const float* __restrict__ A,
 #pragma unroll
     for (int u = 0; u < NS; ++u) {      // step k0 / G3_K == u (mod NS); its tile is in LDS buffer u & 1
       const int kn = k0 + G3_K;
-      {   // stage the next step (loaded NS - 1 steps ago), unconditionally: past K it stores zeros nobody reads -- a
+      // (1) ALL fragments of this step out of LDS first: the stores of the next step's tile below go to the other buffer, but
+      // the compiler orders every LDS read behind every earlier LDS write -- reads first leaves it free to mix what follows
+      const unsigned short* as = sm3 + (u & 1) * BUF;
+      const unsigned short* bs = as + 3 * AIMG;
+      u16x8 fa[G3_K / 16][3], fb[G3_K / 16][3];
+#pragma unroll
+      for (int s = 0; s < G3_K / 16; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          if (A_KM) fa[s][p] = tr_frag(as + p * AIMG, G3_SB, 16 * s, wm * 32, lane);
+          else fa[s][p] = *(const u16x8*)(as + p * AIMG + (wm * 32 + (lane & 31)) * G3_SA + 16 * s + 8 * (lane >> 5));
+          if (B_NK) fb[s][p] = *(const u16x8*)(bs + p * G3_BIMG + (wn * 32 + (lane & 31)) * G3_SA + 16 * s + 8 * (lane >> 5));
+          else fb[s][p] = tr_frag(bs + p * G3_BIMG, G3_SB, 16 * s, wn * 32, lane);
+        }
+      {   // (2) stage the next step (loaded NS - 1 steps ago), unconditionally: past K it stores zeros nobody reads -- a
           // branch here makes the compiler wait for ALL outstanding loads
         const int nx = (u + 1) % NS;
         unsigned short* nb = sm3 + ((u + 1) & 1) * BUF;
@@ -113,24 +130,25 @@ __global__ __launch_bounds__(256) void gemm3_kernel(const float* __restrict__ A,
         g3_load<!A_KM>(rsA, lda, m0, kn + NS * G3_K, tid, ra[nx]);
         g3_load<B_NK>(rsB, ldb, n0, kn + NS * G3_K, tid, rb[nx]);
       }
-      const unsigned short* as = sm3 + (u & 1) * BUF;
-      const unsigned short* bs = as + 3 * AIMG;
+      // (3) the step's 12 MFMAs are ONE dependent chain (a single 32 x 32 accumulator) -- a wave issues in order, and left
+      // alone the compiler puts the ~140 VALU instructions of (2) in front of the chain, which then runs with nothing beside
+      // it.  The scheduling directives below interleave them: one MFMA, a dozen VALU, one LDS store.
 #pragma unroll
       for (int s = 0; s < G3_K / 16; ++s) {
-        u16x8 fa[3], fb[3];
+        acc = mfma32b(fa[s][2], fb[s][0], acc);   // l h   (small terms first)
+        acc = mfma32b(fa[s][0], fb[s][2], acc);   // h l
+        acc = mfma32b(fa[s][1], fb[s][1], acc);   // m m
+        acc = mfma32b(fa[s][1], fb[s][0], acc);   // m h
+        acc = mfma32b(fa[s][0], fb[s][1], acc);   // h m
+        acc = mfma32b(fa[s][0], fb[s][0], acc);   // h h
+      }
+      if (G3_PIPE) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          if (A_KM) fa[p] = tr_frag(as + p * AIMG, G3_SB, 16 * s, wm * 32, lane);
-          else fa[p] = *(const u16x8*)(as + p * AIMG + (wm * 32 + (lane & 31)) * G3_SA + 16 * s + 8 * (lane >> 5));
-          if (B_NK) fb[p] = *(const u16x8*)(bs + p * G3_BIMG + (wn * 32 + (lane & 31)) * G3_SA + 16 * s + 8 * (lane >> 5));
-          else fb[p] = tr_frag(bs + p * G3_BIMG, G3_SB, 16 * s, wn * 32, lane);
+        for (int i = 0; i < 6 * (G3_K / 16); ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);   // VALU
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // DS write
         }
-        acc = mfma32b(fa[2], fb[0], acc);   // l h   (small terms first)
-        acc = mfma32b(fa[0], fb[2], acc);   // h l
-        acc = mfma32b(fa[1], fb[1], acc);   // m m
-        acc = mfma32b(fa[1], fb[0], acc);   // m h
-        acc = mfma32b(fa[0], fb[1], acc);   // h m
-        acc = mfma32b(fa[0], fb[0], acc);   // h h
       }
       __syncthreads();
       k0 = kn;
