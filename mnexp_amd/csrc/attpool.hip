@@ -348,6 +348,9 @@ __device__ __forceinline__ float lane_value(float v, int l) {
 }
 // (per-row scalars -- weight, 1 - a^2, ds -- live in LANE t of every wave and reach the row loops through v_readlane, i.e.
 //  as SGPRs: the kernel sits at 128 VGPRs = 4 workgroups per CU; with them in per-row registers it was 132 = 3)
+// tpb titles per workgroup (title0 + blockIdx.x * tpb ...): the per-title partial sums (datt_w, dconv_b, datt_b, max |dc|)
+// are accumulated over the workgroup's titles -- per wave in LDS, no barrier -- and reduced over the four waves ONCE: one
+// partial-sum row and one maximum per workgroup (row row0 + blockIdx.x) instead of one per title.
 __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restrict__ c, const int32_t* __restrict__ ids,
                                                             const uint32_t* __restrict__ live,
                                                             const float* __restrict__ att_w, const float* __restrict__ a,
@@ -356,83 +359,100 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
                                                             float* __restrict__ parts, int T, int F, uint32_t thresh,
                                                             uint32_t key, float scale, int ldp, int off_aw, int off_cb,
                                                             int off_ab, int relu, const uint32_t* __restrict__ kbits,
-                                                            int title0, float* __restrict__ gparts) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // dw[32] | (unused)[32] | red[4][2][F]
-  float* dwL = sm;
+                                                            int title0, float* __restrict__ gparts, int tpb, int title_end,
+                                                            int row0) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // dw[2][32] | red[4][2][F]
   float* red = sm + 64;
-  const int n = title0 + blockIdx.x, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), F4 = F / 4;
-  const uint32_t lm = title_mask(live, ids, n, T, lane);
-  float4 x[kTitleTok][2];
-  bool nz[kTitleTok];
-  title_load<false>(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz, kbits, n);
-  float4 dp[2], kf[2];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), F4 = F / 4;
   const __amdgpu_buffer_rsrc_t rs_aw = make_rsrc(att_w, (uint32_t)F * 4u);
-  const __amdgpu_buffer_rsrc_t rs_dp = make_rsrc(dpooled + (size_t)n * F, (uint32_t)F * 4u);
-  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(w + (size_t)n * T, (uint32_t)T * 4u);
-  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(a + (size_t)n * T, (uint32_t)T * 4u);
+  float4 kf[2];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {   // columns past F read zeros (descriptor range)
-    dp[h] = buf_load4(rs_dp, (uint32_t)(lane + 64 * h) * 16u, 0);
-    kf[h] = buf_load4(rs_aw, (uint32_t)(lane + 64 * h) * 16u, 0);
+  for (int h = 0; h < 2; ++h) {
+    kf[h] = buf_load4(rs_aw, (uint32_t)(lane + 64 * h) * 16u, 0);   // columns past F read zeros (descriptor range)
+    if (lane + 64 * h < F4) {                                        // this thread's own slots of its wave's two rows
+      ((float4*)(red + (wv * 2 + 0) * F))[lane + 64 * h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ((float4*)(red + (wv * 2 + 1) * F))[lane + 64 * h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
-  // lane t: the title's attention weight (0 for masked / pad rows, and past T) and tanh output of token t
-  const float w_t = buf_load1(rs_w, (uint32_t)lane * 4u, 0), a_t = buf_load1(rs_a, (uint32_t)lane * 4u, 0);
-  {   // dw_t = dp . x_t for the wave's 8 rows at once (group g = lane >> 3 holds row g)
-    float ps[kTitleTok];
+  float gm = 0.f;                                        // max |dc| of this thread's elements (the kernel gradient's fp16 scale)
+  float gab = 0.f;                                       // datt_b (wave 0)
+  for (int k = 0; k < tpb; ++k) {
+    const int n = title0 + (int)blockIdx.x * tpb + k;
+    if (n >= title_end) break;                           // (block-uniform)
+    float* dwL = sm + (k & 1) * 32;                      // two buffers: a wave may be one barrier ahead of another
+    const uint32_t lm = title_mask(live, ids, n, T, lane);
+    float4 x[kTitleTok][2];
+    bool nz[kTitleTok];
+    title_load<false>(c, lm, n, T, F, wv, lane, thresh, key, scale, x, nz, kbits, n);
+    float4 dp[2];
+    const __amdgpu_buffer_rsrc_t rs_dp = make_rsrc(dpooled + (size_t)n * F, (uint32_t)F * 4u);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(w + (size_t)n * T, (uint32_t)T * 4u);
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(a + (size_t)n * T, (uint32_t)T * 4u);
 #pragma unroll
-    for (int i = 0; i < kTitleTok; ++i) ps[i] = dot4(x[i][0], dp[0]) + dot4(x[i][1], dp[1]);
-    const float srow = rows8_sum(ps, lane);
-    const int t = wv + 4 * (lane >> 3);
-    if ((lane & 7) == 0 && t < T) dwL[t] = srow;
-  }
-  __syncthreads();
-  // every wave: lane t holds dw_t (0 where the weight is 0: those rows contribute nothing), then ds_t
-  const float dw_t = (lane < T && w_t != 0.f) ? dwL[lane] : 0.f;
-  const float sum = wave_sum(dw_t * w_t);
-  const float ds_t = (dw_t - sum) * w_t * (1.0f - a_t * a_t);
-  const __amdgpu_buffer_rsrc_t rs_dc = make_rsrc(dc + (size_t)n * T * F, (uint32_t)T * (uint32_t)F * 4u);
-  float4 gaw[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, gcb[2] = {gaw[0], gaw[0]};
-  float gm = 0.f;                                      // max |dc| of this thread's elements (the kernel gradient's fp16 scale)
+    for (int h = 0; h < 2; ++h) dp[h] = buf_load4(rs_dp, (uint32_t)(lane + 64 * h) * 16u, 0);
+    // lane t: the title's attention weight (0 for masked / pad rows, and past T) and tanh output of token t
+    const float w_t = buf_load1(rs_w, (uint32_t)lane * 4u, 0), a_t = buf_load1(rs_a, (uint32_t)lane * 4u, 0);
+    {   // dw_t = dp . x_t for the wave's 8 rows at once (group g = lane >> 3 holds row g)
+      float ps[kTitleTok];
 #pragma unroll
-  for (int i = 0; i < kTitleTok; ++i) {
-    const int t = wv + 4 * i;
-    if (!((lm >> t) & 1u)) continue;                   // pad / missing token: its dconv row is neither read nor written
-    const float wt = lane_value(w_t, t), dst = lane_value(ds_t, t);   // SGPRs
+      for (int i = 0; i < kTitleTok; ++i) ps[i] = dot4(x[i][0], dp[0]) + dot4(x[i][1], dp[1]);
+      const float srow = rows8_sum(ps, lane);
+      const int t = wv + 4 * (lane >> 3);
+      if ((lane & 7) == 0 && t < T) dwL[t] = srow;
+    }
+    __syncthreads();
+    // every wave: lane t holds dw_t (0 where the weight is 0: those rows contribute nothing), then ds_t
+    const float dw_t = (lane < T && w_t != 0.f) ? dwL[lane] : 0.f;
+    const float sum = wave_sum(dw_t * w_t);
+    const float ds_t = (dw_t - sum) * w_t * (1.0f - a_t * a_t);
+    const __amdgpu_buffer_rsrc_t rs_dc = make_rsrc(dc + (size_t)n * T * F, (uint32_t)T * (uint32_t)F * 4u);
+    float4 gaw[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, gcb[2] = {gaw[0], gaw[0]};
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (wt != 0.f) {                                 // (scalar branch)
-        const float4 xv = x[i][h];
-        gaw[h].x += dst * xv.x;
-        gaw[h].y += dst * xv.y;
-        gaw[h].z += dst * xv.z;
-        gaw[h].w += dst * xv.w;
-        o.x = grad_gate(xv.x, relu) ? (dp[h].x * wt + dst * kf[h].x) * scale : 0.f;
-        o.y = grad_gate(xv.y, relu) ? (dp[h].y * wt + dst * kf[h].y) * scale : 0.f;
-        o.z = grad_gate(xv.z, relu) ? (dp[h].z * wt + dst * kf[h].z) * scale : 0.f;
-        o.w = grad_gate(xv.w, relu) ? (dp[h].w * wt + dst * kf[h].w) * scale : 0.f;
-        gcb[h].x += o.x;
-        gcb[h].y += o.y;
-        gcb[h].z += o.z;
-        gcb[h].w += o.w;
-        gm = fmaxf(fmaxf(gm, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    for (int i = 0; i < kTitleTok; ++i) {
+      const int t = wv + 4 * i;
+      if (!((lm >> t) & 1u)) continue;                   // pad / missing token: its dconv row is neither read nor written
+      const float wt = lane_value(w_t, t), dst = lane_value(ds_t, t);   // SGPRs
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wt != 0.f) {                                 // (scalar branch)
+          const float4 xv = x[i][h];
+          gaw[h].x += dst * xv.x;
+          gaw[h].y += dst * xv.y;
+          gaw[h].z += dst * xv.z;
+          gaw[h].w += dst * xv.w;
+          o.x = grad_gate(xv.x, relu) ? (dp[h].x * wt + dst * kf[h].x) * scale : 0.f;
+          o.y = grad_gate(xv.y, relu) ? (dp[h].y * wt + dst * kf[h].y) * scale : 0.f;
+          o.z = grad_gate(xv.z, relu) ? (dp[h].z * wt + dst * kf[h].z) * scale : 0.f;
+          o.w = grad_gate(xv.w, relu) ? (dp[h].w * wt + dst * kf[h].w) * scale : 0.f;
+          gcb[h].x += o.x;
+          gcb[h].y += o.y;
+          gcb[h].z += o.z;
+          gcb[h].w += o.w;
+          gm = fmaxf(fmaxf(gm, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
+        buf_store4(o, rs_dc, (lane + 64 * h < F4) ? ((uint32_t)t * (uint32_t)F + (uint32_t)(lane + 64 * h) * 4u) * 4u : kBufOob, 0);
       }
-      buf_store4(o, rs_dc, (lane + 64 * h < F4) ? ((uint32_t)t * (uint32_t)F + (uint32_t)(lane + 64 * h) * 4u) * 4u : kBufOob, 0);
     }
-  }
+    // this title's sums into the wave's rows (each thread its own slots: no barrier), titles in order
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-    if (lane + 64 * h < F4) {
-      ((float4*)(red + (wv * 2 + 0) * F))[lane + 64 * h] = gaw[h];
-      ((float4*)(red + (wv * 2 + 1) * F))[lane + 64 * h] = gcb[h];
-    }
-  if (gparts) {    // max |dc| of this title (fmaxf drops NaNs: a NaN gradient shows in the loss, not in the scale)
-    gm = wave_max(gm);
-    if (lane == 0) sm[32 + wv] = gm;
+    for (int h = 0; h < 2; ++h)
+      if (lane + 64 * h < F4) {
+        float4* pa = (float4*)(red + (wv * 2 + 0) * F) + lane + 64 * h;
+        float4* pc = (float4*)(red + (wv * 2 + 1) * F) + lane + 64 * h;
+        const float4 ra = *pa, rc = *pc;
+        *pa = make_float4(ra.x + gaw[h].x, ra.y + gaw[h].y, ra.z + gaw[h].z, ra.w + gaw[h].w);
+        *pc = make_float4(rc.x + gcb[h].x, rc.y + gcb[h].y, rc.z + gcb[h].z, rc.w + gcb[h].w);
+      }
+    if (wv == 0)     // datt_b += sum_t ds_t, in lane order (lanes past T hold 0)
+      for (int t = 0; t < T; ++t) gab += lane_value(ds_t, t);
   }
-  __syncthreads();
-  if (gparts && threadIdx.x == 0) gparts[n] = fmaxf(fmaxf(sm[32], sm[33]), fmaxf(sm[34], sm[35]));
-  float* pr = parts + (size_t)n * ldp;
+  __syncthreads();   // every wave's rows are complete; the dw buffers are free
+  if (gparts) {      // max |dc| of this workgroup's titles (fmaxf drops NaNs: a NaN gradient shows in the loss, not in the scale)
+    gm = wave_max(gm);
+    if (lane == 0) sm[wv] = gm;
+  }
+  float* pr = parts + (size_t)(row0 + (int)blockIdx.x) * ldp;
   for (int j = threadIdx.x; j < 2 * F; j += 256) {
     const int which = j / F, f = j - which * F;
     float r = 0.f;
@@ -440,10 +460,10 @@ __global__ __launch_bounds__(256) void att_bwd_title_kernel(const float* __restr
     for (int k = 0; k < 4; ++k) r += red[(k * 2 + which) * F + f];
     pr[(which ? off_cb : off_aw) + f] = r;
   }
-  if (wv == 0) {   // datt_b = sum_t ds_t, in lane order (lanes past T hold 0)
-    float gab = 0.f;
-    for (int t = 0; t < T; ++t) gab += lane_value(ds_t, t);
-    if (lane == 0) pr[off_ab] = gab;
+  if (wv == 0 && lane == 0) pr[off_ab] = gab;
+  if (gparts) {
+    __syncthreads();
+    if (threadIdx.x == 0) gparts[row0 + (int)blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
   }
 }
 
@@ -641,7 +661,8 @@ __global__ __launch_bounds__(128 * kDcRsub) void att_bwd_dc_kernel(
 void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, const float* a, const float* w,
                         const float* dpooled, float* dc, float* parts, float* row_scratch, int n_titles, int T, int F,
                         float drop, uint32_t key, hipStream_t s, int ldp, int off_aw, int off_cb, int off_ab, int relu,
-                        const uint32_t* live, const uint32_t* kbits, int title0, int title_count, float* gparts) {
+                        const uint32_t* live, const uint32_t* kbits, int title0, int title_count, float* gparts, int tpb,
+                        int row0) {
   if (ldp <= 0) {   // default layout of the public entry point: datt_w[F] | dconv_b[F] | datt_b
     ldp = 2 * F + 1;
     off_aw = 0;
@@ -655,10 +676,13 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
   const int nparts = attpool_bwd_parts(n_titles);
   if (title_path(T, F)) {   // (title0, title_count: a sub-range of the titles -- this path only; all arrays stay title-indexed)
     const int cnt = title_count >= 0 ? title_count : n_titles - title0;
+    // tpb > 1 (the training step): one partial-sum row / one maximum per tpb titles, rows row0 .. row0 + cdiv(cnt, tpb) - 1;
+    // the default keeps one row per title at the title's own index
+    const int per = tpb > 1 ? tpb : 1, r0 = tpb > 1 ? row0 : title0;
     if (cnt > 0)
-      hipLaunchKernelGGL(att_bwd_title_kernel, dim3(cnt), dim3(256), (64 + 8 * F) * sizeof(float), s, c, ids, live, att_w, a,
-                         w, dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu,
-                         thresh ? kbits : nullptr, title0, gparts);
+      hipLaunchKernelGGL(att_bwd_title_kernel, dim3(cdiv(cnt, per)), dim3(256), (64 + 8 * F) * sizeof(float), s, c, ids, live,
+                         att_w, a, w, dpooled, dc, parts, T, F, thresh, key, scale, ldp, off_aw, off_cb, off_ab, relu,
+                         thresh ? kbits : nullptr, title0, gparts, per, title0 + cnt, r0);
     return;
   }
   if (F % 4 == 0) {

@@ -1207,6 +1207,10 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
   // streaming kernels: one entry per workgroup), the kernel-gradient launches scale by the maximum over their titles
   float* gp = d.np == 2 ? w.gparts : nullptr;
   const bool gp_titles = attpool_title_path(d.T, d.F);
+  // title-resident attention backward: one partial-sum row / one maximum per kAttBwdTitlesPerWg titles (attpool.hip)
+  // (two titles while the launch is a few rounds of workgroups, four from 8 192 titles on: measured 0.906 / 0.908 / 0.910 ms
+  //  per step with 2 / 3 / 4 titles at B = 64 against 0.919 with one; 4.19 / 4.19 ms with 4 / 8 at B = 512 against 4.30)
+  const int tpb = gp_titles ? (nt >= 8192 ? 4 : 2) : 1;
   // user encoder head
   const float* dhl = w.du;
   // LSTUR-con's Dense over [h | user_vec]: its parameter gradients feed nothing but the optimizer -- they go to the side stream
@@ -1286,12 +1290,13 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
       ProfScope _ps(c, "attpool_bwd_side", sw);
       launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts, w.att_ds, nt, d.T, d.F,
                          drop, key1, sw, ldp, off_aw, off_cb, off_ab, 1, w.live, w.kbits_valid ? w.kbits : nullptr, nW, ncand,
-                         gp);
+                         gp, tpb, cdiv(nW, tpb));
     }
     {
       ProfScope _ps(c, "conv_wgrad_side", sw, true);
       (void)launch_convx_wgrad(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, sw, nullptr, w.offA,
-                               w.offB, d.np, w.cs, gp ? gp + nW : nullptr, ncand, 1.0f, 2, side_base, ncand, &cand_slabs);
+                               w.offB, d.np, w.cs, gp ? gp + cdiv(nW, tpb) : nullptr, cdiv(ncand, tpb), 1.0f, 2, side_base, ncand,
+                               &cand_slabs);
     }
 #ifdef LSTUR_ABLATE
     if (getenv("LSTUR_PIPE_PROBE") && (atoi(getenv("LSTUR_PIPE_PROBE")) & 2)) {   // TIMING ONLY: stale dgates
@@ -1425,10 +1430,12 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
 #endif
   PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
                                          w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 1, w.live,
-                                         w.kbits_valid ? w.kbits : nullptr, 0, split ? nW : nt, gp));
+                                         w.kbits_valid ? w.kbits : nullptr, 0, split ? nW : nt, gp, tpb, 0));
+  // rows of partial sums the launch(es) left: the main launch's, then the candidate titles' launch's
+  const int att_rows = !gp_titles ? attpool_bwd_parts(nt) : split ? cdiv(nW, tpb) + cdiv(ncand, tpb) : cdiv(nt, tpb);
   if (split) (void)hipStreamWaitEvent(s, c->ev_c1, 0);   // the candidate titles' partial sums, gradient rows and slabs
   // (on the side stream this one found no free CU beside the conv kernel gradient and finished behind it)
-  launch_colsum2(w.parts, attpool_bwd_parts(nt), ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch_k[2], s, &jobs[nj++]);
+  launch_colsum2(w.parts, att_rows, ldp, ldp, c->G("conv_b"), 1.f, w.colsum_scratch_k[2], s, &jobs[nj++]);
   if (d.word_trainable) {   // conv input gradient -> word-table gradient (embedding dropout mask = stream 0 of the step)
     (void)hipMemsetAsync(c->buf.word_grad, 0, (size_t)d.V * d.D * sizeof(float), s);
     PROF("conv_dgrad", launch_conv_dgrad_scatter(w.dconv, c->P("conv_w"), w.ids, c->buf.word_grad, w.dgrad_scratch, nt, d.T,
@@ -1440,7 +1447,7 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
   if (d.np) {   // split-operand contraction (convx.hip), like the forward; one reduce job per tap
     ProfScope _ps(c, "conv_wgrad", s, true);
     nj += launch_convx_wgrad(w.e3, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F, w.vcount, s, &jobs[nj],
-                             w.offA, w.offB, d.np, w.cs, gp, !gp_titles ? attpool_bwd_parts(nt) : split ? nW : nt, 1.0f,
+                             w.offA, w.offB, d.np, w.cs, gp, !gp_titles ? attpool_bwd_parts(nt) : cdiv(split ? nW : nt, tpb), 1.0f,
                              split ? 1 : 0, split ? 1 : 0, split ? nW : 0);
   } else
     PROF("conv_wgrad", launch_conv_wgrad(w.emb, w.dconv, c->G("conv_w"), w.wgrad_scratch, nt, d.T, d.D, d.k, d.F,

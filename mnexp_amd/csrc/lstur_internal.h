@@ -296,8 +296,10 @@ void launch_attpool_bwd(const float* c, const int32_t* ids, const float* att_w, 
                         float drop, uint32_t key, hipStream_t s, int ldp = 0, int off_aw = 0, int off_cb = 0,
                         int off_ab = 0, int relu = 1, const uint32_t* live = nullptr, const uint32_t* kbits = nullptr,
                         int title0 = 0, int title_count = -1,
-                        float* gparts = nullptr);     // != NULL: gparts[workgroup] = max |dc| over the rows it wrote (title
+                        float* gparts = nullptr,      // != NULL: gparts[workgroup] = max |dc| over the rows it wrote (title
                                                       // path: one entry per title, indexed by title; else attpool_bwd_parts)
+                        int tpb = 1, int row0 = 0);   // title path, tpb > 1: a workgroup takes tpb titles and leaves ONE
+                                                      // partial-sum row / maximum: rows row0 .. row0 + cdiv(count, tpb) - 1
 bool attpool_title_path(int T, int F);   // the title-resident kernels (the only ones that take a title sub-range)
 
 // ---- mhsa.hip (build-defined multi-head self-attention token stage; T <= 32, F/heads in {16, 32, 64}) -------
