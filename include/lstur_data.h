@@ -37,6 +37,11 @@ int lstur_data_destroy(lstur_data* d);
 
 /* np.random.seed(seed) for this feed's private generator (also restarts the walk and empties the pool). */
 int lstur_data_seed(lstur_data* d, uint32_t seed);
+/* Pointwise tasks: a user with more than max_impression training impressions trains on
+ * random.sample(impressions, max_impression) (task/paper.py:42-43, 271-272: Python's `random`, not NumPy's).  The feed
+ * restates CPython 3's sample() on the same MT19937 core; the host hands over the generator: the 624 state words and the
+ * position of random.getstate()[1].  0 turns the sub-sampling off.  Restarts every walk. */
+int lstur_data_pyrandom(lstur_data* d, const uint32_t* mt624, int32_t pos, int32_t max_impression);
 
 /* Next pool-shuffled batch: user int32 [B], hist int32 [B, W] (front-padded with 0, newest last),
  * cands int32 [B, K+1] (candidate 0 = the clicked doc). */
@@ -80,7 +85,7 @@ void lstur_vocab_free(float* matrix);
  * mode 0: listwise samples of Seq2VecPaperSoftmax[Id] (task/paper.py:385-441, 528-582): cands = [pos, K negatives];
  * mode 1: pointwise rows of Seq2VecPaper / ...Dot / ...Id (task/paper.py:38-97, 266-328): a positive row (label 1), then K
  *         rows of sampled negatives (label 0); cands has ONE column (users with more than max_impression training
- *         impressions are sub-sampled with Python's random.sample in the reference: the host keeps those on its own path);
+ *         impressions are sub-sampled with Python's random.sample in the reference: lstur_data_pyrandom);
  * days > 0: the time-aware click window of the `...Days` tasks (task/paper.py:669-792): an entry is visible for `days` days
  *           (fractions allowed, as timedelta(days=...) allows them).
  * The arrays are copied: the lstur_clicks handle may be destroyed afterwards. */

@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -138,6 +139,12 @@ struct lstur_data {
   int32_t mode = 0;         // 0: listwise samples (user | hist | pos, K negatives); 1: pointwise rows (user | hist | cand | label)
   Clicks tr, va;
   MT19937 rng;
+  // pointwise tasks: a user with more than max_imp training impressions trains on random.sample(impressions, max_imp)
+  // (task/paper.py:42-43, 271-272) -- CPython's generator (the same MT19937 core, state handed over by the host:
+  // lstur_data_pyrandom) and CPython 3's sample(): `chosen[i]` = impression i of the open user is trainable
+  MT19937 pyrng;
+  int32_t max_imp = 0;
+  std::vector<uint8_t> chosen;
   int C = 0, rec = 0;       // candidates per record; ints per record: user | hist[W] | cands[C] | label
   // ---- train_gen: an endless loop over the users of this shard
   int64_t user, imp, pidx;
@@ -197,6 +204,38 @@ struct lstur_data {
       if (tr.imp_off[u + 1] > tr.imp_off[u] && va.imp_off[u + 1] > va.imp_off[u]) return true;
     return false;
   }
+  // random.Random._randbelow_with_getrandbits(n): k = n.bit_length() bits per draw (genrand_uint32 >> (32 - k)), rejected
+  // while >= n
+  uint32_t py_randbelow(uint32_t n) {
+    int k = 0;
+    for (uint32_t v = n; v; v >>= 1) ++k;
+    uint32_t r;
+    do r = pyrng.next32() >> (32 - k);
+    while (r >= n);
+    return r;
+  }
+  // random.sample(range(n), k) as CPython 3.10 draws it (Lib/random.py: pool selection for small n, a set of chosen indices
+  // otherwise); only the membership matters here (the reference builds a set of the sampled impressions)
+  void py_sample(int64_t n, int64_t k) {
+    chosen.assign((size_t)n, 0);
+    double setsize = 21;
+    if (k > 5) setsize += std::pow(4.0, std::ceil(std::log((double)k * 3) / std::log(4.0)));
+    if ((double)n <= setsize) {
+      std::vector<int64_t> pool((size_t)n);
+      for (int64_t i = 0; i < n; ++i) pool[i] = i;
+      for (int64_t i = 0; i < k; ++i) {
+        const uint32_t j = py_randbelow((uint32_t)(n - i));
+        chosen[(size_t)pool[j]] = 1;
+        pool[j] = pool[n - i - 1];
+      }
+    } else {
+      for (int64_t i = 0; i < k; ++i) {
+        uint32_t j = py_randbelow((uint32_t)n);
+        while (chosen[j]) j = py_randbelow((uint32_t)n);
+        chosen[j] = 1;
+      }
+    }
+  }
   int64_t time_of(const Clicks& c, int64_t i) const { return win.timed ? c.time[i] : 0; }
   // one record: user | window as seen at `t` | cands | label
   void fill_head(int32_t* dst, int64_t u, const ClickWindow& w, int64_t t) const {
@@ -255,6 +294,9 @@ struct lstur_data {
         imp = tr.imp_off[user];
         pidx = tr.pos_off[imp];
         user_open = true;
+        const int64_t n_imp = tr.imp_off[user + 1] - tr.imp_off[user];
+        if (mode == 1 && max_imp > 0 && n_imp > max_imp) py_sample(n_imp, max_imp);
+        else chosen.clear();
       }
       if (imp >= tr.imp_off[user + 1]) {   // user exhausted -> next user of the shard (wrapping: `while True`)
         user += world;
@@ -269,7 +311,7 @@ struct lstur_data {
       }
       const int32_t p = tr.pos[pidx++];
       const int64_t t = time_of(tr, imp);
-      const bool emit = win.count(t) > 0;
+      const bool emit = win.count(t) > 0 && (chosen.empty() || chosen[(size_t)(imp - tr.imp_off[user])]);
       if (emit) emit_click(dst, user, win, tr, imp, p, &pending);
       win.push(p, t);                      // ch.push(pos): the history excludes the current click
       if (emit) return;
@@ -466,6 +508,14 @@ int lstur_data_destroy(lstur_data* d) {
   return 0;
 }
 
+int lstur_data_pyrandom(lstur_data* d, const uint32_t* mt624, int32_t pos, int32_t max_impression) {
+  if (!d || !mt624 || pos < 0 || pos > 624 || max_impression < 0) return fail("pyrandom: bad argument");
+  memcpy(d->pyrng.key, mt624, sizeof(d->pyrng.key));
+  d->pyrng.pos = pos;
+  d->max_imp = max_impression;
+  d->restart();
+  return 0;
+}
 int lstur_data_seed(lstur_data* d, uint32_t seed) {
   if (!d) return fail("NULL feed");
   d->rng.seed(seed);

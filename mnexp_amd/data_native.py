@@ -13,6 +13,8 @@ import ctypes as C
 import os
 from datetime import datetime, timedelta
 
+import random
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -25,6 +27,7 @@ SIGNATURES = {
     'lstur_data_create_from_clicks': (_I, [_P, _I, _I, _I, _I, _I, _I, C.c_double, C.POINTER(_P)]),
     'lstur_data_destroy': (_I, [_P]),
     'lstur_data_seed': (_I, [_P, C.c_uint32]),
+    'lstur_data_pyrandom': (_I, [_P, _P, _I, _I]),
     'lstur_data_next_train': (_I, [_P, _P, _P, _P]),
     'lstur_data_next_train_rows': (_I, [_P, _P, _P, _P, _P]),
     'lstur_data_next_valid': (_I, [_P, _P, _P, _P, _P]),
@@ -203,12 +206,6 @@ class NativeFeed:
         world = dist.world_size() if world is None else world
         self._h = C.c_void_p()
         clicks = getattr(task, 'clicks', None)
-        if self.pointwise:
-            mi = int(cfg.max_impression)
-            io = clicks.train['imp_off'] if clicks is not None else np.cumsum([0] + [len(tr) for tr, _ in task.data])
-            if np.diff(io).max(initial=0) > mi:
-                raise NotImplementedError('--native-feed: a user has more than --max-impression training impressions; the '
-                                          'reference sub-samples those with random.sample (task/paper.py:271-272): use --ids')
         if clicks is None:      # a Python-loaded task: CSR of the training histories from its objects (listwise only)
             if self.pointwise or self.days:
                 raise NotImplementedError('--native-feed for {} needs the natively loaded ClickData (--native-load)'.format(
@@ -230,11 +227,23 @@ class NativeFeed:
             _check(lib.lstur_data_create_from_clicks(clicks._h, self.W, self.K, self.B, rank, world, int(self.pointwise),
                                                      self.days, C.byref(self._h)), 'lstur_data_create_from_clicks')
         self.labels = np.tile(np.array([1] + [0] * self.K, dtype=np.int64), (self.B, 1))
+        # pointwise tasks sub-sample users with more than --max-impression training impressions through Python's `random`
+        # (task/paper.py:271-272): the feed continues from the module's current state, privately
+        self._max_impression = int(cfg.max_impression) if self.pointwise else 0
+        self._pyrandom(random.getstate())
         if seed is not None:
             self.seed(seed)
 
+    def _pyrandom(self, state):
+        if not self._max_impression:
+            return
+        words = np.asarray(state[1], dtype=np.uint32)          # 624 state words + the position
+        _check(lib.lstur_data_pyrandom(self._h, words[:624].ctypes.data, int(words[624]), self._max_impression),
+               'lstur_data_pyrandom')
+
     def seed(self, seed):
-        """np.random.seed(seed) for the feed's private generator; restarts every walk."""
+        """np.random.seed(seed) -- and random.seed(seed) -- for the feed's private generators; restarts every walk."""
+        self._pyrandom(random.Random(int(seed)).getstate())
         _check(lib.lstur_data_seed(self._h, int(seed) & 0xFFFFFFFF), 'lstur_data_seed')
 
     def _pack(self, user, hist, cands, label):

@@ -138,14 +138,52 @@ def test_native_task_and_feed_equal_the_python_generators(name, tname, kw):
             _same_batch(b, want[i])
 
 
-def test_pointwise_subsampling_stays_on_the_python_path():
+def test_pointwise_subsampling_matches_the_reference_fixture(tmp_path):
+    """users with more than --max-impression training impressions train on random.sample(impressions, max_impression)
+    (task/paper.py:271-272, Python's `random` module): the Python generators AND the C++ feed -- CPython's sample() restated
+    on the MT19937 state the host hands over (include/lstur_data.h: lstur_data_pyrandom) -- reproduce the rows the reference
+    itself generated (tests/golden/make_golden.py: max_impression = 3, both generators seeded with 31)"""
     cfg = make_config(os.path.join(GOLD, 'tiny'), task='Seq2VecPaperId', max_impression=3, native_load=True, native_feed=True)
     h = task.get(cfg)
-    assert h.native_feed() is None                       # random.sample sub-sampling (paper.py:271-272): Python generators
     np.random.seed(31); random.seed(31)
     gen = h.train_gen_ids()
     X, Y = h._expand([next(gen) for _ in range(150)])
     assert np.array_equal(X[0], G['Seq2VecPaperId_train_user']) and np.array_equal(X[1], G['Seq2VecPaperId_train_clicked'])
+    feed = h.native_feed()
+    assert feed is not None
+    feed.seed(31)
+    user, hist, cands = feed.samples(150)
+    np.random.seed(31); random.seed(31)
+    gen = h.train_gen_ids()
+    rows = [next(gen) for _ in range(150)]
+    assert np.array_equal(user, np.array([r[0] for r in rows]))
+    assert np.array_equal(hist, np.array([r[1] for r in rows]))
+    assert np.array_equal(cands[:, 0], np.array([r[2][0] for r in rows]))
+    assert np.array_equal(user, G['Seq2VecPaperId_train_user'].reshape(-1))
+    # ... and the other branch of sample(): more impressions than its pool threshold (n = 30 > 21 with k = 3 <= 5) makes it
+    # draw indices into a set, rejecting repeats; k = 7 of 30 stays on the pool branch (threshold 21 + 4^3)
+    rng = np.random.RandomState(5)
+    with open(tmp_path / 'DocMeta.tsv', 'w') as f:
+        for i in range(1, 61):
+            f.write('d%d\t%d\tnews\tus\t%s\t1 2\n' % (i, i, ' '.join(str(x) for x in rng.randint(1, 40, size=5))))
+    with open(tmp_path / 'ClickData.tsv', 'w') as f:
+        for u in range(4):
+            imps = ['%d#TAB#%d %d#TAB#01/02/2019 03:04:05 PM#TAB#x' % tuple(rng.randint(1, 61, size=3)) for _ in range(30)]
+            f.write('u%d\tt\t%s\t%s\n' % (u, '#N#'.join(imps), imps[0]))
+    open(tmp_path / 'Vocab.tsv', 'w').close()
+    for k in (3, 7):
+        cfg2 = make_config(str(tmp_path), task='Seq2VecPaperId', max_impression=k, native_load=True, native_feed=True,
+                           title_shape=5, window_size=4)
+        h2 = task.get(cfg2)
+        f2 = h2.native_feed()
+        f2.seed(7)
+        u2, hi2, c2 = f2.samples(300)
+        np.random.seed(7); random.seed(7)
+        g2 = h2.train_gen_ids()
+        r2 = [next(g2) for _ in range(300)]
+        assert np.array_equal(u2, np.array([r[0] for r in r2])) and np.array_equal(c2[:, 0], np.array([r[2][0] for r in r2]))
+        assert np.array_equal(hi2, np.array([r[1] for r in r2]))
+        assert len(set(u2.tolist())) == 4
 
 
 def test_native_load_is_fast_at_scale(tmp_path):
