@@ -230,7 +230,8 @@ int lstur_dp_unpack(lstur_ctx* ctx, const float* tail, int32_t world, int32_t n,
  * stages the tail inside its final reduction launch (no lstur_dp_stage; tail == NULL detaches), and
  * lstur_adam_step_dp(ctx, lr, t, tail, world, n) takes the REDUCED tail as it stands -- with full batches (n == max_batch)
  * the row-gradient matrix is read in place and the row numbers are converted inside the dense Adam launch; a ragged
- * last batch goes through lstur_dp_unpack internally. */
+ * last batch goes through lstur_dp_unpack internally.  The tail is the caller's memory: it must stay valid, and hold
+ * lstur_dp_tail_floats(cfg, world) floats, for as long as it is attached. */
 int lstur_dp_attach(lstur_ctx* ctx, float* tail, int32_t rank, int32_t world);
 int lstur_adam_step_dp(lstur_ctx* ctx, float lr, int32_t t, const float* tail, int32_t world, int32_t n, lstur_stream stream);
 
