@@ -1413,9 +1413,9 @@ int run_backward(lstur_ctx* c, int n, uint32_t step, hipStream_t s, float* stats
     const int ldp = off_cb + (int)((d.F + kParamAlign - 1) / kParamAlign * kParamAlign);
     PROF("attpool_bwd", launch_attpool_bwd(w.conv, w.ids, c->P("att_w"), w.att_a, w.att_wt, w.dpooled, w.dconv, w.parts,
                                            w.att_ds, nt, d.T, d.F, drop, key1, s, ldp, off_aw, off_cb, off_ab, 0, w.live,
-                                           w.kbits_valid ? w.kbits : nullptr));
-    launch_colsum2(w.parts, attpool_bwd_parts(nt), off_ab + 1, ldp, c->G("att_w"), 1.f, w.colsum_scratch_k[2], s,
-                   &jobs[nj++]);
+                                           w.kbits_valid ? w.kbits : nullptr, 0, nt, nullptr, tpb, 0));
+    launch_colsum2(w.parts, gp_titles ? cdiv(nt, tpb) : attpool_bwd_parts(nt), off_ab + 1, ldp, c->G("att_w"), 1.f,
+                   w.colsum_scratch_k[2], s, &jobs[nj++]);
     PROF("mhsa_bwd", launch_mhsa_bwd_bf16(w.qkv, w.dconv, w.ids, w.dqkv, nt, d.T, d.F, d.heads, s));
     // weight AND bias gradient in one product: the bucket keeps qkv_b right behind qkv_w (D * 3F is a multiple of the
     // slot alignment), so row D of [E | 1]^T . dQKV lands on it
