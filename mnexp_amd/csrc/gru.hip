@@ -652,9 +652,9 @@ void launch_gru_pack(const float* U, int H, float* packed, hipStream_t s, bool f
   generic_pack(U, H, packed, packed + 2 * sixth, packed + 3 * sixth, packed + 4 * sixth, s);
 }
 void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
-                    float* hlast, int n, int W, int H, hipStream_t s, bool f16) {
+                    float* hlast, int n, int W, int H, hipStream_t s, bool f16, const GruScore* sc) {
   if (!n) return;
-  if (gru4_supported(H)) return launch_gru4_fwd(xw, gmask, h0, packed, tape, hlast, n, W, H, s, f16);
+  if (gru4_supported(H)) return launch_gru4_fwd(xw, gmask, h0, packed, tape, hlast, n, W, H, s, f16, sc);
   const size_t sixth = generic_pack_floats(H) / 6;
   generic_fwd(xw, gmask, h0, packed, packed + 2 * sixth, tape, hlast, n, W, H, s);
 }
@@ -667,6 +667,7 @@ void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, con
   const size_t sixth = generic_pack_floats(H) / 6;
   generic_bwd(dh_last, gmask, tape, packed + 4 * sixth, packed + 3 * sixth, dgates, rh, hprev, dh0, n, W, H, s);
 }
+bool gru_score_fusable(int H, int K1) { return gru4_supported(H) && H <= 256 && K1 >= 1 && K1 <= 8; }
 bool gru_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh) {
   if (!gru4_supported(H)) return false;
   gru4_tape_rows(tape, n, W, H, hprev, rh);

@@ -321,6 +321,7 @@ struct Gru4Fwd {
   float* zr; float* hh; float* hp; float* rh; float* hlast;
   int n, W, H, dbg;   // dbg: measurement knobs (LSTUR_GRU4_DEBUG): 1 no global stores, 8 per-segment cycle stamps
   int sb, st;         // row of (sample b, step t) in xw / gmask / the tape = b * sb + t * st: (W, 1) sample-major, (1, n) slot-major
+  GruScore sc;        // sc.d != NULL: the workgroup scores its samples behind the last step (lstur_internal.h)
 };
 
 // Strip plan of the forward kernel (host + device).  [z|r] strip s and s+4 are resident on wave s.  A wave whose
@@ -595,6 +596,16 @@ __global__ __launch_bounds__(G4_THREADS) void gru4_fwd_kernel(Gru4Fwd g) {
   for (int i = tid; i < 4 * H; i += G4_THREADS) {
     const int row = i / H, col = i - row * H, b = b0 + row;
     if (b < n && !(g.dbg & 8)) g.hlast[(size_t)b * H + col] = L.hA[aidx(col, row)];
+  }
+  // LSTUR-ini: the last state IS the user vector -- wave j scores sample b0 + j against its candidates here (the scorer's
+  // own kernel was 10 us of launch and dependent loads on the step's critical path for 64 x 5 dot products): the same
+  // arithmetic in the same order, the state read from its LDS image instead of the row just written
+  if (g.sc.d && b0 + wv < n && H <= 256) {
+    float uv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) uv[c] = lane + 64 * c < H ? L.hA[aidx(lane + 64 * c, wv)] : 0.f;
+    score_row<8, 4>(uv, g.sc.d, g.sc.logits, g.sc.probs, g.sc.loss_i, g.sc.correct_i, g.sc.du, g.sc.dd, b0 + wv, lane, g.sc.K1, H,
+                    g.sc.inv_n);
   }
 }
 
@@ -898,21 +909,21 @@ void gru4_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh)
 }
 
 void launch_gru4_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* img, float* tape, float* hlast,
-                     int n, int W, int H, hipStream_t s, bool f16) {
+                     int n, int W, int H, hipStream_t s, bool f16, const GruScore* sc) {
   const int KQ = gru4_kq(H);
   const size_t e = (size_t)n * W * H, ie = (size_t)KQ * 4 * H;
   Gru4Fwd a{xw, gmask, h0, img, img + 2 * ie, img + 6 * ie, tape, tape + 2 * e, tape + 3 * e, tape + 4 * e, hlast, n, W, H, gru4_dbg(),
-            W, 1};
+            W, 1, sc ? *sc : GruScore{}};
   const size_t lds = gru4_fwd_lds(H, KQ);
   const dim3 grid(cdiv(n, 4)), block(G4_THREADS);
 #define LSTUR_G4F(Q)                                                            \
   {                                                                             \
     if (f16) {                                                                  \
       set_lds(gru4_fwd_kernel<Q, true>, lds);                                   \
-      hipLaunchKernelGGL((gru4_fwd_kernel<Q, true>), grid, block, lds, s, a);   \
+      launch_k((gru4_fwd_kernel<Q, true>), grid, block, lds, s, a);             \
     } else {                                                                    \
       set_lds(gru4_fwd_kernel<Q, false>, lds);                                  \
-      hipLaunchKernelGGL((gru4_fwd_kernel<Q, false>), grid, block, lds, s, a);  \
+      launch_k((gru4_fwd_kernel<Q, false>), grid, block, lds, s, a);            \
     }                                                                           \
   }
   if (KQ == 10) LSTUR_G4F(10) else if (KQ == 32) LSTUR_G4F(32) else LSTUR_G4F(50)

@@ -62,6 +62,7 @@ struct Opts {
   bool prof_attach;    // LSTUR_PROF_ATTACH=0: timing brackets recorded around the kernels instead of riding them
   bool wgrad_bf16x3;   // LSTUR_WGRAD_BF16X3=1: parameter-gradient GEMMs on the bf16x3 kernel
   bool gru_f16;        // LSTUR_GRU_F32=1: the recurrence on fp32 4x4x1 MFMAs instead of fp16-pair 4x4x4 ones (gru4.hip)
+  bool score_fuse;     // LSTUR_SCORE_FUSE=0: the listwise scorer as a launch of its own behind the recurrence
   int sweep_blocks;    // LSTUR_SWEEP_BLOCKS=n: workgroups of the thin table sweep (-1: planned)
   int prefetch_blocks; // LSTUR_PREFETCH_BLOCKS=n: workgroups of a prefetched gather (0: all)
   int lazy_log;        // LSTUR_LAZY_LOG=n (power of two): entries of the lazy table's lr_t ring (tests: force wraps)
@@ -81,6 +82,7 @@ struct Opts {
     o.prof_attach = !is("LSTUR_PROF_ATTACH", "0");
     o.wgrad_bf16x3 = getenv("LSTUR_WGRAD_BF16X3") != nullptr;
     o.gru_f16 = gru4_f16_env();
+    o.score_fuse = !is("LSTUR_SCORE_FUSE", "0");
     o.sweep_blocks = getenv("LSTUR_SWEEP_BLOCKS") ? atoi(getenv("LSTUR_SWEEP_BLOCKS")) : -1;
     o.prefetch_blocks = getenv("LSTUR_PREFETCH_BLOCKS") ? atoi(getenv("LSTUR_PREFETCH_BLOCKS")) : 0;
     o.lazy_log = kLazyLog;
@@ -489,6 +491,9 @@ struct ProfKernel {
 
 struct lstur_ctx {
   Opts opt;
+  // the listwise scorer as the tail of the forward recurrence's kernel (run_forward / run_listwise_score): asked for by the
+  // training / evaluation entry point for this call, done = the recurrence took it
+  struct { bool want = false, backward = false, done = false; float inv_n = 0.f; } sfuse;
   float* dp_tail = nullptr;   // lstur_dp_attach: the backward pass stages this rank's user rows here
   int dp_rank = 0, dp_world = 1;
   bool prof_on = false;
@@ -1032,6 +1037,7 @@ void lazy_init(lstur_ctx* c, hipStream_t s) {
 }
 
 // titles already in ws.ids as [n*W history | n*k1 candidates] ; runs the network up to user_vec / doc_vec
+bool cand_split_wanted(lstur_ctx* c, int n);
 void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training, uint32_t step, hipStream_t s) {
   const Dims& d = c->d;
   Workspace& w = c->ws;
@@ -1167,12 +1173,36 @@ void run_forward(lstur_ctx* c, const int32_t* user, int n, int k1, bool training
     // igru / nigru: the last state IS the user vector (H == U): the recurrence writes it in place
     const bool direct = d.arch == LSTUR_ARCH_IGRU || d.arch == LSTUR_ARCH_NIGRU;
     const bool init_user = d.arch == LSTUR_ARCH_IGRU || two_tables(d);   // initial_state = user_vec
+    // igru / nigru with the dot scorer: the recurrence's kernel scores its samples itself (GruScore); the candidate titles'
+    // backward then forks behind IT (run_listwise_score keeps the bookkeeping)
+    GruScore sc;
+    const bool fuse = c->sfuse.want && direct && d.head == LSTUR_HEAD_SOFTMAX && d.score == LSTUR_SCORE_DOT && k1 == d.K1 &&
+                      d.H == d.U && gru_score_fusable(d.H, k1);
+    if (fuse) {
+      const bool bw = c->sfuse.backward;
+      sc.d = w.docvec + (size_t)nW * d.U;
+      sc.logits = w.logits; sc.probs = w.probs; sc.loss_i = w.loss_i; sc.correct_i = w.correct_i;
+      sc.du = bw ? w.du : nullptr;
+      sc.dd = bw ? w.ddocvec + (size_t)nW * d.U : nullptr;
+      sc.K1 = k1;
+      sc.inv_n = c->sfuse.inv_n;
+      const bool fork_c = bw && cand_split_wanted(c, n);
+      if (fork_c) arm_stop_event(c->ev_c0);
+      c->cand_forked = fork_c;
+    }
 #ifdef LSTUR_ABLATE
     if (probe_fwd) (void)hipStreamWaitEvent(s, px1, 0);
     else
 #endif
     PROF("gru_fwd", launch_gru_fwd(w.xw, w.gmask, init_user ? w.uvec : nullptr, w.gru_up,
-                                   w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s, c->opt.gru_f16));
+                                   w.gru_tape, direct ? w.uservec : w.hlast, n, d.W, d.H, s, c->opt.gru_f16, fuse ? &sc : nullptr));
+    if (fuse) {
+      if (stop_event_pending()) {   // (nothing took the armed event: record the classic way)
+        arm_stop_event(nullptr);
+        (void)hipEventRecord(c->ev_c0, s);
+      }
+      c->sfuse.done = true;
+    }
     if (d.arch == LSTUR_ARCH_PGRU) {        // GRU(U)(x) + user_vec (paper.py:624-626)
       launch_add2(w.hlast, w.uvec, w.uservec, (size_t)n * d.U, s);
     } else if (!direct) {
@@ -1504,6 +1534,10 @@ void run_listwise_score(lstur_ctx* c, int n, int k1, float inv_n, bool backward,
   const int nW = n * d.W, rows = n * k1;
   const float* dvec = w.docvec + (size_t)nW * d.U;
   float* ddvec = w.ddocvec + (size_t)nW * d.U;
+  if (c->sfuse.done && !scores) {   // the forward recurrence's kernel scored its samples (run_forward)
+    c->sfuse.done = false;
+    return;
+  }
   if (d.score == LSTUR_SCORE_DOT) {
     if (scores) launch_predict_score(w.uservec, dvec, scores, n, d.U, s);
     else {
@@ -1582,7 +1616,12 @@ int train_impl(lstur_ctx* c, const int32_t* user, const int32_t* hist, const int
   else rc = stage_titles(c, hist, cands, n, d.K1, ids_form, s);
   if (rc) return rc;
   Workspace& w = c->ws;
+  c->sfuse.want = c->opt.score_fuse;
+  c->sfuse.backward = backward;
+  c->sfuse.inv_n = grad_scale / (float)n;
+  c->sfuse.done = false;
   PROF("forward_total", run_forward(c, user, n, d.K1, training, step, s));
+  c->sfuse.want = false;
   c->staged_hit = false;
   run_listwise_score(c, n, d.K1, grad_scale / (float)n, backward, nullptr, s);
   if (stats && !backward) launch_mean2(w.loss_i, w.correct_i, n, stats, s);

@@ -87,4 +87,86 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+
+// ---- listwise scorer of one sample (dot products with its K1 candidate doc vectors, softmax, Keras' categorical
+// cross-entropy with its renormalise / clip semantics, gradients): ONE wave, the user vector in registers (uv[c] = element
+// lane + 64 c, zero past U).  Shared by misc.hip's score_fast_kernel and the tail of the forward recurrence (gru4.hip),
+// which scores its own samples when its last state IS the user vector.   Reference: task/paper.py:446-464, 658.
+template <int KM, int UC>
+__device__ __forceinline__ void score_row(const float (&uv)[UC], const float* __restrict__ d, float* __restrict__ logits,
+                                          float* __restrict__ probs, float* __restrict__ loss_i,
+                                          float* __restrict__ correct_i, float* __restrict__ du, float* __restrict__ dd,
+                                          int b, int lane, int K1, int U, float inv_n) {
+  const __amdgpu_buffer_rsrc_t rsD = make_rsrc(d + (size_t)b * K1 * U, (uint32_t)K1 * (uint32_t)U * 4u);
+  float dv[KM][UC];
+#pragma unroll
+  for (int j = 0; j < KM; ++j)
+#pragma unroll
+    for (int c = 0; c < UC; ++c)
+      dv[j][c] = buf_load1(rsD, (j < K1 && lane + 64 * c < U) ? ((uint32_t)j * (uint32_t)U + (uint32_t)(lane + 64 * c)) * 4u : kBufOob, 0);
+  float z[KM], e[KM];
+#pragma unroll
+  for (int j = 0; j < KM; ++j) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < UC; ++c) acc += uv[c] * dv[j][c];
+    z[j] = wave_sum(acc);
+  }
+  float zmax = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < KM; ++j) zmax = j < K1 ? fmaxf(zmax, z[j]) : zmax;
+  float esum = 0.f;
+#pragma unroll
+  for (int j = 0; j < KM; ++j) {
+    e[j] = j < K1 ? expf(z[j] - zmax) : 0.f;
+    if (j < K1) esum += e[j];
+  }
+  float S = 0.f, p0 = 0.f, pmax = 0.f, pj[KM];
+#pragma unroll
+  for (int j = 0; j < KM; ++j) {
+    pj[j] = e[j] / esum;
+    if (j < K1) {
+      S += pj[j];
+      if (j == 0) p0 = pj[j];
+      pmax = fmaxf(pmax, pj[j]);
+    }
+  }
+  const float q0 = p0 / S;
+  const float cq0 = fminf(fmaxf(q0, LSTUR_EPS), 1.0f - LSTUR_EPS);
+  const bool inside = (q0 >= LSTUR_EPS) && (q0 <= 1.0f - LSTUR_EPS);
+  const float gq0 = inside ? -1.0f / cq0 : 0.f;
+  const float common = (gq0 * p0) / (S * S);
+  float dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < KM; ++j)
+    if (j < K1) dot += ((j == 0 ? gq0 / S : 0.f) - common) * pj[j];
+  if (lane == 0) {
+    loss_i[b] = -logf(cq0);
+    correct_i[b] = (p0 >= pmax) ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < KM; ++j)
+    if (j < K1 && lane == j) {
+      logits[(size_t)b * K1 + j] = z[j];
+      probs[(size_t)b * K1 + j] = pj[j];
+    }
+  if (du == nullptr) return;
+  float dz[KM];
+#pragma unroll
+  for (int j = 0; j < KM; ++j) dz[j] = pj[j] * (((j == 0 ? gq0 / S : 0.f) - common) - dot) * inv_n;
+#pragma unroll
+  for (int c = 0; c < UC; ++c) {
+    const int col = lane + 64 * c;
+    if (col >= U) continue;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < KM; ++j)
+      if (j < K1) {
+        acc += dz[j] * dv[j][c];
+        dd[((size_t)b * K1 + j) * U + col] = dz[j] * uv[c];
+      }
+    du[(size_t)b * U + col] = acc;
+  }
+}
+
 }  // namespace lstur

@@ -363,8 +363,17 @@ void launch_gru_pack(const float* U, int H, float* packed, hipStream_t s, bool f
 // tape: gru_tape_floats(n, W, H) floats of scratch shared by forward and BPTT (layout private to the kernels).
 // xw [n*W,3H] row-major; hlast [n,H]; dgates [n*W,3H], rh / hprev [n*W,H] row-major.  Requires H <= 256.
 size_t gru_tape_floats(int n, int W, int H);
+// The listwise scorer (misc.hip: launch_score, K1 <= 8 candidates, U = H <= 256) as the tail of the forward recurrence's
+// kernel (fast path only): d = the candidates' doc vectors [n * K1, H], the other fields as launch_score's.  d == NULL: none.
+struct GruScore {
+  const float* d = nullptr;
+  float *logits = nullptr, *probs = nullptr, *loss_i = nullptr, *correct_i = nullptr, *du = nullptr, *dd = nullptr;
+  int K1 = 0;
+  float inv_n = 0.f;
+};
+bool gru_score_fusable(int H, int K1);   // the fast recurrence kernel runs for this H and can score K1 candidates
 void launch_gru_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* packed, float* tape,
-                    float* hlast, int n, int W, int H, hipStream_t s, bool f16 = false);
+                    float* hlast, int n, int W, int H, hipStream_t s, bool f16 = false, const GruScore* sc = nullptr);
 void launch_gru_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* packed, float* dgates,
                     float* rh, float* hprev, float* dh0, int n, int W, int H, hipStream_t s);
 // On the fast path the forward already leaves hprev and r*hprev row-major inside the tape: returns true and the two
@@ -380,7 +389,7 @@ void gru4_tape_rows(float* tape, int n, int W, int H, float** hprev, float** rh)
 size_t gru4_image_floats(int H);     // floats of the six operand images (the pack's tail follows: scale, rotating maxima)
 void launch_gru4_pack(const float* U, int H, float* img, hipStream_t s, bool f16 = false, int seq = 0);
 void launch_gru4_fwd(const float* xw, const uint8_t* gmask, const float* h0, const float* img, float* tape, float* hlast,
-                     int n, int W, int H, hipStream_t s, bool f16 = false);
+                     int n, int W, int H, hipStream_t s, bool f16 = false, const GruScore* sc = nullptr);
 void launch_gru4_bwd(const float* dh_last, const uint8_t* gmask, float* tape, const float* img, float* dgates, float* rh,
                      float* hprev, float* dh0, int n, int W, int H, hipStream_t s);
 

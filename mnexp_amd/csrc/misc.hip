@@ -1358,78 +1358,10 @@ __global__ __launch_bounds__(256) void score_fast_kernel(const float* __restrict
   const int b = blockIdx.x * 4 + wv;
   if (b >= n) return;
   const __amdgpu_buffer_rsrc_t rsU = make_rsrc(u + (size_t)b * U, (uint32_t)U * 4u);
-  const __amdgpu_buffer_rsrc_t rsD = make_rsrc(d + (size_t)b * K1 * U, (uint32_t)K1 * (uint32_t)U * 4u);
-  float uv[UC], dv[KM][UC];
+  float uv[UC];
 #pragma unroll
   for (int c = 0; c < UC; ++c) uv[c] = buf_load1(rsU, (uint32_t)(lane + 64 * c) * 4u, 0);      // past U: 0
-#pragma unroll
-  for (int j = 0; j < KM; ++j)
-#pragma unroll
-    for (int c = 0; c < UC; ++c)
-      dv[j][c] = buf_load1(rsD, (j < K1 && lane + 64 * c < U) ? ((uint32_t)j * (uint32_t)U + (uint32_t)(lane + 64 * c)) * 4u : kBufOob, 0);
-  float z[KM], e[KM];
-#pragma unroll
-  for (int j = 0; j < KM; ++j) {
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < UC; ++c) acc += uv[c] * dv[j][c];
-    z[j] = wave_sum(acc);
-  }
-  float zmax = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < KM; ++j) zmax = j < K1 ? fmaxf(zmax, z[j]) : zmax;
-  float esum = 0.f;
-#pragma unroll
-  for (int j = 0; j < KM; ++j) {
-    e[j] = j < K1 ? expf(z[j] - zmax) : 0.f;
-    if (j < K1) esum += e[j];
-  }
-  float S = 0.f, p0 = 0.f, pmax = 0.f, pj[KM];
-#pragma unroll
-  for (int j = 0; j < KM; ++j) {
-    pj[j] = e[j] / esum;
-    if (j < K1) {
-      S += pj[j];
-      if (j == 0) p0 = pj[j];
-      pmax = fmaxf(pmax, pj[j]);
-    }
-  }
-  const float q0 = p0 / S;
-  const float cq0 = fminf(fmaxf(q0, LSTUR_EPS), 1.0f - LSTUR_EPS);
-  const bool inside = (q0 >= LSTUR_EPS) && (q0 <= 1.0f - LSTUR_EPS);
-  const float gq0 = inside ? -1.0f / cq0 : 0.f;
-  const float common = (gq0 * p0) / (S * S);
-  float dot = 0.f;
-#pragma unroll
-  for (int j = 0; j < KM; ++j)
-    if (j < K1) dot += ((j == 0 ? gq0 / S : 0.f) - common) * pj[j];
-  if (lane == 0) {
-    loss_i[b] = -logf(cq0);
-    correct_i[b] = (p0 >= pmax) ? 1.f : 0.f;
-  }
-#pragma unroll
-  for (int j = 0; j < KM; ++j)
-    if (j < K1 && lane == j) {
-      logits[(size_t)b * K1 + j] = z[j];
-      probs[(size_t)b * K1 + j] = pj[j];
-    }
-  if (du == nullptr) return;
-  float dz[KM];
-#pragma unroll
-  for (int j = 0; j < KM; ++j) dz[j] = pj[j] * (((j == 0 ? gq0 / S : 0.f) - common) - dot) * inv_n;
-#pragma unroll
-  for (int c = 0; c < UC; ++c) {
-    const int col = lane + 64 * c;
-    if (col >= U) continue;
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < KM; ++j)
-      if (j < K1) {
-        acc += dz[j] * dv[j][c];
-        dd[((size_t)b * K1 + j) * U + col] = dz[j] * uv[c];
-      }
-    du[(size_t)b * U + col] = acc;
-  }
+  score_row<KM, UC>(uv, d, logits, probs, loss_i, correct_i, du, dd, b, lane, K1, U, inv_n);
 }
 void launch_score(const float* u, const float* d, float* logits, float* probs, float* loss_i, float* correct_i,
                   float* du, float* dd, int n, int K1, int U, float inv_n, hipStream_t s) {
